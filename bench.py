@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched tabulate() hot path on MI355X.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+Lagrange P3 tetrahedron, tabulate order 1 (values + gradient), 23 points per
+request (the size of the degree-6 rule), batch of 100 000 independent requests
+per GPU, synthetic uniformly random points (seed 2), fp64.
+
+One "step" = one pass of the hot path over the whole batch, inputs and outputs
+resident in HBM.  With N > 1 ranks (one process per GPU, torch.distributed over
+RCCL) every rank tabulates its own 100 000 requests (weak scaling, no data-path
+collective: requests are independent); ``--allgather`` additionally times the
+RCCL all-gather that replicates the tables on every GPU and reports it in a
+separate object.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (family, sd, degree, order, npts, default batch)
+    "p3tet": ("Lagrange", 3, 3, 1, 23, 100_000),
+    "n2tet": ("Nedelec", 3, 2, 1, 23, 25_000),
+    "rt2tet": ("RaviartThomas", 3, 2, 1, 23, 25_000),
+    "dg6tet": ("DiscontinuousLagrange", 3, 6, 2, 23, 20_000),
+}
+
+
+def synth_points(sd, nreq, npts, seed):
+    """Uniform points in the UFC simplex: e ~ Exp(1)^(sd+1), x = (e / sum e)[1:]  (SURVEY.md 8d)."""
+    rng = np.random.default_rng(seed)
+    e = rng.exponential(size=(nreq, npts, sd + 1))
+    return (e / e.sum(axis=-1, keepdims=True))[..., 1:].copy()
+
+
+def build_element(name):
+    """Nodal coefficients through the device Vandermonde path; returns the
+    device polynomial set and what the oracle needs for the CPU baseline."""
+    from fiat_amd import elements
+    fam, sd, deg, order, npts, batch = WORKLOADS[name]
+    from fiat_amd.reference_element import ufc_simplex
+    el = getattr(elements, fam)(ufc_simplex(sd), deg)
+    return el, sd, deg, order, npts, batch
+
+
+def cpu_baseline(name, el, sd, deg, order, npts, seconds=12.0):
+    """Oracle (NumPy restatement of FIAT's algorithm, oracle/fiat_oracle.py) on one
+    host core, one tabulate call per request, bounded to ~`seconds` of CPU work."""
+    from oracle import fiat_oracle as fo
+    coeffs = el.get_coeffs()
+    verts = fo.UFC_SIMPLEX[sd]
+    variant, scale = el._expansion_variant, el._expansion_scale
+    pts = synth_points(sd, 4096, npts, 99)
+    fo.element_tabulate(verts, deg, coeffs, order, pts[0], scale, variant)  # warm
+    t0 = time.perf_counter()
+    done = 0
+    while True:
+        fo.element_tabulate(verts, deg, coeffs, order, pts[done % len(pts)], scale, variant)
+        done += 1
+        if done % 16 == 0 and time.perf_counter() - t0 > seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "tabulations/s", "cores": 1, "kind": "port",
+            "sample": f"{done} requests of the same workload, one tabulate call per request, "
+                      f"NumPy oracle on 1 host core, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="p3tet", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="requests per GPU (default: the workload's)")
+    ap.add_argument("--allgather", action="store_true", help="also time the RCCL all-gather of the tables")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", type=int, default=64, help="requests verified against the oracle after timing")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the tabulate path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    el, sd, deg, order, npts, batch = build_element(args.workload)
+    if args.batch:
+        batch = args.batch
+    ps = el.device_polyset()
+    ntab = ps.out_shape(order, 1, 1)[1]
+    rows = ps.ndof * ps.vdim
+    bytes_per_req = 8 * (npts * sd + ntab * rows * npts)     # algorithmic bytes
+
+    pts_h = synth_points(sd, batch, npts, seed=2 + rank)
+    pts = torch.as_tensor(pts_h).cuda()
+    out = torch.empty(ps.out_shape(order, batch, npts), dtype=torch.float64, device="cuda")
+    stream = torch.cuda.current_stream()
+
+    for _ in range(args.warmup):
+        ps.tabulate_batch(order, pts, out=out)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ps.tabulate_batch(order, pts, out=out)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: average launch duration from HIP events on the launch stream
+    kernel_ms = ps.time_tabulate_batch(order, pts, None, out, max(5, args.steps), stream=stream)
+    achieved = bytes_per_req * batch / (kernel_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "tabulate_simplex_kernel", "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_request": bytes_per_req, "requests_per_launch": batch}
+    prof = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(prof):
+        try:
+            with open(prof) as f:
+                tr = json.load(f)
+            if tr.get("workload") == args.workload and tr.get("batch") == batch:
+                roofline["traffic"] = tr["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+
+    # parity spot check of the timed output (never inside the timed region)
+    max_err = None
+    if args.check and rank == 0:
+        from oracle import fiat_oracle as fo
+        co = el.get_coeffs()
+        rng = np.random.default_rng(1)
+        idx = rng.choice(batch, size=min(args.check, batch), replace=False)
+        got = out[torch.as_tensor(idx).cuda()].cpu().numpy()
+        max_err = 0.0
+        for g, r in zip(got, idx):
+            ref = fo.element_tabulate(fo.UFC_SIMPLEX[sd], deg, co, order, pts_h[r],
+                                      el._expansion_scale, el._expansion_variant)
+            for t, a in enumerate(fo.jet_indices(sd, order)):
+                max_err = max(max_err, float(np.max(np.abs(g[t] - ref[a])) / max(1.0, np.max(np.abs(ref[a])))))
+
+    allgather = None
+    if args.allgather and world > 1:
+        gathered = torch.empty((world,) + tuple(out.shape), dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(gathered, out)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        reps = max(2, args.steps // 4)
+        for _ in range(reps):
+            ps.tabulate_batch(order, pts, out=out)
+            dist.all_gather_into_tensor(gathered, out)
+        torch.cuda.synchronize()
+        barrier()
+        dt = (time.perf_counter() - t0) / reps
+        allgather = {"ms_per_step_with_allgather": dt * 1e3,
+                     "value_with_allgather": batch * world / dt,
+                     "gathered_bytes_per_gpu": out.numel() * 8 * world}
+
+    if rank == 0:
+        line = {
+            "metric": "element tabulations/sec (basis+grad, fp64) for batched P3 tet"
+                      if args.workload == "p3tet" else f"element tabulations/sec ({args.workload})",
+            "value": batch * world * args.steps / elapsed,
+            "unit": "tabulations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{WORKLOADS[args.workload][0]} degree {deg} "
+                                   f"{'tetrahedron' if sd == 3 else 'triangle'}, order {order}, "
+                                   f"{npts} points/request, batch {batch} per GPU",
+                       "requests_per_gpu": batch, "points_per_request": npts, "order": order,
+                       "sharding": "independent requests, contiguous blocks per rank, no data-path collective"},
+            "roofline": roofline,
+            "max_rel_err_vs_oracle": max_err,
+        }
+        if allgather:
+            line["allgather"] = allgather
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.workload, el, sd, deg, order, npts)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,669 @@
+// C ABI of libfiat_amd (include/fiat_amd.h): contexts, element plans, launches.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fiat_amd.h"
+#include "aux_kernels.hpp"
+#include "plan.hpp"
+#include "simplex_kernel.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail(FX_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+const double UFC[3][12] = {
+    {0.0, 1.0},
+    {0.0, 0.0, 1.0, 0.0, 0.0, 1.0},
+    {0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0},
+};
+
+// host version of the device cell_map (same closed form)
+bool host_cell_map(int sd, const double* v, double* A, double* b) {
+    if (sd == 1) {
+        double den = v[1] - v[0];
+        if (den == 0.0) return false;
+        A[0] = 2.0 / den;
+        b[0] = -1.0 - A[0] * v[0];
+        return true;
+    }
+    if (sd == 2) {
+        double e00 = v[2] - v[0], e10 = v[3] - v[1], e01 = v[4] - v[0], e11 = v[5] - v[1];
+        double det = e00 * e11 - e01 * e10;
+        if (det == 0.0) return false;
+        double inv = 2.0 / det;
+        A[0] = e11 * inv;
+        A[1] = -e01 * inv;
+        A[2] = -e10 * inv;
+        A[3] = e00 * inv;
+        for (int i = 0; i < 2; ++i) b[i] = -1.0 - (A[i * 2] * v[0] + A[i * 2 + 1] * v[1]);
+        return true;
+    }
+    double e[3][3];
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) e[r][c] = v[3 * (c + 1) + r] - v[r];
+    double c00 = e[1][1] * e[2][2] - e[1][2] * e[2][1];
+    double c01 = e[1][2] * e[2][0] - e[1][0] * e[2][2];
+    double c02 = e[1][0] * e[2][1] - e[1][1] * e[2][0];
+    double det = e[0][0] * c00 + e[0][1] * c01 + e[0][2] * c02;
+    if (det == 0.0) return false;
+    double inv = 2.0 / det;
+    A[0] = c00 * inv;
+    A[1] = (e[0][2] * e[2][1] - e[0][1] * e[2][2]) * inv;
+    A[2] = (e[0][1] * e[1][2] - e[0][2] * e[1][1]) * inv;
+    A[3] = c01 * inv;
+    A[4] = (e[0][0] * e[2][2] - e[0][2] * e[2][0]) * inv;
+    A[5] = (e[0][2] * e[1][0] - e[0][0] * e[1][2]) * inv;
+    A[6] = c02 * inv;
+    A[7] = (e[0][1] * e[2][0] - e[0][0] * e[2][1]) * inv;
+    A[8] = (e[0][0] * e[1][1] - e[0][1] * e[1][0]) * inv;
+    for (int i = 0; i < 3; ++i) b[i] = -1.0 - (A[i * 3] * v[0] + A[i * 3 + 1] * v[1] + A[i * 3 + 2] * v[2]);
+    return true;
+}
+
+double default_simplex_volume(int sd) {
+    // (-1,1)^sd simplex: 2^sd / sd!
+    double v = 1.0;
+    for (int i = 1; i <= sd; ++i) v *= 2.0 / i;
+    return v;
+}
+
+}  // namespace
+
+struct fx_ctx {
+    int device = 0;
+    int num_cu = 0;
+    int lds_per_cu = 0;
+    std::string name;
+};
+
+struct fx_element {
+    fx_ctx* ctx = nullptr;
+    int sd = 0, n = 0, variant = 0, nexp = 0, ndof = 0, vdim = 1;
+    double scale = 0.0;
+    double A0[9] = {0}, b0[3] = {0};
+    fx::Program prog;
+    std::vector<double> T;  // C0 transform (bubble) or empty
+    int KS = 0, MT = 0;
+    fxk::Step* d_steps = nullptr;
+    double* d_afrag = nullptr;
+};
+
+struct fx_line_element {
+    fx_ctx* ctx = nullptr;
+    int nn = 0;
+    double* d_buf = nullptr;  // nodes | wts | dmat
+    std::vector<double> nodes, wts, dmat;
+};
+
+extern "C" {
+
+const char* fx_last_error(void) { return g_err.c_str(); }
+int fx_abi_version(void) { return 1; }
+
+int fx_num_tables(int sd, int order) {
+    if (sd < 1 || sd > 3 || order < 0) return fail(FX_EINVAL, "fx_num_tables: bad sd/order");
+    return fx::binom(sd + order, sd);
+}
+
+int fx_ctx_create(int device_id, fx_ctx** out) {
+    if (!out) return fail(FX_EINVAL, "fx_ctx_create: null output");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(FX_EHIP, "fx_ctx_create: no HIP device available (%s); fiat_amd has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= count) return fail(FX_EINVAL, "fx_ctx_create: device %d out of range", device_id);
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    fx_ctx* c = new fx_ctx;
+    c->device = device_id;
+    c->num_cu = prop.multiProcessorCount;
+    c->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    if (c->lds_per_cu <= 0) c->lds_per_cu = 160 * 1024;
+    c->name = prop.gcnArchName;
+    *out = c;
+    return FX_OK;
+}
+
+int fx_ctx_destroy(fx_ctx* ctx) {
+    delete ctx;
+    return FX_OK;
+}
+
+int fx_ctx_info(fx_ctx* ctx, int* num_cu, int* lds, char* name, int name_len) {
+    if (!ctx) return fail(FX_EINVAL, "fx_ctx_info: null context");
+    if (num_cu) *num_cu = ctx->num_cu;
+    if (lds) *lds = ctx->lds_per_cu;
+    if (name && name_len > 0) {
+        strncpy(name, ctx->name.c_str(), name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// plan introspection (host only; used by the CPU test-suite to check the folded
+// recurrence tables against the oracle without a GPU)
+int fx_plan_steps(int sd, int n, int variant, double scale, int cap, int* nsteps, double* phi0,
+                  int* ints /* [cap][4] */, double* coefs /* [cap][3] */) {
+    if (sd < 1 || sd > 3 || n < 0 || variant < 0 || variant > 2) return fail(FX_EINVAL, "fx_plan_steps: bad arguments");
+    if (variant == FX_VARIANT_BUBBLE && n < 1) return fail(FX_EINVAL, "bubble variant needs degree >= 1");
+    if (scale <= 0.0) scale = std::sqrt(1.0 / default_simplex_volume(sd));
+    fx::Program P = fx::build_program(sd, n, variant, scale);
+    if (nsteps) *nsteps = (int)P.steps.size();
+    if (phi0) *phi0 = P.phi0;
+    int m = std::min<int>(cap, (int)P.steps.size());
+    for (int i = 0; i < m; ++i) {
+        if (ints) {
+            ints[4 * i + 0] = P.steps[i].dst;
+            ints[4 * i + 1] = P.steps[i].cur;
+            ints[4 * i + 2] = P.steps[i].prv;
+            ints[4 * i + 3] = P.steps[i].codim;
+        }
+        if (coefs) {
+            coefs[3 * i + 0] = P.steps[i].A;
+            coefs[3 * i + 1] = P.steps[i].B;
+            coefs[3 * i + 2] = P.steps[i].C;
+        }
+    }
+    return FX_OK;
+}
+
+int fx_plan_c0_transform(int sd, int n, double* T /* [nexp][nexp] */) {
+    if (sd < 1 || sd > 3 || n < 1 || !T) return fail(FX_EINVAL, "fx_plan_c0_transform: bad arguments");
+    std::vector<double> M = fx::c0_transform(sd, n);
+    memcpy(T, M.data(), M.size() * sizeof(double));
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------
+static int upload_coeffs(fx_element* e, int ndof, int vdim, const double* coeffs) {
+    const int rows = ndof * vdim, nexp = e->nexp;
+    std::vector<double> C((size_t)rows * nexp, 0.0);
+    if (coeffs) {
+        C.assign(coeffs, coeffs + (size_t)rows * nexp);
+    } else {
+        if (rows != nexp) return fail(FX_EINVAL, "identity coefficients need ndof*vdim == nexp");
+        for (int i = 0; i < nexp; ++i) C[(size_t)i * nexp + i] = 1.0;
+    }
+    if (!e->T.empty()) {  // tables = coeffs . C0(phi) = (coeffs . T) . phi
+        std::vector<double> CT((size_t)rows * nexp, 0.0);
+        for (int i = 0; i < rows; ++i)
+            for (int j = 0; j < nexp; ++j) {
+                double cij = C[(size_t)i * nexp + j];
+                if (cij == 0.0) continue;
+                const double* trow = &e->T[(size_t)j * nexp];
+                for (int k = 0; k < nexp; ++k) CT[(size_t)i * nexp + k] += cij * trow[k];
+            }
+        C.swap(CT);
+    }
+    std::vector<double> F = fx::pack_a_fragments(C, rows, nexp);
+    if (e->d_afrag) {
+        HIP_TRY(hipFree(e->d_afrag));
+        e->d_afrag = nullptr;
+    }
+    HIP_TRY(hipMalloc(&e->d_afrag, F.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(e->d_afrag, F.data(), F.size() * sizeof(double), hipMemcpyHostToDevice));
+    e->ndof = ndof;
+    e->vdim = vdim;
+    e->MT = (rows + 15) / 16;
+    e->KS = (nexp + 3) / 4;
+    return FX_OK;
+}
+
+int fx_element_create(fx_ctx* ctx, int sd, int n, int variant, double scale, const double* verts,
+                      int ndof, int vdim, const double* coeffs, fx_element** out) {
+    if (!ctx || !out) return fail(FX_EINVAL, "fx_element_create: null argument");
+    if (sd < 1 || sd > 3) return fail(FX_EINVAL, "Invalid number of spatial dimensions");
+    if (n < 0) return fail(FX_EINVAL, "negative degree");
+    if (variant < 0 || variant > 2) return fail(FX_EINVAL, "Invalid variant %d", variant);
+    if (variant == FX_VARIANT_BUBBLE && n < 1) return fail(FX_EINVAL, "bubble variant needs degree >= 1");
+    if (ndof < 1 || vdim < 1) return fail(FX_EINVAL, "bad ndof/vdim");
+    HIP_TRY(hipSetDevice(ctx->device));
+    fx_element* e = new fx_element;
+    e->ctx = ctx;
+    e->sd = sd;
+    e->n = n;
+    e->variant = variant;
+    e->nexp = fx::binom(n + sd, sd);
+    if (scale <= 0.0) {
+        scale = std::sqrt(1.0 / default_simplex_volume(sd));
+        if (n == 0 && sd > 1) scale = 1.0;  // expansions.py:396-398
+    }
+    e->scale = scale;
+    if (!host_cell_map(sd, verts ? verts : UFC[sd - 1], e->A0, e->b0)) {
+        delete e;
+        return fail(FX_EINVAL, "degenerate cell");
+    }
+    e->prog = fx::build_program(sd, n, variant, scale);
+    if (variant == FX_VARIANT_BUBBLE) e->T = fx::c0_transform(sd, n);
+    static_assert(sizeof(fx::Step) == sizeof(fxk::Step), "step layout");
+    size_t sbytes = std::max<size_t>(1, e->prog.steps.size()) * sizeof(fxk::Step);
+    hipError_t he = hipMalloc(&e->d_steps, sbytes);
+    if (he == hipSuccess && !e->prog.steps.empty())
+        he = hipMemcpy(e->d_steps, e->prog.steps.data(), e->prog.steps.size() * sizeof(fxk::Step), hipMemcpyHostToDevice);
+    if (he != hipSuccess) {
+        fx_element_destroy(e);
+        return fail(FX_EHIP, "fx_element_create: %s", hipGetErrorString(he));
+    }
+    int rc = upload_coeffs(e, ndof, vdim, coeffs);
+    if (rc != FX_OK) {
+        fx_element_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return FX_OK;
+}
+
+int fx_element_destroy(fx_element* e) {
+    if (!e) return FX_OK;
+    if (e->d_steps) (void)hipFree(e->d_steps);
+    if (e->d_afrag) (void)hipFree(e->d_afrag);
+    delete e;
+    return FX_OK;
+}
+
+int fx_element_set_coeffs(fx_element* e, int ndof, int vdim, const double* coeffs) {
+    if (!e || ndof < 1 || vdim < 1) return fail(FX_EINVAL, "fx_element_set_coeffs: bad argument");
+    HIP_TRY(hipSetDevice(e->ctx->device));
+    return upload_coeffs(e, ndof, vdim, coeffs);
+}
+
+int fx_element_dims(const fx_element* e, int* sd, int* n, int* nexp, int* ndof, int* vdim) {
+    if (!e) return fail(FX_EINVAL, "fx_element_dims: null element");
+    if (sd) *sd = e->sd;
+    if (n) *n = e->n;
+    if (nexp) *nexp = e->nexp;
+    if (ndof) *ndof = e->ndof;
+    if (vdim) *vdim = e->vdim;
+    return FX_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------
+namespace {
+
+struct Launch {
+    fxk::TabArgs args;
+    int grid = 0, lds_bytes = 0;
+    bool fast_p3 = false;
+};
+
+template <int SD, int ORDER, int KS_T, int MT_T>
+int launch_one(const Launch& L, hipStream_t s) {
+    auto kern = fxk::tabulate_simplex_kernel<SD, ORDER, 1, KS_T, MT_T>;
+    if (L.lds_bytes > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    L.lds_bytes));
+    }
+    hipLaunchKernelGGL(kern, dim3(L.grid), dim3(64), L.lds_bytes, s, L.args);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+template <int SD>
+int launch_sd(int order, const Launch& L, hipStream_t s) {
+    const int KS = L.args.KS, MT = L.args.MT;
+    switch (order) {
+        case 0:
+            return launch_one<SD, 0, 0, 0>(L, s);
+        case 1:
+            if (SD == 3 && KS == 5 && MT == 2) return launch_one<SD, 1, 5, 2>(L, s);  // P3 tet
+            if (SD == 3 && KS == 3 && MT == 4) return launch_one<SD, 1, 3, 4>(L, s);  // N2 tet
+            if (SD == 3 && KS == 3 && MT == 3) return launch_one<SD, 1, 3, 3>(L, s);  // RT2 tet
+            return launch_one<SD, 1, 0, 0>(L, s);
+        case 2:
+            return launch_one<SD, 2, 0, 0>(L, s);
+    }
+    return fail(FX_ENOTIMPL, "derivative order %d > 2 is not implemented on the device", order);
+}
+
+int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, const double* pts,
+                const double* verts, double* out, Launch& L) {
+    if (!ctx || !e) return fail(FX_EINVAL, "null context/element");
+    if (order < 0) return fail(FX_EINVAL, "negative derivative order");
+    if (order > 2) return fail(FX_ENOTIMPL, "derivative order %d > 2 is not implemented on the device", order);
+    if (nreq < 0 || npts < 0) return fail(FX_EINVAL, "negative batch size");
+    if ((nreq > 0 && npts > 0) && (!pts || !out)) return fail(FX_EINVAL, "null device pointer");
+    const int ntab = fx::binom(e->sd + order, e->sd);
+    const int rows = e->ndof * e->vdim;
+    fxk::TabArgs& a = L.args;
+    memset(&a, 0, sizeof a);
+    a.pts = pts;
+    a.verts = verts;
+    a.out = out;
+    a.afrag = e->d_afrag;
+    a.steps = e->d_steps;
+    a.phi0 = e->prog.phi0;
+    memcpy(a.A0, e->A0, sizeof a.A0);
+    memcpy(a.b0, e->b0, sizeof a.b0);
+    a.nreq = nreq;
+    a.npts = npts;
+    a.rows = rows;
+    a.nexp = e->nexp;
+    a.nsteps = (int)e->prog.steps.size();
+    a.KS = e->KS;
+    a.MT = e->MT;
+    a.ntab = ntab;
+
+    // ---- choose the work-item shape under a per-wave LDS budget ----
+    const long long budget = 32 * 1024;  // bytes per wave: >= 5 resident waves per CU
+    const long long hard = 64 * 1024;
+    auto phi_bytes = [&](long long cols) { return ((cols + 15) / 16) * (long long)e->KS * 64 * 8; };
+    const long long reqbytes = (long long)ntab * rows * npts * 8;
+    int P = 1, pc = npts, nchunk = 1;
+    long long stage = 0;
+    if (npts <= 64 && phi_bytes((long long)ntab * npts) + reqbytes <= budget) {
+        // whole requests, output staged through LDS; pack as many as fit in a wave
+        int pmax = 64 / npts;
+        P = 1;
+        for (int p = 2; p <= pmax; ++p)
+            if (phi_bytes((long long)p * ntab * npts) + p * reqbytes <= budget) P = p;
+        stage = P * reqbytes;
+    } else {
+        // point-chunked, direct stores
+        pc = std::min(npts, 64);
+        while (pc > 1 && phi_bytes((long long)ntab * pc) > budget) --pc;
+        if (phi_bytes((long long)ntab * pc) > hard)
+            return fail(FX_ENOTIMPL, "expansion degree too large for the LDS tile (nexp=%d, ntab=%d)", e->nexp, ntab);
+        nchunk = (npts + pc - 1) / pc;
+    }
+    a.P = P;
+    a.pc = pc;
+    a.nchunk = nchunk;
+    a.nitems = nchunk > 1 ? nreq * nchunk : (nreq + P - 1) / P;
+    a.phi_doubles = (int)(phi_bytes((long long)P * ntab * pc) / 8);
+    a.stage_doubles = (int)((stage / 8 + 1) & ~1LL);
+    if (stage == 0) a.stage_doubles = 0;
+    L.lds_bytes = (a.phi_doubles + a.stage_doubles) * 8;
+    int per_cu = std::max(1, std::min(16, ctx->lds_per_cu / std::max(1, L.lds_bytes)));
+    long long want = (long long)ctx->num_cu * per_cu * 4;
+    L.grid = (int)std::max<long long>(1, std::min<long long>(a.nitems, want));
+    return FX_OK;
+}
+
+int run_tabulate(fx_ctx* ctx, const fx_element* e, int order, const Launch& L, hipStream_t s) {
+    if (L.args.nitems == 0 || L.args.npts == 0) return FX_OK;
+    switch (e->sd) {
+        case 1: return launch_sd<1>(order, L, s);
+        case 2: return launch_sd<2>(order, L, s);
+        case 3: return launch_sd<3>(order, L, s);
+    }
+    return fail(FX_EINVAL, "Invalid number of spatial dimensions");
+}
+
+}  // namespace
+
+extern "C" {
+
+int fx_tabulate_batch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, const double* pts,
+                      const double* verts, double* out, void* stream) {
+    Launch L;
+    int rc = plan_launch(ctx, e, order, nreq, npts, pts, verts, out, L);
+    if (rc != FX_OK) return rc;
+    return run_tabulate(ctx, e, order, L, (hipStream_t)stream);
+}
+
+int fx_time_tabulate_batch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, const double* pts,
+                           const double* verts, double* out, void* stream, int reps, float* ms) {
+    if (reps < 1 || !ms) return fail(FX_EINVAL, "fx_time_tabulate_batch: bad reps/ms");
+    Launch L;
+    int rc = plan_launch(ctx, e, order, nreq, npts, pts, verts, out, L);
+    if (rc != FX_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t t0, t1;
+    HIP_TRY(hipEventCreate(&t0));
+    HIP_TRY(hipEventCreate(&t1));
+    HIP_TRY(hipEventRecord(t0, s));
+    for (int i = 0; i < reps; ++i) {
+        rc = run_tabulate(ctx, e, order, L, s);
+        if (rc != FX_OK) break;
+    }
+    HIP_TRY(hipEventRecord(t1, s));
+    HIP_TRY(hipEventSynchronize(t1));
+    float total = 0.f;
+    HIP_TRY(hipEventElapsedTime(&total, t0, t1));
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    *ms = total / reps;
+    return rc;
+}
+
+int fx_tabulate_batch_host(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, const double* pts,
+                           const double* verts, double* out) {
+    if (!ctx || !e) return fail(FX_EINVAL, "null context/element");
+    if (order < 0 || order > 2) return fail(order < 0 ? FX_EINVAL : FX_ENOTIMPL, "unsupported derivative order %d", order);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int ntab = fx::binom(e->sd + order, e->sd);
+    size_t pbytes = (size_t)nreq * npts * e->sd * 8, vbytes = (size_t)nreq * (e->sd + 1) * e->sd * 8;
+    size_t obytes = (size_t)nreq * ntab * e->ndof * e->vdim * npts * 8;
+    if (pbytes == 0 || obytes == 0) return FX_OK;
+    double *dp = nullptr, *dv = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(&dp, pbytes));
+    HIP_TRY(hipMalloc(&dout, obytes));
+    HIP_TRY(hipMemcpy(dp, pts, pbytes, hipMemcpyHostToDevice));
+    if (verts) {
+        HIP_TRY(hipMalloc(&dv, vbytes));
+        HIP_TRY(hipMemcpy(dv, verts, vbytes, hipMemcpyHostToDevice));
+    }
+    int rc = fx_tabulate_batch(ctx, e, order, nreq, npts, dp, dv, dout, nullptr);
+    if (rc == FX_OK) {
+        hipError_t he = hipDeviceSynchronize();
+        if (he != hipSuccess) rc = fail(FX_EHIP, "tabulate kernel: %s", hipGetErrorString(he));
+    }
+    if (rc == FX_OK) {
+        hipError_t he = hipMemcpy(out, dout, obytes, hipMemcpyDeviceToHost);
+        if (he != hipSuccess) rc = fail(FX_EHIP, "copy back: %s", hipGetErrorString(he));
+    }
+    (void)hipFree(dp);
+    (void)hipFree(dout);
+    if (dv) (void)hipFree(dv);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------
+int fx_riesz_assemble(fx_ctx* ctx, int nrows, int nq, int nexp, const double* wts, const double* ev, double* mat,
+                      void* stream) {
+    if (!ctx || nrows < 0 || nq < 0 || nexp < 0) return fail(FX_EINVAL, "fx_riesz_assemble: bad argument");
+    long long total = (long long)nrows * nexp;
+    if (total == 0) return FX_OK;
+    int grid = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(fxk::riesz_assemble_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, nrows, nq, nexp, wts,
+                       ev, mat);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+int fx_vandermonde_solve_batch(fx_ctx* ctx, int64_t nsys, int ndof, int m, const double* A, const double* B, double* X,
+                               double* Vout, int* info, void* stream) {
+    if (!ctx || nsys < 0 || ndof < 1 || m < 1 || !info) return fail(FX_EINVAL, "fx_vandermonde_solve_batch: bad argument");
+    if (nsys == 0) return FX_OK;
+    size_t lds = ((size_t)ndof * ndof + (size_t)ndof * m) * 8;
+    if (lds > 150 * 1024) return fail(FX_ENOTIMPL, "system too large for the LDS-resident solver (ndof=%d, m=%d)", ndof, m);
+    auto kern = fxk::vandermonde_solve_kernel;
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nsys), dim3(256), lds, (hipStream_t)stream, ndof, m, A, B, X, Vout, info);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+// ---------------------------------------------------------------------------------
+int fx_line_element_create(fx_ctx* ctx, int nn, const double* nodes, fx_line_element** out) {
+    if (!ctx || !nodes || !out) return fail(FX_EINVAL, "fx_line_element_create: null argument");
+    if (nn < 1 || nn > fxk::NN_MAX) return fail(FX_ENOTIMPL, "1-D Lagrange with %d nodes (max %d)", nn, fxk::NN_MAX);
+    HIP_TRY(hipSetDevice(ctx->device));
+    fx_line_element* e = new fx_line_element;
+    e->ctx = ctx;
+    e->nn = nn;
+    e->nodes.assign(nodes, nodes + nn);
+    // make_dmat (barycentric_interpolation.py:50-59)
+    std::vector<double> D((size_t)nn * nn), w(nn);
+    for (int i = 0; i < nn; ++i)
+        for (int j = 0; j < nn; ++j) D[(size_t)i * nn + j] = (i == j) ? 1.0 : nodes[j] - nodes[i];
+    for (int j = 0; j < nn; ++j) {
+        double p = 1.0;
+        for (int i = 0; i < nn; ++i) p *= D[(size_t)i * nn + j];
+        if (p == 0.0) {
+            delete e;
+            return fail(FX_EINVAL, "repeated interpolation node");
+        }
+        w[j] = 1.0 / p;
+    }
+    for (int i = 0; i < nn; ++i)
+        for (int j = 0; j < nn; ++j) D[(size_t)i * nn + j] = (w[i] / w[j]) / D[(size_t)i * nn + j];
+    std::vector<double> colsum(nn, 0.0);
+    for (int i = 0; i < nn; ++i)
+        for (int j = 0; j < nn; ++j) colsum[j] += D[(size_t)i * nn + j];
+    for (int i = 0; i < nn; ++i) D[(size_t)i * nn + i] -= colsum[i];
+    e->wts = w;
+    e->dmat = D;
+    std::vector<double> buf;
+    buf.insert(buf.end(), e->nodes.begin(), e->nodes.end());
+    buf.insert(buf.end(), w.begin(), w.end());
+    buf.insert(buf.end(), D.begin(), D.end());
+    hipError_t he = hipMalloc(&e->d_buf, buf.size() * 8);
+    if (he == hipSuccess) he = hipMemcpy(e->d_buf, buf.data(), buf.size() * 8, hipMemcpyHostToDevice);
+    if (he != hipSuccess) {
+        fx_line_element_destroy(e);
+        return fail(FX_EHIP, "fx_line_element_create: %s", hipGetErrorString(he));
+    }
+    *out = e;
+    return FX_OK;
+}
+
+int fx_line_element_destroy(fx_line_element* e) {
+    if (!e) return FX_OK;
+    if (e->d_buf) (void)hipFree(e->d_buf);
+    delete e;
+    return FX_OK;
+}
+
+static fxk::LineDesc line_desc(const fx_line_element* e) {
+    fxk::LineDesc L;
+    L.nodes = e->d_buf;
+    L.wts = e->d_buf + e->nn;
+    L.dmat = e->d_buf + 2 * e->nn;
+    L.nn = e->nn;
+    return L;
+}
+
+int fx_line_tabulate_batch(fx_ctx* ctx, const fx_line_element* e, int order, int64_t nreq, int npts, const double* pts,
+                           double* out, void* stream) {
+    if (!ctx || !e || order < 0 || nreq < 0 || npts < 0) return fail(FX_EINVAL, "fx_line_tabulate_batch: bad argument");
+    long long total = (long long)nreq * npts;
+    if (total == 0) return FX_OK;
+    int grid = (int)((total + 127) / 128);
+    hipLaunchKernelGGL(fxk::line_tabulate_kernel, dim3(grid), dim3(128), 0, (hipStream_t)stream, line_desc(e), order,
+                       (long long)nreq, npts, pts, out);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+static void fill_alpha(int nf, int order, fxk::TensorArgs& a) {
+    // mis(nf, k), k = 0..order (polynomial_set.py:23-32)
+    int t = 0;
+    for (int k = 0; k <= order; ++k) {
+        if (nf == 1) {
+            a.alpha[t][0] = k;
+            ++t;
+        } else if (nf == 2) {
+            for (int i = 0; i <= k; ++i) {
+                a.alpha[t][0] = k - i;
+                a.alpha[t][1] = i;
+                ++t;
+            }
+        } else {
+            for (int i = 0; i <= k; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    a.alpha[t][0] = k - i;
+                    a.alpha[t][1] = i - j;
+                    a.alpha[t][2] = j;
+                    ++t;
+                }
+        }
+    }
+    a.ntab = t;
+}
+
+static int tensor_launch(fx_ctx* ctx, int nf, const fx_line_element* const* factors, int order, int64_t nreq, int npts,
+                         int q, const double* pts, double* out, void* stream, bool grid_mode) {
+    if (!ctx || !factors || nf < 1 || nf > 3) return fail(FX_EINVAL, "tensor tabulate: 1..3 interval factors supported");
+    if (order < 0) return fail(FX_EINVAL, "negative derivative order");
+    if (order > 2) return fail(FX_ENOTIMPL, "derivative order %d > 2 is not implemented on the device", order);
+    if (nreq < 0 || npts < 0) return fail(FX_EINVAL, "negative batch size");
+    if (nreq == 0 || npts == 0) return FX_OK;
+    fxk::TensorArgs a;
+    memset(&a, 0, sizeof a);
+    size_t lds = 0;
+    const int w = grid_mode ? q : npts;
+    for (int f = 0; f < nf; ++f) {
+        if (!factors[f]) return fail(FX_EINVAL, "null factor");
+        a.L[f] = line_desc(factors[f]);
+        lds += (size_t)(order + 1) * factors[f]->nn * w * 8;
+    }
+    if (lds > 150 * 1024) return fail(FX_ENOTIMPL, "factor tables exceed LDS (%zu bytes)", lds);
+    a.nf = nf;
+    a.order = order;
+    fill_alpha(nf, order, a);
+    a.nreq = nreq;
+    a.npts = npts;
+    a.q = q;
+    a.pts = pts;
+    a.out = out;
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)ctx->lds_per_cu / std::max<size_t>(lds, 1)));
+    int grid = (int)std::min<long long>(nreq, (long long)ctx->num_cu * per_cu * 2);
+    if (grid_mode) {
+        auto kern = fxk::tensor_tabulate_kernel<true>;
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    } else {
+        auto kern = fxk::tensor_tabulate_kernel<false>;
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+int fx_tensor_tabulate_batch(fx_ctx* ctx, int nf, const fx_line_element* const* factors, int order, int64_t nreq,
+                             int npts, const double* pts, double* out, void* stream) {
+    return tensor_launch(ctx, nf, factors, order, nreq, npts, 0, pts, out, stream, false);
+}
+
+int fx_tensor_tabulate_grid_batch(fx_ctx* ctx, int nf, const fx_line_element* const* factors, int order, int64_t nreq,
+                                  int q, const double* grid, double* out, void* stream) {
+    if (q < 0) return fail(FX_EINVAL, "negative grid size");
+    long long npts = 1;
+    for (int f = 0; f < nf; ++f) npts *= q;
+    return tensor_launch(ctx, nf, factors, order, nreq, (int)npts, q, grid, out, stream, true);
+}
+
+}  // extern "C"

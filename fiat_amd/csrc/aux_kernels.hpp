@@ -1,0 +1,286 @@
+// Auxiliary gfx950 kernels of the tabulate path: Riesz/Vandermonde assembly and
+// solve (construction side), 1-D barycentric Lagrange tabulation and
+// tensor-product expansion (hex/quad side).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fxk {
+
+// mat[i][k] = sum_q wts[i][q] * ev[k][q]      (dual_set.py:172)
+__global__ void riesz_assemble_kernel(int nrows, int nq, int nexp, const double* __restrict__ wts,
+                                      const double* __restrict__ ev, double* __restrict__ mat) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)nrows * nexp) return;
+    int i = (int)(idx / nexp), k = (int)(idx - (long long)i * nexp);
+    const double* w = wts + (size_t)i * nq;
+    const double* e = ev + (size_t)k * nq;
+    double s = 0.0;
+    for (int q = 0; q < nq; ++q) s += w[q] * e[q];
+    mat[idx] = s;
+}
+
+// One workgroup per system:  V = A B^T ;  X = solve(V^T, B)  by LU with partial
+// pivoting (finite_element.py:141-159; scipy.linalg.solve(V, B, transposed=True)
+// is LAPACK gesv, the same elimination order).  LDS: M = V^T (n x n) followed
+// by the right-hand sides / solution (n x m).
+__global__ __launch_bounds__(256) void vandermonde_solve_kernel(int n, int m, const double* __restrict__ Aall,
+                                                               const double* __restrict__ Ball,
+                                                               double* __restrict__ Xall,
+                                                               double* __restrict__ Vall,
+                                                               int* __restrict__ info_all) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* M = sm;                    // n x n, M[r][c] = V[c][r]
+    double* R = sm + (size_t)n * n;    // n x m
+    __shared__ int s_piv;
+    __shared__ int s_info;
+    __shared__ double s_red[256];
+    __shared__ int s_idx[256];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const size_t sys = blockIdx.x;
+    const double* A = Aall + sys * (size_t)n * m;
+    const double* B = Ball + sys * (size_t)n * m;
+    if (tid == 0) s_info = 0;
+    for (int e = tid; e < n * n; e += nt) {
+        int i = e / n, j = e - i * n;  // V[i][j] = sum_k A[i][k] B[j][k]
+        double s = 0.0;
+        for (int k = 0; k < m; ++k) s += A[(size_t)i * m + k] * B[(size_t)j * m + k];
+        M[(size_t)j * n + i] = s;
+        if (Vall) Vall[sys * (size_t)n * n + e] = s;
+    }
+    for (int e = tid; e < n * m; e += nt) R[e] = B[e];
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        // pivot search in column k, rows >= k
+        double best = -1.0;
+        int bi = k;
+        for (int r = k + tid; r < n; r += nt) {
+            double v = fabs(M[(size_t)r * n + k]);
+            if (v > best) { best = v; bi = r; }
+        }
+        s_red[tid] = best;
+        s_idx[tid] = bi;
+        __syncthreads();
+        for (int s = nt >> 1; s > 0; s >>= 1) {
+            if (tid < s) {
+                double o = s_red[tid + s];
+                int oi = s_idx[tid + s];
+                if (o > s_red[tid] || (o == s_red[tid] && oi < s_idx[tid])) { s_red[tid] = o; s_idx[tid] = oi; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            s_piv = s_idx[0];
+            if (!(s_red[0] > 0.0) && s_info == 0) s_info = k + 1;
+        }
+        __syncthreads();
+        const int piv = s_piv;
+        if (piv != k) {
+            for (int c = tid; c < n; c += nt) {
+                double t = M[(size_t)k * n + c];
+                M[(size_t)k * n + c] = M[(size_t)piv * n + c];
+                M[(size_t)piv * n + c] = t;
+            }
+            for (int c = tid; c < m; c += nt) {
+                double t = R[(size_t)k * m + c];
+                R[(size_t)k * m + c] = R[(size_t)piv * m + c];
+                R[(size_t)piv * m + c] = t;
+            }
+        }
+        __syncthreads();
+        const double pinv = 1.0 / M[(size_t)k * n + k];
+        // multipliers (stored in place), then rank-1 update of the trailing block and of R
+        for (int r = k + 1 + tid; r < n; r += nt) M[(size_t)r * n + k] *= pinv;
+        __syncthreads();
+        const int nr = n - k - 1, ncM = n - k - 1;
+        for (int e = tid; e < nr * (ncM + m); e += nt) {
+            int r = k + 1 + e / (ncM + m);
+            int c = e % (ncM + m);
+            double l = M[(size_t)r * n + k];
+            if (c < ncM)
+                M[(size_t)r * n + k + 1 + c] -= l * M[(size_t)k * n + k + 1 + c];
+            else
+                R[(size_t)r * m + (c - ncM)] -= l * R[(size_t)k * m + (c - ncM)];
+        }
+        __syncthreads();
+    }
+    // back substitution, threads <-> right-hand-side columns
+    for (int c = tid; c < m; c += nt) {
+        for (int r = n - 1; r >= 0; --r) {
+            double s = R[(size_t)r * m + c];
+            for (int j = r + 1; j < n; ++j) s -= M[(size_t)r * n + j] * R[(size_t)j * m + c];
+            R[(size_t)r * m + c] = s / M[(size_t)r * n + r];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < n * m; e += nt) Xall[sys * (size_t)n * m + e] = R[e];
+    if (tid == 0) info_all[sys] = s_info;
+}
+
+// ---------------------------------------------------------------------------
+// 1-D Lagrange basis by the second barycentric formula
+// (barycentric_interpolation.py:22-47).  tab layout [k][i] in registers of the
+// calling lane for one point; NN_MAX bounds the node count.
+constexpr int NN_MAX = 16;
+
+struct LineDesc {
+    const double* nodes;  // [nn]
+    const double* wts;    // [nn] barycentric weights
+    const double* dmat;   // [nn][nn] differentiation matrix
+    int nn;
+};
+
+// values phi[i] at x; exact Kronecker delta when x hits a node
+// (barycentric_interpolation.py:35-40: NaN -> 1 after the normalisation).
+__device__ __forceinline__ void lagrange_values(const LineDesc& L, double x, double* phi) {
+    double sum = 0.0;
+    int hit = -1;
+#pragma unroll
+    for (int i = 0; i < NN_MAX; ++i) {
+        if (i < L.nn) {
+            double d = x - L.nodes[i];
+            if (d == 0.0) hit = i;
+            double t = L.wts[i] / d;
+            phi[i] = t;
+            sum += t;
+        }
+    }
+    double inv = 1.0 / sum;
+#pragma unroll
+    for (int i = 0; i < NN_MAX; ++i) {
+        if (i < L.nn) phi[i] = (hit >= 0) ? ((i == hit) ? 1.0 : 0.0) : phi[i] * inv;
+    }
+}
+
+// out = dmat . in
+__device__ __forceinline__ void lagrange_diff(const LineDesc& L, const double* in, double* out) {
+#pragma unroll
+    for (int i = 0; i < NN_MAX; ++i) {
+        if (i < L.nn) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < NN_MAX; ++j)
+                if (j < L.nn) s += L.dmat[i * L.nn + j] * in[j];
+            out[i] = s;
+        }
+    }
+}
+
+// out[r][k][i][p], one thread per (r, p)
+__global__ void line_tabulate_kernel(LineDesc L, int order, long long nreq, int npts,
+                                     const double* __restrict__ pts, double* __restrict__ out) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nreq * npts) return;
+    long long r = idx / npts;
+    int p = (int)(idx - r * npts);
+    double a[NN_MAX], b[NN_MAX];
+    lagrange_values(L, pts[idx], a);
+    double* o = out + (size_t)r * (order + 1) * L.nn * npts + p;
+    for (int k = 0; k <= order; ++k) {
+        if (k > 0) {
+            lagrange_diff(L, a, b);
+#pragma unroll
+            for (int i = 0; i < NN_MAX; ++i) a[i] = b[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NN_MAX; ++i)
+            if (i < L.nn) o[((size_t)k * L.nn + i) * npts] = a[i];
+    }
+}
+
+// Tensor-product expansion (tensor_product.py:231-292, scalar factors, nested
+// left to right).  One workgroup per request:
+//   phase 1: factor tables T[f][k][i][p] -> LDS (threads <-> (f, p))
+//   phase 2: out[t][(i0,i1,i2)][p] = prod_f T[f][alpha_t[f]][i_f][p_f], streamed
+//            row by row with lanes <-> points.
+// GRID == true: points are the tensor grid of per-request 1-D coordinates
+// (grid[r][f][q], point index = (j0*q + j1)*q + j2), the factor tables are
+// only q wide (sum-factorised form); otherwise pts[r][p][nf].
+struct TensorArgs {
+    LineDesc L[3];
+    int nf, order, ntab;
+    int alpha[10][3];  // derivative multi-indices in mis() order
+    long long nreq;
+    int npts;  // output points per request
+    int q;     // grid mode: points per direction
+    const double* pts;
+    double* out;
+};
+
+template <bool GRID>
+__global__ __launch_bounds__(256) void tensor_tabulate_kernel(TensorArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double T[];  // [f][k][i][w]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int w = GRID ? a.q : a.npts;  // width of the factor tables
+    const int K = a.order + 1;
+    int fofs[4];
+    fofs[0] = 0;
+    for (int f = 0; f < a.nf; ++f) fofs[f + 1] = fofs[f] + K * a.L[f].nn * w;
+    for (long long r = blockIdx.x; r < a.nreq; r += gridDim.x) {
+        __syncthreads();
+        for (int e = tid; e < a.nf * w; e += nthr) {
+            int f = e / w, p = e - f * w;
+            const LineDesc& L = a.L[f];
+            double x = GRID ? a.pts[((size_t)r * a.nf + f) * a.q + p] : a.pts[((size_t)r * a.npts + p) * a.nf + f];
+            double va[NN_MAX], vb[NN_MAX];
+            lagrange_values(L, x, va);
+            for (int k = 0; k < K; ++k) {
+                if (k > 0) {
+                    lagrange_diff(L, va, vb);
+#pragma unroll
+                    for (int i = 0; i < NN_MAX; ++i) va[i] = vb[i];
+                }
+#pragma unroll
+                for (int i = 0; i < NN_MAX; ++i)
+                    if (i < L.nn) T[fofs[f] + (k * L.nn + i) * w + p] = va[i];
+            }
+        }
+        __syncthreads();
+        const int n0 = a.L[0].nn;
+        const int n1 = a.nf > 1 ? a.L[1].nn : 1;
+        const int n2 = a.nf > 2 ? a.L[2].nn : 1;
+        const int nbf = n0 * n1 * n2;
+        const int nrows = a.ntab * nbf;
+        double* o = a.out + (size_t)r * nrows * a.npts;
+        const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+        for (int row = wave; row < nrows; row += nw) {
+            int t = row / nbf;
+            int bf = row - t * nbf;
+            int i0 = bf / (n1 * n2);
+            int rem = bf - i0 * (n1 * n2);
+            int i1 = rem / n2;
+            int i2 = rem - i1 * n2;
+            const double* t0 = T + fofs[0] + (a.alpha[t][0] * n0 + i0) * w;
+            const double* t1 = a.nf > 1 ? T + fofs[1] + (a.alpha[t][1] * n1 + i1) * w : nullptr;
+            const double* t2 = a.nf > 2 ? T + fofs[2] + (a.alpha[t][2] * n2 + i2) * w : nullptr;
+            double* orow = o + (size_t)row * a.npts;
+            for (int p = lane; p < a.npts; p += 64) {
+                double v;
+                if (GRID) {
+                    int j0, j1 = 0, j2 = 0;
+                    if (a.nf == 1) {
+                        j0 = p;
+                    } else if (a.nf == 2) {
+                        j0 = p / a.q;
+                        j1 = p - j0 * a.q;
+                    } else {
+                        j0 = p / (a.q * a.q);
+                        int rr = p - j0 * a.q * a.q;
+                        j1 = rr / a.q;
+                        j2 = rr - j1 * a.q;
+                    }
+                    v = t0[j0];
+                    if (a.nf > 1) v *= t1[j1];
+                    if (a.nf > 2) v *= t2[j2];
+                } else {
+                    v = t0[p];
+                    if (a.nf > 1) v *= t1[p];
+                    if (a.nf > 2) v *= t2[p];
+                }
+                orow[p] = v;
+            }
+        }
+    }
+}
+
+}  // namespace fxk

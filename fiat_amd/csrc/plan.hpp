@@ -1,0 +1,250 @@
+// Host-side "plan" for one expansion set: the Dubiner recurrence flattened into
+// a table of uniform three-term steps, plus the C0 (bubble) post-processing
+// folded into a member-space matrix.  Device kernels only ever see the tables.
+//
+// Reference behaviour being reproduced: FIAT/expansions.py:140-267
+// (dubiner_recurrence), :24-40 (jrc / integrated_jrc), :251-266 (per-codim
+// normalisation) and :270-322 (C0_basis).  The reference rescales members in
+// place after every codimension; here every member is kept in its *final*
+// scaling and the ratios of the scale factors are folded into the step
+// coefficients, so a step is always
+//     m_dst = (A*fa - B*fb) * m_cur - C*fc * m_prv
+// with (fa, fb, fc) the collapsed-coordinate factors of the step's codimension.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace fx {
+
+struct Step {
+    int dst, cur, prv, codim;  // member indices; prv < 0: two-term (first) step
+    double A, B, C;
+};
+
+inline int member_index(int sd, const int* idx) {
+    if (sd == 1) return idx[0];
+    if (sd == 2) {
+        int t = idx[0] + idx[1];
+        return t * (t + 1) / 2 + idx[1];
+    }
+    int t = idx[0] + idx[1] + idx[2];
+    int u = idx[1] + idx[2];
+    return t * (t + 1) * (t + 2) / 6 + u * (u + 1) / 2 + idx[2];
+}
+
+inline int binom(int n, int k) {
+    if (k < 0 || k > n) return 0;
+    long long r = 1;
+    for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+    return (int)r;
+}
+
+inline void jacobi_abc(double a, double b, int n, double& an, double& bn, double& cn) {
+    double s = a + b;
+    an = (2 * n + 1 + s) * (2 * n + 2 + s) / (2 * (n + 1) * (n + 1 + s));
+    bn = s * (a - b) * (2 * n + 1 + s) / (2 * (n + 1) * (n + 1 + s) * (2 * n + s));
+    cn = (n + a) * (n + b) * (2 * n + 2 + s) / ((n + 1) * (n + 1 + s) * (2 * n + s));
+}
+
+inline void integrated_jacobi_abc(double a, double b, int n, double& an, double& bn, double& cn) {
+    if (n == 1) {
+        an = (a + b + 2) / 2;
+        bn = (a - 3 * b - 2) / 2;
+        cn = 0.0;
+    } else {
+        jacobi_abc(a - 1, b + 1, n - 1, an, bn, cn);
+    }
+}
+
+// sqrt(norm2) applied to the member with (length d = codim+1) index `idx`
+// when codimension `codim` has been completed (expansions.py:251-266).
+inline double level_norm(int variant, int codim, const int* idx) {
+    int d = codim + 1;
+    double norm2;
+    if (variant != 0) {
+        int shift = (variant == 2) ? 1 : 0;
+        int p = idx[d - 1] + shift;
+        int s = 0;
+        for (int i = 0; i < d - 1; ++i) s += idx[i];
+        int al = 2 * (s + d * shift) - 1;
+        norm2 = (0.5 + d) / d;
+        if (p > 0 && p + al > 0) norm2 *= double(p + al) * double(2 * p + al) / double(p);
+    } else {
+        int s = 0;
+        for (int i = 0; i < d; ++i) s += idx[i];
+        norm2 = double(2 * s + d) / double(d);
+    }
+    return std::sqrt(norm2);
+}
+
+// product of the normalisations applied at codimensions >= codim to the member
+// whose index (zero padded to sd entries) is idx.
+inline double tail_norm(int variant, int sd, int codim, const int* idx) {
+    double w = 1.0;
+    for (int c = codim; c < sd; ++c) w *= level_norm(variant, c, idx);
+    return w;
+}
+
+struct Program {
+    int sd = 0, n = 0, variant = 0, nexp = 0;
+    double phi0 = 0.0;        // final value of member 0
+    std::vector<Step> steps;  // in dependency order, chains contiguous
+};
+
+// enumerate prefixes (length codim) with sum < n in the reference's order
+// (reference_element.py:64-76: last entry slowest).
+inline void prefixes(int codim, int n, std::vector<std::vector<int>>& out) {
+    out.clear();
+    if (codim == 0) {
+        out.push_back({});
+    } else if (codim == 1) {
+        for (int i = 0; i < n; ++i) out.push_back({i});
+    } else {
+        for (int last = 0; last < n; ++last)
+            for (int first = 0; first < n - last; ++first) out.push_back({first, last});
+    }
+}
+
+inline Program build_program(int sd, int n, int variant, double scale) {
+    Program P;
+    P.sd = sd;
+    P.n = n;
+    P.variant = variant;
+    P.nexp = binom(n + sd, sd);
+    if (variant == 1) scale = -scale;  // expansions.py:176-177
+    int zero[3] = {0, 0, 0};
+    if (n == 0) {  // expansions.py:193-194: returned before any normalisation
+        P.phi0 = scale;
+        return P;
+    }
+    P.phi0 = scale * tail_norm(variant, sd, 0, zero);
+    const int beta = (variant == 2) ? 1 : 0;
+    std::vector<std::vector<int>> subs;
+    for (int codim = 0; codim < sd; ++codim) {
+        prefixes(codim, n, subs);
+        for (const auto& sub : subs) {
+            int s = 0;
+            for (int v : sub) s += v;
+            double alpha, a, b, c;
+            if (variant == 1) {
+                alpha = 2 * s;
+                a = b = -0.5;
+            } else {
+                alpha = 2 * s + codim;
+                if (variant == 2) alpha += 1 + codim;
+                a = 0.5 * (alpha + beta) + 1.0;
+                b = 0.5 * (alpha - beta);
+            }
+            int len = n - s;  // members i = 0..len along this chain
+            std::vector<int> id(len + 1);
+            std::vector<double> lam(len + 1);
+            for (int i = 0; i <= len; ++i) {
+                int idx[3] = {0, 0, 0};
+                for (int j = 0; j < codim; ++j) idx[j] = sub[j];
+                idx[codim] = i;
+                id[i] = member_index(sd, idx);
+                lam[i] = tail_norm(variant, sd, codim, idx);
+            }
+            Step st;
+            st.codim = codim;
+            st.dst = id[1];
+            st.cur = id[0];
+            st.prv = -1;
+            st.A = a * lam[1] / lam[0];
+            st.B = b * lam[1] / lam[0];
+            st.C = 0.0;
+            P.steps.push_back(st);
+            for (int i = 1; i < len; ++i) {
+                if (variant == 1)
+                    integrated_jacobi_abc(alpha, beta, i, a, b, c);
+                else
+                    jacobi_abc(alpha, beta, i, a, b, c);
+                st.dst = id[i + 1];
+                st.cur = id[i];
+                st.prv = id[i - 1];
+                st.A = a * lam[i + 1] / lam[i];
+                st.B = b * lam[i + 1] / lam[i];
+                st.C = c * lam[i + 1] / lam[i - 1];
+                P.steps.push_back(st);
+            }
+        }
+    }
+    return P;
+}
+
+// Row-major nexp x nexp matrix T with C0_basis(phi) = T phi (expansions.py:270-322).
+inline std::vector<double> c0_transform(int sd, int n) {
+    int nexp = binom(n + sd, sd);
+    std::vector<double> M((size_t)nexp * nexp, 0.0);
+    for (int i = 0; i < nexp; ++i) M[(size_t)i * nexp + i] = 1.0;
+    auto row_scale = [&](int r, double w) {
+        for (int k = 0; k < nexp; ++k) M[(size_t)r * nexp + k] *= w;
+    };
+    auto row_sub = [&](int r, int src) {
+        for (int k = 0; k < nexp; ++k) M[(size_t)r * nexp + k] -= M[(size_t)src * nexp + k];
+    };
+    auto ix2 = [&](int p, int q) { int t[3] = {p, q, 0}; return member_index(2, t); };
+    auto ix3 = [&](int p, int q, int r) { int t[3] = {p, q, r}; return member_index(3, t); };
+    row_scale(0, -1.0);
+    for (int j = 1; j <= sd; ++j) row_sub(0, j);
+    if (sd == 2) {
+        for (int i = 2; i <= n; ++i) row_sub(ix2(0, i), ix2(1, i - 1));
+    } else if (sd == 3) {
+        for (int i = 2; i <= n; ++i) {
+            for (int j = 0; j <= n - i; ++j) row_sub(ix3(0, i, j), ix3(1, i - 1, j));
+            row_sub(ix3(0, 0, i), ix3(0, 1, i - 1));
+            row_sub(ix3(0, 0, i), ix3(1, 0, i - 1));
+        }
+    }
+    std::vector<int> dofs;
+    for (int i = 0; i <= sd; ++i) dofs.push_back(i);
+    if (sd == 1) {
+        for (int i = 2; i <= n; ++i) dofs.push_back(i);
+    } else if (sd == 2) {
+        for (int i = 2; i <= n; ++i) dofs.push_back(ix2(1, i - 1));
+        for (int i = 2; i <= n; ++i) dofs.push_back(ix2(0, i));
+        for (int i = 2; i <= n; ++i) dofs.push_back(ix2(i, 0));
+        for (int j = 1; j <= n; ++j)
+            for (int i = 2; i <= n - j; ++i) dofs.push_back(ix2(i, j));
+    } else {
+        for (int i = 2; i <= n; ++i) dofs.push_back(ix3(0, 1, i - 1));
+        for (int i = 2; i <= n; ++i) dofs.push_back(ix3(1, 0, i - 1));
+        for (int i = 2; i <= n; ++i) dofs.push_back(ix3(1, i - 1, 0));
+        for (int i = 2; i <= n; ++i) dofs.push_back(ix3(0, 0, i));
+        for (int i = 2; i <= n; ++i) dofs.push_back(ix3(0, i, 0));
+        for (int i = 2; i <= n; ++i) dofs.push_back(ix3(i, 0, 0));
+        for (int j = 1; j <= n; ++j)
+            for (int i = 2; i <= n - j; ++i) dofs.push_back(ix3(1, i - 1, j));
+        for (int j = 1; j <= n; ++j)
+            for (int i = 2; i <= n - j; ++i) dofs.push_back(ix3(0, i, j));
+        for (int j = 1; j <= n; ++j)
+            for (int i = 2; i <= n - j; ++i) dofs.push_back(ix3(i, 0, j));
+        for (int j = 1; j <= n; ++j)
+            for (int i = 2; i <= n - j; ++i) dofs.push_back(ix3(i, j, 0));
+        for (int k = 1; k <= n; ++k)
+            for (int j = 1; j <= n - k; ++j)
+                for (int i = 2; i <= n - j - k; ++i) dofs.push_back(ix3(i, j, k));
+    }
+    std::vector<double> T((size_t)nexp * nexp);
+    for (int r = 0; r < nexp; ++r)
+        for (int k = 0; k < nexp; ++k) T[(size_t)r * nexp + k] = M[(size_t)dofs[r] * nexp + k];
+    return T;
+}
+
+// MFMA A-operand fragments of the (rows x nexp) coefficient matrix for
+// v_mfma_f64_16x16x4_f64: fragment (mt, ks), lane l holds
+// C[16*mt + (l & 15)][4*ks + (l >> 4)], zero padded.
+inline std::vector<double> pack_a_fragments(const std::vector<double>& C, int rows, int nexp) {
+    int MT = (rows + 15) / 16, KS = (nexp + 3) / 4;
+    std::vector<double> F((size_t)MT * KS * 64, 0.0);
+    for (int mt = 0; mt < MT; ++mt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int l = 0; l < 64; ++l) {
+                int m = 16 * mt + (l & 15), k = 4 * ks + (l >> 4);
+                if (m < rows && k < nexp) F[((size_t)mt * KS + ks) * 64 + l] = C[(size_t)m * nexp + k];
+            }
+    return F;
+}
+
+}  // namespace fx

@@ -1,0 +1,233 @@
+"""Device runtime: contexts, element handles and the batched entry points.
+
+PyTorch-ROCm is used only as the owner of device memory and streams; every
+computation goes through the C ABI (include/fiat_amd.h) into the HIP kernels.
+"""
+import ctypes
+import math
+from ctypes import c_float, c_int, c_void_p
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import VARIANTS, check, host_ptr, lib
+
+_contexts = {}
+
+
+class Context:
+    """One per GPU (fx_ctx).  ``Context.get()`` returns the context of the
+    current torch device; creation fails loudly when no GPU is present."""
+
+    def __init__(self, device_index):
+        h = c_void_p()
+        check(lib.fx_ctx_create(int(device_index), ctypes.byref(h)))
+        self.handle = h
+        self.device = torch.device("cuda", device_index)
+        ncu, lds = c_int(0), c_int(0)
+        name = ctypes.create_string_buffer(64)
+        check(lib.fx_ctx_info(h, ctypes.byref(ncu), ctypes.byref(lds), name, 64))
+        self.num_cu, self.lds_per_cu, self.arch = ncu.value, lds.value, name.value.decode()
+
+    @staticmethod
+    def get(device=None):
+        if device is None:
+            if not torch.cuda.is_available():
+                # let the C library produce the error message
+                idx = 0
+            else:
+                idx = torch.cuda.current_device()
+        else:
+            idx = torch.device(device).index or 0
+        if idx not in _contexts:
+            _contexts[idx] = Context(idx)
+        return _contexts[idx]
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return c_void_p(stream.cuda_stream)
+
+
+def _dev_ptr(t):
+    return c_void_p(t.data_ptr())
+
+
+def _as_device(x, ctx):
+    if isinstance(x, torch.Tensor):
+        if x.device != ctx.device or x.dtype != torch.float64 or not x.is_contiguous():
+            x = x.to(device=ctx.device, dtype=torch.float64).contiguous()
+        return x
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64)).to(ctx.device)
+
+
+def num_tables(sd, order):
+    return math.comb(sd + order, sd)
+
+
+class SimplexPolySet:
+    """Device-resident polynomial set over a simplex expansion set (fx_element):
+    coeffs (ndof, *value_shape, nexp) over the Dubiner basis of degree n."""
+
+    def __init__(self, sd, n, variant=None, scale=None, verts=None, coeffs=None, ndof=None,
+                 value_shape=(), ctx=None):
+        self.ctx = ctx or Context.get()
+        self.sd, self.n, self.variant = sd, n, variant
+        self.nexp = math.comb(n + sd, sd)
+        self.value_shape = tuple(value_shape)
+        self.vdim = int(np.prod(self.value_shape, dtype=int)) if self.value_shape else 1
+        self.verts = None if verts is None else np.ascontiguousarray(verts, dtype=np.float64).reshape(sd + 1, sd)
+        if coeffs is not None:
+            coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+            ndof = coeffs.shape[0]
+            assert coeffs.size == ndof * self.vdim * self.nexp
+        elif ndof is None:
+            ndof = self.nexp
+        self.ndof = ndof
+        h = c_void_p()
+        check(lib.fx_element_create(self.ctx.handle, sd, n, VARIANTS[variant],
+                                    -1.0 if scale is None else float(scale),
+                                    None if self.verts is None else host_ptr(self.verts),
+                                    ndof, self.vdim, None if coeffs is None else host_ptr(coeffs),
+                                    ctypes.byref(h)))
+        self.handle = h
+
+    def set_coeffs(self, coeffs):
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+        ndof = coeffs.shape[0]
+        assert coeffs.size == ndof * self.vdim * self.nexp
+        check(lib.fx_element_set_coeffs(self.handle, ndof, self.vdim, host_ptr(coeffs)))
+        self.ndof = ndof
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                lib.fx_element_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def out_shape(self, order, nreq, npts):
+        return (nreq, num_tables(self.sd, order), self.ndof) + self.value_shape + (npts,)
+
+    def tabulate_batch(self, order, pts, verts=None, out=None, stream=None):
+        """pts (nreq, npts, sd) -> (nreq, ntab, ndof, *value_shape, npts) on the GPU."""
+        ctx = self.ctx
+        pts = _as_device(pts, ctx)
+        if pts.dim() != 3 or pts.shape[2] != self.sd:
+            raise ValueError(f"points must have shape (nreq, npts, {self.sd}), got {tuple(pts.shape)}")
+        nreq, npts = pts.shape[0], pts.shape[1]
+        if verts is not None:
+            verts = _as_device(verts, ctx)
+            if tuple(verts.shape) != (nreq, self.sd + 1, self.sd):
+                raise ValueError("verts must have shape (nreq, sd+1, sd)")
+        shape = self.out_shape(order, nreq, npts)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float64, device=ctx.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.float64 or not out.is_contiguous():
+            raise ValueError("out has the wrong shape/dtype/layout")
+        check(lib.fx_tabulate_batch(ctx.handle, self.handle, int(order), nreq, npts, _dev_ptr(pts),
+                                    None if verts is None else _dev_ptr(verts), _dev_ptr(out), _stream_ptr(stream)))
+        return out
+
+    def time_tabulate_batch(self, order, pts, verts, out, reps, stream=None):
+        """Average kernel milliseconds over ``reps`` launches (HIP events on the launch stream)."""
+        ms = c_float(0.0)
+        check(lib.fx_time_tabulate_batch(self.ctx.handle, self.handle, int(order), pts.shape[0], pts.shape[1],
+                                         _dev_ptr(pts), None if verts is None else _dev_ptr(verts), _dev_ptr(out),
+                                         _stream_ptr(stream), int(reps), ctypes.byref(ms)))
+        return ms.value
+
+
+def riesz_assemble(wts, expvals, ctx=None):
+    """mat[i, k] = sum_q wts[i, q] expvals[k, q] on the device."""
+    ctx = ctx or Context.get()
+    wts = _as_device(wts, ctx)
+    expvals = _as_device(expvals, ctx)
+    nrows, nq = wts.shape
+    nexp = expvals.shape[0]
+    assert expvals.shape[1] == nq
+    mat = torch.empty((nrows, nexp), dtype=torch.float64, device=ctx.device)
+    check(lib.fx_riesz_assemble(ctx.handle, nrows, nq, nexp, _dev_ptr(wts), _dev_ptr(expvals), _dev_ptr(mat),
+                                _stream_ptr(None)))
+    return mat
+
+
+def vandermonde_solve_batch(A, B, ctx=None, return_V=False):
+    """X = solve((A B^T)^T, B) per system; raises LinAlgError on a zero pivot
+    ("Singular Vandermonde matrix", finite_element.py:156)."""
+    ctx = ctx or Context.get()
+    A = _as_device(A, ctx)
+    B = _as_device(B, ctx)
+    if A.dim() == 2:
+        A, B = A[None], B[None]
+    nsys, ndof, m = A.shape
+    assert B.shape == A.shape
+    X = torch.empty_like(A)
+    V = torch.empty((nsys, ndof, ndof), dtype=torch.float64, device=ctx.device) if return_V else None
+    info = torch.zeros((nsys,), dtype=torch.int32, device=ctx.device)
+    check(lib.fx_vandermonde_solve_batch(ctx.handle, nsys, ndof, m, _dev_ptr(A), _dev_ptr(B), _dev_ptr(X),
+                                         None if V is None else _dev_ptr(V), _dev_ptr(info), _stream_ptr(None)))
+    if int(info.abs().max().item()) != 0:
+        raise _lib.LinAlgError("Singular Vandermonde matrix")
+    return (X, V) if return_V else X
+
+
+class LineLagrange:
+    """1-D Lagrange basis on given nodes (fx_line_element)."""
+
+    def __init__(self, nodes, ctx=None):
+        self.ctx = ctx or Context.get()
+        self.nodes = np.ascontiguousarray(nodes, dtype=np.float64).reshape(-1)
+        h = c_void_p()
+        check(lib.fx_line_element_create(self.ctx.handle, len(self.nodes), host_ptr(self.nodes), ctypes.byref(h)))
+        self.handle = h
+        self.nn = len(self.nodes)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                lib.fx_line_element_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def tabulate_batch(self, order, pts, out=None, stream=None):
+        """pts (nreq, npts) -> (nreq, order+1, nn, npts)."""
+        ctx = self.ctx
+        pts = _as_device(pts, ctx)
+        nreq, npts = pts.shape
+        if out is None:
+            out = torch.empty((nreq, order + 1, self.nn, npts), dtype=torch.float64, device=ctx.device)
+        check(lib.fx_line_tabulate_batch(ctx.handle, self.handle, int(order), nreq, npts, _dev_ptr(pts), _dev_ptr(out),
+                                         _stream_ptr(stream)))
+        return out
+
+
+def tensor_tabulate_batch(factors, order, pts, out=None, stream=None, grid=False):
+    """Tensor-product tabulation of 1..3 LineLagrange factors.
+    grid=False: pts (nreq, npts, nf); grid=True: pts (nreq, nf, q) 1-D coordinates."""
+    ctx = factors[0].ctx
+    nf = len(factors)
+    pts = _as_device(pts, ctx)
+    arr = (c_void_p * nf)(*[f.handle for f in factors])
+    nbf = int(np.prod([f.nn for f in factors]))
+    ntab = num_tables(nf, order)
+    if grid:
+        nreq, nf_, q = pts.shape
+        assert nf_ == nf
+        npts = q ** nf
+    else:
+        nreq, npts, nf_ = pts.shape
+        assert nf_ == nf
+    if out is None:
+        out = torch.empty((nreq, ntab, nbf, npts), dtype=torch.float64, device=ctx.device)
+    if grid:
+        check(lib.fx_tensor_tabulate_grid_batch(ctx.handle, nf, arr, int(order), nreq, q, _dev_ptr(pts), _dev_ptr(out),
+                                                _stream_ptr(stream)))
+    else:
+        check(lib.fx_tensor_tabulate_batch(ctx.handle, nf, arr, int(order), nreq, npts, _dev_ptr(pts), _dev_ptr(out),
+                                           _stream_ptr(stream)))
+    return out

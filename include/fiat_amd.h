@@ -1,0 +1,161 @@
+/* fiat_amd -- MI355X-native batched finite-element tabulator: C ABI.
+ *
+ * The reference (firedrakeproject/fiat) has no FFI layer: the boundary of its
+ * tabulate() hot path is the Python object API.  Each entry point below names
+ * the reference interface it stands behind (paths relative to the reference
+ * root).  The Python facade in fiat_amd/ binds these with ctypes and keeps the
+ * reference's class/method signatures; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all arithmetic and all bulk arrays are IEEE double, row-major, dense;
+ *   - pointers documented "device" are HBM pointers valid on the context's
+ *     GPU (16-byte aligned); "host" pointers are ordinary memory;
+ *   - the library never frees or retains caller memory;
+ *   - every function returns FX_OK (0) or a negative FX_E* code and records a
+ *     message retrievable with fx_last_error() (thread local);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all
+ *     work is enqueued asynchronously on it, nothing synchronises unless said;
+ *   - there is NO CPU fallback: with no usable gfx950 device fx_ctx_create fails.
+ */
+#ifndef FIAT_AMD_H
+#define FIAT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FX_OK 0
+#define FX_EINVAL (-1)    /* ValueError in the reference            */
+#define FX_ENOTIMPL (-2)  /* NotImplementedError in the reference   */
+#define FX_ESINGULAR (-3) /* numpy.linalg.LinAlgError (finite_element.py:151-156) */
+#define FX_EHIP (-4)      /* HIP runtime failure                    */
+#define FX_ENOMEM (-5)
+
+/* expansion-set variants (FIAT/expansions.py:174-177) */
+#define FX_VARIANT_DEFAULT 0 /* variant=None : orthonormal Dubiner  */
+#define FX_VARIANT_BUBBLE 1  /* "bubble": integrated Jacobi + C0_basis */
+#define FX_VARIANT_DUAL 2    /* "dual" */
+
+typedef struct fx_ctx fx_ctx;
+typedef struct fx_element fx_element;
+typedef struct fx_line_element fx_line_element;
+
+const char* fx_last_error(void);
+int fx_abi_version(void);
+
+/* One context per GPU (one process per GPU in multi-GPU runs). */
+int fx_ctx_create(int device_id, fx_ctx** ctx);
+int fx_ctx_destroy(fx_ctx* ctx);
+/* Device facts used by the benchmark: CU count and bytes of LDS per CU. */
+int fx_ctx_info(fx_ctx* ctx, int* num_cu, int* lds_bytes_per_cu, char* name, int name_len);
+
+/* ---- simplex elements ------------------------------------------------------
+ * A polynomial set over the Dubiner expansion set of one simplex cell:
+ *   coeffs[ndof][vdim][nexp]  (FIAT/polynomial_set.py:42-66, PolynomialSet),
+ *   nexp = C(n+sd, sd).  coeffs == NULL means the identity (ONPolynomialSet,
+ *   polynomial_set.py:110-134): tabulation then returns the raw expansion set,
+ *   i.e. ExpansionSet._tabulate (expansions.py:449-490).
+ * verts: host, (sd+1)*sd cell vertices, or NULL for the UFC simplex
+ *   (reference_element.py:1006-1152).  scale: first-member scale
+ *   (expansions.py:371-373, 386-399); pass <= 0 for the default
+ *   sqrt(1/vol(default simplex)).
+ */
+int fx_element_create(fx_ctx* ctx, int sd, int n, int variant, double scale,
+                      const double* verts, int ndof, int vdim,
+                      const double* coeffs, fx_element** elem);
+int fx_element_destroy(fx_element* elem);
+/* Replace the coefficient tensor (after the Vandermonde solve). Host pointer. */
+int fx_element_set_coeffs(fx_element* elem, int ndof, int vdim, const double* coeffs);
+int fx_element_dims(const fx_element* elem, int* sd, int* n, int* nexp, int* ndof, int* vdim);
+
+/* Number of derivative multi-indices of total order <= order: C(sd+order, sd)
+ * (keys of the dict built at expansions.py:427-432, in mis() order). */
+int fx_num_tables(int sd, int order);
+
+/* THE HOT ENTRY.  Batched CiarletElement.tabulate (finite_element.py:181-197
+ * -> polynomial_set.py:68-72 -> expansions.py:411-447,140-267,270-322).
+ *   pts   device [nreq][npts][sd]   points in the coordinates of each request's cell
+ *   verts device [nreq][sd+1][sd]   per-request cell vertices, or NULL: every
+ *                                    request uses the element's own cell
+ *   out   device [nreq][ntab][ndof][vdim][npts],  ntab = fx_num_tables(sd, order);
+ *         table t of request r is exactly tabulate(order, pts[r])[alpha_t].
+ * order <= 2.  Derivatives are with respect to the caller's coordinates. */
+int fx_tabulate_batch(fx_ctx* ctx, const fx_element* elem, int order,
+                      int64_t nreq, int npts, const double* pts,
+                      const double* verts, double* out, void* stream);
+
+/* Same, host pointers, synchronous (stages through device memory). */
+int fx_tabulate_batch_host(fx_ctx* ctx, const fx_element* elem, int order,
+                           int64_t nreq, int npts, const double* pts,
+                           const double* verts, double* out);
+
+/* ---- Vandermonde / Riesz assembly and solve -----------------------------------
+ * DualSet.to_riesz (dual_set.py:150-172): mat[i][v][k] = sum_q wts[i][v][q] *
+ * expvals[k][q], where expvals is the expansion set tabulated at the union of
+ * functional points (use fx_tabulate_batch with identity coeffs, order 0).
+ * All device pointers. */
+int fx_riesz_assemble(fx_ctx* ctx, int nrows, int nq, int nexp,
+                      const double* wts, const double* expvals, double* mat, void* stream);
+
+/* CiarletElement.__init__ (finite_element.py:141-159), batched:
+ *   V = A B^T ; X = solve(V^T, B)   with A = dualmat[nsys][ndof][m], B =
+ *   prime coeffs [nsys][ndof][m] (m = vdim*nexp).  X device [nsys][ndof][m],
+ *   Vout (optional, may be NULL) device [nsys][ndof][ndof], info device
+ *   int[nsys]: 0 ok, >0 zero pivot (singular) at that column.  Partial-pivot LU. */
+int fx_vandermonde_solve_batch(fx_ctx* ctx, int64_t nsys, int ndof, int m,
+                               const double* A, const double* B, double* X,
+                               double* Vout, int* info, void* stream);
+
+/* ---- 1-D Lagrange by barycentric interpolation and tensor products -----------
+ * LagrangeLineExpansionSet / barycentric_interpolation / make_dmat
+ * (barycentric_interpolation.py:22-93).  nodes: host [nn]. */
+int fx_line_element_create(fx_ctx* ctx, int nn, const double* nodes, fx_line_element** elem);
+int fx_line_element_destroy(fx_line_element* elem);
+
+/* Batched 1-D tabulate: pts device [nreq][npts], out device [nreq][order+1][nn][npts]. */
+int fx_line_tabulate_batch(fx_ctx* ctx, const fx_line_element* elem, int order,
+                           int64_t nreq, int npts, const double* pts, double* out, void* stream);
+
+/* TensorProductElement.tabulate, scalar factors (tensor_product.py:231-292),
+ * nested left to right over nf <= 3 interval factors (quad / hex).
+ *   pts device [nreq][npts][nf];  out device [nreq][ntab][prod nn_f][npts],
+ *   ntab = fx_num_tables(nf, order), basis index a*nB + b (row-major over factors). */
+int fx_tensor_tabulate_batch(fx_ctx* ctx, int nf, const fx_line_element* const* factors,
+                             int order, int64_t nreq, int npts, const double* pts,
+                             double* out, void* stream);
+
+/* Sum-factorised variant: per-request 1-D coordinates of a tensor grid,
+ *   grid device [nreq][nf][q]; points are the q^nf grid (x fastest last, as
+ *   make_tensor_product_quadrature, quadrature.py:258-268); same out layout
+ *   with npts = q^nf. */
+int fx_tensor_tabulate_grid_batch(fx_ctx* ctx, int nf, const fx_line_element* const* factors,
+                                  int order, int64_t nreq, int q, const double* grid,
+                                  double* out, void* stream);
+
+/* ---- plan introspection (host only, no GPU needed) -------------------------------
+ * The device kernels never evaluate recurrence coefficients: the host flattens
+ * dubiner_recurrence (expansions.py:140-267) into a table of steps
+ *   m_dst = (A*fa - B*fb) * m_cur - C*fc * m_prv        (fa, fb, fc of `codim`)
+ * with the per-codimension normalisation (expansions.py:251-266) folded into
+ * (A, B, C).  These two calls expose the table and the C0_basis matrix
+ * (expansions.py:270-322) so the CPU test-suite can check them against the oracle.
+ *   ints[i] = {dst, cur, prv (-1: none), codim}, coefs[i] = {A, B, C}. */
+int fx_plan_steps(int sd, int n, int variant, double scale, int cap, int* nsteps,
+                  double* phi0, int* ints, double* coefs);
+int fx_plan_c0_transform(int sd, int n, double* T /* host [nexp][nexp] */);
+
+/* ---- measurement helpers ---------------------------------------------------------
+ * Time `reps` launches of fx_tabulate_batch with HIP events on `stream`;
+ * returns average milliseconds per launch in *ms. */
+int fx_time_tabulate_batch(fx_ctx* ctx, const fx_element* elem, int order,
+                           int64_t nreq, int npts, const double* pts,
+                           const double* verts, double* out, void* stream,
+                           int reps, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIAT_AMD_H */

@@ -1,0 +1,297 @@
+"""Parity of the HIP path (through the C ABI) against golden vectors generated
+from the reference and against the CPU oracle on seeded batches.
+
+Tolerances (BASELINE.json north_star): <= 1e-12 relative on values, <= 1e-10 on
+derivatives, error norm  max|x - ref| / max(1, max|ref|)  per table."""
+import numpy as np
+import pytest
+
+from oracle import fiat_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+TOL_VAL = 1e-12
+TOL_DER = 1e-10
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from fiat_amd import runtime
+    runtime.Context.get()
+    return runtime
+
+
+def table_errors(got, ref):
+    """got/ref: (ntab, ...) -> list of per-table relative errors."""
+    errs = []
+    for g, r in zip(got, ref):
+        errs.append(float(np.max(np.abs(g - r)) / max(1.0, np.max(np.abs(r)))))
+    return errs
+
+
+def assert_tables(got, ref, sd, what=""):
+    got = np.asarray(got)
+    ref = np.asarray(ref)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert np.all(np.isfinite(got)), what
+    errs = table_errors(got, ref)
+    assert errs[0] <= TOL_VAL, (what, "values", errs[0])
+    if len(errs) > 1:
+        assert max(errs[1:]) <= TOL_DER, (what, "derivatives", max(errs[1:]))
+
+
+def rand_points(rng, sd, shape):
+    e = rng.exponential(size=tuple(shape) + (sd + 1,))
+    bary = e / e.sum(axis=-1, keepdims=True)
+    return bary[..., 1:].copy()
+
+
+# ---- a5-a7: raw expansion sets -------------------------------------------------------
+@pytest.mark.parametrize("sd", [1, 2, 3])
+@pytest.mark.parametrize("variant", [None, "bubble", "dual"])
+def test_expansion_tables_vs_reference(rt, golden, sd, variant):
+    g = golden("expansion")
+    n_checked = 0
+    for ci in (0, 1):
+        verts = g[f"verts_sd{sd}_c{ci}"]
+        pts = g[f"cpts_sd{sd}_c{ci}"]
+        for n in (0, 1, 2, 3, 4, 6):
+            for order in (0, 1, 2):
+                key = f"exp_sd{sd}_c{ci}_{variant}_n{n}_o{order}"
+                if key not in g:
+                    continue
+                ps = rt.SimplexPolySet(sd, n, variant=variant, verts=verts)
+                out = ps.tabulate_batch(order, pts[None]).cpu().numpy()[0]
+                assert_tables(out, g[key], sd, key)
+                n_checked += 1
+    assert n_checked >= 20
+
+
+@pytest.mark.parametrize("sd", [1, 2, 3])
+def test_expansion_physical_cell_both_ways(rt, golden, sd):
+    """Cell given at element creation and cell given per request must agree with
+    the reference built on that physical cell."""
+    g = golden("expansion")
+    verts, pts = g[f"verts_sd{sd}_phys"], g[f"cpts_sd{sd}_phys"]
+    for variant, scale in ((None, None), ("bubble", 1)):
+        for n in (2, 3):
+            ref = g[f"exp_sd{sd}_phys_{variant}_n{n}_o2"]
+            ps = rt.SimplexPolySet(sd, n, variant=variant, scale=scale, verts=verts)
+            assert_tables(ps.tabulate_batch(2, pts[None]).cpu().numpy()[0], ref, sd, "fixed cell")
+            ps2 = rt.SimplexPolySet(sd, n, variant=variant, scale=scale)
+            got = ps2.tabulate_batch(2, pts[None], verts=verts[None]).cpu().numpy()[0]
+            assert_tables(got, ref, sd, "per-request cell")
+
+
+def test_bad_arguments(rt):
+    with pytest.raises(ValueError):
+        rt.SimplexPolySet(4, 1)
+    with pytest.raises(ValueError):
+        rt.SimplexPolySet(2, 0, variant="bubble")
+    ps = rt.SimplexPolySet(2, 2)
+    with pytest.raises(NotImplementedError):
+        ps.tabulate_batch(3, np.zeros((1, 2, 2)))
+    with pytest.raises(ValueError):
+        ps.tabulate_batch(1, np.zeros((1, 2, 3)))
+    # empty batches are fine
+    assert ps.tabulate_batch(1, np.zeros((0, 5, 2))).shape == (0, 3, 6, 5)
+    assert ps.tabulate_batch(1, np.zeros((3, 0, 2))).shape == (3, 3, 6, 0)
+
+
+# ---- C1: P1 triangle ---------------------------------------------------------------
+def test_c1_p1_triangle(rt, golden):
+    g = golden("elements")
+    ps = rt.SimplexPolySet(2, 1, variant="bubble", scale=1, coeffs=g["c1_p1tri_coeffs"])
+    out = ps.tabulate_batch(1, g["c1_p1tri_pts"][None]).cpu().numpy()[0]
+    assert_tables(out, g["c1_p1tri_tab"], 2, "C1")
+
+
+# ---- C2: P3 tetrahedron ------------------------------------------------------------
+def test_c2_p3_tet_golden(rt, golden):
+    g = golden("elements")
+    ps = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=g["c2_p3tet_q6_coeffs"])
+    out = ps.tabulate_batch(1, g["tet_q6_pts"][None]).cpu().numpy()[0]
+    assert_tables(out, g["c2_p3tet_q6_tab"], 3, "C2 q6")
+    out = ps.tabulate_batch(1, g["c2_p3tet_rand_pts"]).cpu().numpy()
+    for o, r in zip(out, g["c2_p3tet_rand_tab"]):
+        assert_tables(o, r, 3, "C2 random")
+    out = ps.tabulate_batch(2, g["c2_p3tet_rand_pts"][:1]).cpu().numpy()[0]
+    assert_tables(out, g["c2_p3tet_o2_tab"], 3, "C2 order 2")
+
+
+@pytest.mark.parametrize("nreq", [1, 2, 3, 64, 1001])
+def test_c2_batch_vs_oracle(rt, golden, nreq):
+    """Ragged batch sizes (odd counts exercise the packing tail)."""
+    g = golden("elements")
+    co = g["c2_p3tet_q6_coeffs"]
+    rng = np.random.default_rng(2)
+    pts = rand_points(rng, 3, (nreq, 23))
+    ps = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=co)
+    out = ps.tabulate_batch(1, pts).cpu().numpy()
+    idx = range(nreq) if nreq <= 64 else rng.choice(nreq, 48, replace=False)
+    for r in idx:
+        ref = fo.element_tabulate(fo.UFC_SIMPLEX[3], 3, co, 1, pts[r], 1, "bubble")
+        ref = np.stack([ref[a] for a in fo.jet_indices(3, 1)])
+        assert_tables(out[r], ref, 3, f"request {r}")
+
+
+def test_c2_physical_cells(rt, golden):
+    g = golden("elements")
+    co = g["c2_p3tet_q6_coeffs"]   # affine-invariant
+    ps = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=co)
+    out = ps.tabulate_batch(1, g["c2_phys_pts"], verts=g["c2_phys_verts"]).cpu().numpy()
+    for o, r in zip(out, g["c2_phys_tab"]):
+        assert_tables(o, r, 3, "C2 physical")
+
+
+@pytest.mark.parametrize("npts", [1, 3, 16, 17, 64, 65, 130])
+def test_point_counts(rt, golden, npts):
+    """Empty/ragged point counts: one point, tile boundaries, more than a wave."""
+    g = golden("elements")
+    co = g["c2_p3tet_q6_coeffs"]
+    rng = np.random.default_rng(npts)
+    pts = rand_points(rng, 3, (5, npts))
+    ps = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=co)
+    out = ps.tabulate_batch(1, pts).cpu().numpy()
+    for r in range(5):
+        ref = fo.element_tabulate(fo.UFC_SIMPLEX[3], 3, co, 1, pts[r], 1, "bubble")
+        assert_tables(out[r], np.stack([ref[a] for a in fo.jet_indices(3, 1)]), 3, f"npts={npts}")
+
+
+# ---- C3: N2 / RT2 (vector valued) ----------------------------------------------------
+@pytest.mark.parametrize("name,n", [("n2", 2), ("rt2", 2), ("n1", 1), ("rt1", 1)])
+def test_c3_hcurl_hdiv(rt, golden, name, n):
+    g = golden("elements")
+    tag = f"c3_{name}tet_q6" if n == 2 else f"c3_{name}tet"
+    co = g[f"{tag}_coeffs"]
+    ps = rt.SimplexPolySet(3, n, coeffs=co, value_shape=(3,))
+    out = ps.tabulate_batch(1, g[f"{tag}_pts"][None]).cpu().numpy()[0]
+    assert_tables(out, g[f"{tag}_tab"], 3, tag)
+    if n == 2:
+        out = ps.tabulate_batch(1, g["c2_p3tet_rand_pts"][:2]).cpu().numpy()
+        for o, r in zip(out, g[f"c3_{name}tet_rand_tab"]):
+            assert_tables(o, r, 3, tag + " random")
+
+
+def test_c3_mixed_batch(rt, golden):
+    """The C3 workload: N2 and RT2 requests interleaved = two launches on
+    disjoint halves of the batch."""
+    g = golden("elements")
+    rng = np.random.default_rng(3)
+    pts = rand_points(rng, 3, (200, 23))
+    for name in ("n2", "rt2"):
+        co = g[f"c3_{name}tet_q6_coeffs"]
+        ps = rt.SimplexPolySet(3, 2, coeffs=co, value_shape=(3,))
+        sub = pts[0::2] if name == "n2" else pts[1::2]
+        out = ps.tabulate_batch(1, sub).cpu().numpy()
+        for r in (0, 37, 99):
+            ref = fo.element_tabulate(fo.UFC_SIMPLEX[3], 2, co, 1, sub[r])
+            assert_tables(out[r], np.stack([ref[a] for a in fo.jet_indices(3, 1)]), 3, name)
+
+
+# ---- C4: DG P6 tet, Hessians ---------------------------------------------------------
+def test_c4_dg6(rt, golden):
+    g = golden("elements")
+    co = g["c4_dg6tet_q6_coeffs"]
+    ps = rt.SimplexPolySet(3, 6, coeffs=co)
+    out = ps.tabulate_batch(2, g["tet_q6_pts"][None]).cpu().numpy()[0]
+    assert_tables(out, g["c4_dg6tet_q6_tab"], 3, "C4 q6")
+    out = ps.tabulate_batch(2, g["c2_p3tet_rand_pts"][1:2]).cpu().numpy()[0]
+    assert_tables(out, g["c4_dg6tet_rand_tab"], 3, "C4 random")
+    out = ps.tabulate_batch(2, g["tet_q12_pts"][None]).cpu().numpy()[0]
+    assert_tables(out, g["c4_dg6tet_q12_tab"], 3, "C4 q12 (122 points)")
+
+
+@pytest.mark.parametrize("sd", [2, 3])
+@pytest.mark.parametrize("deg", [1, 2, 3, 4])
+def test_lagrange_dg_families(rt, golden, sd, deg):
+    g = golden("elements")
+    for fam, variant, scale in (("lag", "bubble", 1), ("dg", None, None)):
+        tag = f"{fam}_sd{sd}_p{deg}"
+        ps = rt.SimplexPolySet(sd, deg, variant=variant, scale=scale, coeffs=g[f"{tag}_coeffs"])
+        out = ps.tabulate_batch(2, g[f"{tag}_pts"][None]).cpu().numpy()[0]
+        assert_tables(out, g[f"{tag}_tab"], sd, tag)
+
+
+# ---- a11/a12: Vandermonde assembly and solve on the device -------------------------------
+@pytest.mark.parametrize("tag,sd,n,variant,scale", [
+    ("c2_p3tet_q6", 3, 3, "bubble", 1), ("c4_dg6tet_q6", 3, 6, None, None),
+    ("lag_sd2_p4", 2, 4, "bubble", 1), ("dg_sd3_p2", 3, 2, None, None)])
+def test_vandermonde_point_evaluation(rt, golden, tag, sd, n, variant, scale):
+    g = golden("elements")
+    verts = fo.UFC_SIMPLEX[sd]
+    nodes, _ = (fo.lagrange_nodes if variant == "bubble" else fo.broken_lagrange_nodes)(verts, n)
+    nodes = np.array(nodes)
+    es = rt.SimplexPolySet(sd, n, variant=variant, scale=scale)
+    # expansion values at the nodes: (nexp, nnodes); Riesz matrix rows = functionals
+    ev = es.tabulate_batch(0, nodes[None])[0, 0]
+    import torch
+    wts = torch.eye(len(nodes), dtype=torch.float64, device=ev.device)
+    R = rt.riesz_assemble(wts, ev)
+    B = torch.eye(len(nodes), dtype=torch.float64, device=ev.device)
+    X, V = rt.vandermonde_solve_batch(R, B, return_V=True)
+    V = V.cpu().numpy()[0]
+    X = X.cpu().numpy()[0]
+    assert np.max(np.abs(V - g[f"{tag}_V"])) / np.max(np.abs(g[f"{tag}_V"])) < 1e-13
+    ref = g[f"{tag}_coeffs"]
+    assert np.max(np.abs(X - ref)) / np.max(np.abs(ref)) < 1e-11
+
+
+def test_vandermonde_singular_raises(rt):
+    A = np.ones((1, 4, 4))
+    B = np.eye(4)[None]
+    with pytest.raises(np.linalg.LinAlgError):
+        rt.vandermonde_solve_batch(A, B)
+
+
+def test_vandermonde_batch_random(rt):
+    rng = np.random.default_rng(7)
+    A = rng.normal(size=(33, 20, 30))
+    B = rng.normal(size=(33, 20, 30))
+    X = rt.vandermonde_solve_batch(A, B).cpu().numpy()
+    for s in (0, 16, 32):
+        V = A[s] @ B[s].T
+        ref = np.linalg.solve(V.T, B[s])
+        assert np.max(np.abs(X[s] - ref)) / np.max(np.abs(ref)) < 1e-9 * np.linalg.cond(V)
+
+
+# ---- a8 / a14: 1-D Lagrange and tensor products -------------------------------------------
+def test_line_lagrange(rt, golden):
+    g = golden("lagrange_line")
+    L = rt.LineLagrange(g["nodes"])
+    out = L.tabulate_batch(2, g["pts"].reshape(1, -1)).cpu().numpy()[0]
+    assert_tables(out, g["tab"], 1, "line")
+    assert np.array_equal(out[0][:, -1], np.eye(5)[:, 4])   # node hit -> exact delta
+
+
+def test_c5_hex(rt, golden):
+    g = golden("tensor_product")
+    L = rt.LineLagrange(g["p4_nodes"])
+    out = rt.tensor_tabulate_batch([L, L, L], 1, g["hex_rand_pts"][None]).cpu().numpy()[0]
+    assert_tables(out, g["hex_rand_tab"], 3, "hex random points")
+    out = rt.tensor_tabulate_batch([L, L, L], 1, g["hex_pts"][None]).cpu().numpy()[0]
+    assert_tables(out, g["hex_tab"], 3, "hex grid points")
+
+
+def test_c5_hex_grid_mode_matches_point_mode(rt):
+    rng = np.random.default_rng(5)
+    nodes = np.array([0.0, 1.0, 0.25, 0.5, 0.75])
+    L = rt.LineLagrange(nodes)
+    grid = np.sort(rng.uniform(0, 1, size=(7, 3, 5)), axis=2)
+    pts = np.stack([np.array([[x, y, z] for x in g[0] for y in g[1] for z in g[2]]) for g in grid])
+    a = rt.tensor_tabulate_batch([L, L, L], 1, grid, grid=True).cpu().numpy()
+    b = rt.tensor_tabulate_batch([L, L, L], 1, pts).cpu().numpy()
+    assert a.shape == b.shape == (7, 4, 125, 125)
+    assert np.array_equal(a, b)
+    ref = fo.hex_lagrange_tabulate(nodes, 1, pts[3])
+    assert_tables(a[3], np.stack([ref[al] for al in fo.jet_indices(3, 1)]), 3, "hex vs oracle")
+
+
+def test_quad_mixed(rt, golden):
+    g = golden("tensor_product")
+    La = rt.LineLagrange(g["p4_nodes"])
+    Lb = rt.LineLagrange(np.array([0.0, 1.0, 0.5]))
+    out = rt.tensor_tabulate_batch([La, Lb], 2, g["quad_pts"][None]).cpu().numpy()[0]
+    assert_tables(out, g["quad_tab"], 2, "quad")
