@@ -370,6 +370,11 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     a.KS = e->KS;
     a.MT = e->MT;
     a.ntab = ntab;
+    if (nreq == 0 || npts == 0) {  // empty batch / empty point set: nothing to launch
+        a.nitems = 0;
+        L.grid = 0;
+        return FX_OK;
+    }
 
     // ---- choose the work-item shape under a per-wave LDS budget ----
     const long long budget = 32 * 1024;  // bytes per wave: >= 5 resident waves per CU

@@ -1,0 +1,347 @@
+"""Reference cells for the tabulate path: simplices (UFC and default), their
+topology, lattices and entity maps.  Host-side bookkeeping only (no arithmetic
+of the hot path lives here).
+
+Mirrors the parts of FIAT/reference_element.py the path uses: cell classes
+(:880-1152), ``make_lattice`` (:79-98, equispaced family), ``lattice_iter``
+(:64-76), entity transforms (:570-609), ``make_affine_mapping`` (:1621-1654),
+``ufc_simplex``/``default_simplex`` (:1680-1715).
+"""
+import math
+
+import numpy
+
+POINT = 0
+LINE = 1
+TRIANGLE = 2
+TETRAHEDRON = 3
+QUADRILATERAL = 11
+HEXAHEDRON = 111
+TENSORPRODUCT = 99
+
+
+def lattice_iter(start, finish, depth):
+    """Integer tuples (i_1..i_depth) with start <= i_k and sum < finish; the last
+    entry varies slowest."""
+    if depth == 0:
+        yield ()
+        return
+    if depth == 1:
+        for i in range(start, finish):
+            yield (i,)
+        return
+    for last in range(start, finish):
+        for head in lattice_iter(start, finish - last, depth - 1):
+            yield head + (last,)
+
+
+def multiindex_equal(d, isum, imin=0):
+    """d-tuples with entries >= imin summing to isum."""
+    if d <= 0:
+        return
+    imax = isum - (d - 1) * imin
+    if imax < imin:
+        return
+    for i in range(imin, imax):
+        for a in multiindex_equal(d - 1, isum - i, imin=imin):
+            yield a + (i,)
+    yield (imin,) * (d - 1) + (imax,)
+
+
+def make_lattice(verts, n, interior=0, variant=None):
+    """Lattice of points on the simplex spanned by ``verts``; ``interior`` layers
+    next to the boundary are dropped.  Only the equispaced family is available:
+    the spectral families need the third-party ``recursivenodes`` package."""
+    if variant not in (None, "equispaced"):
+        raise NotImplementedError(f"point variant {variant!r}: only 'equispaced' is supported by fiat_amd")
+    X = numpy.asarray(verts, dtype=float)
+    D = len(verts)
+    pts = []
+    for alpha in multiindex_equal(D, n, interior):
+        bary = numpy.asarray(alpha, dtype=float) / n if n > 0 else numpy.full(D, 1.0 / D)
+        pts.append(tuple(numpy.dot(bary, X)))
+    return pts
+
+
+def make_affine_mapping(xs, ys):
+    """(A, b) with A xs[i] + b = ys[i] for the vertices of two simplices."""
+    xs = numpy.asarray(xs, dtype=float)
+    ys = numpy.asarray(ys, dtype=float)
+    if len(xs) != len(ys):
+        raise ValueError("simplices with different numbers of vertices")
+    # homogeneous coordinates: [A | b] [x; 1] = y  for every vertex
+    H = numpy.hstack([xs, numpy.ones((len(xs), 1))])
+    if H.shape[0] == H.shape[1]:
+        sol = numpy.linalg.solve(H, ys)
+    else:
+        sol = numpy.linalg.lstsq(H, ys, rcond=None)[0]
+    return sol[:-1].T.copy(), sol[-1].copy()
+
+
+class Cell:
+    """Vertices + topology {dim: {entity: vertex ids}}."""
+
+    def __init__(self, shape, vertices, topology):
+        self.shape = shape
+        self.vertices = tuple(tuple(float(c) for c in v) for v in vertices)
+        self.topology = topology
+        self.sub_entities = {}
+        for dim, ents in topology.items():
+            self.sub_entities[dim] = {}
+            for e, vids in ents.items():
+                vs = frozenset(vids)
+                self.sub_entities[dim][e] = sorted((d_, e_) for d_, es_ in topology.items()
+                                                   for e_, v_ in es_.items() if vs.issuperset(v_))
+
+    def get_shape(self):
+        return self.shape
+
+    def get_vertices(self):
+        return self.vertices
+
+    def get_spatial_dimension(self):
+        return len(self.vertices[0])
+
+    def get_dimension(self):
+        return self.get_spatial_dimension()
+
+    def get_topology(self):
+        return self.topology
+
+    def get_vertices_of_subcomplex(self, t):
+        return tuple(self.vertices[i] for i in t)
+
+    def get_parent(self):
+        return None
+
+    def is_macrocell(self):
+        return False
+
+    def __eq__(self, other):
+        return (type(self) is type(other) and self.shape == other.shape
+                and self.vertices == other.vertices and self.topology == other.topology)
+
+    def __hash__(self):
+        return hash((type(self).__name__, self.shape, self.vertices))
+
+
+class Simplex(Cell):
+    def volume(self):
+        v = numpy.asarray(self.vertices)
+        sd = self.get_spatial_dimension()
+        if sd == 0:
+            return 1.0
+        return abs(numpy.linalg.det(v[1:] - v[0])) / math.factorial(sd)
+
+    def make_points(self, dim, entity_id, order, variant=None, interior=1):
+        """Lattice points in the interior of a sub-entity."""
+        if dim == 0:
+            return (self.vertices[self.topology[0][entity_id][0]],)
+        if 0 < dim <= self.get_spatial_dimension():
+            ev = self.get_vertices_of_subcomplex(self.topology[dim][entity_id])
+            return make_lattice(ev, order, interior=interior, variant=variant)
+        raise ValueError("illegal dimension")
+
+    def compute_tangents(self, dim, i):
+        """Un-normalised tangents of entity i: vertex differences to its first vertex."""
+        vs = numpy.array(self.get_vertices_of_subcomplex(self.topology[dim][i]))
+        return vs[1:] - vs[:1]
+
+    def compute_edge_tangent(self, edge_i):
+        return self.compute_tangents(1, edge_i)[0]
+
+    def compute_face_tangents(self, face_i):
+        if self.get_spatial_dimension() != 3:
+            raise ValueError("face tangents need a tetrahedron")
+        return self.compute_tangents(2, face_i)
+
+    def compute_normal(self, facet_i):
+        """Unit outward normal of a codimension-1 facet."""
+        sd = self.get_spatial_dimension()
+        v = numpy.asarray(self.vertices)
+        fverts = self.topology[sd - 1][facet_i]
+        opposite = next(i for i in range(sd + 1) if i not in fverts)
+        if sd == 1:
+            n = v[fverts[0]] - v[opposite]
+            return n / numpy.linalg.norm(n)
+        # gradient of the barycentric coordinate of the opposite vertex points inwards
+        A, _ = make_affine_mapping(v, numpy.eye(sd + 1))
+        n = -A[opposite]
+        return n / numpy.linalg.norm(n)
+
+    def compute_scaled_normal(self, facet_i):
+        """Outward normal scaled by the facet volume."""
+        sd = self.get_spatial_dimension()
+        facet = self.construct_subelement(sd - 1)
+        fv = numpy.asarray(self.get_vertices_of_subcomplex(self.topology[sd - 1][facet_i]))
+        if sd == 1:
+            vol = 1.0
+        else:
+            E = fv[1:] - fv[0]
+            vol = math.sqrt(abs(numpy.linalg.det(E @ E.T))) / math.factorial(sd - 1)
+        del facet
+        return self.compute_normal(facet_i) * vol
+
+    def compute_reference_normal(self, facet_dim, facet_i):
+        n = Simplex.compute_normal(self, facet_i)
+        return n / numpy.linalg.norm(n, numpy.inf)
+
+    def get_entity_transform(self, dim, entity):
+        """Map from the reference sub-entity's coordinates into this cell."""
+        sd = self.get_spatial_dimension()
+        if dim == sd:
+            if entity != 0:
+                raise ValueError("a simplex has a single cell")
+            return lambda x: x
+        if dim == 0:
+            offset = numpy.asarray(self.vertices[self.topology[0][entity][0]])
+            return lambda x: numpy.tile(offset, (len(x), 1)) if numpy.ndim(x) > 1 else offset.copy()
+        sub = self.construct_subelement(dim)
+        ve = numpy.asarray(sub.get_vertices())
+        vc = numpy.asarray(self.get_vertices_of_subcomplex(self.topology[dim][entity]))
+        C = numpy.linalg.solve(ve[1:] - ve[:1], vc[1:] - vc[:1])
+        offset = vc[0] - ve[0] @ C
+
+        def transform(point):
+            return numpy.asarray(point, dtype=float) @ C + offset
+        return transform
+
+    def construct_subelement(self, dimension):
+        raise NotImplementedError
+
+
+class UFCSimplex(Simplex):
+    def construct_subelement(self, dimension):
+        return ufc_simplex(dimension)
+
+
+class DefaultSimplex(Simplex):
+    def construct_subelement(self, dimension):
+        return default_simplex(dimension)
+
+
+class Point(Simplex):
+    def __init__(self):
+        super().__init__(POINT, ((),), {0: {0: (0,)}})
+
+    def get_spatial_dimension(self):
+        return 0
+
+    def construct_subelement(self, dimension):
+        return self
+
+
+def _edges(pairs):
+    return {i: p for i, p in enumerate(pairs)}
+
+
+# UFC numbering: entity i of dimension d-1 is opposite vertex i; edges of the
+# tetrahedron are ordered by the pair of vertices they do NOT touch.
+_UFC_TOPOLOGY = {
+    1: {0: {0: (0,), 1: (1,)}, 1: {0: (0, 1)}},
+    2: {0: {0: (0,), 1: (1,), 2: (2,)},
+        1: _edges([(1, 2), (0, 2), (0, 1)]),
+        2: {0: (0, 1, 2)}},
+    3: {0: {0: (0,), 1: (1,), 2: (2,), 3: (3,)},
+        1: _edges([(2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)]),
+        2: _edges([(1, 2, 3), (0, 2, 3), (0, 1, 3), (0, 1, 2)]),
+        3: {0: (0, 1, 2, 3)}},
+}
+_DEFAULT_TOPOLOGY = {
+    1: {0: {0: (0,), 1: (1,)}, 1: {0: (0, 1)}},
+    2: {0: {0: (0,), 1: (1,), 2: (2,)},
+        1: _edges([(1, 2), (2, 0), (0, 1)]),
+        2: {0: (0, 1, 2)}},
+    3: {0: {0: (0,), 1: (1,), 2: (2,), 3: (3,)},
+        1: _edges([(1, 2), (2, 0), (0, 1), (0, 3), (1, 3), (2, 3)]),
+        2: _edges([(1, 3, 2), (2, 3, 0), (3, 1, 0), (0, 1, 2)]),
+        3: {0: (0, 1, 2, 3)}},
+}
+_SHAPES = {1: LINE, 2: TRIANGLE, 3: TETRAHEDRON}
+
+
+def _unit_vertices(sd, lo, hi):
+    verts = [[lo] * sd]
+    for i in range(sd):
+        v = [lo] * sd
+        v[i] = hi
+        verts.append(v)
+    return verts
+
+
+def ufc_simplex(spatial_dim):
+    """UFC reference simplex: vertices 0 and the unit vectors."""
+    if spatial_dim == 0:
+        return Point()
+    if spatial_dim not in (1, 2, 3):
+        raise RuntimeError(f"Can't create UFC simplex of dimension {spatial_dim}.")
+    return UFCSimplex(_SHAPES[spatial_dim], _unit_vertices(spatial_dim, 0.0, 1.0), _UFC_TOPOLOGY[spatial_dim])
+
+
+def default_simplex(spatial_dim):
+    """Default simplex with vertices (-1,..,-1), (1,-1,..), ... used by the expansion sets."""
+    if spatial_dim == 0:
+        return Point()
+    if spatial_dim not in (1, 2, 3):
+        raise RuntimeError(f"Can't create default simplex of dimension {spatial_dim}.")
+    return DefaultSimplex(_SHAPES[spatial_dim], _unit_vertices(spatial_dim, -1.0, 1.0),
+                          _DEFAULT_TOPOLOGY[spatial_dim])
+
+
+def UFCInterval():
+    return ufc_simplex(1)
+
+
+def UFCTriangle():
+    return ufc_simplex(2)
+
+
+def UFCTetrahedron():
+    return ufc_simplex(3)
+
+
+def DefaultLine():
+    return default_simplex(1)
+
+
+def DefaultTriangle():
+    return default_simplex(2)
+
+
+def DefaultTetrahedron():
+    return default_simplex(3)
+
+
+def physical_simplex(vertices):
+    """A simplex with the UFC topology and arbitrary (affine) vertex positions:
+    elements may be constructed directly on a physical cell
+    (test/finat/test_point_evaluation.py:35-70 exercises that use)."""
+    vertices = numpy.asarray(vertices, dtype=float)
+    sd = vertices.shape[1]
+    return UFCSimplex(_SHAPES[sd], vertices, _UFC_TOPOLOGY[sd])
+
+
+class TensorProductCell(Cell):
+    """Product of interval cells (quadrilateral / hexahedron)."""
+
+    def __init__(self, *cells):
+        self.cells = tuple(cells)
+        import itertools
+        verts = [sum((tuple(v) for v in combo), ()) for combo in
+                 itertools.product(*[c.get_vertices() for c in cells])]
+        self.shape = TENSORPRODUCT
+        self.vertices = tuple(verts)
+        self.topology = None
+        self.sub_entities = None
+
+    def get_spatial_dimension(self):
+        return sum(c.get_spatial_dimension() for c in self.cells)
+
+    def get_dimension(self):
+        return tuple(c.get_dimension() for c in self.cells)
+
+    def __eq__(self, other):
+        return isinstance(other, TensorProductCell) and self.cells == other.cells
+
+    def __hash__(self):
+        return hash(("TensorProductCell", self.cells))
