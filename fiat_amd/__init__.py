@@ -1,0 +1,35 @@
+"""fiat_amd -- MI355X-native batched finite-element tabulator.
+
+Drop-in for the tabulate() hot path of FIAT (firedrakeproject/fiat): the same
+class names, constructor signatures and return conventions for the in-scope
+families, with every table computed by hand-written HIP kernels for gfx950
+through the C ABI in include/fiat_amd.h.  There is no CPU fallback.
+
+    from fiat_amd import Lagrange, ufc_simplex, create_quadrature
+    el = Lagrange(ufc_simplex(3), 3)
+    tab = el.tabulate(1, pts)                 # {alpha: ndarray}, as FIAT
+    dev = el.tabulate_batch(1, pts_batch)     # (nreq, ntab, ndof, npts) on the GPU
+"""
+from . import _lib  # noqa: F401  (fails loudly if the HIP extension is missing)
+from .reference_element import (DefaultLine, DefaultTetrahedron, DefaultTriangle,  # noqa: F401
+                                UFCInterval, UFCTetrahedron, UFCTriangle, default_simplex,
+                                make_affine_mapping, make_lattice, physical_simplex, ufc_simplex)
+from .quadrature import create_quadrature, make_quadrature  # noqa: F401
+from .polynomial_set import ONPolynomialSet, PolynomialSet, mis  # noqa: F401
+from .expansions import ExpansionSet  # noqa: F401
+from .finite_element import CiarletElement, FiniteElement  # noqa: F401
+from .lagrange import Lagrange  # noqa: F401
+from .discontinuous_lagrange import P0, DiscontinuousLagrange  # noqa: F401
+from .nedelec import Nedelec  # noqa: F401
+from .raviart_thomas import RaviartThomas  # noqa: F401
+from .tensor_product import FlattenedDimensions, TensorProductElement  # noqa: F401
+
+# the element registry of the reference (FIAT/__init__.py:72-131), in-scope subset
+supported_elements = {
+    "Lagrange": Lagrange,
+    "Discontinuous Lagrange": DiscontinuousLagrange,
+    "Nedelec 1st kind H(curl)": Nedelec,
+    "Raviart-Thomas": RaviartThomas,
+    "TensorProductElement": TensorProductElement,
+    "FlattenedDimensions": FlattenedDimensions,
+}

