@@ -47,10 +47,9 @@ def synth_points(sd, nreq, npts, seed):
 def build_element(name):
     """Nodal coefficients through the device Vandermonde path; returns the
     device polynomial set and what the oracle needs for the CPU baseline."""
-    from fiat_amd import elements
+    import fiat_amd
     fam, sd, deg, order, npts, batch = WORKLOADS[name]
-    from fiat_amd.reference_element import ufc_simplex
-    el = getattr(elements, fam)(ufc_simplex(sd), deg)
+    el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg)
     return el, sd, deg, order, npts, batch
 
 

@@ -8,6 +8,11 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 import numpy as np
+# PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  Import it
+# BEFORE loading libfiat_amd.so so that both share ONE runtime instance (device
+# memory and streams are handed over from torch); loading ours first would pull a
+# second runtime from /opt/rocm that does not see torch's devices.
+import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfiat_amd.so")
