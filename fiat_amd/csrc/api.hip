@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -13,6 +14,7 @@
 #include "aux_kernels.hpp"
 #include "plan.hpp"
 #include "simplex_kernel.hpp"
+#include "simplex_fixed.hpp"
 
 namespace {
 
@@ -109,6 +111,8 @@ struct fx_element {
     int KS = 0, MT = 0;
     fxk::Step* d_steps = nullptr;
     double* d_afrag = nullptr;
+    double* d_afrag_split = nullptr;  // layout of the shape-specialised kernels
+    double* d_coef = nullptr;         // [nsteps][3]
 };
 
 struct fx_line_element {
@@ -228,6 +232,13 @@ static int upload_coeffs(fx_element* e, int ndof, int vdim, const double* coeffs
     }
     HIP_TRY(hipMalloc(&e->d_afrag, F.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(e->d_afrag, F.data(), F.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> F2 = fx::pack_a_fragments_split(C, rows, nexp);
+    if (e->d_afrag_split) {
+        HIP_TRY(hipFree(e->d_afrag_split));
+        e->d_afrag_split = nullptr;
+    }
+    HIP_TRY(hipMalloc(&e->d_afrag_split, F2.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(e->d_afrag_split, F2.data(), F2.size() * sizeof(double), hipMemcpyHostToDevice));
     e->ndof = ndof;
     e->vdim = vdim;
     e->MT = (rows + 15) / 16;
@@ -270,6 +281,20 @@ int fx_element_create(fx_ctx* ctx, int sd, int n, int variant, double scale, con
         fx_element_destroy(e);
         return fail(FX_EHIP, "fx_element_create: %s", hipGetErrorString(he));
     }
+    {
+        std::vector<double> cf(std::max<size_t>(1, e->prog.steps.size()) * 3, 0.0);
+        for (size_t i = 0; i < e->prog.steps.size(); ++i) {
+            cf[3 * i + 0] = e->prog.steps[i].A;
+            cf[3 * i + 1] = e->prog.steps[i].B;
+            cf[3 * i + 2] = e->prog.steps[i].C;
+        }
+        he = hipMalloc(&e->d_coef, cf.size() * sizeof(double));
+        if (he == hipSuccess) he = hipMemcpy(e->d_coef, cf.data(), cf.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (he != hipSuccess) {
+            fx_element_destroy(e);
+            return fail(FX_EHIP, "fx_element_create: %s", hipGetErrorString(he));
+        }
+    }
     int rc = upload_coeffs(e, ndof, vdim, coeffs);
     if (rc != FX_OK) {
         fx_element_destroy(e);
@@ -283,6 +308,8 @@ int fx_element_destroy(fx_element* e) {
     if (!e) return FX_OK;
     if (e->d_steps) (void)hipFree(e->d_steps);
     if (e->d_afrag) (void)hipFree(e->d_afrag);
+    if (e->d_afrag_split) (void)hipFree(e->d_afrag_split);
+    if (e->d_coef) (void)hipFree(e->d_coef);
     delete e;
     return FX_OK;
 }
@@ -311,8 +338,50 @@ namespace {
 struct Launch {
     fxk::TabArgs args;
     int grid = 0, lds_bytes = 0;
-    bool fast_p3 = false;
+    // shape-specialised path
+    int fixed_id = -1;
+    fxk::FixedArgs fargs;
+    int fgrid = 0, flds_bytes = 0;
 };
+
+// ---- registry of shape-specialised kernels ----------------------------------------
+// One entry per <SD, N, ORDER, ROWS, NT>; everything else runs the generic kernel.
+constexpr int FIXED_NW = 4;  // 256-thread workgroups: one wave per SIMD, 2 workgroups per CU
+struct FixedShape {
+    int sd, n, order, rows, nt;
+};
+const FixedShape kFixedShapes[] = {
+    {3, 3, 1, 20, 6},  // Lagrange P3 tetrahedron, values + gradient, 21..24 points
+};
+
+template <int SD, int N>
+bool table_matches(const fx::Program& P) {
+    constexpr fxk::StepTable<SD, N> T{};
+    if ((int)P.steps.size() != T.count) return false;
+    for (int i = 0; i < T.count; ++i)
+        if (P.steps[i].dst != T.dst[i] || P.steps[i].cur != T.cur[i] || P.steps[i].prv != T.prv[i] ||
+            P.steps[i].codim != T.codim[i])
+            return false;
+    return true;
+}
+
+template <int SD, int N, int ORDER, int ROWS, int NT>
+int launch_fixed(const Launch& L, hipStream_t s) {
+    auto kern = fxk::tabulate_simplex_fixed<SD, N, ORDER, ROWS, NT, FIXED_NW>;
+    if (L.flds_bytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    L.flds_bytes));
+    hipLaunchKernelGGL(kern, dim3(L.fgrid), dim3(64 * FIXED_NW), L.flds_bytes, s, L.fargs);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+int run_fixed(const Launch& L, hipStream_t s) {
+    switch (L.fixed_id) {
+        case 0: return launch_fixed<3, 3, 1, 20, 6>(L, s);
+    }
+    return fail(FX_EINVAL, "internal: unknown fixed kernel %d", L.fixed_id);
+}
 
 template <int SD, int ORDER, int KS_T, int MT_T>
 int launch_one(const Launch& L, hipStream_t s) {
@@ -370,6 +439,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     a.KS = e->KS;
     a.MT = e->MT;
     a.ntab = ntab;
+    if (const char* dbg = getenv("FIAT_AMD_DEBUG")) a.debug = atoi(dbg);  // ablation switches (measurement only)
     if (nreq == 0 || npts == 0) {  // empty batch / empty point set: nothing to launch
         a.nitems = 0;
         L.grid = 0;
@@ -406,6 +476,46 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     a.stage_doubles = (int)((stage / 8 + 1) & ~1LL);
     if (stage == 0) a.stage_doubles = 0;
     L.lds_bytes = (a.phi_doubles + a.stage_doubles) * 8;
+    // ---- shape-specialised kernel available? ----
+    L.fixed_id = -1;
+    const char* nofixed = getenv("FIAT_AMD_NO_FIXED");
+    if (!(nofixed && atoi(nofixed)) && npts <= 64) {
+        const int nt_need = (ntab * npts + 15) / 16;
+        for (size_t i = 0; i < sizeof(kFixedShapes) / sizeof(kFixedShapes[0]); ++i) {
+            const FixedShape& f = kFixedShapes[i];
+            if (f.sd != e->sd || f.n != e->n || f.order != order || f.rows != rows || f.nt != nt_need) continue;
+            bool ok = (e->sd == 3 && e->n == 3) ? table_matches<3, 3>(e->prog) : false;
+            if (!ok) continue;
+            fxk::FixedArgs& fa = L.fargs;
+            memset(&fa, 0, sizeof fa);
+            fa.pts = pts;
+            fa.verts = verts;
+            fa.out = out;
+            fa.afrag = e->d_afrag_split;
+            fa.coef = e->d_coef;
+            fa.phi0 = e->prog.phi0;
+            memcpy(fa.A0, e->A0, sizeof fa.A0);
+            memcpy(fa.b0, e->b0, sizeof fa.b0);
+            fa.nreq = nreq;
+            fa.npts = npts;
+            fa.debug = a.debug;
+            long long need = std::max<long long>((long long)f.nt * e->KS * 64, (long long)ntab * rows * npts);
+            need = (need + 1) & ~1LL;
+            // 8 waves per CU (2 workgroups of 4 waves): pad the request to 1/2 of the CU's LDS
+            long long per_wave = std::max<long long>(need * 8, (long long)(ctx->lds_per_cu / 8));
+            per_wave &= ~15LL;
+            if (per_wave < need * 8) per_wave = need * 8;
+            fa.lds_doubles = (int)(per_wave / 8);
+            L.flds_bytes = (int)(per_wave * FIXED_NW);
+            if (L.flds_bytes > ctx->lds_per_cu) continue;
+            int wg_per_cu = std::max(1, ctx->lds_per_cu / L.flds_bytes);
+            long long want = (long long)ctx->num_cu * wg_per_cu;
+            long long nwg = (nreq + FIXED_NW - 1) / FIXED_NW;
+            L.fgrid = (int)std::max<long long>(1, std::min<long long>(nwg, want));
+            L.fixed_id = (int)i;
+            break;
+        }
+    }
     int per_cu = std::max(1, std::min(16, ctx->lds_per_cu / std::max(1, L.lds_bytes)));
     long long want = (long long)ctx->num_cu * per_cu * 4;
     L.grid = (int)std::max<long long>(1, std::min<long long>(a.nitems, want));
@@ -414,6 +524,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
 
 int run_tabulate(fx_ctx* ctx, const fx_element* e, int order, const Launch& L, hipStream_t s) {
     if (L.args.nitems == 0 || L.args.npts == 0) return FX_OK;
+    if (L.fixed_id >= 0) return run_fixed(L, s);
     switch (e->sd) {
         case 1: return launch_sd<1>(order, L, s);
         case 2: return launch_sd<2>(order, L, s);

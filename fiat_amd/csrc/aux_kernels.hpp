@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void vandermonde_solve_kernel(int n, int m, co
     double* R = sm + (size_t)n * n;    // n x m
     __shared__ int s_piv;
     __shared__ int s_info;
+    __shared__ double s_anorm;
     __shared__ double s_red[256];
     __shared__ int s_idx[256];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -50,6 +51,22 @@ __global__ __launch_bounds__(256) void vandermonde_solve_kernel(int n, int m, co
     }
     for (int e = tid; e < n * m; e += nt) R[e] = B[e];
     __syncthreads();
+    {   // max |V_ij|: scale for the singularity test
+        double mx = 0.0;
+        for (int e = tid; e < n * n; e += nt) mx = fmax(mx, fabs(M[e]));
+        s_red[tid] = mx;
+        __syncthreads();
+        for (int s = nt >> 1; s > 0; s >>= 1) {
+            if (tid < s) s_red[tid] = fmax(s_red[tid], s_red[tid + s]);
+            __syncthreads();
+        }
+        if (tid == 0) s_anorm = s_red[0];
+        __syncthreads();
+    }
+    // a pivot below n*eps*max|V| means V is singular to working precision: the
+    // reference turns LAPACK's rcond < eps warning into LinAlgError
+    // (finite_element.py:151-156)
+    const double tiny = (double)n * 2.220446049250313e-16 * s_anorm;
     for (int k = 0; k < n; ++k) {
         // pivot search in column k, rows >= k
         double best = -1.0;
@@ -71,7 +88,7 @@ __global__ __launch_bounds__(256) void vandermonde_solve_kernel(int n, int m, co
         }
         if (tid == 0) {
             s_piv = s_idx[0];
-            if (!(s_red[0] > 0.0) && s_info == 0) s_info = k + 1;
+            if (!(s_red[0] > tiny) && s_info == 0) s_info = k + 1;
         }
         __syncthreads();
         const int piv = s_piv;
@@ -88,7 +105,8 @@ __global__ __launch_bounds__(256) void vandermonde_solve_kernel(int n, int m, co
             }
         }
         __syncthreads();
-        const double pinv = 1.0 / M[(size_t)k * n + k];
+        const double pkk = M[(size_t)k * n + k];
+        const double pinv = (pkk != 0.0) ? 1.0 / pkk : 0.0;
         // multipliers (stored in place), then rank-1 update of the trailing block and of R
         for (int r = k + 1 + tid; r < n; r += nt) M[(size_t)r * n + k] *= pinv;
         __syncthreads();

@@ -247,4 +247,30 @@ inline std::vector<double> pack_a_fragments(const std::vector<double>& C, int ro
     return F;
 }
 
+// Fragments for the shape-specialised kernel (simplex_fixed.hpp): full 16-row
+// tiles first ([MT16][KS][64]), then 4-row blocks for v_mfma_f64_4x4x4_4b
+// ([M4][KS][64]; lane l holds C[base + (l & 3)][4*ks + (l >> 4)], the block bits
+// (l >> 2) & 3 see the same A).  A remainder of 13..15 rows uses a padded 16-row tile.
+inline std::vector<double> pack_a_fragments_split(const std::vector<double>& C, int rows, int nexp) {
+    int rem = rows % 16;
+    bool split = rem != 0 && rem <= 12;
+    int MT16 = split ? rows / 16 : (rows + 15) / 16;
+    int M4 = split ? (rem + 3) / 4 : 0;
+    int KS = (nexp + 3) / 4;
+    std::vector<double> F((size_t)(MT16 + M4) * KS * 64, 0.0);
+    for (int mt = 0; mt < MT16; ++mt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int l = 0; l < 64; ++l) {
+                int m = 16 * mt + (l & 15), k = 4 * ks + (l >> 4);
+                if (m < rows && k < nexp) F[((size_t)mt * KS + ks) * 64 + l] = C[(size_t)m * nexp + k];
+            }
+    for (int m4 = 0; m4 < M4; ++m4)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int l = 0; l < 64; ++l) {
+                int m = 16 * MT16 + 4 * m4 + (l & 3), k = 4 * ks + (l >> 4);
+                if (m < rows && k < nexp) F[((size_t)(MT16 + m4) * KS + ks) * 64 + l] = C[(size_t)m * nexp + k];
+            }
+    return F;
+}
+
 }  // namespace fx

@@ -1,0 +1,295 @@
+// Shape-specialised simplex tabulation kernel (gfx950).
+//
+// Same three phases as simplex_kernel.hpp, with the element shape known at
+// compile time <SD, N, ORDER, ROWS> and one whole request per wave iteration:
+//  * the recurrence is fully unrolled from a constexpr step table (member
+//    indices, codimensions); only the three coefficients per step are loaded,
+//    from constant offsets of a device table (scalar loads the compiler batches);
+//    every LDS store uses an immediate offset;
+//  * all B fragments of the request are read into registers before the first
+//    MFMA, so the output image is built in the SAME LDS bytes the Phi tile
+//    occupied: LDS per wave = max(Phi, image) instead of the sum;
+//  * rows beyond the last full 16-row tile go through v_mfma_f64_4x4x4_4b
+//    (four 4x4x4 blocks sharing the 16x16x4 B-operand layout: lane = 16*k + col,
+//    D lane = 16*row + col -- probed on MI355X, tools/probe_mfma.hip), so a
+//    20-row coefficient matrix costs 64 + 16 MFMA cycles per K-step, not 128;
+//  * per-lane column offsets of the image are computed once per kernel.
+#pragma once
+#include "simplex_kernel.hpp"
+
+namespace fxk {
+
+constexpr int cx_binom(int n, int k) {
+    if (k < 0 || k > n) return 0;
+    long long r = 1;
+    for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+    return (int)r;
+}
+
+constexpr int cx_member_index(int sd, int p, int q, int r) {
+    if (sd == 1) return p;
+    if (sd == 2) return (p + q) * (p + q + 1) / 2 + q;
+    int t = p + q + r, u = q + r;
+    return t * (t + 1) * (t + 2) / 6 + u * (u + 1) / 2 + r;
+}
+
+// Index part of the recurrence program; must enumerate exactly as
+// fx::build_program (plan.hpp) so that coefficient i belongs to step i.
+template <int SD, int N> struct StepTable {
+    static constexpr int NEXP = cx_binom(N + SD, SD);
+    static constexpr int NSTEPS = NEXP > 1 ? NEXP - 1 : 1;
+    int dst[NSTEPS] = {}, cur[NSTEPS] = {}, prv[NSTEPS] = {}, codim[NSTEPS] = {};
+    int count = 0;
+    constexpr void chain(int cd, int p, int q) {
+        int s = (cd >= 1 ? p : 0) + (cd >= 2 ? q : 0);
+        int len = N - s;
+        int id_prev = 0, id_cur = 0;
+        for (int i = 0; i <= len; ++i) {
+            int a = cd == 0 ? i : p, b = cd == 0 ? 0 : (cd == 1 ? i : q), c = cd == 2 ? i : 0;
+            int id = cx_member_index(SD, a, b, c);
+            if (i >= 1) {
+                dst[count] = id;
+                cur[count] = id_cur;
+                prv[count] = i >= 2 ? id_prev : -1;
+                codim[count] = cd;
+                ++count;
+            }
+            id_prev = id_cur;
+            id_cur = id;
+        }
+    }
+    constexpr StepTable() {
+        for (int cd = 0; cd < SD; ++cd) {
+            if (cd == 0) {
+                chain(0, 0, 0);
+            } else if (cd == 1) {
+                for (int p = 0; p < N; ++p) chain(1, p, 0);
+            } else {
+                for (int last = 0; last < N; ++last)
+                    for (int first = 0; first < N - last; ++first) chain(2, first, last);
+            }
+        }
+    }
+};
+
+struct FixedArgs {
+    const double* pts;    // [nreq][npts][SD]
+    const double* verts;  // [nreq][SD+1][SD] or nullptr
+    double* out;          // [nreq][NTAB][ROWS][npts]
+    const double* afrag;  // 16x16x4 fragments [MT16][KS][64] then 4x4x4 fragments [M4][KS][64]
+    const double* coef;   // [nsteps][3] = A, B, C
+    double phi0;
+    double A0[9];
+    double b0[3];
+    long long nreq;
+    int npts;
+    int lds_doubles;  // per-wave LDS doubles (>= Phi fragments and >= output image)
+    int debug;
+};
+
+// number of full 16-row tiles / trailing 4-row blocks of a ROWS-row matrix
+constexpr int rows_full16(int rows) { return (rows % 16 != 0 && rows % 16 <= 12) ? rows / 16 : (rows + 15) / 16; }
+constexpr int rows_blk4(int rows) { return (rows % 16 != 0 && rows % 16 <= 12) ? (rows % 16 + 3) / 4 : 0; }
+
+template <int SD, int N, int ORDER, int ROWS, int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArgs a) {
+    constexpr int NTAB = NTab<SD, ORDER>::value;
+    constexpr StepTable<SD, N> TBL{};
+    constexpr int NEXP = StepTable<SD, N>::NEXP;
+    constexpr int KS = (NEXP + 3) / 4;
+    constexpr int MT16 = rows_full16(ROWS);
+    constexpr int M4 = rows_blk4(ROWS);
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double* phi = lds + (size_t)wave * a.lds_doubles;
+
+    const int npts = a.npts;
+    const int table = ROWS * npts;
+    const int reqsize = NTAB * table;
+    const int ncols = NTAB * npts;
+
+    for (int i = lane; i < a.lds_doubles; i += 64) phi[i] = 0.0;
+    wave_lds_fence();
+
+    // A fragments stay in registers for the whole kernel
+    double areg[MT16 * KS > 0 ? MT16 * KS : 1];
+    double areg4[M4 * KS > 0 ? M4 * KS : 1];
+#pragma unroll
+    for (int i = 0; i < MT16 * KS; ++i) areg[i] = a.afrag[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < M4 * KS; ++i) areg4[i] = a.afrag[(MT16 * KS + i) * 64 + lane];
+
+    // image offset (doubles) of this lane's output column in tile nt, row (lane>>4); -1: no column
+    int soff[NT];
+    {
+        const float rinv = 1.0f / (float)npts;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = (nt << 4) + (lane & 15);
+            const int ct = idiv_small(c, rinv);
+            const int cp = c - ct * npts;
+            soff[nt] = (c < ncols) ? ct * table + cp + (lane >> 4) * npts : -1;
+        }
+    }
+    // recurrence lanes: lane <-> point
+    const bool active = lane < npts;
+    const int pl = active ? lane : 0;
+    int colbase[NTAB];
+#pragma unroll
+    for (int t = 0; t < NTAB; ++t) {
+        const int c = t * npts + pl;
+        colbase[t] = (c >> 4) * KS * 64 + (c & 15);
+    }
+
+    for (long long req = (long long)blockIdx.x * NW + wave; req < a.nreq; req += (long long)gridDim.x * NW) {
+        // ---------------- phase 1: recurrence ----------------
+        double X[SD];
+        double J[SD][SD];
+        {
+            double x[SD];
+            const double* pp = a.pts + ((size_t)req * npts + pl) * SD;
+#pragma unroll
+            for (int d = 0; d < SD; ++d) x[d] = pp[d];
+            double bb[SD];
+            if (a.verts != nullptr) {
+                cell_map<SD>(a.verts + (size_t)req * (SD + 1) * SD, J, bb);
+            } else {
+#pragma unroll
+                for (int i = 0; i < SD; ++i) {
+                    bb[i] = a.b0[i];
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) J[i][d] = a.A0[i * SD + d];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < SD; ++i) {
+                double t = bb[i];
+#pragma unroll
+                for (int d = 0; d < SD; ++d) t += J[i][d] * x[d];
+                X[i] = t;
+            }
+        }
+        auto put = [&](int k, const Jet<SD, ORDER>& j) {
+            const int kofs = (k >> 2) * 64 + (k & 3) * 16;
+            if (active) {
+                phi[colbase[0] + kofs] = j.v;
+                if constexpr (ORDER >= 1) {
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) phi[colbase[1 + d] + kofs] = j.g[d];
+                }
+                if constexpr (ORDER >= 2) {
+#pragma unroll
+                    for (int h = 0; h < SD * (SD + 1) / 2; ++h) phi[colbase[1 + SD + h] + kofs] = j.h[h];
+                }
+            }
+        };
+        auto get = [&](int k, Jet<SD, ORDER>& j) {
+            const int kofs = (k >> 2) * 64 + (k & 3) * 16;
+            j.v = phi[colbase[0] + kofs];
+            if constexpr (ORDER >= 1) {
+#pragma unroll
+                for (int d = 0; d < SD; ++d) j.g[d] = phi[colbase[1 + d] + kofs];
+            }
+            if constexpr (ORDER >= 2) {
+#pragma unroll
+                for (int h = 0; h < SD * (SD + 1) / 2; ++h) j.h[h] = phi[colbase[1 + SD + h] + kofs];
+            }
+        };
+        if (!(a.debug & 1)) {
+            Jet<SD, ORDER> cur, prv, nw;
+            jet_zero(cur);
+            jet_zero(prv);
+            cur.v = a.phi0;
+            put(0, cur);
+            if constexpr (4 * KS > NEXP) {  // K padding rows must read as zero
+                Jet<SD, ORDER> z;
+                jet_zero(z);
+#pragma unroll
+                for (int k = NEXP; k < 4 * KS; ++k) put(k, z);
+            }
+            Factors<SD, ORDER> F;
+            int last_dst = 0;
+            int fcodim = -1;
+#pragma unroll
+            for (int s = 0; s < (NEXP > 1 ? NEXP - 1 : 0); ++s) {
+                if (TBL.codim[s] != fcodim) {
+                    fcodim = TBL.codim[s];
+                    make_factors<SD, ORDER>(F, fcodim, X, J);
+                }
+                if (TBL.prv[s] < 0) {
+                    if (TBL.cur[s] != last_dst) get(TBL.cur[s], cur);
+                    jet_zero(prv);
+                }
+                const double cA = a.coef[3 * s + 0], cB = a.coef[3 * s + 1], cC = a.coef[3 * s + 2];
+                apply_step<SD, ORDER>(nw, cur, prv, F, cA, cB, cC);
+                put(TBL.dst[s], nw);
+                prv = cur;
+                cur = nw;
+                last_dst = TBL.dst[s];
+            }
+        }
+        wave_lds_fence();
+
+        // ---------------- phase 2: contraction ----------------
+        double* gout = a.out + (size_t)req * reqsize;
+        if (!(a.debug & 2)) {
+            double breg[NT][KS];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) breg[nt][ks] = phi[(nt * KS + ks) * 64 + lane];
+            wave_lds_fence();  // every Phi read is done: the image may overwrite it
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int so = soff[nt];
+#pragma unroll
+                for (int mt = 0; mt < MT16; ++mt) {
+                    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[mt * KS + ks], breg[nt][ks], acc, 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        constexpr int dummy = 0;
+                        (void)dummy;
+                        const int mbase = 16 * mt + 4 * j;  // + (lane >> 4)
+                        if (mbase + 3 < ROWS) {
+                            if (so >= 0) phi[so + mbase * npts] = acc[j];
+                        } else if (mbase < ROWS) {
+                            if (so >= 0 && mbase + (lane >> 4) < ROWS) phi[so + mbase * npts] = acc[j];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int m4 = 0; m4 < M4; ++m4) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        acc = __builtin_amdgcn_mfma_f64_4x4x4f64(areg4[m4 * KS + ks], breg[nt][ks], acc, 0, 0, 0);
+                    const int mbase = 16 * MT16 + 4 * m4;
+                    if (mbase + 3 < ROWS) {
+                        if (so >= 0) phi[so + mbase * npts] = acc;
+                    } else {
+                        if (so >= 0 && mbase + (lane >> 4) < ROWS) phi[so + mbase * npts] = acc;
+                    }
+                }
+            }
+        }
+        wave_lds_fence();
+
+        // ---------------- phase 3: image -> HBM, 16 B per lane ----------------
+        if (!(a.debug & 4)) {
+            if ((reqsize & 1) == 0) {
+                const v2d* s2 = reinterpret_cast<const v2d*>(phi);
+                v2d* g2 = reinterpret_cast<v2d*>(gout);
+                for (int i = lane; i < (reqsize >> 1); i += 64) g2[i] = s2[i];
+            } else {
+                for (int i = lane; i < reqsize; i += 64) gout[i] = phi[i];
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+}  // namespace fxk

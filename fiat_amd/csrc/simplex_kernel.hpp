@@ -46,6 +46,7 @@ struct TabArgs {
     int nchunk;  // point chunks per request (1 unless chunked)
     int phi_doubles;    // per-wave LDS doubles for the Phi fragments
     int stage_doubles;  // per-wave LDS doubles for the output image (0: direct stores)
+    int debug;          // measurement builds only: 1 skip recurrence, 2 skip MFMA, 4 skip HBM stores
 };
 
 template <int SD> struct Dims {
@@ -343,7 +344,8 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
             Factors<SD, ORDER> F;
             int fcodim = -1;
             int last_dst = 0;
-            for (int s = 0; s < a.nsteps; ++s) {
+            const int nsteps = (a.debug & 1) ? 0 : a.nsteps;
+            for (int s = 0; s < nsteps; ++s) {
                 const Step st = a.steps[s];
                 if (st.codim != fcodim) {
                     fcodim = st.codim;
@@ -371,7 +373,8 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
         const int NT = (ncols + 15) >> 4;
         const bool staged = a.stage_doubles > 0;
         double* gout = a.out + (size_t)r0 * reqsize;
-        for (int nt = 0; nt < NT; ++nt) {
+        const int NTrun = (a.debug & 2) ? 0 : NT;
+        for (int nt = 0; nt < NTrun; ++nt) {
             // decode this lane's output column
             const int c = (nt << 4) + (lane & 15);
             const int cr = idiv_small(c, rinv_req);
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
             }
         }
 
-        if (staged) {
+        if (staged && !(a.debug & 4)) {
             wave_lds_fence();
             const long long total = (long long)Pcur * reqsize;  // doubles, contiguous in HBM
             if ((reqsize & 1) == 0) {
