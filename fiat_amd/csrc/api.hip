@@ -340,7 +340,8 @@ struct Launch {
     int grid = 0, lds_bytes = 0;
     // shape-specialised path
     int fixed_id = -1;
-    fxk::FixedArgs fargs;
+    fxk::FixedArgs<0> fhead;           // everything but the coefficients
+    std::vector<double> fcoef;         // [nsteps][3]
     int fgrid = 0, flds_bytes = 0;
 };
 
@@ -367,11 +368,26 @@ bool table_matches(const fx::Program& P) {
 
 template <int SD, int N, int ORDER, int ROWS, int NT>
 int launch_fixed(const Launch& L, hipStream_t s) {
+    constexpr int NC = fxk::FixedNC<SD, N>::value;
+    fxk::FixedArgs<NC> fa;
+    fa.pts = L.fhead.pts;
+    fa.verts = L.fhead.verts;
+    fa.out = L.fhead.out;
+    fa.afrag = L.fhead.afrag;
+    fa.phi0 = L.fhead.phi0;
+    memcpy(fa.A0, L.fhead.A0, sizeof fa.A0);
+    memcpy(fa.b0, L.fhead.b0, sizeof fa.b0);
+    fa.nreq = L.fhead.nreq;
+    fa.npts = L.fhead.npts;
+    fa.lds_doubles = L.fhead.lds_doubles;
+    fa.debug = L.fhead.debug;
+    if ((int)L.fcoef.size() != NC) return fail(FX_EINVAL, "internal: coefficient table size mismatch");
+    memcpy(fa.coef, L.fcoef.data(), NC * sizeof(double));
     auto kern = fxk::tabulate_simplex_fixed<SD, N, ORDER, ROWS, NT, FIXED_NW>;
     if (L.flds_bytes > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     L.flds_bytes));
-    hipLaunchKernelGGL(kern, dim3(L.fgrid), dim3(64 * FIXED_NW), L.flds_bytes, s, L.fargs);
+    hipLaunchKernelGGL(kern, dim3(L.fgrid), dim3(64 * FIXED_NW), L.flds_bytes, s, fa);
     HIP_TRY(hipGetLastError());
     return FX_OK;
 }
@@ -486,13 +502,18 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             if (f.sd != e->sd || f.n != e->n || f.order != order || f.rows != rows || f.nt != nt_need) continue;
             bool ok = (e->sd == 3 && e->n == 3) ? table_matches<3, 3>(e->prog) : false;
             if (!ok) continue;
-            fxk::FixedArgs& fa = L.fargs;
+            fxk::FixedArgs<0>& fa = L.fhead;
             memset(&fa, 0, sizeof fa);
+            L.fcoef.resize(e->prog.steps.size() * 3);
+            for (size_t k = 0; k < e->prog.steps.size(); ++k) {
+                L.fcoef[3 * k + 0] = e->prog.steps[k].A;
+                L.fcoef[3 * k + 1] = e->prog.steps[k].B;
+                L.fcoef[3 * k + 2] = e->prog.steps[k].C;
+            }
             fa.pts = pts;
             fa.verts = verts;
             fa.out = out;
             fa.afrag = e->d_afrag_split;
-            fa.coef = e->d_coef;
             fa.phi0 = e->prog.phi0;
             memcpy(fa.A0, e->A0, sizeof fa.A0);
             memcpy(fa.b0, e->b0, sizeof fa.b0);

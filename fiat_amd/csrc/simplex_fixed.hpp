@@ -72,12 +72,27 @@ template <int SD, int N> struct StepTable {
     }
 };
 
-struct FixedArgs {
+// NC = 3 * number of steps.  The coefficients travel BY VALUE in the kernel
+// argument segment: that is constant address space, so every use is a scalar load
+// with a compile-time offset (a pointer into global memory makes hipcc fall back to
+// vector loads + vmcnt(0) stalls inside the recurrence, measured 2x slower).
+template <int NC> // Two doubles that are meaningful in the lower 32 lanes -> one double whose lower
+// half carries `a` and whose upper half carries b's lower half (v_permlane32_swap).
+// Lets one LDS store instruction carry two table components of <= 32 points.
+__device__ __forceinline__ double pack_halves(double a, double b) {
+    unsigned a0 = (unsigned)__double2loint(a), a1 = (unsigned)__double2hiint(a);
+    unsigned b0 = (unsigned)__double2loint(b), b1 = (unsigned)__double2hiint(b);
+    auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    return __hiloint2double((int)r1[0], (int)r0[0]);
+}
+
+template <int NC> struct FixedArgs {
     const double* pts;    // [nreq][npts][SD]
     const double* verts;  // [nreq][SD+1][SD] or nullptr
     double* out;          // [nreq][NTAB][ROWS][npts]
     const double* afrag;  // 16x16x4 fragments [MT16][KS][64] then 4x4x4 fragments [M4][KS][64]
-    const double* coef;   // [nsteps][3] = A, B, C
+    double coef[NC > 0 ? NC : 1];  // [nsteps][3] = A, B, C
     double phi0;
     double A0[9];
     double b0[3];
@@ -91,8 +106,12 @@ struct FixedArgs {
 constexpr int rows_full16(int rows) { return (rows % 16 != 0 && rows % 16 <= 12) ? rows / 16 : (rows + 15) / 16; }
 constexpr int rows_blk4(int rows) { return (rows % 16 != 0 && rows % 16 <= 12) ? (rows % 16 + 3) / 4 : 0; }
 
+template <int SD, int N> struct FixedNC {
+    static constexpr int value = 3 * (cx_binom(N + SD, SD) - 1);
+};
+
 template <int SD, int N, int ORDER, int ROWS, int NT, int NW>
-__global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArgs a) {
+__global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArgs<FixedNC<SD, N>::value> a) {
     constexpr int NTAB = NTab<SD, ORDER>::value;
     constexpr StepTable<SD, N> TBL{};
     constexpr int NEXP = StepTable<SD, N>::NEXP;
@@ -132,25 +151,46 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArg
             soff[nt] = (c < ncols) ? ct * table + cp + (lane >> 4) * npts : -1;
         }
     }
-    // recurrence lanes: lane <-> point
+    // recurrence lanes: lane <-> point (lanes 0..npts-1; npts <= 32 for this kernel).
+    // LDS stores are packed: lanes 32.. carry the odd component of each pair.
     const bool active = lane < npts;
     const int pl = active ? lane : 0;
+    const int pu = ((lane & 31) < npts) ? (lane & 31) : 0;  // point of this lane for packed stores
+    const bool active_pair = (lane & 31) < npts;
     int colbase[NTAB];
 #pragma unroll
     for (int t = 0; t < NTAB; ++t) {
         const int c = t * npts + pl;
         colbase[t] = (c >> 4) * KS * 64 + (c & 15);
     }
+    int pairbase[NTAB / 2 > 0 ? NTAB / 2 : 1];
+#pragma unroll
+    for (int u = 0; u < NTAB / 2; ++u) {
+        const int c = (2 * u + (lane >> 5)) * npts + pu;
+        pairbase[u] = (c >> 4) * KS * 64 + (c & 15);
+    }
 
-    for (long long req = (long long)blockIdx.x * NW + wave; req < a.nreq; req += (long long)gridDim.x * NW) {
+    const long long stride = (long long)gridDim.x * NW;
+    long long req = (long long)blockIdx.x * NW + wave;
+    double xnext[SD];  // points of the NEXT request are fetched while this one is computed
+    if (req < a.nreq) {
+        const double* pp = a.pts + ((size_t)req * npts + pl) * SD;
+#pragma unroll
+        for (int d = 0; d < SD; ++d) xnext[d] = pp[d];
+    }
+    for (; req < a.nreq; req += stride) {
         // ---------------- phase 1: recurrence ----------------
         double X[SD];
         double J[SD][SD];
         {
             double x[SD];
-            const double* pp = a.pts + ((size_t)req * npts + pl) * SD;
 #pragma unroll
-            for (int d = 0; d < SD; ++d) x[d] = pp[d];
+            for (int d = 0; d < SD; ++d) x[d] = xnext[d];
+            if (req + stride < a.nreq) {
+                const double* pp = a.pts + ((size_t)(req + stride) * npts + pl) * SD;
+#pragma unroll
+                for (int d = 0; d < SD; ++d) xnext[d] = pp[d];
+            }
             double bb[SD];
             if (a.verts != nullptr) {
                 cell_map<SD>(a.verts + (size_t)req * (SD + 1) * SD, J, bb);
@@ -172,16 +212,23 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArg
         }
         auto put = [&](int k, const Jet<SD, ORDER>& j) {
             const int kofs = (k >> 2) * 64 + (k & 3) * 16;
-            if (active) {
-                phi[colbase[0] + kofs] = j.v;
-                if constexpr (ORDER >= 1) {
+            double comp[NTAB];
+            comp[0] = j.v;
+            if constexpr (ORDER >= 1) {
 #pragma unroll
-                    for (int d = 0; d < SD; ++d) phi[colbase[1 + d] + kofs] = j.g[d];
-                }
-                if constexpr (ORDER >= 2) {
+                for (int d = 0; d < SD; ++d) comp[1 + d] = j.g[d];
+            }
+            if constexpr (ORDER >= 2) {
 #pragma unroll
-                    for (int h = 0; h < SD * (SD + 1) / 2; ++h) phi[colbase[1 + SD + h] + kofs] = j.h[h];
-                }
+                for (int h = 0; h < SD * (SD + 1) / 2; ++h) comp[1 + SD + h] = j.h[h];
+            }
+#pragma unroll
+            for (int u = 0; u < NTAB / 2; ++u) {
+                const double packed = pack_halves(comp[2 * u], comp[2 * u + 1]);
+                if (active_pair) phi[pairbase[u] + kofs] = packed;
+            }
+            if constexpr (NTAB % 2 == 1) {
+                if (active) phi[colbase[NTAB - 1] + kofs] = comp[NTAB - 1];
             }
         };
         auto get = [&](int k, Jet<SD, ORDER>& j) {
@@ -197,11 +244,13 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArg
             }
         };
         if (!(a.debug & 1)) {
-            Jet<SD, ORDER> cur, prv, nw;
-            jet_zero(cur);
-            jet_zero(prv);
-            cur.v = a.phi0;
-            put(0, cur);
+            // every member lives in a register array with compile-time indices: the
+            // compiler keeps only the seeds still needed by later chains alive, and
+            // the recurrence never reads LDS back
+            Jet<SD, ORDER> mem[NEXP];
+            jet_zero(mem[0]);
+            mem[0].v = a.phi0;
+            put(0, mem[0]);
             if constexpr (4 * KS > NEXP) {  // K padding rows must read as zero
                 Jet<SD, ORDER> z;
                 jet_zero(z);
@@ -209,7 +258,8 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArg
                 for (int k = NEXP; k < 4 * KS; ++k) put(k, z);
             }
             Factors<SD, ORDER> F;
-            int last_dst = 0;
+            Jet<SD, ORDER> zero;
+            jet_zero(zero);
             int fcodim = -1;
 #pragma unroll
             for (int s = 0; s < (NEXP > 1 ? NEXP - 1 : 0); ++s) {
@@ -217,16 +267,10 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArg
                     fcodim = TBL.codim[s];
                     make_factors<SD, ORDER>(F, fcodim, X, J);
                 }
-                if (TBL.prv[s] < 0) {
-                    if (TBL.cur[s] != last_dst) get(TBL.cur[s], cur);
-                    jet_zero(prv);
-                }
                 const double cA = a.coef[3 * s + 0], cB = a.coef[3 * s + 1], cC = a.coef[3 * s + 2];
-                apply_step<SD, ORDER>(nw, cur, prv, F, cA, cB, cC);
-                put(TBL.dst[s], nw);
-                prv = cur;
-                cur = nw;
-                last_dst = TBL.dst[s];
+                apply_step<SD, ORDER>(mem[TBL.dst[s]], mem[TBL.cur[s]], TBL.prv[s] < 0 ? zero : mem[TBL.prv[s]], F, cA,
+                                      cB, cC);
+                put(TBL.dst[s], mem[TBL.dst[s]]);
             }
         }
         wave_lds_fence();
@@ -254,10 +298,11 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArg
                         constexpr int dummy = 0;
                         (void)dummy;
                         const int mbase = 16 * mt + 4 * j;  // + (lane >> 4)
+                        double* dst = (a.debug & 8) ? gout : phi;
                         if (mbase + 3 < ROWS) {
-                            if (so >= 0) phi[so + mbase * npts] = acc[j];
+                            if (so >= 0) dst[so + mbase * npts] = acc[j];
                         } else if (mbase < ROWS) {
-                            if (so >= 0 && mbase + (lane >> 4) < ROWS) phi[so + mbase * npts] = acc[j];
+                            if (so >= 0 && mbase + (lane >> 4) < ROWS) dst[so + mbase * npts] = acc[j];
                         }
                     }
                 }
@@ -268,10 +313,11 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArg
                     for (int ks = 0; ks < KS; ++ks)
                         acc = __builtin_amdgcn_mfma_f64_4x4x4f64(areg4[m4 * KS + ks], breg[nt][ks], acc, 0, 0, 0);
                     const int mbase = 16 * MT16 + 4 * m4;
+                    double* dst = (a.debug & 8) ? gout : phi;
                     if (mbase + 3 < ROWS) {
-                        if (so >= 0) phi[so + mbase * npts] = acc;
+                        if (so >= 0) dst[so + mbase * npts] = acc;
                     } else {
-                        if (so >= 0 && mbase + (lane >> 4) < ROWS) phi[so + mbase * npts] = acc;
+                        if (so >= 0 && mbase + (lane >> 4) < ROWS) dst[so + mbase * npts] = acc;
                     }
                 }
             }
@@ -279,11 +325,25 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArg
         wave_lds_fence();
 
         // ---------------- phase 3: image -> HBM, 16 B per lane ----------------
-        if (!(a.debug & 4)) {
+        if (!(a.debug & (4 | 8))) {
             if ((reqsize & 1) == 0) {
+                // all LDS reads are issued before the first store so that their
+                // latencies overlap (NT column tiles bound the image size)
+                constexpr int NIT = (NT * 16 * ROWS / 2 + 63) / 64;
                 const v2d* s2 = reinterpret_cast<const v2d*>(phi);
                 v2d* g2 = reinterpret_cast<v2d*>(gout);
-                for (int i = lane; i < (reqsize >> 1); i += 64) g2[i] = s2[i];
+                const int nchunk = reqsize >> 1;
+                v2d buf[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int i = it * 64 + lane;
+                    if (i < nchunk) buf[it] = s2[i];
+                }
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int i = it * 64 + lane;
+                    if (i < nchunk) g2[i] = buf[it];
+                }
             } else {
                 for (int i = lane; i < reqsize; i += 64) gout[i] = phi[i];
             }
