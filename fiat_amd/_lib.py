@@ -15,7 +15,7 @@ import numpy as np
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfiat_amd.so")
+LIB_PATH = os.environ.get("FIAT_AMD_LIB", os.path.join(_HERE, "csrc", "libfiat_amd.so"))  # override: A/B builds
 
 FX_OK = 0
 FX_EINVAL, FX_ENOTIMPL, FX_ESINGULAR, FX_EHIP, FX_ENOMEM = -1, -2, -3, -4, -5

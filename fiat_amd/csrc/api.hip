@@ -15,6 +15,7 @@
 #include "plan.hpp"
 #include "simplex_kernel.hpp"
 #include "simplex_fixed.hpp"
+#include "simplex_stream.hpp"
 
 namespace {
 
@@ -112,6 +113,7 @@ struct fx_element {
     fxk::Step* d_steps = nullptr;
     double* d_afrag = nullptr;
     double* d_afrag_split = nullptr;  // layout of the shape-specialised kernels
+    double* d_afrag_stream = nullptr; // same, K in production order (K-streamed kernel)
     double* d_coef = nullptr;         // [nsteps][3]
 };
 
@@ -239,6 +241,15 @@ static int upload_coeffs(fx_element* e, int ndof, int vdim, const double* coeffs
     }
     HIP_TRY(hipMalloc(&e->d_afrag_split, F2.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(e->d_afrag_split, F2.data(), F2.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<int> kperm(nexp, 0);
+    for (size_t i = 0; i < e->prog.steps.size() && (int)i + 1 < nexp; ++i) kperm[i + 1] = e->prog.steps[i].dst;
+    std::vector<double> F3 = fx::pack_a_fragments_split(C, rows, nexp, &kperm);
+    if (e->d_afrag_stream) {
+        HIP_TRY(hipFree(e->d_afrag_stream));
+        e->d_afrag_stream = nullptr;
+    }
+    HIP_TRY(hipMalloc(&e->d_afrag_stream, F3.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(e->d_afrag_stream, F3.data(), F3.size() * sizeof(double), hipMemcpyHostToDevice));
     e->ndof = ndof;
     e->vdim = vdim;
     e->MT = (rows + 15) / 16;
@@ -309,6 +320,7 @@ int fx_element_destroy(fx_element* e) {
     if (e->d_steps) (void)hipFree(e->d_steps);
     if (e->d_afrag) (void)hipFree(e->d_afrag);
     if (e->d_afrag_split) (void)hipFree(e->d_afrag_split);
+    if (e->d_afrag_stream) (void)hipFree(e->d_afrag_stream);
     if (e->d_coef) (void)hipFree(e->d_coef);
     delete e;
     return FX_OK;
@@ -342,7 +354,9 @@ struct Launch {
     int fixed_id = -1;
     fxk::FixedArgs<0> fhead;           // everything but the coefficients
     std::vector<double> fcoef;         // [nsteps][3]
+    std::vector<double> fucoef;        // [nsteps][12], uniform-cell factor derivatives
     int fgrid = 0, flds_bytes = 0;
+    int fkind = 0;  // 0: LDS-image kernel (simplex_fixed.hpp), 1: K-streamed kernel (simplex_stream.hpp)
 };
 
 // ---- registry of shape-specialised kernels ----------------------------------------
@@ -368,6 +382,7 @@ bool table_matches(const fx::Program& P) {
 
 template <int SD, int N, int ORDER, int ROWS, int NT>
 int launch_fixed(const Launch& L, hipStream_t s) {
+    using KernT = void (*)(const fxk::FixedArgs<fxk::FixedNC<SD, N>::value>);
     constexpr int NC = fxk::FixedNC<SD, N>::value;
     fxk::FixedArgs<NC> fa;
     fa.pts = L.fhead.pts;
@@ -381,9 +396,13 @@ int launch_fixed(const Launch& L, hipStream_t s) {
     fa.npts = L.fhead.npts;
     fa.lds_doubles = L.fhead.lds_doubles;
     fa.debug = L.fhead.debug;
-    if ((int)L.fcoef.size() != NC) return fail(FX_EINVAL, "internal: coefficient table size mismatch");
+    if ((int)L.fcoef.size() != NC || (int)L.fucoef.size() != 4 * NC)
+        return fail(FX_EINVAL, "internal: coefficient table size mismatch");
     memcpy(fa.coef, L.fcoef.data(), NC * sizeof(double));
-    auto kern = fxk::tabulate_simplex_fixed<SD, N, ORDER, ROWS, NT, FIXED_NW>;
+    memcpy(fa.ucoef, L.fucoef.data(), 4 * NC * sizeof(double));
+    KernT kern = L.fkind == 1 ? (L.fhead.verts ? (KernT)fxk::tabulate_simplex_stream<SD, N, ORDER, ROWS, NT, FIXED_NW, false>
+                                               : (KernT)fxk::tabulate_simplex_stream<SD, N, ORDER, ROWS, NT, FIXED_NW, true>)
+                              : (KernT)fxk::tabulate_simplex_fixed<SD, N, ORDER, ROWS, NT, FIXED_NW>;
     if (L.flds_bytes > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     L.flds_bytes));
@@ -505,15 +524,38 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             fxk::FixedArgs<0>& fa = L.fhead;
             memset(&fa, 0, sizeof fa);
             L.fcoef.resize(e->prog.steps.size() * 3);
+            L.fucoef.assign(e->prog.steps.size() * 12, 0.0);
             for (size_t k = 0; k < e->prog.steps.size(); ++k) {
-                L.fcoef[3 * k + 0] = e->prog.steps[k].A;
-                L.fcoef[3 * k + 1] = e->prog.steps[k].B;
-                L.fcoef[3 * k + 2] = e->prog.steps[k].C;
+                const fx::Step& st = e->prog.steps[k];
+                L.fcoef[3 * k + 0] = st.A;
+                L.fcoef[3 * k + 1] = st.B;
+                L.fcoef[3 * k + 2] = st.C;
+                // point-independent derivatives of the collapsed-coordinate factors on the
+                // element's own cell (rows of A0 padded with zeros, expansions.py:43-63)
+                const int sd = e->sd;
+                double dfa[3] = {0, 0, 0}, dfb[3] = {0, 0, 0};
+                for (int d = 0; d < sd; ++d) {
+                    double dx = e->A0[st.codim * sd + d];
+                    double dy = st.codim + 1 < sd ? e->A0[(st.codim + 1) * sd + d] : 0.0;
+                    double dz = st.codim + 2 < sd ? e->A0[(st.codim + 2) * sd + d] : 0.0;
+                    dfb[d] = 0.5 * (dy + dz);
+                    dfa[d] = dx + dfb[d];
+                }
+                double* u = &L.fucoef[12 * k];
+                for (int d = 0; d < sd; ++d) {
+                    u[d] = st.A * dfa[d] - st.B * dfb[d];
+                    u[3 + d] = -2.0 * st.C * dfb[d];
+                }
+                int h = 0;
+                for (int d1 = 0; d1 < sd; ++d1)
+                    for (int d2 = d1; d2 < sd; ++d2) u[6 + h++] = -2.0 * st.C * dfb[d1] * dfb[d2];
             }
             fa.pts = pts;
             fa.verts = verts;
             fa.out = out;
-            fa.afrag = e->d_afrag_split;
+            const char* kk = getenv("FIAT_AMD_KERNEL");
+            L.fkind = (kk && !strcmp(kk, "stream")) ? 1 : 0;  // default: LDS-image kernel
+            fa.afrag = L.fkind == 1 ? e->d_afrag_stream : e->d_afrag_split;
             fa.phi0 = e->prog.phi0;
             memcpy(fa.A0, e->A0, sizeof fa.A0);
             memcpy(fa.b0, e->b0, sizeof fa.b0);
@@ -522,6 +564,22 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             fa.debug = a.debug;
             long long need = std::max<long long>((long long)f.nt * e->KS * 64, (long long)ntab * rows * npts);
             need = (need + 1) & ~1LL;
+            if (L.fkind == 1) {
+                if (npts > 32) continue;  // packed LDS stores need the points in one half-wave
+                fa.lds_doubles = f.nt * 64;
+                {
+                    int rem = rows % 16;
+                    bool split = rem != 0 && rem <= 12;
+                    int nfrag = ((split ? rows / 16 : (rows + 15) / 16) + (split ? (rem + 3) / 4 : 0)) * e->KS;
+                    L.flds_bytes = (nfrag * 64 + f.nt * 64 * FIXED_NW) * 8;
+                }
+                // registers bound the occupancy: ask for every workgroup the CU can hold
+                long long want = (long long)ctx->num_cu * 4;
+                long long nwg = (nreq + FIXED_NW - 1) / FIXED_NW;
+                L.fgrid = (int)std::max<long long>(1, std::min<long long>(nwg, want));
+                L.fixed_id = (int)i;
+                break;
+            }
             // 8 waves per CU (2 workgroups of 4 waves): pad the request to 1/2 of the CU's LDS
             long long per_wave = std::max<long long>(need * 8, (long long)(ctx->lds_per_cu / 8));
             per_wave &= ~15LL;

@@ -251,7 +251,10 @@ inline std::vector<double> pack_a_fragments(const std::vector<double>& C, int ro
 // tiles first ([MT16][KS][64]), then 4-row blocks for v_mfma_f64_4x4x4_4b
 // ([M4][KS][64]; lane l holds C[base + (l & 3)][4*ks + (l >> 4)], the block bits
 // (l >> 2) & 3 see the same A).  A remainder of 13..15 rows uses a padded 16-row tile.
-inline std::vector<double> pack_a_fragments_split(const std::vector<double>& C, int rows, int nexp) {
+inline std::vector<double> pack_a_fragments_split(const std::vector<double>& C, int rows, int nexp,
+                                                  const std::vector<int>* kperm = nullptr) {
+    // kperm (optional): K slot -> member index (production order of the recurrence)
+    auto col = [&](int k) { return kperm ? (*kperm)[k] : k; };
     int rem = rows % 16;
     bool split = rem != 0 && rem <= 12;
     int MT16 = split ? rows / 16 : (rows + 15) / 16;
@@ -262,13 +265,13 @@ inline std::vector<double> pack_a_fragments_split(const std::vector<double>& C, 
         for (int ks = 0; ks < KS; ++ks)
             for (int l = 0; l < 64; ++l) {
                 int m = 16 * mt + (l & 15), k = 4 * ks + (l >> 4);
-                if (m < rows && k < nexp) F[((size_t)mt * KS + ks) * 64 + l] = C[(size_t)m * nexp + k];
+                if (m < rows && k < nexp) F[((size_t)mt * KS + ks) * 64 + l] = C[(size_t)m * nexp + col(k)];
             }
     for (int m4 = 0; m4 < M4; ++m4)
         for (int ks = 0; ks < KS; ++ks)
             for (int l = 0; l < 64; ++l) {
                 int m = 16 * MT16 + 4 * m4 + (l & 3), k = 4 * ks + (l >> 4);
-                if (m < rows && k < nexp) F[((size_t)(MT16 + m4) * KS + ks) * 64 + l] = C[(size_t)m * nexp + k];
+                if (m < rows && k < nexp) F[((size_t)(MT16 + m4) * KS + ks) * 64 + l] = C[(size_t)m * nexp + col(k)];
             }
     return F;
 }

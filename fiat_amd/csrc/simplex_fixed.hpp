@@ -17,6 +17,14 @@
 #pragma once
 #include "simplex_kernel.hpp"
 
+// build-time switches of the LDS-image kernel (A/B measured)
+#ifndef FX_PACK
+#define FX_PACK 0          // 1: pack two tables per LDS store with v_permlane32_swap
+#endif
+#ifndef FX_UNROLL_COPY
+#define FX_UNROLL_COPY 0   // 1: issue all image reads before the first HBM store
+#endif
+
 namespace fxk {
 
 constexpr int cx_binom(int n, int k) {
@@ -76,7 +84,7 @@ template <int SD, int N> struct StepTable {
 // argument segment: that is constant address space, so every use is a scalar load
 // with a compile-time offset (a pointer into global memory makes hipcc fall back to
 // vector loads + vmcnt(0) stalls inside the recurrence, measured 2x slower).
-template <int NC> // Two doubles that are meaningful in the lower 32 lanes -> one double whose lower
+// Two doubles that are meaningful in the lower 32 lanes -> one double whose lower
 // half carries `a` and whose upper half carries b's lower half (v_permlane32_swap).
 // Lets one LDS store instruction carry two table components of <= 32 points.
 __device__ __forceinline__ double pack_halves(double a, double b) {
@@ -93,6 +101,12 @@ template <int NC> struct FixedArgs {
     double* out;          // [nreq][NTAB][ROWS][npts]
     const double* afrag;  // 16x16x4 fragments [MT16][KS][64] then 4x4x4 fragments [M4][KS][64]
     double coef[NC > 0 ? NC : 1];  // [nsteps][3] = A, B, C
+    // uniform-cell case (verts == nullptr): factor derivatives do not depend on the
+    // point, the host folds them with the step coefficients:
+    //   ucoef[s][0..2]  = d/dx_d (A fa - B fb)          = A dfa[d] - B dfb[d]
+    //   ucoef[s][3..5]  = K_d with d/dx_d (-C fc) = K_d fb,  K_d = -2 C dfb[d]
+    //   ucoef[s][6..11] = -2 C dfb[d1] dfb[d2]  (d1 <= d2), the Hessian of -C fc
+    double ucoef[NC > 0 ? 4 * NC : 1];
     double phi0;
     double A0[9];
     double b0[3];
@@ -106,12 +120,64 @@ template <int NC> struct FixedArgs {
 constexpr int rows_full16(int rows) { return (rows % 16 != 0 && rows % 16 <= 12) ? rows / 16 : (rows + 15) / 16; }
 constexpr int rows_blk4(int rows) { return (rows % 16 != 0 && rows % 16 <= 12) ? (rows % 16 + 3) / 4 : 0; }
 
+// uniform-cell step: same algebra as apply_step with the point-independent factor
+// derivatives taken from scalar registers (u = ucoef row of the step)
+template <int SD, int ORDER>
+__device__ __forceinline__ void apply_step_uniform(Jet<SD, ORDER>& nw, const Jet<SD, ORDER>& cur,
+                                                   const Jet<SD, ORDER>& prv, double fa, double fb, double fc,
+                                                   double A, double B, double C,
+                                                   const __attribute__((address_space(4))) double* u) {
+    const double f = A * fa - B * fb;
+    const double g = -C * fc;
+    nw.v = cur.v * f + prv.v * g;
+    if constexpr (ORDER >= 1) {
+        double dg[SD];
+#pragma unroll
+        for (int d = 0; d < SD; ++d) {
+            dg[d] = u[3 + d] * fb;
+            nw.g[d] = cur.g[d] * f + cur.v * u[d] + prv.g[d] * g + prv.v * dg[d];
+        }
+        if constexpr (ORDER >= 2) {
+            int h = 0;
+#pragma unroll
+            for (int d1 = 0; d1 < SD; ++d1)
+#pragma unroll
+                for (int d2 = d1; d2 < SD; ++d2) {
+                    double t = cur.h[h] * f + u[d1] * cur.g[d2] + u[d2] * cur.g[d1];
+                    t += prv.h[h] * g + dg[d1] * prv.g[d2] + dg[d2] * prv.g[d1];
+                    t += u[6 + h] * prv.v;
+                    nw.h[h] = t;
+                    ++h;
+                }
+        }
+    }
+}
+
+// fa, fb, fc of one codimension from the reference coordinates (no derivatives)
+template <int SD>
+__device__ __forceinline__ void point_factors(int codim, const double* X, double& fa, double& fb, double& fc) {
+    double x = X[0], y = -1.0, z = -1.0;
+    if (codim == 0) {
+        x = X[0];
+        if constexpr (SD > 1) y = X[1];
+        if constexpr (SD > 2) z = X[2];
+    } else if (codim == 1) {
+        if constexpr (SD > 1) x = X[1];
+        if constexpr (SD > 2) y = X[2];
+    } else {
+        if constexpr (SD > 2) x = X[2];
+    }
+    fb = 0.5 * (y + z);
+    fa = x + (fb + 1.0);
+    fc = fb * fb;
+}
+
 template <int SD, int N> struct FixedNC {
     static constexpr int value = 3 * (cx_binom(N + SD, SD) - 1);
 };
 
 template <int SD, int N, int ORDER, int ROWS, int NT, int NW>
-__global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArgs<FixedNC<SD, N>::value> a) {
+__global__ __launch_bounds__(64 * NW, 2) void tabulate_simplex_fixed(const FixedArgs<FixedNC<SD, N>::value> a) {
     constexpr int NTAB = NTab<SD, ORDER>::value;
     constexpr StepTable<SD, N> TBL{};
     constexpr int NEXP = StepTable<SD, N>::NEXP;
@@ -222,13 +288,20 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArg
 #pragma unroll
                 for (int h = 0; h < SD * (SD + 1) / 2; ++h) comp[1 + SD + h] = j.h[h];
             }
+            if constexpr (FX_PACK) {
 #pragma unroll
-            for (int u = 0; u < NTAB / 2; ++u) {
-                const double packed = pack_halves(comp[2 * u], comp[2 * u + 1]);
-                if (active_pair) phi[pairbase[u] + kofs] = packed;
-            }
-            if constexpr (NTAB % 2 == 1) {
-                if (active) phi[colbase[NTAB - 1] + kofs] = comp[NTAB - 1];
+                for (int u = 0; u < NTAB / 2; ++u) {
+                    const double packed = pack_halves(comp[2 * u], comp[2 * u + 1]);
+                    if (active_pair) phi[pairbase[u] + kofs] = packed;
+                }
+                if constexpr (NTAB % 2 == 1) {
+                    if (active) phi[colbase[NTAB - 1] + kofs] = comp[NTAB - 1];
+                }
+            } else {
+                if (active) {
+#pragma unroll
+                    for (int t = 0; t < NTAB; ++t) phi[colbase[t] + kofs] = comp[t];
+                }
             }
         };
         auto get = [&](int k, Jet<SD, ORDER>& j) {
@@ -298,11 +371,10 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArg
                         constexpr int dummy = 0;
                         (void)dummy;
                         const int mbase = 16 * mt + 4 * j;  // + (lane >> 4)
-                        double* dst = (a.debug & 8) ? gout : phi;
                         if (mbase + 3 < ROWS) {
-                            if (so >= 0) dst[so + mbase * npts] = acc[j];
+                            if (so >= 0) phi[so + mbase * npts] = acc[j];
                         } else if (mbase < ROWS) {
-                            if (so >= 0 && mbase + (lane >> 4) < ROWS) dst[so + mbase * npts] = acc[j];
+                            if (so >= 0 && mbase + (lane >> 4) < ROWS) phi[so + mbase * npts] = acc[j];
                         }
                     }
                 }
@@ -313,11 +385,10 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArg
                     for (int ks = 0; ks < KS; ++ks)
                         acc = __builtin_amdgcn_mfma_f64_4x4x4f64(areg4[m4 * KS + ks], breg[nt][ks], acc, 0, 0, 0);
                     const int mbase = 16 * MT16 + 4 * m4;
-                    double* dst = (a.debug & 8) ? gout : phi;
                     if (mbase + 3 < ROWS) {
-                        if (so >= 0) dst[so + mbase * npts] = acc;
+                        if (so >= 0) phi[so + mbase * npts] = acc;
                     } else {
-                        if (so >= 0 && mbase + (lane >> 4) < ROWS) dst[so + mbase * npts] = acc;
+                        if (so >= 0 && mbase + (lane >> 4) < ROWS) phi[so + mbase * npts] = acc;
                     }
                 }
             }
@@ -325,8 +396,13 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_fixed(const FixedArg
         wave_lds_fence();
 
         // ---------------- phase 3: image -> HBM, 16 B per lane ----------------
-        if (!(a.debug & (4 | 8))) {
-            if ((reqsize & 1) == 0) {
+        if (!(a.debug & 4)) {
+            if ((reqsize & 1) == 0 && !FX_UNROLL_COPY) {
+                const v2d* s2 = reinterpret_cast<const v2d*>(phi);
+                v2d* g2 = reinterpret_cast<v2d*>(gout);
+#pragma unroll 4
+                for (int i = lane; i < (reqsize >> 1); i += 64) g2[i] = s2[i];
+            } else if ((reqsize & 1) == 0) {
                 // all LDS reads are issued before the first store so that their
                 // latencies overlap (NT column tiles bound the image size)
                 constexpr int NIT = (NT * 16 * ROWS / 2 + 63) / 64;

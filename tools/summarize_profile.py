@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh output directory into the tracked profiles/ folder:
+kernel-trace stats (csv copy), PMC counters per launch of the dominant kernel, and
+HBM traffic per launch with the gfx950 FETCH_SIZE correction (MI355X_MICROARCH.md:
+FETCH_SIZE reports 1/2 of the bytes of a wide coalesced read; WRITE_SIZE is exact;
+both are in KiB)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src = sys.argv[1]                 # e.g. gpurun_out/prof_r1c
+tag = sys.argv[2]                 # e.g. r01_p3tet
+kernel_substr = sys.argv[3] if len(sys.argv) > 3 else "tabulate_simplex"
+workload = sys.argv[4] if len(sys.argv) > 4 else "p3tet"
+batch = int(sys.argv[5]) if len(sys.argv) > 5 else 100000
+os.makedirs("profiles", exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], f"profiles/{tag}_kernel_stats.csv")
+counters = {}
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        agg = collections.defaultdict(list)
+        meta = {}
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
+                                          "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size") if k in r}
+        for k, v in agg.items():
+            counters[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+        if meta:
+            counters["_dispatch"] = meta
+dur = None
+if stats:
+    for r in csv.DictReader(open(stats[0])):
+        if kernel_substr in r["Name"]:
+            dur = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                   "max_ns": float(r["MaxNs"]), "name": r["Name"]}
+            break
+summary = {"source": src, "kernel": dur, "counters": counters}
+if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+    fetch = counters["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2      # gfx950: FETCH_SIZE counts 64 B per 128-B request
+    write = counters["WRITE_SIZE"]["mean_per_launch"] * 1024
+    summary["hbm_traffic"] = {"read_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+                              "total_bytes_per_launch": fetch + write,
+                              "note": "FETCH_SIZE*1024*2 (gfx950 half-count correction) + WRITE_SIZE*1024"}
+    with open("profiles/traffic_latest.json", "w") as f:
+        json.dump({"workload": workload, "batch": batch, "hbm_bytes_per_launch": fetch + write,
+                   "read": fetch, "write": write, "from": f"profiles/{tag}_summary.json"}, f, indent=1)
+with open(f"profiles/{tag}_summary.json", "w") as f:
+    json.dump(summary, f, indent=1)
+print(json.dumps(summary, indent=1)[:3000])
