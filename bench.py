@@ -78,8 +78,8 @@ def cpu_baseline(name, el, sd, deg, order, npts, seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="p3tet", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="requests per GPU (default: the workload's)")
     ap.add_argument("--allgather", action="store_true", help="also time the RCCL all-gather of the tables")
@@ -141,7 +141,8 @@ def main():
     achieved = bytes_per_req * batch / (kernel_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "tabulate_simplex_kernel", "kernel_ms": kernel_ms,
+                "kernel": "fxk::tabulate_simplex_stream" if args.workload == "p3tet" else "fxk::tabulate_simplex_kernel",
+                "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_request": bytes_per_req, "requests_per_launch": batch}
     prof = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(prof):

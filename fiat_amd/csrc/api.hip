@@ -554,7 +554,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             fa.verts = verts;
             fa.out = out;
             const char* kk = getenv("FIAT_AMD_KERNEL");
-            L.fkind = (kk && !strcmp(kk, "stream")) ? 1 : 0;  // default: LDS-image kernel
+            L.fkind = (kk && !strcmp(kk, "image")) ? 0 : 1;  // default: K-streamed kernel (A/B: FIAT_AMD_KERNEL=image)
             fa.afrag = L.fkind == 1 ? e->d_afrag_stream : e->d_afrag_split;
             fa.phi0 = e->prog.phi0;
             memcpy(fa.A0, e->A0, sizeof fa.A0);
@@ -565,13 +565,16 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             long long need = std::max<long long>((long long)f.nt * e->KS * 64, (long long)ntab * rows * npts);
             need = (need + 1) & ~1LL;
             if (L.fkind == 1) {
-                if (npts > 32) continue;  // packed LDS stores need the points in one half-wave
-                fa.lds_doubles = f.nt * 64;
                 {
+                    // per wave: half image (>= the K-step slab that aliases it) + 64-double dump row
+                    const int th = (ntab + 1) / 2;
+                    long long per_wave = std::max<long long>((long long)th * rows * npts, (long long)f.nt * 64) + 64;
+                    per_wave = (per_wave + 1) & ~1LL;
+                    fa.lds_doubles = (int)per_wave;
                     int rem = rows % 16;
                     bool split = rem != 0 && rem <= 12;
                     int nfrag = ((split ? rows / 16 : (rows + 15) / 16) + (split ? (rem + 3) / 4 : 0)) * e->KS;
-                    L.flds_bytes = (nfrag * 64 + f.nt * 64 * FIXED_NW) * 8;
+                    L.flds_bytes = (int)((nfrag * 64 + per_wave * FIXED_NW) * 8);
                 }
                 // registers bound the occupancy: ask for every workgroup the CU can hold
                 long long want = (long long)ctx->num_cu * 4;

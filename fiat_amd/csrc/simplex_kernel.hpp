@@ -163,12 +163,14 @@ __device__ __forceinline__ void apply_step(Jet<SD, ORDER>& nw, const Jet<SD, ORD
 }
 
 __device__ __forceinline__ void wave_lds_fence() {
-    // LDS operations of one wave complete in order; this only stops the
-    // compiler from moving LDS accesses of different lanes across the phase
-    // boundary.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // LDS operations of one wave complete in order; this only stops the compiler from
+    // moving LDS accesses of different lanes across a phase boundary.  The fences are
+    // restricted to the LDS address space ("local"): an unrestricted release fence makes
+    // hipcc wait vmcnt(0), i.e. for every outstanding HBM store of the wave -- measured
+    // to serialise the store phase with the next request's compute.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 // affine map of the request's cell onto the default (-1,1)^SD simplex:

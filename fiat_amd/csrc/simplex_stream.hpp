@@ -12,16 +12,22 @@
 //   * the recurrence of K-step j+1 is issued between the LDS stores of K-step j
 //     and their read-back, hiding the LDS latency, and overlaps with the MFMAs
 //     of K-step j (separate pipes);
-//   * finished D tiles are stored straight from the accumulators (8 B per lane,
-//     16 lanes = one 128-B run of a table row); staging them through an LDS image
-//     for 16-B-per-lane stores measured no faster and cost the LDS.
+//   * finished D tiles go to HBM through an LDS image of HALF a request (the
+//     first / last ceil(NTAB/2) tables), flushed twice per request with 16-byte-
+//     per-lane full-line stores.  Storing the accumulators directly (8 B per lane,
+//     partial 128-B lines) was measured to double the HBM traffic: the memory
+//     side reads every partially written line back (FETCH_SIZE ~ output size).
 #pragma once
 #include "simplex_fixed.hpp"
+
+#ifndef FX_STREAM_WAVES
+#define FX_STREAM_WAVES 2  // minimum waves per SIMD requested from the register allocator
+#endif
 
 namespace fxk {
 
 template <int SD, int N, int ORDER, int ROWS, int NT, int NW, bool UNIFORM>
-__global__ __launch_bounds__(64 * NW, 2) void tabulate_simplex_stream(const FixedArgs<FixedNC<SD, N>::value> a) {
+__global__ __launch_bounds__(64 * NW, FX_STREAM_WAVES) void tabulate_simplex_stream(const FixedArgs<FixedNC<SD, N>::value> a) {
     constexpr int NTAB = NTab<SD, ORDER>::value;
     constexpr StepTable<SD, N> TBL{};
     constexpr int NEXP = StepTable<SD, N>::NEXP;
@@ -33,10 +39,13 @@ __global__ __launch_bounds__(64 * NW, 2) void tabulate_simplex_stream(const Fixe
     const int lane = threadIdx.x & 63;
     // wave index as a scalar: everything derived from it (request number, output base) stays in SGPRs
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // LDS: [A fragments, shared by the workgroup] [one slab per wave]
+    // LDS: [A fragments, shared by the workgroup] [per wave: half image (the slab aliases its
+    // start) | 64-double dump row for inactive lanes]
     constexpr int NAF = (MT16 + M4) * KS;
     double* afr = lds;
-    double* slab = lds + NAF * 64 + (size_t)wave * SLAB;
+    double* img = lds + NAF * 64 + (size_t)wave * a.lds_doubles;
+    double* slab = img;
+    const int dump = a.lds_doubles - 64;  // doubles from img
 
     typedef const __attribute__((address_space(4))) double CDouble;
     typedef FixedArgs<FixedNC<SD, N>::value> ArgsT;
@@ -50,13 +59,28 @@ __global__ __launch_bounds__(64 * NW, 2) void tabulate_simplex_stream(const Fixe
     const int reqsize = NTAB * table;
     const int ncols = NTAB * npts;
 
-    for (int i = lane; i < SLAB; i += 64) slab[i] = 0.0;
+    for (int i = lane; i < a.lds_doubles; i += 64) img[i] = 0.0;
     // A fragments (production-order K): LDS resident, two 512-B reads per K-step
     for (int i = threadIdx.x; i < NAF * 64; i += 64 * NW) afr[i] = a.afrag[i];
     __syncthreads();
 
-    // offset (doubles, within the request) of this lane's output column in tile nt, row (lane>>4)
-    int soff[NT];
+    // recurrence: lanes 0..npts-1 <-> points; the other lanes store into the dump row,
+    // so no store needs an exec mask
+    const bool active = lane < npts;
+    const int pl = active ? lane : 0;
+    int colbase[NTAB];
+#pragma unroll
+    for (int t = 0; t < NTAB; ++t) {
+        const int c = t * npts + pl;
+        colbase[t] = active ? (c >> 4) * 64 + (c & 15) : dump + (lane & 15);  // + kk*16 stays inside the dump row
+    }
+    // output image: tables [0, TH) form half 0, [TH, NTAB) half 1
+    constexpr int TH = (NTAB + 1) / 2;
+    // store instructions per half-image flush: NT tiles bound the points (16*NT >= NTAB*npts)
+    constexpr int NFL = (TH * ROWS * ((16 * NT) / NTAB) / 2 + 63) / 64;
+    constexpr int NSTORE = NFL * (NTAB > TH ? 2 : 1);  // vector-memory stores per request
+    int ioff[NT];   // offset (doubles) inside its half image of this lane's column, row (lane>>4); -1: none
+    int ihalf = 0;  // bit nt set: the column of tile nt belongs to half 1
     {
         const float rinv = 1.0f / (float)npts;
 #pragma unroll
@@ -64,35 +88,31 @@ __global__ __launch_bounds__(64 * NW, 2) void tabulate_simplex_stream(const Fixe
             const int c = (nt << 4) + (lane & 15);
             const int ct = idiv_small(c, rinv);
             const int cp = c - ct * npts;
-            soff[nt] = (c < ncols) ? ct * table + cp + (lane >> 4) * npts : -1;
+            const int h = ct >= TH ? 1 : 0;
+            ioff[nt] = (c < ncols) ? (ct - h * TH) * table + cp + (lane >> 4) * npts : -1;
+            ihalf |= h << nt;
         }
     }
-    // recurrence: lanes 0..npts-1 <-> points (npts <= 32); the LDS stores are packed,
-    // lanes 32.. carry the odd table of each pair (v_permlane32_swap)
-    const bool active = lane < npts;
-    const int pl = active ? lane : 0;
-    const int pu = ((lane & 31) < npts) ? (lane & 31) : 0;
-    const bool active_pair = (lane & 31) < npts;
-    int pairbase[NTAB / 2 > 0 ? NTAB / 2 : 1];
-#pragma unroll
-    for (int u = 0; u < NTAB / 2; ++u) {
-        const int c = (2 * u + (lane >> 5)) * npts + pu;
-        pairbase[u] = (c >> 4) * 64 + (c & 15);
-    }
-    int lastbase = 0;
-    if constexpr (NTAB % 2 == 1) {
-        const int c = (NTAB - 1) * npts + pl;
-        lastbase = (c >> 4) * 64 + (c & 15);
-    }
-
     const long long stride = (long long)gridDim.x * NW;
     long long req = (long long)blockIdx.x * NW + wave;
+    // Points of the NEXT request are fetched while this one is computed.  vmcnt counts loads
+    // and stores together, in issue order: if the prefetched registers were first used at the
+    // top of the next iteration, hipcc (which cannot count stores across the loop back-edge)
+    // would wait with vmcnt(0) there, i.e. for every HBM store of this request -- measured: the
+    // wave then idles for the write latency once per request.  Instead the load is issued
+    // before the request's stores, whose number is a compile-time constant, and "used" by an
+    // empty asm at the END of the same iteration: hipcc then emits the exact vmcnt(NSTORE),
+    // which leaves the stores in flight.
     double xnext[SD];
     if (req < a.nreq) {
         const double* pp = a.pts + ((size_t)req * npts + pl) * SD;
 #pragma unroll
         for (int d = 0; d < SD; ++d) xnext[d] = pp[d];
     }
+    // complete the first fetch before the loop: with a load pending on loop entry hipcc
+    // puts a conservative vmcnt wait at the top of EVERY iteration (= wait for the stores)
+#pragma unroll
+    for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
     for (; req < a.nreq; req += stride) {
         double X[SD];
         double J[SD][SD];
@@ -100,8 +120,10 @@ __global__ __launch_bounds__(64 * NW, 2) void tabulate_simplex_stream(const Fixe
             double x[SD];
 #pragma unroll
             for (int d = 0; d < SD; ++d) x[d] = xnext[d];
-            if (req + stride < a.nreq) {
-                const double* pp = a.pts + ((size_t)(req + stride) * npts + pl) * SD;
+            {
+                // always issued (clamped to the last request) so that the count below is exact
+                const long long rn = (req + stride < a.nreq) ? req + stride : req;
+                const double* pp = a.pts + ((size_t)rn * npts + pl) * SD;
 #pragma unroll
                 for (int d = 0; d < SD; ++d) xnext[d] = pp[d];
             }
@@ -182,58 +204,64 @@ __global__ __launch_bounds__(64 * NW, 2) void tabulate_simplex_stream(const Fixe
             return zero;
         };
         auto put = [&](int kk, const Jet<SD, ORDER>& j) {
-            double comp[NTAB];
-            comp[0] = j.v;
+            slab[colbase[0] + kk * 16] = j.v;
             if constexpr (ORDER >= 1) {
 #pragma unroll
-                for (int d = 0; d < SD; ++d) comp[1 + d] = j.g[d];
+                for (int d = 0; d < SD; ++d) slab[colbase[1 + d] + kk * 16] = j.g[d];
             }
             if constexpr (ORDER >= 2) {
 #pragma unroll
-                for (int h = 0; h < SD * (SD + 1) / 2; ++h) comp[1 + SD + h] = j.h[h];
-            }
-#pragma unroll
-            for (int u = 0; u < NTAB / 2; ++u) {
-                const double packed = pack_halves(comp[2 * u], comp[2 * u + 1]);
-                if (active_pair) slab[pairbase[u] + kk * 16] = packed;
-            }
-            if constexpr (NTAB % 2 == 1) {
-                if (active) slab[lastbase + kk * 16] = comp[NTAB - 1];
+                for (int h = 0; h < SD * (SD + 1) / 2; ++h) slab[colbase[1 + SD + h] + kk * 16] = j.h[h];
             }
         };
 
-        // D tile nt -> HBM: address = scalar base (request, row block) + 32-bit per-lane byte offset
-        char* gbase = reinterpret_cast<char*>(a.out + (size_t)req * reqsize);
-        auto store_tile = [&](int nt) {
-            const int so = soff[nt];
-            unsigned lane_off = (unsigned)(so < 0 ? 0 : so) * 8u;
-            // opaque to the optimiser: keeps hipcc from materialising all the 64-bit
-            // store addresses at the top of the request (60 VGPRs, spilled)
-            asm volatile("" : "+v"(lane_off));
+        // accumulators of tile nt -> half image `half` (lanes whose column belongs to it)
+        auto image_tile = [&](int nt, int half) {
+            const int so = ioff[nt];
+            const bool mine = so >= 0 && ((ihalf >> nt) & 1) == half;
 #pragma unroll
             for (int mt = 0; mt < MT16; ++mt) {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int mbase = 16 * mt + 4 * jj;  // + (lane >> 4)
-                    double* dst = reinterpret_cast<double*>(gbase + (size_t)(mbase * npts) * 8 + lane_off);
                     if (mbase + 3 < ROWS) {
-                        if (so >= 0) *dst = acc16[nt][mt][jj];
+                        if (mine) img[so + mbase * npts] = acc16[nt][mt][jj];
                     } else if (mbase < ROWS) {
-                        if (so >= 0 && mbase + (lane >> 4) < ROWS) *dst = acc16[nt][mt][jj];
+                        if (mine && mbase + (lane >> 4) < ROWS) img[so + mbase * npts] = acc16[nt][mt][jj];
                     }
                 }
             }
 #pragma unroll
             for (int m4 = 0; m4 < M4; ++m4) {
                 const int mbase = 16 * MT16 + 4 * m4;
-                double* dst = reinterpret_cast<double*>(gbase + (size_t)(mbase * npts) * 8 + lane_off);
                 if (mbase + 3 < ROWS) {
-                    if (so >= 0) *dst = acc4[nt][m4];
+                    if (mine) img[so + mbase * npts] = acc4[nt][m4];
                 } else {
-                    if (so >= 0 && mbase + (lane >> 4) < ROWS) *dst = acc4[nt][m4];
+                    if (mine && mbase + (lane >> 4) < ROWS) img[so + mbase * npts] = acc4[nt][m4];
                 }
             }
         };
+        // half image -> HBM, 16 B per lane, whole 128-B lines except at the seam of the halves.
+        // The number of store instructions is a compile-time constant (lanes past the end
+        // rewrite the last chunk): the exact vmcnt wait on the prefetched points relies on it.
+        auto flush_half = [&](int half) {
+            const int ntab_h = half == 0 ? TH : NTAB - TH;
+            const int nch = (ntab_h * table) >> 1;  // 16-byte chunks (even sizes only, checked by the host)
+            const v2d* s2 = reinterpret_cast<const v2d*>(img);
+            v2d* g2 = reinterpret_cast<v2d*>(a.out + (size_t)req * reqsize + (size_t)half * TH * table);
+            v2d buf[NFL];
+#pragma unroll
+            for (int it = 0; it < NFL; ++it) {
+                const int i = min(it * 64 + lane, nch - 1);
+                buf[it] = s2[i];
+            }
+#pragma unroll
+            for (int it = 0; it < NFL; ++it) {
+                const int i = min(it * 64 + lane, nch - 1);
+                g2[i] = buf[it];
+            }
+        };
+
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) produce(kk);
 #pragma unroll
@@ -265,12 +293,32 @@ __global__ __launch_bounds__(64 * NW, 2) void tabulate_simplex_stream(const Fixe
 #pragma unroll
                     for (int m4 = 0; m4 < M4; ++m4)
                         acc4[nt][m4] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[m4], b[nt], acc4[nt][m4], 0, 0, 0);
-                    // the tile is final after the last K-step: store it while the next tile's MFMAs run
-                    if (j == KS - 1 && !(a.debug & 4)) store_tile(nt);
                 }
             }
         }
 
+        // ---------------- D tiles -> half images -> HBM ----------------
+        if (!(a.debug & 4)) {
+            wave_lds_fence();  // the slab (aliasing the image) has been read for the last K-step
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) image_tile(nt, 0);
+            wave_lds_fence();
+            flush_half(0);
+            wave_lds_fence();
+            if constexpr (NTAB > TH) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) image_tile(nt, 1);
+                wave_lds_fence();
+                flush_half(1);
+                wave_lds_fence();
+            }
+            // first use of the prefetched points: hipcc places s_waitcnt vmcnt(NSTORE) here
+#pragma unroll
+            for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
+        } else {
+#pragma unroll
+            for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
+        }
     }
 }
 
