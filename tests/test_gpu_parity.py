@@ -137,6 +137,26 @@ def test_c2_batch_vs_oracle(rt, golden, nreq):
         assert_tables(out[r], ref, 3, f"request {r}")
 
 
+def test_c2_full_baseline_batch(rt, golden):
+    """BASELINE config 2 at full size: 100 000 requests x 23 points, every table of every
+    request against the C restatement of the oracle (pinned in tests/test_oracle_c.py)."""
+    from oracle import c_oracle
+    g = golden("elements")
+    co = g["c2_p3tet_q6_coeffs"]
+    rng = np.random.default_rng(2)
+    pts = rand_points(rng, 3, (100000, 23))
+    ps = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=co)
+    out = ps.tabulate_batch(1, pts).cpu().numpy()
+    ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[3], 3, co, 1, pts, scale=1, variant="bubble")
+    num = np.abs(out - ref).max(axis=(2, 3))
+    den = np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))
+    err = (num / den).max(axis=0)
+    assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
+    # size-independent property: the Lagrange basis is a partition of unity, its gradient sums to zero
+    assert np.abs(out[:, 0].sum(axis=1) - 1.0).max() < 1e-12
+    assert np.abs(out[:, 1:].sum(axis=2)).max() < 1e-10
+
+
 def test_c2_physical_cells(rt, golden):
     g = golden("elements")
     co = g["c2_p3tet_q6_coeffs"]   # affine-invariant (SURVEY.md App. A)
