@@ -44,6 +44,30 @@ def synth_points(sd, nreq, npts, seed):
     return (e / e.sum(axis=-1, keepdims=True))[..., 1:].copy()
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota
+    (a GPU box gives each job a share of the host, oversubscribing OpenMP threads thrashes)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, int(os.environ.get("FIAT_AMD_BENCH_THREADS", "16"))))
+
+
 def build_element(name):
     """Nodal coefficients through the device Vandermonde path; returns the
     device polynomial set and what the oracle needs for the CPU baseline."""
@@ -60,10 +84,7 @@ def cpu_baseline(name, el, sd, deg, order, npts, seconds=12.0):
     coeffs = el.get_coeffs()
     verts = fo.UFC_SIMPLEX[sd]
     variant, scale = el._expansion_variant, el._expansion_scale
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = host_cpu_share()
     chunk = 4096
     pts = synth_points(sd, chunk, npts, 99)
     c_oracle.tabulate_batch(verts, deg, coeffs, order, pts[:64], scale=scale, variant=variant, nthreads=cores)  # warm

@@ -185,22 +185,9 @@ static void dubiner_point(int sd, int n, int order, int variant, double scale, c
     }
 }
 
-/* in-place C0_basis on members [nexp][nc]; `perm` receives the reordering, `work` nexp*nc doubles */
-static void c0_basis(int sd, int n, int nc, double* phi, double* work) {
+/* member order (vertices, edges, faces, interior) of C0_basis (expansions.py:297-322) */
+static int* c0_permutation(int sd, int n) {
     const int nexp = binom(n + sd, sd);
-#define ROW(m) (phi + (m) * nc)
-#define SUB(dst, src) for (int t = 0; t < nc; ++t) ROW(dst)[t] -= ROW(src)[t]
-    for (int t = 0; t < nc; ++t) ROW(0)[t] *= -1.0;
-    for (int j = 1; j <= sd; ++j) SUB(0, j);
-    if (sd == 2) {
-        for (int i = 2; i <= n; ++i) SUB(member_index(2, 0, i, 0), member_index(2, 1, i - 1, 0));
-    } else if (sd == 3) {
-        for (int i = 2; i <= n; ++i) {
-            for (int j = 0; j <= n - i; ++j) SUB(member_index(3, 0, i, j), member_index(3, 1, i - 1, j));
-            SUB(member_index(3, 0, 0, i), member_index(3, 0, 1, i - 1));
-            SUB(member_index(3, 0, 0, i), member_index(3, 1, 0, i - 1));
-        }
-    }
     int* dofs = (int*)malloc(sizeof(int) * nexp);
     int k = 0;
     for (int i = 0; i <= sd; ++i) dofs[k++] = i;
@@ -231,9 +218,27 @@ static void c0_basis(int sd, int n, int nc, double* phi, double* work) {
             for (int j = 1; j <= n - kk; ++j)
                 for (int i = 2; i <= n - j - kk; ++i) dofs[k++] = member_index(3, i, j, kk);
     }
+    return dofs;
+}
+
+/* in-place C0_basis on members [nexp][nc]; `dofs` = c0_permutation, `work` nexp*nc doubles */
+static void c0_basis(int sd, int n, int nc, double* phi, double* work, const int* dofs) {
+    const int nexp = binom(n + sd, sd);
+#define ROW(m) (phi + (m) * nc)
+#define SUB(dst, src) for (int t = 0; t < nc; ++t) ROW(dst)[t] -= ROW(src)[t]
+    for (int t = 0; t < nc; ++t) ROW(0)[t] *= -1.0;
+    for (int j = 1; j <= sd; ++j) SUB(0, j);
+    if (sd == 2) {
+        for (int i = 2; i <= n; ++i) SUB(member_index(2, 0, i, 0), member_index(2, 1, i - 1, 0));
+    } else if (sd == 3) {
+        for (int i = 2; i <= n; ++i) {
+            for (int j = 0; j <= n - i; ++j) SUB(member_index(3, 0, i, j), member_index(3, 1, i - 1, j));
+            SUB(member_index(3, 0, 0, i), member_index(3, 0, 1, i - 1));
+            SUB(member_index(3, 0, 0, i), member_index(3, 1, 0, i - 1));
+        }
+    }
     memcpy(work, phi, sizeof(double) * nexp * nc);
     for (int r = 0; r < nexp; ++r) memcpy(phi + r * nc, work + dofs[r] * nc, sizeof(double) * nc);
-    free(dofs);
 #undef ROW
 #undef SUB
 }
@@ -281,6 +286,7 @@ int fo_tabulate_batch(int sd, int n, int variant, double scale, const double* ce
     const int nc = ncomp(sd, order), nexp = binom(n + sd, sd);
     double A0[9], b0[3];
     cell_map(sd, cell, A0, b0);
+    int* dofs = (variant == 1 && n >= 1) ? c0_permutation(sd, n) : NULL;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
@@ -307,7 +313,7 @@ int fo_tabulate_batch(int sd, int n, int variant, double scale, const double* ce
                     X[i] = t;
                 }
                 dubiner_point(sd, n, order, variant, scale, X, A, phi);
-                if (variant == 1) c0_basis(sd, n, nc, phi, work);
+                if (variant == 1) c0_basis(sd, n, nc, phi, work, dofs);
                 for (int t = 0; t < nc; ++t)
                     for (int i = 0; i < rows; ++i) {
                         double s = 0.0;
@@ -319,6 +325,7 @@ int fo_tabulate_batch(int sd, int n, int variant, double scale, const double* ce
         }
         free(phi);
     }
+    free(dofs);
     return 0;
 }
 
