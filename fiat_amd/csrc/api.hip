@@ -825,6 +825,11 @@ static int tensor_launch(fx_ctx* ctx, int nf, const fx_line_element* const* fact
         a.L[f] = line_desc(factors[f]);
         lds += (size_t)(order + 1) * factors[f]->nn * w * 8;
     }
+    {   // + row table: 4 ints per output row
+        long long nbf = 1;
+        for (int f = 0; f < nf; ++f) nbf *= factors[f]->nn;
+        lds += (size_t)fx::binom(nf + order, nf) * nbf * 16;
+    }
     if (lds > 150 * 1024) return fail(FX_ENOTIMPL, "factor tables exceed LDS (%zu bytes)", lds);
     a.nf = nf;
     a.order = order;

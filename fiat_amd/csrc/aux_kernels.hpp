@@ -7,6 +7,9 @@
 
 namespace fxk {
 
+// floor(c / d) for 0 <= c < 2^20, rinv = 1.0f / d
+__device__ __forceinline__ int idiv_small(int c, float rinv);
+
 // mat[i][k] = sum_q wts[i][q] * ev[k][q]      (dual_set.py:172)
 __global__ void riesz_assemble_kernel(int nrows, int nq, int nexp, const double* __restrict__ wts,
                                       const double* __restrict__ ev, double* __restrict__ mat) {
@@ -225,6 +228,8 @@ struct TensorArgs {
     double* out;
 };
 
+constexpr int TP_NIT = 2;  // 16-byte chunks per lane and row group in the fast path (row groups <= 256 doubles)
+
 template <bool GRID>
 __global__ __launch_bounds__(256) void tensor_tabulate_kernel(TensorArgs a) {
     extern __shared__ __attribute__((aligned(16))) double T[];  // [f][k][i][w]
@@ -234,6 +239,63 @@ __global__ __launch_bounds__(256) void tensor_tabulate_kernel(TensorArgs a) {
     int fofs[4];
     fofs[0] = 0;
     for (int f = 0; f < a.nf; ++f) fofs[f + 1] = fofs[f] + K * a.L[f].nn * w;
+    const int nn1 = a.nf > 1 ? a.L[1].nn : 1, nn2 = a.nf > 2 ? a.L[2].nn : 1;
+    const float rinv_nbf = 1.0f / (float)(a.L[0].nn * nn1 * nn2);
+    const float rinv_n12 = 1.0f / (float)(nn1 * nn2);
+    const float rinv_n2 = 1.0f / (float)nn2;
+    const float rinv_npts = 1.0f / (float)a.npts;
+    const float rinv_q = 1.0f / (float)(a.q > 0 ? a.q : 1);
+    const float rinv_qq = 1.0f / (float)(a.q > 0 ? a.q * a.q : 1);
+    // LDS row table: for every output row (table t, basis function (i0,i1,i2)) the LDS offsets of
+    // its three factor rows -- identical for every request, decoded once per kernel
+    int* rowbase = reinterpret_cast<int*>(T + fofs[a.nf]);
+    {
+        const int n0_ = a.L[0].nn;
+        const int nbf_ = n0_ * nn1 * nn2;
+        for (int row = tid; row < a.ntab * nbf_; row += nthr) {
+            const int t = row / nbf_;
+            const int bf = row - t * nbf_;
+            const int i0 = bf / (nn1 * nn2);
+            const int rem = bf - i0 * (nn1 * nn2);
+            const int i1 = rem / nn2;
+            const int i2 = rem - i1 * nn2;
+            rowbase[row * 4 + 0] = fofs[0] + (a.alpha[t][0] * n0_ + i0) * w;
+            rowbase[row * 4 + 1] = a.nf > 1 ? fofs[1] + (a.alpha[t][1] * nn1 + i1) * w : 0;
+            rowbase[row * 4 + 2] = a.nf > 2 ? fofs[2] + (a.alpha[t][2] * nn2 + i2) * w : 0;
+            rowbase[row * 4 + 3] = 0;
+        }
+    }
+    // per-lane decode of the two elements of chunk (it*64 + lane) inside a row group
+    const int lane_id = tid & 63;
+    int tp_sel[TP_NIT][2];
+    int tp_j[TP_NIT][2][3];
+    {
+        const int np = a.npts;
+#pragma unroll
+        for (int it = 0; it < TP_NIT; ++it)
+#pragma unroll
+            for (int el = 0; el < 2; ++el) {
+                const int e = 2 * (it * 64 + lane_id) + el;
+                const int sel = e >= np ? 1 : 0;
+                const int p = min(e - sel * np, np - 1);
+                tp_sel[it][el] = sel;
+                int j0 = p, j1 = p, j2 = p;
+                if (GRID) {
+                    if (a.nf == 2) {
+                        j0 = p / a.q;
+                        j1 = p - j0 * a.q;
+                    } else if (a.nf == 3) {
+                        j0 = p / (a.q * a.q);
+                        const int rr = p - j0 * a.q * a.q;
+                        j1 = rr / a.q;
+                        j2 = rr - j1 * a.q;
+                    }
+                }
+                tp_j[it][el][0] = j0;
+                tp_j[it][el][1] = j1;
+                tp_j[it][el][2] = j2;
+            }
+    }
     for (long long r = blockIdx.x; r < a.nreq; r += gridDim.x) {
         __syncthreads();
         for (int e = tid; e < a.nf * w; e += nthr) {
@@ -259,44 +321,78 @@ __global__ __launch_bounds__(256) void tensor_tabulate_kernel(TensorArgs a) {
         const int n2 = a.nf > 2 ? a.L[2].nn : 1;
         const int nbf = n0 * n1 * n2;
         const int nrows = a.ntab * nbf;
-        double* o = a.out + (size_t)r * nrows * a.npts;
-        const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
-        for (int row = wave; row < nrows; row += nw) {
-            int t = row / nbf;
-            int bf = row - t * nbf;
-            int i0 = bf / (n1 * n2);
-            int rem = bf - i0 * (n1 * n2);
-            int i1 = rem / n2;
-            int i2 = rem - i1 * n2;
-            const double* t0 = T + fofs[0] + (a.alpha[t][0] * n0 + i0) * w;
-            const double* t1 = a.nf > 1 ? T + fofs[1] + (a.alpha[t][1] * n1 + i1) * w : nullptr;
-            const double* t2 = a.nf > 2 ? T + fofs[2] + (a.alpha[t][2] * n2 + i2) * w : nullptr;
-            double* orow = o + (size_t)row * a.npts;
-            for (int p = lane; p < a.npts; p += 64) {
-                double v;
-                if (GRID) {
-                    int j0, j1 = 0, j2 = 0;
-                    if (a.nf == 1) {
-                        j0 = p;
-                    } else if (a.nf == 2) {
-                        j0 = p / a.q;
-                        j1 = p - j0 * a.q;
-                    } else {
-                        j0 = p / (a.q * a.q);
-                        int rr = p - j0 * a.q * a.q;
-                        j1 = rr / a.q;
-                        j2 = rr - j1 * a.q;
-                    }
-                    v = t0[j0];
-                    if (a.nf > 1) v *= t1[j1];
-                    if (a.nf > 2) v *= t2[j2];
+        const int npts = a.npts;
+        const long long total = (long long)nrows * npts;  // doubles of this request, contiguous in HBM
+        double* o = a.out + (size_t)r * total;
+        // value of table row `row` at point p
+        auto value = [&](int row, int p) -> double {
+            const int t = idiv_small(row, rinv_nbf);
+            const int bf = row - t * nbf;
+            const int i0 = idiv_small(bf, rinv_n12);
+            const int rem = bf - i0 * (n1 * n2);
+            const int i1 = idiv_small(rem, rinv_n2);
+            const int i2 = rem - i1 * n2;
+            int j0 = p, j1 = p, j2 = p;
+            if (GRID) {
+                if (a.nf == 1) {
+                    j0 = p;
+                } else if (a.nf == 2) {
+                    j0 = idiv_small(p, rinv_q);
+                    j1 = p - j0 * a.q;
                 } else {
-                    v = t0[p];
-                    if (a.nf > 1) v *= t1[p];
-                    if (a.nf > 2) v *= t2[p];
+                    j0 = idiv_small(p, rinv_qq);
+                    const int rr = p - j0 * a.q * a.q;
+                    j1 = idiv_small(rr, rinv_q);
+                    j2 = rr - j1 * a.q;
                 }
-                orow[p] = v;
             }
+            double v = T[fofs[0] + (a.alpha[t][0] * n0 + i0) * w + j0];
+            if (a.nf > 1) v *= T[fofs[1] + (a.alpha[t][1] * n1 + i1) * w + j1];
+            if (a.nf > 2) v *= T[fofs[2] + (a.alpha[t][2] * n2 + i2) * w + j2];
+            return v;
+        };
+        // Fast path: the request is one contiguous block written 16 bytes per lane.  Rows are
+        // taken in groups of RG (1 if npts is even, else 2) so that a group is a whole number of
+        // 16-byte chunks; which row / point a lane's two elements belong to is the same for every
+        // group and is decoded once per kernel (tp_*), the per-group row decode is scalar.
+        const int RG = (npts & 1) ? 2 : 1;
+        const int gch = (RG * npts) >> 1;  // chunks per group
+        if ((total & 1) == 0 && (nrows % RG) == 0 && gch <= 64 * TP_NIT) {
+            typedef double v2d_t __attribute__((ext_vector_type(2)));
+            v2d_t* o2 = reinterpret_cast<v2d_t*>(o);
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = nthr >> 6;
+            const int ngroups = nrows / RG;
+            for (int g = wave; g < ngroups; g += nw) {
+                // LDS row bases of the (up to two) rows of this group, per factor (broadcast reads)
+                int base[2][3];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int row = min(g * RG + s2, nrows - 1);
+#pragma unroll
+                    for (int f = 0; f < 3; ++f) base[s2][f] = rowbase[row * 4 + f];
+                }
+                const size_t gofs = (size_t)g * gch;
+#pragma unroll
+                for (int it = 0; it < TP_NIT; ++it) {
+                    const int c = it * 64 + lane_id;
+                    if (c < gch) {
+                        v2d_t v;
+#pragma unroll
+                        for (int el = 0; el < 2; ++el) {
+                            const int sel = tp_sel[it][el];
+                            double x = T[(sel ? base[1][0] : base[0][0]) + tp_j[it][el][0]];
+                            if (a.nf > 1) x *= T[(sel ? base[1][1] : base[0][1]) + tp_j[it][el][1]];
+                            if (a.nf > 2) x *= T[(sel ? base[1][2] : base[0][2]) + tp_j[it][el][2]];
+                            if (el == 0) v.x = x; else v.y = x;
+                        }
+                        o2[gofs + c] = v;
+                    }
+                }
+            }
+        } else {
+            const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+            for (int row = wave; row < nrows; row += nw)
+                for (int p = lane; p < npts; p += 64) o[(size_t)row * npts + p] = value(row, p);
         }
     }
 }
