@@ -16,6 +16,7 @@
 #include "simplex_kernel.hpp"
 #include "simplex_fixed.hpp"
 #include "simplex_stream.hpp"
+#include "coop_kernel.hpp"
 
 namespace {
 
@@ -115,6 +116,12 @@ struct fx_element {
     double* d_afrag_split = nullptr;  // layout of the shape-specialised kernels
     double* d_afrag_stream = nullptr; // same, K in production order (K-streamed kernel)
     double* d_coef = nullptr;         // [nsteps][3]
+    // cooperative (large-shape) plan
+    int coop_KS = 0, coop_emax = 0;
+    int* d_coop_eint = nullptr;
+    double* d_coop_edbl = nullptr;
+    int* d_coop_kstart = nullptr;
+    double* d_afrag_coop = nullptr;
 };
 
 struct fx_line_element {
@@ -250,6 +257,65 @@ static int upload_coeffs(fx_element* e, int ndof, int vdim, const double* coeffs
     }
     HIP_TRY(hipMalloc(&e->d_afrag_stream, F3.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(e->d_afrag_stream, F3.data(), F3.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (e->n >= 1) {
+        // cooperative plan: entry tables of the four producers + A fragments in slot order
+        fx::CoopPlan cp = fx::build_coop_plan(e->prog);
+        int emax = 1;
+        for (int w = 0; w < 4; ++w) emax = std::max<int>(emax, (int)cp.entries[w].size());
+        std::vector<int> eint((size_t)4 * emax * 4, 0);
+        std::vector<double> edbl((size_t)4 * emax * 16, 0.0);
+        std::vector<int> kst((size_t)4 * (cp.KS + 1), 0);
+        const int sd = e->sd;
+        for (int w = 0; w < 4; ++w) {
+            for (size_t i = 0; i < cp.entries[w].size(); ++i) {
+                const fx::CoopEntry& ce = cp.entries[w][i];
+                int* ip = &eint[((size_t)w * emax + i) * 4];
+                ip[0] = ce.level;
+                ip[1] = ce.seed;
+                ip[2] = ce.publish;
+                ip[3] = ce.member;
+                double* dp = &edbl[((size_t)w * emax + i) * 16];
+                dp[0] = ce.A;
+                dp[1] = ce.B;
+                dp[2] = ce.C;
+                if (ce.level >= 0) {  // uniform-cell factor derivatives, as for the stream kernel
+                    double dfa[3] = {0, 0, 0}, dfb[3] = {0, 0, 0};
+                    for (int d = 0; d < sd; ++d) {
+                        double dx = e->A0[ce.level * sd + d];
+                        double dy = ce.level + 1 < sd ? e->A0[(ce.level + 1) * sd + d] : 0.0;
+                        double dz = ce.level + 2 < sd ? e->A0[(ce.level + 2) * sd + d] : 0.0;
+                        dfb[d] = 0.5 * (dy + dz);
+                        dfa[d] = dx + dfb[d];
+                    }
+                    double* u = dp + 3;
+                    for (int d = 0; d < sd; ++d) {
+                        u[d] = ce.A * dfa[d] - ce.B * dfb[d];
+                        u[3 + d] = -2.0 * ce.C * dfb[d];
+                    }
+                    int h = 0;
+                    for (int d1 = 0; d1 < sd; ++d1)
+                        for (int d2 = d1; d2 < sd; ++d2) u[6 + h++] = -2.0 * ce.C * dfb[d1] * dfb[d2];
+                }
+            }
+            for (int j = 0; j <= cp.KS; ++j) kst[(size_t)w * (cp.KS + 1) + j] = cp.kstart[w][j];
+        }
+        std::vector<double> F4 = fx::pack_a_fragments_split(C, rows, nexp, &cp.kperm);
+        auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+            if (*dst) {
+                (void)hipFree(*dst);
+                *dst = nullptr;
+            }
+            hipError_t he = hipMalloc(dst, bytes);
+            if (he == hipSuccess) he = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+            return he;
+        };
+        HIP_TRY(upload((void**)&e->d_coop_eint, eint.data(), eint.size() * sizeof(int)));
+        HIP_TRY(upload((void**)&e->d_coop_edbl, edbl.data(), edbl.size() * sizeof(double)));
+        HIP_TRY(upload((void**)&e->d_coop_kstart, kst.data(), kst.size() * sizeof(int)));
+        HIP_TRY(upload((void**)&e->d_afrag_coop, F4.data(), F4.size() * sizeof(double)));
+        e->coop_KS = cp.KS;
+        e->coop_emax = emax;
+    }
     e->ndof = ndof;
     e->vdim = vdim;
     e->MT = (rows + 15) / 16;
@@ -322,6 +388,10 @@ int fx_element_destroy(fx_element* e) {
     if (e->d_afrag_split) (void)hipFree(e->d_afrag_split);
     if (e->d_afrag_stream) (void)hipFree(e->d_afrag_stream);
     if (e->d_coef) (void)hipFree(e->d_coef);
+    if (e->d_coop_eint) (void)hipFree(e->d_coop_eint);
+    if (e->d_coop_edbl) (void)hipFree(e->d_coop_edbl);
+    if (e->d_coop_kstart) (void)hipFree(e->d_coop_kstart);
+    if (e->d_afrag_coop) (void)hipFree(e->d_afrag_coop);
     delete e;
     return FX_OK;
 }
@@ -357,6 +427,10 @@ struct Launch {
     std::vector<double> fucoef;        // [nsteps][12], uniform-cell factor derivatives
     int fgrid = 0, flds_bytes = 0;
     int fkind = 0;  // 0: LDS-image kernel (simplex_fixed.hpp), 1: K-streamed kernel (simplex_stream.hpp)
+    // cooperative large-shape kernel
+    int coop_id = -1;
+    fxk::CoopArgs cargs;
+    int cgrid = 0, clds_bytes = 0;
 };
 
 // ---- registry of shape-specialised kernels ----------------------------------------
@@ -409,6 +483,36 @@ int launch_fixed(const Launch& L, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(L.fgrid), dim3(64 * FIXED_NW), L.flds_bytes, s, fa);
     HIP_TRY(hipGetLastError());
     return FX_OK;
+}
+
+// ---- registry of cooperative (large-shape) kernels: <SD, ORDER, MT16, M4, TPW> ------
+struct CoopShape {
+    int sd, order, mt16, m4, tpw;
+};
+const CoopShape kCoopShapes[] = {
+    {3, 2, 5, 1, 4},  // DG P6 tetrahedron (84 rows) with Hessians, <= 25 points
+    {3, 1, 5, 1, 2},  // DG P6 tetrahedron, values + gradient, <= 32 points
+};
+
+template <int SD, int ORDER, int MT16, int M4, int TPW>
+int launch_coop(const Launch& L, hipStream_t s) {
+    using KernT = void (*)(const fxk::CoopArgs);
+    KernT kern = L.cargs.verts ? (KernT)fxk::tabulate_simplex_coop<SD, ORDER, MT16, M4, TPW, false>
+                               : (KernT)fxk::tabulate_simplex_coop<SD, ORDER, MT16, M4, TPW, true>;
+    if (L.clds_bytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    L.clds_bytes));
+    hipLaunchKernelGGL(kern, dim3(L.cgrid), dim3(512), L.clds_bytes, s, L.cargs);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+int run_coop(const Launch& L, hipStream_t s) {
+    switch (L.coop_id) {
+        case 0: return launch_coop<3, 2, 5, 1, 4>(L, s);
+        case 1: return launch_coop<3, 1, 5, 1, 2>(L, s);
+    }
+    return fail(FX_EINVAL, "internal: unknown cooperative kernel %d", L.coop_id);
 }
 
 int run_fixed(const Launch& L, hipStream_t s) {
@@ -511,6 +615,55 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     a.stage_doubles = (int)((stage / 8 + 1) & ~1LL);
     if (stage == 0) a.stage_doubles = 0;
     L.lds_bytes = (a.phi_doubles + a.stage_doubles) * 8;
+    // ---- cooperative kernel for large shapes? ----
+    L.coop_id = -1;
+    {
+        const char* nocoop = getenv("FIAT_AMD_NO_COOP");
+        const int rem = rows % 16;
+        const bool split = rem != 0 && rem <= 12;
+        const int mt16 = split ? rows / 16 : (rows + 15) / 16, m4 = split ? (rem + 3) / 4 : 0;
+        const int nt_need = (ntab * npts + 15) / 16;
+        if (!(nocoop && atoi(nocoop)) && npts <= 64 && e->d_coop_eint) {
+            for (size_t i = 0; i < sizeof(kCoopShapes) / sizeof(kCoopShapes[0]); ++i) {
+                const CoopShape& c = kCoopShapes[i];
+                if (c.sd != e->sd || c.order != order || c.mt16 != mt16 || c.m4 != m4 || nt_need > 4 * c.tpw) continue;
+                const int table = rows * npts;
+                int TR = std::max(1, (int)((32 * 1024) / ((long long)table * 8)));
+                TR = std::min(TR, ntab);
+                long long img = std::max<long long>(2LL * (nt_need * 64 + 64), (long long)TR * table);
+                img = (img + 1) & ~1LL;
+                if (npts > 32) continue;  // LDS-resident chain state holds 32 points
+                long long ldsb = ((long long)(mt16 + m4) * e->coop_KS * 64 + img + 4LL * 4 * ntab * 32) * 8;
+                if (ldsb > ctx->lds_per_cu) continue;
+                fxk::CoopArgs& ca = L.cargs;
+                memset(&ca, 0, sizeof ca);
+                ca.pts = pts;
+                ca.verts = verts;
+                ca.out = out;
+                ca.afrag = e->d_afrag_coop;
+                ca.eint = e->d_coop_eint;
+                ca.edbl = e->d_coop_edbl;
+                ca.kstart = e->d_coop_kstart;
+                ca.phi0 = e->prog.phi0;
+                memcpy(ca.A0, e->A0, sizeof ca.A0);
+                memcpy(ca.b0, e->b0, sizeof ca.b0);
+                ca.nreq = nreq;
+                ca.npts = npts;
+                ca.rows = rows;
+                ca.KS = e->coop_KS;
+                ca.NT = nt_need;
+                ca.emax = e->coop_emax;
+                ca.TR = TR;
+                ca.slab_doubles = nt_need * 64 + 64;
+                ca.img_doubles = (int)img;
+                L.clds_bytes = (int)ldsb;
+                int per_cu = std::max(1, std::min(2, ctx->lds_per_cu / L.clds_bytes));
+                L.cgrid = (int)std::max<long long>(1, std::min<long long>(nreq, (long long)ctx->num_cu * per_cu));
+                L.coop_id = (int)i;
+                break;
+            }
+        }
+    }
     // ---- shape-specialised kernel available? ----
     L.fixed_id = -1;
     const char* nofixed = getenv("FIAT_AMD_NO_FIXED");
@@ -607,6 +760,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
 int run_tabulate(fx_ctx* ctx, const fx_element* e, int order, const Launch& L, hipStream_t s) {
     if (L.args.nitems == 0 || L.args.npts == 0) return FX_OK;
     if (L.fixed_id >= 0) return run_fixed(L, s);
+    if (L.coop_id >= 0) return run_coop(L, s);
     switch (e->sd) {
         case 1: return launch_sd<1>(order, L, s);
         case 2: return launch_sd<2>(order, L, s);

@@ -11,6 +11,7 @@
 //     m_dst = (A*fa - B*fb) * m_cur - C*fc * m_prv
 // with (fa, fb, fc) the collapsed-coordinate factors of the step's codimension.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -247,6 +248,178 @@ inline std::vector<double> pack_a_fragments(const std::vector<double>& C, int ro
     return F;
 }
 
+// ---------------------------------------------------------------------------------
+// Cooperative plan for large shapes (coop_kernel.hpp): the same steps as
+// build_program, re-ordered depth first and split over NPROD producer waves.
+// The (p,q) chains of the last codimension are the units of ownership: the owner
+// of chain (p,q) publishes its head (p,q,0) and its members (p,q,r>0); the
+// lower-codimension steps that lead to the head are executed by every wave that
+// needs them (cheap) and published by the owner only.  Wave w's j-th published
+// member occupies K slot 4*j + w, so every K-step takes exactly one member from
+// every producer (zero rows pad the tail).
+struct CoopEntry {
+    int level;    // codimension of the step; -1: the constant member 0
+    int seed;     // -2: continue the chain of `level`; -1: chain starts from the constant;
+                  // 0/1: chain starts from the current member of that level
+    int publish;  // 1: store the result into this wave's slab row, 0: keep in registers only
+    int member;   // member index produced (for the K permutation), -1 for a zero pad
+    double A, B, C;
+};
+
+struct CoopPlan {
+    int sd = 0, n = 0, nexp = 0, KS = 0;
+    double phi0 = 0.0;
+    std::vector<CoopEntry> entries[4];
+    std::vector<int> kstart[4];  // entries of K-step j: [kstart[j], kstart[j+1])
+    std::vector<int> kperm;      // K slot (4*j + w) -> member, -1: none
+};
+
+inline CoopPlan build_coop_plan(const Program& P) {
+    CoopPlan C;
+    C.sd = P.sd;
+    C.n = P.n;
+    C.nexp = P.nexp;
+    C.phi0 = P.phi0;
+    const int sd = P.sd, n = P.n;
+    // step that produces each member
+    std::vector<int> step_of(P.nexp, -1);
+    for (size_t i = 0; i < P.steps.size(); ++i) step_of[P.steps[i].dst] = (int)i;
+    auto mid = [&](int p, int q, int r) { int t[3] = {p, q, r}; return member_index(sd, t); };
+    // ownership units: chains of the last codimension, keyed by their prefix
+    struct Unit { int p, q, size; };
+    std::vector<Unit> units;
+    if (sd == 1) {
+        units.push_back({0, 0, n + 1});
+    } else if (sd == 2) {
+        for (int p = 0; p <= n; ++p) units.push_back({p, 0, n - p + 1});
+    } else {
+        for (int p = 0; p <= n; ++p)
+            for (int q = 0; q <= n - p; ++q) units.push_back({p, q, n - p - q + 1});
+    }
+    std::vector<int> order(units.size());
+    for (size_t i = 0; i < units.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return units[a].size > units[b].size; });
+    int load[4] = {0, 0, 0, 0};
+    std::vector<int> owner(units.size(), 0);
+    for (int u : order) {
+        int w = 0;
+        for (int k = 1; k < 4; ++k)
+            if (load[k] < load[w]) w = k;
+        owner[u] = w;
+        load[w] += units[u].size;
+    }
+    auto owner_of = [&](int p, int q) {
+        for (size_t i = 0; i < units.size(); ++i)
+            if (units[i].p == p && units[i].q == q) return owner[i];
+        return 0;
+    };
+    for (int w = 0; w < 4; ++w) {
+        std::vector<CoopEntry>& E = C.entries[w];
+        int cur_p = 0, cur_q = 0;       // members currently held by levels 0 and 1
+        bool have_q = false;            // level 1 holds (cur_p, cur_q, 0) with cur_q > 0
+        auto emit_step = [&](int member, int publish) {
+            const Step& st = P.steps[step_of[member]];
+            CoopEntry e;
+            e.level = st.codim;
+            e.publish = publish;
+            e.member = member;
+            e.A = st.A;
+            e.B = st.B;
+            e.C = st.C;
+            if (st.prv >= 0) {
+                e.seed = -2;
+            } else {  // chain start: where does the seed member live?
+                int seedm = st.cur;
+                if (seedm == 0) {
+                    e.seed = -1;
+                } else {
+                    e.seed = P.steps[step_of[seedm]].codim;  // level that produced the seed
+                }
+            }
+            E.push_back(e);
+        };
+        for (size_t ui = 0; ui < units.size(); ++ui) {  // units are in (p, q) lexicographic order
+            if (owner[ui] != w) continue;
+            const int p = units[ui].p, q = units[ui].q;
+            if (sd >= 2 || true) {
+                // level 0: advance to (p,0,0)
+                while (cur_p < p) {
+                    ++cur_p;
+                    int pub = 0;
+                    if (sd == 1) pub = 0;  // sd == 1 has a single unit; handled below
+                    else pub = (owner_of(cur_p, 0) == w && (sd == 2 || true)) ? 1 : 0;
+                    if (sd == 2) pub = owner_of(cur_p, 0) == w ? 1 : 0;
+                    if (sd == 3) pub = owner_of(cur_p, 0) == w ? 1 : 0;
+                    emit_step(sd == 1 ? mid(cur_p, 0, 0) : mid(cur_p, 0, 0), pub);
+                    cur_q = 0;
+                    have_q = false;
+                }
+            }
+            if (p == 0 && q == 0) {  // the constant member heads chain (0,0)
+                CoopEntry e;
+                e.level = -1;
+                e.seed = -1;
+                e.publish = 1;
+                e.member = 0;
+                e.A = e.B = e.C = 0.0;
+                E.push_back(e);
+            }
+            if (sd == 1) {
+                for (int i = 1; i <= n; ++i) emit_step(mid(i, 0, 0), 1);
+                continue;
+            }
+            if (sd == 2) {  // unit = chain p along q (codim 1)
+                for (int i = 1; i <= n - p; ++i) emit_step(mid(p, i, 0), 1);
+                continue;
+            }
+            // sd == 3: level 1 advances to (p,q,0), then the codim-2 chain
+            while (cur_q < q) {
+                ++cur_q;
+                emit_step(mid(p, cur_q, 0), owner_of(p, cur_q) == w ? 1 : 0);
+                have_q = true;
+            }
+            (void)have_q;
+            for (int r = 1; r <= n - p - q; ++r) emit_step(mid(p, q, r), 1);
+        }
+    }
+    // K-step boundaries: a K-step ends with the wave's next published entry
+    int KS = 0;
+    for (int w = 0; w < 4; ++w) {
+        int pubs = 0;
+        for (const auto& e : C.entries[w]) pubs += e.publish;
+        KS = std::max(KS, pubs);
+    }
+    C.KS = KS;
+    C.kperm.assign((size_t)4 * KS, -1);
+    for (int w = 0; w < 4; ++w) {
+        std::vector<CoopEntry>& E = C.entries[w];
+        std::vector<int>& ks = C.kstart[w];
+        ks.clear();
+        ks.push_back(0);
+        int j = 0;
+        for (size_t i = 0; i < E.size(); ++i) {
+            if (E[i].publish) {
+                C.kperm[(size_t)4 * j + w] = E[i].member;
+                ++j;
+                ks.push_back((int)i + 1);
+            }
+        }
+        // trailing unpublished entries cannot exist (every list ends with a published chain)
+        while (j < KS) {  // zero pads
+            CoopEntry e;
+            e.level = -1;
+            e.seed = -2;  // marks a zero row
+            e.publish = 1;
+            e.member = -1;
+            e.A = e.B = e.C = 0.0;
+            E.push_back(e);
+            ++j;
+            ks.push_back((int)E.size());
+        }
+    }
+    return C;
+}
+
 // Fragments for the shape-specialised kernel (simplex_fixed.hpp): full 16-row
 // tiles first ([MT16][KS][64]), then 4-row blocks for v_mfma_f64_4x4x4_4b
 // ([M4][KS][64]; lane l holds C[base + (l & 3)][4*ks + (l >> 4)], the block bits
@@ -254,24 +427,26 @@ inline std::vector<double> pack_a_fragments(const std::vector<double>& C, int ro
 inline std::vector<double> pack_a_fragments_split(const std::vector<double>& C, int rows, int nexp,
                                                   const std::vector<int>* kperm = nullptr) {
     // kperm (optional): K slot -> member index (production order of the recurrence)
-    auto col = [&](int k) { return kperm ? (*kperm)[k] : k; };
+    auto col = [&](int k) { return kperm ? (*kperm)[k] : k; };  // -1: no member in this K slot
     int rem = rows % 16;
     bool split = rem != 0 && rem <= 12;
     int MT16 = split ? rows / 16 : (rows + 15) / 16;
     int M4 = split ? (rem + 3) / 4 : 0;
-    int KS = (nexp + 3) / 4;
+    // with a permutation the K extent is the permutation's length (may include empty slots)
+    int nk = kperm ? (int)kperm->size() : nexp;
+    int KS = (nk + 3) / 4;
     std::vector<double> F((size_t)(MT16 + M4) * KS * 64, 0.0);
     for (int mt = 0; mt < MT16; ++mt)
         for (int ks = 0; ks < KS; ++ks)
             for (int l = 0; l < 64; ++l) {
                 int m = 16 * mt + (l & 15), k = 4 * ks + (l >> 4);
-                if (m < rows && k < nexp) F[((size_t)mt * KS + ks) * 64 + l] = C[(size_t)m * nexp + col(k)];
+                if (m < rows && k < nk && col(k) >= 0) F[((size_t)mt * KS + ks) * 64 + l] = C[(size_t)m * nexp + col(k)];
             }
     for (int m4 = 0; m4 < M4; ++m4)
         for (int ks = 0; ks < KS; ++ks)
             for (int l = 0; l < 64; ++l) {
                 int m = 16 * MT16 + 4 * m4 + (l & 3), k = 4 * ks + (l >> 4);
-                if (m < rows && k < nexp) F[((size_t)(MT16 + m4) * KS + ks) * 64 + l] = C[(size_t)m * nexp + col(k)];
+                if (m < rows && k < nk && col(k) >= 0) F[((size_t)(MT16 + m4) * KS + ks) * 64 + l] = C[(size_t)m * nexp + col(k)];
             }
     return F;
 }

@@ -153,6 +153,68 @@ __device__ __forceinline__ void apply_step_uniform(Jet<SD, ORDER>& nw, const Jet
     }
 }
 
+// In-place form: the new member overwrites `p` (the older of the two inputs).  Components
+// are produced highest derivative first, so every input is read before it is replaced.
+template <int SD, int ORDER>
+__device__ __forceinline__ void apply_step_uniform_inplace(const Jet<SD, ORDER>& cur, Jet<SD, ORDER>& p, double fa,
+                                                           double fb, double fc, double A, double B, double C,
+                                                           const __attribute__((address_space(4))) double* u) {
+    const double f = A * fa - B * fb;
+    const double g = -C * fc;
+    if constexpr (ORDER >= 1) {
+        double dg[SD];
+#pragma unroll
+        for (int d = 0; d < SD; ++d) dg[d] = u[3 + d] * fb;
+        if constexpr (ORDER >= 2) {
+            int h = 0;
+#pragma unroll
+            for (int d1 = 0; d1 < SD; ++d1)
+#pragma unroll
+                for (int d2 = d1; d2 < SD; ++d2) {
+                    double t = cur.h[h] * f + u[d1] * cur.g[d2] + u[d2] * cur.g[d1];
+                    t += p.h[h] * g + dg[d1] * p.g[d2] + dg[d2] * p.g[d1];
+                    t += u[6 + h] * p.v;
+                    p.h[h] = t;
+                    ++h;
+                }
+        }
+#pragma unroll
+        for (int d = 0; d < SD; ++d) p.g[d] = cur.g[d] * f + cur.v * u[d] + p.g[d] * g + p.v * dg[d];
+    }
+    p.v = cur.v * f + p.v * g;
+}
+
+template <int SD, int ORDER>
+__device__ __forceinline__ void apply_step_inplace(const Jet<SD, ORDER>& cur, Jet<SD, ORDER>& p,
+                                                   const Factors<SD, ORDER>& F, double A, double B, double C) {
+    const double f = A * F.fa - B * F.fb;
+    const double g = -C * F.fc;
+    if constexpr (ORDER >= 1) {
+        double df[SD], dg[SD];
+#pragma unroll
+        for (int d = 0; d < SD; ++d) {
+            df[d] = A * F.dfa[d] - B * F.dfb[d];
+            dg[d] = -C * F.dfc[d];
+        }
+        if constexpr (ORDER >= 2) {
+            int h = 0;
+#pragma unroll
+            for (int d1 = 0; d1 < SD; ++d1)
+#pragma unroll
+                for (int d2 = d1; d2 < SD; ++d2) {
+                    double t = cur.h[h] * f + df[d1] * cur.g[d2] + df[d2] * cur.g[d1];
+                    t += p.h[h] * g + dg[d1] * p.g[d2] + dg[d2] * p.g[d1];
+                    t += (-C * F.ddfc[h]) * p.v;
+                    p.h[h] = t;
+                    ++h;
+                }
+        }
+#pragma unroll
+        for (int d = 0; d < SD; ++d) p.g[d] = cur.g[d] * f + cur.v * df[d] + p.g[d] * g + p.v * dg[d];
+    }
+    p.v = cur.v * f + p.v * g;
+}
+
 // fa, fb, fc of one codimension from the reference coordinates (no derivatives)
 template <int SD>
 __device__ __forceinline__ void point_factors(int codim, const double* X, double& fa, double& fb, double& fc) {
