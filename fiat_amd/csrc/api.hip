@@ -656,6 +656,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 ca.TR = TR;
                 ca.slab_doubles = nt_need * 64 + 64;
                 ca.img_doubles = (int)img;
+                ca.debug = a.debug;
                 L.clds_bytes = (int)ldsb;
                 int per_cu = std::max(1, std::min(2, ctx->lds_per_cu / L.clds_bytes));
                 L.cgrid = (int)std::max<long long>(1, std::min<long long>(nreq, (long long)ctx->num_cu * per_cu));

@@ -38,7 +38,17 @@ struct CoopArgs {
     int TR;           // tables per image round
     int slab_doubles; // NT*64 B-fragment doubles + a 64-double dump row for inactive lanes
     int img_doubles;  // >= max(2*slab_doubles, TR*rows*npts)
+    int debug;        // measurement only: 1 skip recurrence math, 2 skip MFMAs, 4 skip output rounds
 };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a full
+// workgroup-scope fence, for which hipcc emits s_waitcnt vmcnt(0): every barrier after a
+// flush would wait for the HBM stores to be acknowledged (microseconds, 11 times per request).
+__device__ __forceinline__ void wg_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 template <int SD, int ORDER, int MT16, int M4, int TPW, bool UNIFORM>
 __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a) {
@@ -62,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
     for (int i = tid; i < a.img_doubles; i += 512) img[i] = 0.0;
     __syncthreads();
 
-    const int nrounds = (NTAB + a.TR - 1) / a.TR;
+    const int nrounds = (a.debug & 4) ? 0 : (NTAB + a.TR - 1) / a.TR;
 
     if (wave < 4) {
         // =========================== producer ===========================
@@ -170,13 +180,13 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                 for (int t = 1; t < NTAB; ++t) slab[colbase[t]] = 0.0;
             };
             // older <- step(newer, older): the result replaces the older member
-            auto step = [&](const Jet<SD, ORDER>& newer, Jet<SD, ORDER>& older, int codim, CDouble* d) {
+            auto step = [&](const Jet<SD, ORDER>& newer, Jet<SD, ORDER>& older, int codim, const double* d) {
                 const double cA = d[0], cB = d[1], cC = d[2];
                 if constexpr (UNIFORM) {
                     const double fa = codim == 0 ? pfa[0] : (codim == 1 ? pfa[SD > 1 ? 1 : 0] : pfa[SD > 2 ? 2 : 0]);
                     const double fb = codim == 0 ? pfb[0] : (codim == 1 ? pfb[SD > 1 ? 1 : 0] : pfb[SD > 2 ? 2 : 0]);
                     const double fc = codim == 0 ? pfc[0] : (codim == 1 ? pfc[SD > 1 ? 1 : 0] : pfc[SD > 2 ? 2 : 0]);
-                    apply_step_uniform_inplace<SD, ORDER>(newer, older, fa, fb, fc, cA, cB, cC, d + 3);
+                    apply_step_uniform_inplace<SD, ORDER, const double*>(newer, older, fa, fb, fc, cA, cB, cC, d + 3);
                 } else {
                     Factors<SD, ORDER> F;
                     make_factors<SD, ORDER>(F, codim, X, J);
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                 }
             };
             // one step of an LDS-resident level (0 or 1)
-            auto lds_level_step = [&](int level, int& par, int seed, int publish, double* slab, CDouble* d) {
+            auto lds_level_step = [&](int level, int& par, int seed, int publish, double* slab, const double* d) {
                 Jet<SD, ORDER> nw, od;
                 if (seed != -2) {  // chain start: newer = seed, older = 0
                     if (seed == -1) set_const(nw); else lld(0 + par0, nw);  // only level 1 has a level-0 seed
@@ -201,12 +211,37 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                 if (publish) put(slab, od);
             };
 
+            // The entry records are wave uniform and read with scalar loads.  Each record is
+            // fetched as ONE block (ints + 15 doubles), one entry ahead of its use: per-field
+            // loads cost a scalar-cache round trip and an lgkmcnt(0) drain each (~1000 s_load per
+            // request measured before).
+            int nlevel = eint[0], nseed = eint[1], npublish = eint[2];
+            double nd_[15];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) nd_[i] = edbl[i];
+            int e = 0;
             for (int ks = 0; ks < KS; ++ks) {
                 double* slab = img + (size_t)(ks & 1) * a.slab_doubles;
-                const int e0 = kst[ks], e1 = kst[ks + 1];
-                for (int e = e0; e < e1; ++e) {
-                    const int level = eint[e * 4 + 0], seed = eint[e * 4 + 1], publish = eint[e * 4 + 2];
-                    CDouble* d = edbl + (size_t)e * 16;
+                // readfirstlane: make the control values provably wave uniform (scalar branches,
+                // no exec-mask juggling around every level / parity test)
+                const int e1 = __builtin_amdgcn_readfirstlane(kst[ks + 1]);
+                if (a.debug & 1) e = e1;
+                for (; e < e1; ++e) {
+                    const int level = __builtin_amdgcn_readfirstlane(nlevel);
+                    const int seed = __builtin_amdgcn_readfirstlane(nseed);
+                    const int publish = __builtin_amdgcn_readfirstlane(npublish);
+                    double dreg[15];
+#pragma unroll
+                    for (int i = 0; i < 15; ++i) dreg[i] = nd_[i];
+                    {   // prefetch the next record (clamped: the table has emax rows)
+                        const int en = min(e + 1, a.emax - 1);
+                        nlevel = eint[en * 4 + 0];
+                        nseed = eint[en * 4 + 1];
+                        npublish = eint[en * 4 + 2];
+#pragma unroll
+                        for (int i = 0; i < 15; ++i) nd_[i] = edbl[(size_t)en * 16 + i];
+                    }
+                    const double* d = dreg;
                     if (level < 0) {
                         // zero pad row (seed == -2) or the constant member
                         if (publish) put_zero(slab, seed == -2 ? 0.0 : phi0);
@@ -235,12 +270,12 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                 // Barrier #ks: slab ks is complete.  No second barrier is needed before this
                 // buffer is overwritten at K-step ks+2: a producer gets past barrier #ks+1 only
                 // when every consumer has arrived there, i.e. after its reads of slab ks.
-                __syncthreads();
+                wg_lds_barrier();
             }
-            __syncthreads();  // every consumer has read the last slab: the image may overwrite it
+            wg_lds_barrier();  // every consumer has read the last slab: the image may overwrite it
             // output rounds: the consumers fill the image, everybody flushes it
             for (int r = 0; r < nrounds; ++r) {
-                __syncthreads();  // image round r written
+                wg_lds_barrier();  // image round r written
                 const int t0 = r * a.TR;
                 const int nt_r = min(a.TR, NTAB - t0);
                 const long long nd = (long long)nt_r * table;
@@ -252,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                 } else {
                     for (int i = tid; i < (int)nd; i += 512) g[i] = img[i];
                 }
-                __syncthreads();  // image may be overwritten
+                wg_lds_barrier();  // image may be overwritten
             }
         }
     } else {
@@ -285,8 +320,14 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
 #pragma unroll
                 for (int m4 = 0; m4 < M4; ++m4) acc4[t][m4] = 0.0;
             }
+            // A fragments of K-step ks+1 are fetched while the MFMAs of K-step ks run
+            double a16n[MT16 > 0 ? MT16 : 1], a4n[M4 > 0 ? M4 : 1];
+#pragma unroll
+            for (int mt = 0; mt < MT16; ++mt) a16n[mt] = afr[((size_t)mt * KS) * 64 + lane];
+#pragma unroll
+            for (int m4 = 0; m4 < M4; ++m4) a4n[m4] = afr[((size_t)(MT16 + m4) * KS) * 64 + lane];
             for (int ks = 0; ks < KS; ++ks) {
-                __syncthreads();  // barrier #ks: slab ks published
+                wg_lds_barrier();  // barrier #ks: slab ks published
                 const double* slab = img + (size_t)(ks & 1) * a.slab_doubles;
                 double b[TPW];
 #pragma unroll
@@ -296,9 +337,17 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                 }
                 double a16[MT16 > 0 ? MT16 : 1], a4[M4 > 0 ? M4 : 1];
 #pragma unroll
-                for (int mt = 0; mt < MT16; ++mt) a16[mt] = afr[((size_t)mt * KS + ks) * 64 + lane];
+                for (int mt = 0; mt < MT16; ++mt) a16[mt] = a16n[mt];
 #pragma unroll
-                for (int m4 = 0; m4 < M4; ++m4) a4[m4] = afr[((size_t)(MT16 + m4) * KS + ks) * 64 + lane];
+                for (int m4 = 0; m4 < M4; ++m4) a4[m4] = a4n[m4];
+                {
+                    const int kn = min(ks + 1, KS - 1);
+#pragma unroll
+                    for (int mt = 0; mt < MT16; ++mt) a16n[mt] = afr[((size_t)mt * KS + kn) * 64 + lane];
+#pragma unroll
+                    for (int m4 = 0; m4 < M4; ++m4) a4n[m4] = afr[((size_t)(MT16 + m4) * KS + kn) * 64 + lane];
+                }
+                if (!(a.debug & 2))
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) {
 #pragma unroll
@@ -309,11 +358,12 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                         acc4[t][m4] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[m4], b[t], acc4[t][m4], 0, 0, 0);
                 }
             }
-            __syncthreads();  // every consumer has read the last slab: the image may overwrite it
+            wg_lds_barrier();  // every consumer has read the last slab: the image may overwrite it
             for (int r = 0; r < nrounds; ++r) {
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) {
                     const bool mine = iround[t] == r;
+                    if (__ballot(mine) == 0ull) continue;  // wave uniform: no lane of this tile in round r
                     const int so = ioff[t];
 #pragma unroll
                     for (int mt = 0; mt < MT16; ++mt)
@@ -328,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                         if (mine && mbase + (lane >> 4) < rows) img[so + mbase * npts] = acc4[t][m4];
                     }
                 }
-                __syncthreads();  // image round r written
+                wg_lds_barrier();  // image round r written
                 const int t0 = r * a.TR;
                 const int nt_r = min(a.TR, NTAB - t0);
                 const long long nd = (long long)nt_r * table;
@@ -340,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                 } else {
                     for (int i = tid; i < (int)nd; i += 512) g[i] = img[i];
                 }
-                __syncthreads();  // image may be overwritten
+                wg_lds_barrier();  // image may be overwritten
             }
         }
     }

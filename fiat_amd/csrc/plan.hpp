@@ -315,8 +315,7 @@ inline CoopPlan build_coop_plan(const Program& P) {
     };
     for (int w = 0; w < 4; ++w) {
         std::vector<CoopEntry>& E = C.entries[w];
-        int cur_p = 0, cur_q = 0;       // members currently held by levels 0 and 1
-        bool have_q = false;            // level 1 holds (cur_p, cur_q, 0) with cur_q > 0
+        int cur_p = 0, cur_q = 0;  // members currently held by levels 0 and 1
         auto emit_step = [&](int member, int publish) {
             const Step& st = P.steps[step_of[member]];
             CoopEntry e;
@@ -341,19 +340,12 @@ inline CoopPlan build_coop_plan(const Program& P) {
         for (size_t ui = 0; ui < units.size(); ++ui) {  // units are in (p, q) lexicographic order
             if (owner[ui] != w) continue;
             const int p = units[ui].p, q = units[ui].q;
-            if (sd >= 2 || true) {
-                // level 0: advance to (p,0,0)
-                while (cur_p < p) {
-                    ++cur_p;
-                    int pub = 0;
-                    if (sd == 1) pub = 0;  // sd == 1 has a single unit; handled below
-                    else pub = (owner_of(cur_p, 0) == w && (sd == 2 || true)) ? 1 : 0;
-                    if (sd == 2) pub = owner_of(cur_p, 0) == w ? 1 : 0;
-                    if (sd == 3) pub = owner_of(cur_p, 0) == w ? 1 : 0;
-                    emit_step(sd == 1 ? mid(cur_p, 0, 0) : mid(cur_p, 0, 0), pub);
-                    cur_q = 0;
-                    have_q = false;
-                }
+            // level 0: advance to (p,0,0); published by the owner of chain (p,0) only
+            // (sd == 1 has a single unit with p == 0, so this loop never runs there)
+            while (cur_p < p) {
+                ++cur_p;
+                emit_step(mid(cur_p, 0, 0), owner_of(cur_p, 0) == w ? 1 : 0);
+                cur_q = 0;
             }
             if (p == 0 && q == 0) {  // the constant member heads chain (0,0)
                 CoopEntry e;
@@ -376,9 +368,7 @@ inline CoopPlan build_coop_plan(const Program& P) {
             while (cur_q < q) {
                 ++cur_q;
                 emit_step(mid(p, cur_q, 0), owner_of(p, cur_q) == w ? 1 : 0);
-                have_q = true;
             }
-            (void)have_q;
             for (int r = 1; r <= n - p - q; ++r) emit_step(mid(p, q, r), 1);
         }
     }

@@ -155,10 +155,10 @@ __device__ __forceinline__ void apply_step_uniform(Jet<SD, ORDER>& nw, const Jet
 
 // In-place form: the new member overwrites `p` (the older of the two inputs).  Components
 // are produced highest derivative first, so every input is read before it is replaced.
-template <int SD, int ORDER>
+template <int SD, int ORDER, typename UPtr>
 __device__ __forceinline__ void apply_step_uniform_inplace(const Jet<SD, ORDER>& cur, Jet<SD, ORDER>& p, double fa,
                                                            double fb, double fc, double A, double B, double C,
-                                                           const __attribute__((address_space(4))) double* u) {
+                                                           UPtr u) {
     const double f = A * fa - B * fb;
     const double g = -C * fc;
     if constexpr (ORDER >= 1) {
