@@ -166,10 +166,12 @@ def main():
     achieved = bytes_per_req * batch / (kernel_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "fxk::tabulate_simplex_stream" if args.workload == "p3tet" else "fxk::tabulate_simplex_kernel",
+                "kernel": ps.kernel_name(order, batch, npts),
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_request": bytes_per_req, "requests_per_launch": batch}
-    prof = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    prof = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+    if not os.path.exists(prof):
+        prof = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(prof):
         try:
             with open(prof) as f:

@@ -782,6 +782,21 @@ int fx_tabulate_batch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq,
     return run_tabulate(ctx, e, order, L, (hipStream_t)stream);
 }
 
+int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, int has_verts, char* name,
+                   int name_len) {
+    if (!name || name_len < 1) return fail(FX_EINVAL, "fx_plan_kernel: bad name buffer");
+    Launch L;
+    // plan_launch only records the pointers; a non-null dummy stands for "per-request cells given"
+    static double dummy;
+    int rc = plan_launch(ctx, e, order, nreq, npts, &dummy, has_verts ? &dummy : nullptr, &dummy, L);
+    if (rc != FX_OK) return rc;
+    const char* k = "fxk::tabulate_simplex_kernel";
+    if (L.fixed_id >= 0) k = L.fkind == 0 ? "fxk::tabulate_simplex_fixed" : "fxk::tabulate_simplex_stream";
+    else if (L.coop_id >= 0) k = "fxk::tabulate_simplex_coop";
+    snprintf(name, (size_t)name_len, "%s", k);
+    return FX_OK;
+}
+
 int fx_time_tabulate_batch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, const double* pts,
                            const double* verts, double* out, void* stream, int reps, float* ms) {
     if (reps < 1 || !ms) return fail(FX_EINVAL, "fx_time_tabulate_batch: bad reps/ms");

@@ -132,6 +132,13 @@ class SimplexPolySet:
                                     None if verts is None else _dev_ptr(verts), _dev_ptr(out), _stream_ptr(stream)))
         return out
 
+    def kernel_name(self, order, nreq, npts, has_verts=False):
+        """Device kernel ``tabulate_batch`` launches for this request shape (fx_plan_kernel)."""
+        buf = ctypes.create_string_buffer(96)
+        check(lib.fx_plan_kernel(self.ctx.handle, self.handle, int(order), int(nreq), int(npts), int(bool(has_verts)),
+                                 buf, 96))
+        return buf.value.decode()
+
     def time_tabulate_batch(self, order, pts, verts, out, reps, stream=None):
         """Average kernel milliseconds over ``reps`` launches (HIP events on the launch stream)."""
         ms = c_float(0.0)

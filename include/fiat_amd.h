@@ -147,6 +147,13 @@ int fx_plan_steps(int sd, int n, int variant, double scale, int cap, int* nsteps
                   double* phi0, int* ints, double* coefs);
 int fx_plan_c0_transform(int sd, int n, double* T /* host [nexp][nexp] */);
 
+/* Name of the device kernel fx_tabulate_batch would launch for this element and request shape
+ * ("fxk::tabulate_simplex_stream", "..._fixed", "..._coop" or the generic "..._kernel"); has_verts != 0
+ * stands for per-request cell geometry.  Lets benchmarks and tests name the kernel they measured
+ * (no reference counterpart: FIAT has a single NumPy path, FIAT/expansions.py:449-490). */
+int fx_plan_kernel(fx_ctx* ctx, const fx_element* elem, int order, int64_t nreq, int npts, int has_verts, char* name,
+                   int name_len);
+
 /* ---- measurement helpers ---------------------------------------------------------
  * Time `reps` launches of fx_tabulate_batch with HIP events on `stream`;
  * returns average milliseconds per launch in *ms. */

@@ -315,3 +315,16 @@ def test_quad_mixed(rt, golden):
     Lb = rt.LineLagrange(np.array([0.0, 1.0, 0.5]))
     out = rt.tensor_tabulate_batch([La, Lb], 2, g["quad_pts"][None]).cpu().numpy()[0]
     assert_tables(out, g["quad_tab"], 2, "quad")
+
+
+# ---- kernel selection: the benchmark shapes must run on their specialised kernels -----
+def test_kernel_selection(rt, golden):
+    g = golden("elements")
+    p3 = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=g["c2_p3tet_q6_coeffs"])
+    assert p3.kernel_name(1, 1000, 23) == "fxk::tabulate_simplex_stream"
+    assert p3.kernel_name(1, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_stream"
+    assert p3.kernel_name(1, 1000, 40) == "fxk::tabulate_simplex_kernel"     # more points than one tile row
+    assert p3.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_kernel"
+    dg6 = rt.SimplexPolySet(3, 6, coeffs=g["c4_dg6tet_q6_coeffs"])
+    assert dg6.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_coop"
+    assert dg6.kernel_name(2, 1000, 122) == "fxk::tabulate_simplex_kernel"

@@ -10,6 +10,7 @@ import glob
 import json
 import os
 import shutil
+import statistics
 import sys
 
 src = sys.argv[1]                 # e.g. gpurun_out/prof_r1c
@@ -33,7 +34,9 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
                 meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
                                           "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size") if k in r}
         for k, v in agg.items():
-            counters[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+            # median, not mean: element construction launches the generic kernel once on a tiny
+            # batch before the timed launches, which would skew a mean
+            counters[k] = {"mean_per_launch": statistics.median(v), "launches": len(v), "statistic": "median"}
         if meta:
             counters["_dispatch"] = meta
 dur = None
@@ -50,7 +53,7 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     summary["hbm_traffic"] = {"read_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                               "total_bytes_per_launch": fetch + write,
                               "note": "FETCH_SIZE*1024*2 (gfx950 half-count correction) + WRITE_SIZE*1024"}
-    with open("profiles/traffic_latest.json", "w") as f:
+    with open(f"profiles/traffic_{workload}.json", "w") as f:
         json.dump({"workload": workload, "batch": batch, "hbm_bytes_per_launch": fetch + write,
                    "read": fetch, "write": write, "from": f"profiles/{tag}_summary.json"}, f, indent=1)
 with open(f"profiles/{tag}_summary.json", "w") as f:
