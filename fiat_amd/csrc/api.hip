@@ -16,6 +16,7 @@
 #include "simplex_kernel.hpp"
 #include "simplex_fixed.hpp"
 #include "simplex_stream.hpp"
+#include "simplex_pair.hpp"
 #include "coop_kernel.hpp"
 
 namespace {
@@ -425,8 +426,10 @@ struct Launch {
     fxk::FixedArgs<0> fhead;           // everything but the coefficients
     std::vector<double> fcoef;         // [nsteps][3]
     std::vector<double> fucoef;        // [nsteps][12], uniform-cell factor derivatives
-    int fgrid = 0, flds_bytes = 0;
-    int fkind = 0;  // 0: LDS-image kernel (simplex_fixed.hpp), 1: K-streamed kernel (simplex_stream.hpp)
+    int fgrid = 0, flds_bytes = 0, ncu = 0;
+    // 0: LDS-image kernel (simplex_fixed.hpp), 1: K-streamed kernel (simplex_stream.hpp),
+    // 2: K-streamed, two requests per wave (simplex_pair.hpp)
+    int fkind = 0;
     // cooperative large-shape kernel
     int coop_id = -1;
     fxk::CoopArgs cargs;
@@ -474,13 +477,29 @@ int launch_fixed(const Launch& L, hipStream_t s) {
         return fail(FX_EINVAL, "internal: coefficient table size mismatch");
     memcpy(fa.coef, L.fcoef.data(), NC * sizeof(double));
     memcpy(fa.ucoef, L.fucoef.data(), 4 * NC * sizeof(double));
-    KernT kern = L.fkind == 1 ? (L.fhead.verts ? (KernT)fxk::tabulate_simplex_stream<SD, N, ORDER, ROWS, NT, FIXED_NW, false>
-                                               : (KernT)fxk::tabulate_simplex_stream<SD, N, ORDER, ROWS, NT, FIXED_NW, true>)
-                              : (KernT)fxk::tabulate_simplex_fixed<SD, N, ORDER, ROWS, NT, FIXED_NW>;
+    KernT kern;
+    if (L.fkind == 2)
+        kern = L.fhead.verts ? (KernT)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, FIXED_NW, false>
+                             : (KernT)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, FIXED_NW, true>;
+    else if (L.fkind == 1)
+        kern = L.fhead.verts ? (KernT)fxk::tabulate_simplex_stream<SD, N, ORDER, ROWS, NT, FIXED_NW, false>
+                             : (KernT)fxk::tabulate_simplex_stream<SD, N, ORDER, ROWS, NT, FIXED_NW, true>;
+    else
+        kern = (KernT)fxk::tabulate_simplex_fixed<SD, N, ORDER, ROWS, NT, FIXED_NW>;
     if (L.flds_bytes > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     L.flds_bytes));
-    hipLaunchKernelGGL(kern, dim3(L.fgrid), dim3(64 * FIXED_NW), L.flds_bytes, s, fa);
+    int grid = L.fgrid;
+    if (L.fkind == 2) {
+        // persistent waves: as many workgroups as the registers and LDS of the chip hold
+        int occ = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 64 * FIXED_NW,
+                                                             (size_t)L.flds_bytes));
+        grid = std::max(1, std::min(L.fgrid, L.ncu * std::max(1, occ)));
+        static const bool verbose = getenv("FIAT_AMD_VERBOSE") != nullptr;
+        if (verbose) fprintf(stderr, "[fiat_amd] pair kernel: occupancy %d WG/CU, grid %d, lds %d B\n", occ, grid, L.flds_bytes);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FIXED_NW), L.flds_bytes, s, fa);
     HIP_TRY(hipGetLastError());
     return FX_OK;
 }
@@ -708,8 +727,16 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             fa.verts = verts;
             fa.out = out;
             const char* kk = getenv("FIAT_AMD_KERNEL");
-            L.fkind = (kk && !strcmp(kk, "image")) ? 0 : 1;  // default: K-streamed kernel (A/B: FIAT_AMD_KERNEL=image)
-            fa.afrag = L.fkind == 1 ? e->d_afrag_stream : e->d_afrag_split;
+            // default: K-streamed kernel, two requests per wave when the points of two requests fit
+            // one wave (A/B: FIAT_AMD_KERNEL=image|stream|pair)
+            // (pair kernel: the tables of each output half must fit half of the column tiles)
+            const bool pair_ok = npts <= 32 && (ntab == 1 || (f.nt % 2 == 0 && (f.nt / 2) * 16 >= ((ntab + 1) / 2) * npts));
+            L.fkind = (pair_ok && !verts) ? 2 : 1;
+            if (kk && !strcmp(kk, "image")) L.fkind = 0;
+            if (kk && !strcmp(kk, "stream")) L.fkind = 1;
+            if (kk && !strcmp(kk, "pair") && pair_ok) L.fkind = 2;
+            L.ncu = ctx->num_cu;
+            fa.afrag = L.fkind >= 1 ? e->d_afrag_stream : e->d_afrag_split;
             fa.phi0 = e->prog.phi0;
             memcpy(fa.A0, e->A0, sizeof fa.A0);
             memcpy(fa.b0, e->b0, sizeof fa.b0);
@@ -718,11 +745,12 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             fa.debug = a.debug;
             long long need = std::max<long long>((long long)f.nt * e->KS * 64, (long long)ntab * rows * npts);
             need = (need + 1) & ~1LL;
-            if (L.fkind == 1) {
+            if (L.fkind >= 1) {
                 {
                     // per wave: half image (>= the K-step slab that aliases it) + 64-double dump row
                     const int th = (ntab + 1) / 2;
-                    long long per_wave = std::max<long long>((long long)th * rows * npts, (long long)f.nt * 64) + 64;
+                    long long per_wave =
+                        std::max<long long>((long long)th * rows * npts, (long long)f.nt * 64 * (L.fkind == 2 ? 2 : 1)) + 64;
                     per_wave = (per_wave + 1) & ~1LL;
                     fa.lds_doubles = (int)per_wave;
                     int rem = rows % 16;
@@ -732,8 +760,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 }
                 // registers bound the occupancy: ask for every workgroup the CU can hold
                 long long want = (long long)ctx->num_cu * 4;
-                long long nwg = (nreq + FIXED_NW - 1) / FIXED_NW;
-                L.fgrid = (int)std::max<long long>(1, std::min<long long>(nwg, want));
+                const long long units = L.fkind == 2 ? (nreq + 1) / 2 : nreq;  // requests or pairs, one per wave
+                long long nwg = (units + FIXED_NW - 1) / FIXED_NW;
+                L.fgrid = (int)std::max<long long>(1, std::min<long long>(nwg, L.fkind == 2 ? nwg : want));
                 L.fixed_id = (int)i;
                 break;
             }
@@ -791,7 +820,8 @@ int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, in
     int rc = plan_launch(ctx, e, order, nreq, npts, &dummy, has_verts ? &dummy : nullptr, &dummy, L);
     if (rc != FX_OK) return rc;
     const char* k = "fxk::tabulate_simplex_kernel";
-    if (L.fixed_id >= 0) k = L.fkind == 0 ? "fxk::tabulate_simplex_fixed" : "fxk::tabulate_simplex_stream";
+    if (L.fixed_id >= 0)
+        k = L.fkind == 0 ? "fxk::tabulate_simplex_fixed" : L.fkind == 1 ? "fxk::tabulate_simplex_stream" : "fxk::tabulate_simplex_pair";
     else if (L.coop_id >= 0) k = "fxk::tabulate_simplex_coop";
     snprintf(name, (size_t)name_len, "%s", k);
     return FX_OK;

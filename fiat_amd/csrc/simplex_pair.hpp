@@ -1,0 +1,372 @@
+// Paired K-streamed simplex tabulation kernel (gfx950): TWO requests per wave.
+//
+// Measured on MI355X (tools/ubench2.hip): fp64 MFMA and fp64/fp32 VALU instructions of
+// different waves do not overlap on a SIMD -- a wave issuing v_mfma_f64 stalls the other
+// waves' VALU work for the 64 (16x16x4) / 16 (4x4x4) cycles it takes, and the fp64 MFMA
+// rate equals the fp64 FMA rate (32 flop/cycle/SIMD).  The specialised kernels are therefore
+// bound by MFMA cycles + VALU cycles per request, not by HBM alone, and the recurrence
+// (lanes <-> points, 23 of 64 lanes busy for a degree-6 rule) is the part that can shrink:
+// here lanes 0..31 carry the points of request 2i and lanes 32..63 those of request 2i+1,
+// so every recurrence instruction, coordinate map and LDS store of expansion values serves
+// two requests.  The contraction runs over 2*NT column tiles (same MFMA count per request);
+// everything else follows simplex_stream.hpp (K-streamed slab aliasing a half-request output
+// image, full-line 16-byte stores, exact vmcnt on the prefetched points).
+#pragma once
+#include "simplex_stream.hpp"
+
+#ifndef FX_DBG
+#define FX_DBG 0  // ablation builds only (make dbg-libs): 1 skip recurrence, 2 skip MFMA, 8 skip LDS stores of Phi
+#endif
+#ifndef FX_PAIR_WAVES
+#define FX_PAIR_WAVES 2  // waves per SIMD requested from the register allocator (2*NT accumulator tiles)
+#endif
+
+namespace fxk {
+
+template <int SD, int N, int ORDER, int ROWS, int NT, int NW, bool UNIFORM>
+__global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(const FixedArgs<FixedNC<SD, N>::value> a) {
+    constexpr int NTAB = NTab<SD, ORDER>::value;
+    constexpr StepTable<SD, N> TBL{};
+    constexpr int NEXP = StepTable<SD, N>::NEXP;
+    constexpr int KS = (NEXP + 3) / 4;
+    constexpr int MT16 = rows_full16(ROWS);
+    constexpr int M4 = rows_blk4(ROWS);
+    constexpr int NT2 = 2 * NT;  // column tiles of the pair: [0, NT) request 2i, [NT, 2NT) request 2i+1
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // LDS: [A fragments, shared by the workgroup] [per wave: half image of ONE request (the
+    // K-step slab of the pair aliases its start) | 64-double dump row for inactive lanes]
+    constexpr int NAF = (MT16 + M4) * KS;
+    double* afr = lds;
+    double* img = lds + NAF * 64 + (size_t)wave * a.lds_doubles;
+    double* slab = img;
+    const int dump = a.lds_doubles - 64;
+
+    typedef const __attribute__((address_space(4))) double CDouble;
+    typedef FixedArgs<FixedNC<SD, N>::value> ArgsT;
+    const __attribute__((address_space(4))) char* kargs =
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    CDouble* kcoef = (CDouble*)(kargs + __builtin_offsetof(ArgsT, coef));
+    CDouble* kucoef = (CDouble*)(kargs + __builtin_offsetof(ArgsT, ucoef));
+
+    const int npts = a.npts;  // <= 32 (host-checked)
+    const int table = ROWS * npts;
+    const int reqsize = NTAB * table;
+    const int ncols = NTAB * npts;
+
+    for (int i = lane; i < a.lds_doubles; i += 64) img[i] = 0.0;
+    for (int i = threadIdx.x; i < NAF * 64; i += 64 * NW) afr[i] = a.afrag[i];
+    __syncthreads();
+
+    const int sub = lane >> 5;  // which request of the pair this lane's point belongs to
+    const int lp = lane & 31;
+    const bool active = lp < npts;
+    const int pl = active ? lp : 0;
+    // Column order of the contraction: the tables of output half h (h = 0: tables [0, TH),
+    // h = 1: tables [TH, NTAB)) occupy the column tiles [h*NT/2, (h+1)*NT/2) of their request, so
+    // that no tile straddles the two half images (host-checked: (NT/2)*16 >= TH*npts).  The
+    // epilogue is then free of branches and masks, which keeps hipcc's vmcnt bookkeeping exact.
+    static_assert(NT % 2 == 0 || NTAB == 1, "half-aligned column tiles need an even tile count");
+    constexpr int TH = (NTAB + 1) / 2;
+    constexpr int NTH = NTAB > TH ? NT / 2 : NT;  // tiles per half
+    int colbase[NTAB];
+#pragma unroll
+    for (int t = 0; t < NTAB; ++t) {
+        const int h = t >= TH ? 1 : 0;
+        const int c = (t - h * TH) * npts + pl;  // column inside the half
+        colbase[t] = active ? (sub * NT + h * NTH + (c >> 4)) * 64 + (c & 15) : dump + (lane & 15);
+    }
+    constexpr int NFL = (TH * ROWS * ((16 * NTH) / TH) / 2 + 63) / 64;
+    constexpr int NSTORE = 2 * NFL * (NTAB > TH ? 2 : 1);  // vector-memory stores per pair
+    (void)NSTORE;
+    // image offset (inside its half image) of this lane's column of tile nt, row (lane >> 4);
+    // padding columns go to the dump row
+    int ioff[NT];
+    {
+        const float rinv = 1.0f / (float)npts;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int h = nt / NTH;
+            const int c = ((nt - h * NTH) << 4) + (lane & 15);
+            const int ct = idiv_small(c, rinv);
+            const int cp = c - ct * npts;
+            const int nth = h == 0 ? TH : NTAB - TH;
+            ioff[nt] = (ct < nth) ? ct * table + cp + (lane >> 4) * npts : -1;
+        }
+    }
+
+#ifdef FX_STAGGER
+    // ablation: start the second half of the grid (the second workgroup of every CU) half a
+    // pair period late, so that the two waves of a SIMD are in different phases
+    if (blockIdx.x >= gridDim.x / 2) {
+        for (int i = 0; i < FX_STAGGER; ++i) __builtin_amdgcn_s_sleep(100);
+    }
+#endif
+    const long long npairs = (a.nreq + 1) >> 1;
+    const long long stride = (long long)gridDim.x * NW;
+    long long pr = (long long)blockIdx.x * NW + wave;
+    // request of this lane's half of the pair (the last pair of an odd batch has no second
+    // request: its lanes recompute the first one and the stores are skipped)
+    auto lane_req = [&](long long p) -> long long {
+        long long r = 2 * p + sub;
+        if (FX_DBG & 128) r &= 1023;  // ablation: cache-resident input window
+        return r < a.nreq ? r : a.nreq - 1;
+    };
+    double xnext[SD];
+    if (pr < npairs) {
+        const double* pp = a.pts + ((size_t)lane_req(pr) * npts + pl) * SD;
+#pragma unroll
+        for (int d = 0; d < SD; ++d) xnext[d] = pp[d];
+    }
+#pragma unroll
+    for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
+    for (; pr < npairs; pr += stride) {
+        double X[SD];
+        double J[SD][SD];
+        {
+            double x[SD];
+#pragma unroll
+            for (int d = 0; d < SD; ++d) x[d] = xnext[d];
+            {
+                const long long pn = (pr + stride < npairs) ? pr + stride : pr;
+                const double* pp = a.pts + ((size_t)lane_req(pn) * npts + pl) * SD;
+#pragma unroll
+                for (int d = 0; d < SD; ++d) xnext[d] = pp[d];
+            }
+            double bb[SD];
+            if constexpr (!UNIFORM) {
+                cell_map<SD>(a.verts + (size_t)lane_req(pr) * (SD + 1) * SD, J, bb);  // per lane: two cells per wave
+#pragma unroll
+                for (int i = 0; i < SD; ++i) {
+                    double t = bb[i];
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) t += J[i][d] * x[d];
+                    X[i] = t;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < SD; ++i) {
+                    double t = a.b0[i];
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) t += a.A0[i * SD + d] * x[d];
+                    X[i] = t;
+                }
+            }
+        }
+
+        v4d acc16[NT2][MT16 > 0 ? MT16 : 1];
+        double acc4[NT2][M4 > 0 ? M4 : 1];
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+#pragma unroll
+            for (int mt = 0; mt < MT16; ++mt) acc16[nt][mt] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int m4 = 0; m4 < M4; ++m4) acc4[nt][m4] = 0.0;
+        }
+
+        Jet<SD, ORDER> mem[NEXP];
+        Jet<SD, ORDER> zero;
+        jet_zero(zero);
+        Factors<SD, ORDER> F;
+        double ufa = 0.0, ufb = 0.0, ufc = 0.0;
+        int fcodim = -1;
+
+        auto produce = [&](int slot) {
+            if (slot == 0) {
+                jet_zero(mem[0]);
+                mem[0].v = a.phi0;
+            } else if (FX_DBG & 1) {
+                if (slot < NEXP) {
+                    jet_zero(mem[TBL.dst[slot - 1]]);
+                    mem[TBL.dst[slot - 1]].v = X[0];
+                }
+            } else if (slot < NEXP) {
+                const int s = slot - 1;
+                // (the BASE pointers are made opaque, the step's offset stays an immediate of the
+                // scalar load: opaque per-step pointers get precomputed outside the request loop
+                // and spilled, 2 x 19 64-bit SGPR pairs read back with v_readlane per request)
+                const CDouble* cb = kcoef;
+                const CDouble* ub = kucoef;
+                asm volatile("" : "+s"(cb), "+s"(ub));
+                const CDouble* cp = cb + 3 * s;
+                const CDouble* up = ub + 12 * s;
+                const double cA = cp[0], cB = cp[1], cC = cp[2];
+                if constexpr (UNIFORM) {
+                    if (TBL.codim[s] != fcodim) {
+                        fcodim = TBL.codim[s];
+                        point_factors<SD>(fcodim, X, ufa, ufb, ufc);
+                    }
+                    apply_step_uniform<SD, ORDER>(mem[TBL.dst[s]], mem[TBL.cur[s]],
+                                                  TBL.prv[s] < 0 ? zero : mem[TBL.prv[s]], ufa, ufb, ufc, cA, cB, cC,
+                                                  up);
+                } else {
+                    if (TBL.codim[s] != fcodim) {
+                        fcodim = TBL.codim[s];
+                        make_factors<SD, ORDER>(F, fcodim, X, J);
+                    }
+                    apply_step<SD, ORDER>(mem[TBL.dst[s]], mem[TBL.cur[s]], TBL.prv[s] < 0 ? zero : mem[TBL.prv[s]],
+                                          F, cA, cB, cC);
+                }
+            }
+        };
+        auto slot_jet = [&](int slot) -> const Jet<SD, ORDER>& {
+            if (slot == 0) return mem[0];
+            if (slot < NEXP) return mem[TBL.dst[slot - 1]];
+            return zero;
+        };
+        auto put = [&](int kk, const Jet<SD, ORDER>& j) {
+            if (FX_DBG & 8) return;
+            slab[colbase[0] + kk * 16] = j.v;
+            if constexpr (ORDER >= 1) {
+#pragma unroll
+                for (int d = 0; d < SD; ++d) slab[colbase[1 + d] + kk * 16] = j.g[d];
+            }
+            if constexpr (ORDER >= 2) {
+#pragma unroll
+                for (int h = 0; h < SD * (SD + 1) / 2; ++h) slab[colbase[1 + SD + h] + kk * 16] = j.h[h];
+            }
+        };
+
+        int elane = lane;  // epilogue copies of the lane- and npts-derived offsets, see below
+        int eoff[NT];
+        int enpts = npts;
+        // accumulators of tile nt (of half nt / NTH) of request `rq` of the pair -> half image;
+        // every lane stores: padding columns and rows past the end land in the dump row
+        auto image_tile = [&](int rq, int nt) {
+            const int so = eoff[nt];
+            const bool mine = so >= 0;
+            const int an = rq * NT + nt;
+            const int dsink = dump + elane;
+#pragma unroll
+            for (int mt = 0; mt < MT16; ++mt) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int mbase = 16 * mt + 4 * jj;  // + (lane >> 4)
+                    if (FX_DBG & 32) {
+                        if (mbase + 3 < ROWS) {
+                            if (mine) img[so + mbase * enpts] = acc16[an][mt][jj];
+                        } else if (mbase < ROWS) {
+                            if (mine && mbase + (elane >> 4) < ROWS) img[so + mbase * enpts] = acc16[an][mt][jj];
+                        }
+                    } else if (mbase + 3 < ROWS) {
+                        img[mine ? so + mbase * enpts : dsink] = acc16[an][mt][jj];
+                    } else if (mbase < ROWS) {
+                        img[(mine && mbase + (elane >> 4) < ROWS) ? so + mbase * enpts : dsink] = acc16[an][mt][jj];
+                    }
+                }
+            }
+#pragma unroll
+            for (int m4 = 0; m4 < M4; ++m4) {
+                const int mbase = 16 * MT16 + 4 * m4;
+                if (FX_DBG & 32) {
+                    if (mine && mbase + (elane >> 4) < ROWS) img[so + mbase * enpts] = acc4[an][m4];
+                } else if (mbase + 3 < ROWS) {
+                    img[mine ? so + mbase * enpts : dsink] = acc4[an][m4];
+                } else {
+                    img[(mine && mbase + (elane >> 4) < ROWS) ? so + mbase * enpts : dsink] = acc4[an][m4];
+                }
+            }
+        };
+        auto flush_half = [&](long long req, int half) {
+            const int ntab_h = half == 0 ? TH : NTAB - TH;
+            const int nch = (ntab_h * ROWS * enpts) >> 1;
+            const v2d* s2 = reinterpret_cast<const v2d*>(img);
+            v2d* g2 = reinterpret_cast<v2d*>(a.out + (size_t)req * (NTAB * ROWS * enpts) + (size_t)half * TH * ROWS * enpts);
+            v2d buf[NFL];
+#pragma unroll
+            for (int it = 0; it < NFL; ++it) {
+                const int i = min(it * 64 + elane, nch - 1);
+                buf[it] = s2[i];
+            }
+#pragma unroll
+            for (int it = 0; it < NFL; ++it) {
+                const int i = min(it * 64 + elane, nch - 1);
+                stream_store(&g2[i], buf[it]);
+            }
+        };
+
+        // fp64 MFMA and VALU share the SIMD's pipe (no overlap to win), so the K-steps run
+        // strictly one after the other: produce -> LDS -> fragments -> MFMA.  That keeps the
+        // live registers at  accumulators + max(fragments, new members);  the LDS round trip
+        // is covered by the other wave of the SIMD.
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) produce(4 * j + kk);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) put(kk, slot_jet(4 * j + kk));
+            wave_lds_fence();
+            double a16[MT16 > 0 ? MT16 : 1], a4[M4 > 0 ? M4 : 1];
+#pragma unroll
+            for (int mt = 0; mt < MT16; ++mt) a16[mt] = afr[(mt * KS + j) * 64 + lane];
+#pragma unroll
+            for (int m4 = 0; m4 < M4; ++m4) a4[m4] = afr[((MT16 + m4) * KS + j) * 64 + lane];
+#pragma unroll
+            for (int rq = 0; rq < 2; ++rq) {
+                double b[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[nt] = slab[(rq * NT + nt) * 64 + lane];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int an = rq * NT + nt;
+                    if (FX_DBG & 2) {
+                        acc4[an][0] += b[nt] * a4[0];
+                        continue;
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT16; ++mt)
+                        acc16[an][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a16[mt], b[nt], acc16[an][mt], 0, 0, 0);
+#pragma unroll
+                    for (int m4 = 0; m4 < M4; ++m4)
+                        acc4[an][m4] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[m4], b[nt], acc4[an][m4], 0, 0, 0);
+                }
+            }
+            wave_lds_fence();  // fragments read before the next K-step overwrites the slab
+        }
+
+        // ---------------- D tiles -> half images -> HBM, one request of the pair after the other ----------------
+        const bool second = 2 * pr + 1 < a.nreq;
+        // Everything the epilogue derives from the lane number (image offsets per row block,
+        // chunk indices and 64-bit addresses of the stores: ~50 VGPRs) is recomputed here per
+        // pair: left to itself hipcc hoists it out of the request loop and the K loop then
+        // spills.  The opaque copies pin the computations below this point.
+        elane = lane;
+        asm volatile("" : "+v"(elane));
+        enpts = npts;
+        asm volatile("" : "+s"(enpts));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            eoff[nt] = ioff[nt];
+            asm volatile("" : "+v"(eoff[nt]));
+        }
+        if (!(a.debug & 4)) {
+            wave_lds_fence();
+#pragma unroll
+            for (int rq = 0; rq < 2; ++rq) {
+#pragma unroll
+                for (int half = 0; half < (NTAB > TH ? 2 : 1); ++half) {
+#pragma unroll
+                    for (int nt = 0; nt < NTH; ++nt) image_tile(rq, half * NTH + nt);
+                    wave_lds_fence();
+                    // the missing second request of an odd batch is written onto the first
+                    // (same values), which keeps the store count per pair constant
+                    long long oreq = rq == 0 || second ? 2 * pr + rq : 2 * pr;
+                    if (FX_DBG & 64) oreq &= 1023;  // ablation: L2-resident output window
+                    flush_half(oreq, half);
+                    wave_lds_fence();
+                }
+            }
+            // first use of the prefetched points, in the SAME block as the stores: hipcc places
+            // the exact s_waitcnt vmcnt(NSTORE) here (after a control-flow join it gives up: vmcnt(0))
+            if (FX_DBG & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ablation: drain the stores per pair
+#pragma unroll
+            for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
+        } else {
+#pragma unroll
+            for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
+        }
+    }
+}
+
+}  // namespace fxk

@@ -24,7 +24,22 @@
 #define FX_STREAM_WAVES 2  // minimum waves per SIMD requested from the register allocator
 #endif
 
+#ifndef FX_NT_STORES
+#define FX_NT_STORES 1
+#endif
+
 namespace fxk {
+
+// Output tables are written once and read by later kernels: non-temporal stores let the L2
+// stream them out instead of holding them as dirty lines until an eviction is forced
+// (measured on the P3 tet benchmark: 303 -> 292 us per 100 000 requests, same box and run).
+template <class T> __device__ __forceinline__ void stream_store(T* p, const T& v) {
+#if FX_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 
 template <int SD, int N, int ORDER, int ROWS, int NT, int NW, bool UNIFORM>
 __global__ __launch_bounds__(64 * NW, FX_STREAM_WAVES) void tabulate_simplex_stream(const FixedArgs<FixedNC<SD, N>::value> a) {
@@ -176,9 +191,14 @@ __global__ __launch_bounds__(64 * NW, FX_STREAM_WAVES) void tabulate_simplex_str
                 // address space -> scalar loads).  The pointers are made opaque so that the
                 // loads are issued here, one step at a time, instead of all being hoisted to
                 // the top of the request (hundreds of SGPR spills otherwise).
-                const CDouble* cp = kcoef + 3 * s;
-                const CDouble* up = kucoef + 12 * s;
-                asm volatile("" : "+s"(cp), "+s"(up));
+                // (the BASE pointers are made opaque, the step's offset stays an immediate of the
+                // scalar load: opaque per-step pointers get precomputed outside the request loop
+                // and spilled, 2 x 19 64-bit SGPR pairs read back with v_readlane per request)
+                const CDouble* cb = kcoef;
+                const CDouble* ub = kucoef;
+                asm volatile("" : "+s"(cb), "+s"(ub));
+                const CDouble* cp = cb + 3 * s;
+                const CDouble* up = ub + 12 * s;
                 const double cA = cp[0], cB = cp[1], cC = cp[2];
                 if constexpr (UNIFORM) {
                     if (TBL.codim[s] != fcodim) {
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, FX_STREAM_WAVES) void tabulate_simplex_str
 #pragma unroll
             for (int it = 0; it < NFL; ++it) {
                 const int i = min(it * 64 + lane, nch - 1);
-                g2[i] = buf[it];
+                stream_store(&g2[i], buf[it]);
             }
         };
 

@@ -321,7 +321,7 @@ def test_quad_mixed(rt, golden):
 def test_kernel_selection(rt, golden):
     g = golden("elements")
     p3 = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=g["c2_p3tet_q6_coeffs"])
-    assert p3.kernel_name(1, 1000, 23) == "fxk::tabulate_simplex_stream"
+    assert p3.kernel_name(1, 1000, 23) == "fxk::tabulate_simplex_pair"
     assert p3.kernel_name(1, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_stream"
     assert p3.kernel_name(1, 1000, 40) == "fxk::tabulate_simplex_kernel"     # more points than one tile row
     assert p3.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_kernel"
