@@ -17,6 +17,7 @@
 #include "simplex_fixed.hpp"
 #include "simplex_stream.hpp"
 #include "simplex_pair.hpp"
+#include "simplex_defer.hpp"
 #include "coop_kernel.hpp"
 
 namespace {
@@ -102,7 +103,10 @@ struct fx_ctx {
     int num_cu = 0;
     int lds_per_cu = 0;
     std::string name;
+    double* d_trash = nullptr;  // 64 KB scratch: destination of the deferred kernel's first (empty) image
+    unsigned long long* d_queue = nullptr;  // work counters of the dynamically scheduled kernels, 128 B apart
 };
+constexpr int FX_QUEUE_GROUPS = 256;
 
 struct fx_element {
     fx_ctx* ctx = nullptr;
@@ -159,11 +163,18 @@ int fx_ctx_create(int device_id, fx_ctx** out) {
     c->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
     if (c->lds_per_cu <= 0) c->lds_per_cu = 160 * 1024;
     c->name = prop.gcnArchName;
+    if (hipMalloc(&c->d_trash, 64 * 1024) != hipSuccess || hipMalloc(&c->d_queue, FX_QUEUE_GROUPS * 128) != hipSuccess) {
+        if (c->d_trash) (void)hipFree(c->d_trash);
+        delete c;
+        return fail(FX_ENOMEM, "fx_ctx_create: out of device memory");
+    }
     *out = c;
     return FX_OK;
 }
 
 int fx_ctx_destroy(fx_ctx* ctx) {
+    if (ctx && ctx->d_trash) (void)hipFree(ctx->d_trash);
+    if (ctx && ctx->d_queue) (void)hipFree(ctx->d_queue);
     delete ctx;
     return FX_OK;
 }
@@ -427,6 +438,8 @@ struct Launch {
     std::vector<double> fcoef;         // [nsteps][3]
     std::vector<double> fucoef;        // [nsteps][12], uniform-cell factor derivatives
     int fgrid = 0, flds_bytes = 0, ncu = 0;
+    double* trash = nullptr;
+    unsigned long long* queue = nullptr;
     // 0: LDS-image kernel (simplex_fixed.hpp), 1: K-streamed kernel (simplex_stream.hpp),
     // 2: K-streamed, two requests per wave (simplex_pair.hpp)
     int fkind = 0;
@@ -457,6 +470,43 @@ bool table_matches(const fx::Program& P) {
     return true;
 }
 
+#if defined(FX_DBG) && (FX_DBG & 512)
+// ablation build: lifetimes of the waves of the last launch (written to the scratch area by the kernel)
+hipError_t report_wave_lifetimes(const double* trash, int grid, int wg_waves) {
+    const int nw = std::min(grid * wg_waves, 3000);
+    std::vector<double> t(2 * nw);
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(t.data(), trash + 2048, t.size() * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return e;
+    std::vector<double> us(nw), mhz(nw);
+    for (int i = 0; i < nw; ++i) {
+        us[i] = t[2 * i + 1] / 100.0;
+        mhz[i] = t[2 * i] / us[i];
+    }
+    std::vector<double> su = us, sm = mhz;
+    std::sort(su.begin(), su.end());
+    std::sort(sm.begin(), sm.end());
+    fprintf(stderr, "[fiat_amd] %d waves: lifetime us min %.1f p10 %.1f median %.1f p90 %.1f max %.1f | clock MHz min %.0f median %.0f max %.0f\n",
+            nw, su[0], su[nw / 10], su[nw / 2], su[nw * 9 / 10], su[nw - 1], sm[0], sm[nw / 2], sm[nw - 1]);
+    for (int x = 0; x < 8; ++x) {  // workgroup b runs on XCD b % 8
+        std::vector<double> v;
+        for (int i = 0; i < nw; ++i)
+            if (((i / wg_waves) % 8) == x) v.push_back(us[i]);
+        std::sort(v.begin(), v.end());
+        fprintf(stderr, " xcd%d %.0f..%.0f..%.0f", x, v[0], v[v.size() / 2], v.back());
+    }
+    fprintf(stderr, "\n workgroup lifetimes (max over its waves), XCD0:");
+    for (int b = 0; b < grid; b += 8) {
+        double m = 0;
+        for (int w = 0; w < wg_waves && b * wg_waves + w < nw; ++w) m = std::max(m, us[b * wg_waves + w]);
+        fprintf(stderr, " %.0f", m);
+    }
+    fprintf(stderr, "\n");
+    return hipSuccess;
+}
+#endif
+
 template <int SD, int N, int ORDER, int ROWS, int NT>
 int launch_fixed(const Launch& L, hipStream_t s) {
     using KernT = void (*)(const fxk::FixedArgs<fxk::FixedNC<SD, N>::value>);
@@ -477,11 +527,50 @@ int launch_fixed(const Launch& L, hipStream_t s) {
         return fail(FX_EINVAL, "internal: coefficient table size mismatch");
     memcpy(fa.coef, L.fcoef.data(), NC * sizeof(double));
     memcpy(fa.ucoef, L.fucoef.data(), 4 * NC * sizeof(double));
+    if (L.fkind == 3) {
+        using KernD = void (*)(const fxk::FixedArgs<NC>, double*);
+        constexpr int DEFER_NW = 8;  // one 512-thread workgroup per CU, two waves per SIMD
+        KernD kd = L.fhead.verts ? (KernD)fxk::tabulate_simplex_defer<SD, N, ORDER, ROWS, NT, DEFER_NW, false>
+                                 : (KernD)fxk::tabulate_simplex_defer<SD, N, ORDER, ROWS, NT, DEFER_NW, true>;
+        const int lds_bytes = 16 + (L.flds_bytes - (int)(fa.lds_doubles * 8) * FIXED_NW) + (int)(fa.lds_doubles * 8) * DEFER_NW;
+        if (lds_bytes > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        int occ = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kd), 64 * DEFER_NW, (size_t)lds_bytes));
+        const long long nwg = (L.fhead.nreq + DEFER_NW - 1) / DEFER_NW;
+        const int grid = (int)std::max<long long>(1, std::min<long long>(nwg, (long long)L.ncu * std::max(1, occ)));
+        static const bool verbose = getenv("FIAT_AMD_VERBOSE") != nullptr;
+        if (verbose) fprintf(stderr, "[fiat_amd] deferred kernel: occupancy %d WG/CU, grid %d, lds %d B\n", occ, grid, lds_bytes);
+        hipLaunchKernelGGL(kd, dim3(grid), dim3(64 * DEFER_NW), lds_bytes, s, fa, L.trash);
+        HIP_TRY(hipGetLastError());
+#if defined(FX_DBG) && (FX_DBG & 512)
+        if (verbose) HIP_TRY(report_wave_lifetimes(L.trash, grid, DEFER_NW));
+#endif
+        return FX_OK;
+    }
+    if (L.fkind == 2) {
+        constexpr int PAIR_NW = 8;  // one 512-thread workgroup per CU, two waves per SIMD, LDS work counter
+        using KernP = void (*)(const fxk::FixedArgs<NC>, double*);
+        KernP kp = L.fhead.verts ? (KernP)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, PAIR_NW, false>
+                                 : (KernP)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, PAIR_NW, true>;
+        const int lds_bytes = 16 + (L.flds_bytes - (int)(fa.lds_doubles * 8) * FIXED_NW) + (int)(fa.lds_doubles * 8) * PAIR_NW;
+        if (lds_bytes > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        int occ = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kp), 64 * PAIR_NW, (size_t)lds_bytes));
+        const long long nwg = ((L.fhead.nreq + 1) / 2 + PAIR_NW - 1) / PAIR_NW;
+        const int grid = (int)std::max<long long>(1, std::min<long long>(nwg, (long long)L.ncu * std::max(1, occ)));
+        static const bool verbose = getenv("FIAT_AMD_VERBOSE") != nullptr;
+        if (verbose) fprintf(stderr, "[fiat_amd] pair kernel: occupancy %d WG/CU, grid %d, lds %d B\n", occ, grid, lds_bytes);
+        hipLaunchKernelGGL(kp, dim3(grid), dim3(64 * PAIR_NW), lds_bytes, s, fa, L.trash);
+        HIP_TRY(hipGetLastError());
+#if defined(FX_DBG) && (FX_DBG & 512)
+        if (verbose) HIP_TRY(report_wave_lifetimes(L.trash, grid, PAIR_NW));
+#endif
+        return FX_OK;
+    }
     KernT kern;
-    if (L.fkind == 2)
-        kern = L.fhead.verts ? (KernT)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, FIXED_NW, false>
-                             : (KernT)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, FIXED_NW, true>;
-    else if (L.fkind == 1)
+    if (L.fkind == 1)
         kern = L.fhead.verts ? (KernT)fxk::tabulate_simplex_stream<SD, N, ORDER, ROWS, NT, FIXED_NW, false>
                              : (KernT)fxk::tabulate_simplex_stream<SD, N, ORDER, ROWS, NT, FIXED_NW, true>;
     else
@@ -489,16 +578,7 @@ int launch_fixed(const Launch& L, hipStream_t s) {
     if (L.flds_bytes > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     L.flds_bytes));
-    int grid = L.fgrid;
-    if (L.fkind == 2) {
-        // persistent waves: as many workgroups as the registers and LDS of the chip hold
-        int occ = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kern), 64 * FIXED_NW,
-                                                             (size_t)L.flds_bytes));
-        grid = std::max(1, std::min(L.fgrid, L.ncu * std::max(1, occ)));
-        static const bool verbose = getenv("FIAT_AMD_VERBOSE") != nullptr;
-        if (verbose) fprintf(stderr, "[fiat_amd] pair kernel: occupancy %d WG/CU, grid %d, lds %d B\n", occ, grid, L.flds_bytes);
-    }
+    const int grid = L.fgrid;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FIXED_NW), L.flds_bytes, s, fa);
     HIP_TRY(hipGetLastError());
     return FX_OK;
@@ -735,14 +815,23 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             if (kk && !strcmp(kk, "image")) L.fkind = 0;
             if (kk && !strcmp(kk, "stream")) L.fkind = 1;
             if (kk && !strcmp(kk, "pair") && pair_ok) L.fkind = 2;
+            // deferred-output kernel: whole-request image + slab + dump row per wave, two workgroups per CU
+            const long long defer_wave = (((long long)ntab * rows * npts + 1) & ~1LL) + (long long)f.nt * 64 + 64;
+            const bool defer_ok = defer_wave * 8 * 8 + 8 * 1024 <= ctx->lds_per_cu;  // 8 waves + A fragments in one CU
+            if (kk && !strcmp(kk, "defer") && defer_ok) L.fkind = 3;
             L.ncu = ctx->num_cu;
+            L.trash = ctx->d_trash;
+            L.queue = ctx->d_queue;
             fa.afrag = L.fkind >= 1 ? e->d_afrag_stream : e->d_afrag_split;
             fa.phi0 = e->prog.phi0;
             memcpy(fa.A0, e->A0, sizeof fa.A0);
             memcpy(fa.b0, e->b0, sizeof fa.b0);
             fa.nreq = nreq;
             fa.npts = npts;
-            fa.debug = a.debug;
+            // bits 8..12: log2 of the claim chunk of the dynamically scheduled kernels (consecutive
+            // units a workgroup takes before it jumps gridDim.x chunks ahead)
+            static const int chunk_shift = getenv("FIAT_AMD_CHUNK") ? atoi(getenv("FIAT_AMD_CHUNK")) : 3;
+            fa.debug = (a.debug & 0xff) | ((chunk_shift & 31) << 8);
             long long need = std::max<long long>((long long)f.nt * e->KS * 64, (long long)ntab * rows * npts);
             need = (need + 1) & ~1LL;
             if (L.fkind >= 1) {
@@ -752,6 +841,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     long long per_wave =
                         std::max<long long>((long long)th * rows * npts, (long long)f.nt * 64 * (L.fkind == 2 ? 2 : 1)) + 64;
                     per_wave = (per_wave + 1) & ~1LL;
+                    if (L.fkind == 3) per_wave = defer_wave;
                     fa.lds_doubles = (int)per_wave;
                     int rem = rows % 16;
                     bool split = rem != 0 && rem <= 12;
@@ -762,7 +852,8 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 long long want = (long long)ctx->num_cu * 4;
                 const long long units = L.fkind == 2 ? (nreq + 1) / 2 : nreq;  // requests or pairs, one per wave
                 long long nwg = (units + FIXED_NW - 1) / FIXED_NW;
-                L.fgrid = (int)std::max<long long>(1, std::min<long long>(nwg, L.fkind == 2 ? nwg : want));
+                L.fgrid = (int)std::max<long long>(1, std::min<long long>(nwg, L.fkind >= 2 ? nwg : want));
+                if (L.flds_bytes > ctx->lds_per_cu) continue;
                 L.fixed_id = (int)i;
                 break;
             }
@@ -821,7 +912,10 @@ int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, in
     if (rc != FX_OK) return rc;
     const char* k = "fxk::tabulate_simplex_kernel";
     if (L.fixed_id >= 0)
-        k = L.fkind == 0 ? "fxk::tabulate_simplex_fixed" : L.fkind == 1 ? "fxk::tabulate_simplex_stream" : "fxk::tabulate_simplex_pair";
+        k = L.fkind == 0   ? "fxk::tabulate_simplex_fixed"
+            : L.fkind == 1 ? "fxk::tabulate_simplex_stream"
+            : L.fkind == 2 ? "fxk::tabulate_simplex_pair"
+                           : "fxk::tabulate_simplex_defer";
     else if (L.coop_id >= 0) k = "fxk::tabulate_simplex_coop";
     snprintf(name, (size_t)name_len, "%s", k);
     return FX_OK;

@@ -24,7 +24,8 @@
 namespace fxk {
 
 template <int SD, int N, int ORDER, int ROWS, int NT, int NW, bool UNIFORM>
-__global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(const FixedArgs<FixedNC<SD, N>::value> a) {
+__global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(const FixedArgs<FixedNC<SD, N>::value> a,
+                                                                                double* __restrict__ trash) {
     constexpr int NTAB = NTab<SD, ORDER>::value;
     constexpr StepTable<SD, N> TBL{};
     constexpr int NEXP = StepTable<SD, N>::NEXP;
@@ -38,8 +39,9 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
     // LDS: [A fragments, shared by the workgroup] [per wave: half image of ONE request (the
     // K-step slab of the pair aliases its start) | 64-double dump row for inactive lanes]
     constexpr int NAF = (MT16 + M4) * KS;
-    double* afr = lds;
-    double* img = lds + NAF * 64 + (size_t)wave * a.lds_doubles;
+    unsigned int* wq = reinterpret_cast<unsigned int*>(lds);  // work counter of the workgroup (first 16 bytes)
+    double* afr = lds + 2;
+    double* img = afr + NAF * 64 + (size_t)wave * a.lds_doubles;
     double* slab = img;
     const int dump = a.lds_doubles - 64;
 
@@ -57,6 +59,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
 
     for (int i = lane; i < a.lds_doubles; i += 64) img[i] = 0.0;
     for (int i = threadIdx.x; i < NAF * 64; i += 64 * NW) afr[i] = a.afrag[i];
+    if (threadIdx.x == 0) wq[0] = 0;
     __syncthreads();
 
     const int sub = lane >> 5;  // which request of the pair this lane's point belongs to
@@ -96,16 +99,32 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
         }
     }
 
-#ifdef FX_STAGGER
-    // ablation: start the second half of the grid (the second workgroup of every CU) half a
-    // pair period late, so that the two waves of a SIMD are in different phases
-    if (blockIdx.x >= gridDim.x / 2) {
-        for (int i = 0; i < FX_STAGGER; ++i) __builtin_amdgcn_s_sleep(100);
-    }
-#endif
+    // The waves of a workgroup (NW = 8, the whole CU at two waves per SIMD) claim the
+    // workgroup's pairs one at a time from a counter in LDS (a static split per
+    // wave leaves a tail: the SIMD arbiter favours the older of its two waves, see simplex_defer.hpp).
     const long long npairs = (a.nreq + 1) >> 1;
-    const long long stride = (long long)gridDim.x * NW;
-    long long pr = (long long)blockIdx.x * NW + wave;
+    // claim k of workgroup b is pair b + k*gridDim.x: at any time the whole grid works inside
+    // one moving window of the batch (8 * gridDim.x pairs), so that the concurrent HBM writes
+    // cover a compact address range instead of one distant region per workgroup
+    const long long phi = npairs;
+    const int cshift = (a.debug >> 8) & 31;
+    auto claim = [&]() -> long long {
+        unsigned int r = 0;
+        if (lane == 0) r = __hip_atomic_fetch_add(wq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const long long k = (long long)__builtin_amdgcn_readfirstlane(r);
+        if (cshift == 31) {  // one contiguous range per workgroup
+            const long long lo = (long long)blockIdx.x * npairs / gridDim.x, up = (long long)(blockIdx.x + 1) * npairs / gridDim.x;
+            return lo + k < up ? lo + k : npairs;
+        }
+        const long long blk = k >> cshift;  // chunks of 2^cshift consecutive units per workgroup
+        return ((blk * gridDim.x + blockIdx.x) << cshift) + (k & ((1LL << cshift) - 1));
+    };
+    long long pr = claim();
+    if (pr >= phi) return;
+    long long pnext = claim();
+#if FX_DBG & 512
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // request of this lane's half of the pair (the last pair of an odd batch has no second
     // request: its lanes recompute the first one and the stores are skipped)
     auto lane_req = [&](long long p) -> long long {
@@ -114,14 +133,14 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
         return r < a.nreq ? r : a.nreq - 1;
     };
     double xnext[SD];
-    if (pr < npairs) {
+    {
         const double* pp = a.pts + ((size_t)lane_req(pr) * npts + pl) * SD;
 #pragma unroll
         for (int d = 0; d < SD; ++d) xnext[d] = pp[d];
     }
 #pragma unroll
     for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
-    for (; pr < npairs; pr += stride) {
+    while (true) {
         double X[SD];
         double J[SD][SD];
         {
@@ -129,7 +148,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
 #pragma unroll
             for (int d = 0; d < SD; ++d) x[d] = xnext[d];
             {
-                const long long pn = (pr + stride < npairs) ? pr + stride : pr;
+                const long long pn = pnext < phi ? pnext : pr;
                 const double* pp = a.pts + ((size_t)lane_req(pn) * npts + pl) * SD;
 #pragma unroll
                 for (int d = 0; d < SD; ++d) xnext[d] = pp[d];
@@ -366,7 +385,19 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
 #pragma unroll
             for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
         }
+        if (pnext >= phi) break;
+        pr = pnext;
+        pnext = claim();
     }
+#if FX_DBG & 512
+    if (lane == 0) {  // ablation build: lifetime of every wave (shader cycles, 100 MHz ticks)
+        const long long gw = (long long)blockIdx.x * NW + wave;
+        if (gw < 3000) {
+            trash[2048 + 2 * gw] = (double)(__builtin_readcyclecounter() - clk0);
+            trash[2049 + 2 * gw] = (double)(__builtin_amdgcn_s_memrealtime() - rt0);
+        }
+    }
+#endif
 }
 
 }  // namespace fxk
