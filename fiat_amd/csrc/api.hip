@@ -17,7 +17,6 @@
 #include "simplex_fixed.hpp"
 #include "simplex_stream.hpp"
 #include "simplex_pair.hpp"
-#include "simplex_defer.hpp"
 #include "coop_kernel.hpp"
 
 namespace {
@@ -103,8 +102,8 @@ struct fx_ctx {
     int num_cu = 0;
     int lds_per_cu = 0;
     std::string name;
-    double* d_trash = nullptr;  // 64 KB scratch: destination of the deferred kernel's first (empty) image
-    unsigned long long* d_queue = nullptr;  // work counters of the dynamically scheduled kernels, 128 B apart
+    double* d_trash = nullptr;  // 64 KB scratch (ablation builds: wave lifetimes, FX_DBG & 512)
+    unsigned long long* d_queue = nullptr;  // chunk counter of the dynamically scheduled kernels (work_queue.hpp)
 };
 constexpr int FX_QUEUE_GROUPS = 256;
 
@@ -527,33 +526,12 @@ int launch_fixed(const Launch& L, hipStream_t s) {
         return fail(FX_EINVAL, "internal: coefficient table size mismatch");
     memcpy(fa.coef, L.fcoef.data(), NC * sizeof(double));
     memcpy(fa.ucoef, L.fucoef.data(), 4 * NC * sizeof(double));
-    if (L.fkind == 3) {
-        using KernD = void (*)(const fxk::FixedArgs<NC>, double*);
-        constexpr int DEFER_NW = 8;  // one 512-thread workgroup per CU, two waves per SIMD
-        KernD kd = L.fhead.verts ? (KernD)fxk::tabulate_simplex_defer<SD, N, ORDER, ROWS, NT, DEFER_NW, false>
-                                 : (KernD)fxk::tabulate_simplex_defer<SD, N, ORDER, ROWS, NT, DEFER_NW, true>;
-        const int lds_bytes = 16 + (L.flds_bytes - (int)(fa.lds_doubles * 8) * FIXED_NW) + (int)(fa.lds_doubles * 8) * DEFER_NW;
-        if (lds_bytes > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        int occ = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kd), 64 * DEFER_NW, (size_t)lds_bytes));
-        const long long nwg = (L.fhead.nreq + DEFER_NW - 1) / DEFER_NW;
-        const int grid = (int)std::max<long long>(1, std::min<long long>(nwg, (long long)L.ncu * std::max(1, occ)));
-        static const bool verbose = getenv("FIAT_AMD_VERBOSE") != nullptr;
-        if (verbose) fprintf(stderr, "[fiat_amd] deferred kernel: occupancy %d WG/CU, grid %d, lds %d B\n", occ, grid, lds_bytes);
-        hipLaunchKernelGGL(kd, dim3(grid), dim3(64 * DEFER_NW), lds_bytes, s, fa, L.trash);
-        HIP_TRY(hipGetLastError());
-#if defined(FX_DBG) && (FX_DBG & 512)
-        if (verbose) HIP_TRY(report_wave_lifetimes(L.trash, grid, DEFER_NW));
-#endif
-        return FX_OK;
-    }
     if (L.fkind == 2) {
         constexpr int PAIR_NW = 8;  // one 512-thread workgroup per CU, two waves per SIMD, LDS work counter
-        using KernP = void (*)(const fxk::FixedArgs<NC>, double*);
+        using KernP = void (*)(const fxk::FixedArgs<NC>, double*, unsigned int*);
         KernP kp = L.fhead.verts ? (KernP)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, PAIR_NW, false>
                                  : (KernP)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, PAIR_NW, true>;
-        const int lds_bytes = 16 + (L.flds_bytes - (int)(fa.lds_doubles * 8) * FIXED_NW) + (int)(fa.lds_doubles * 8) * PAIR_NW;
+        const int lds_bytes = fxk::WQ_CTL_DOUBLES * 8 + (L.flds_bytes - (int)(fa.lds_doubles * 8) * FIXED_NW) + (int)(fa.lds_doubles * 8) * PAIR_NW;
         if (lds_bytes > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         int occ = 0;
@@ -562,7 +540,8 @@ int launch_fixed(const Launch& L, hipStream_t s) {
         const int grid = (int)std::max<long long>(1, std::min<long long>(nwg, (long long)L.ncu * std::max(1, occ)));
         static const bool verbose = getenv("FIAT_AMD_VERBOSE") != nullptr;
         if (verbose) fprintf(stderr, "[fiat_amd] pair kernel: occupancy %d WG/CU, grid %d, lds %d B\n", occ, grid, lds_bytes);
-        hipLaunchKernelGGL(kp, dim3(grid), dim3(64 * PAIR_NW), lds_bytes, s, fa, L.trash);
+        HIP_TRY(hipMemsetAsync(L.queue, 0, 128, s));  // the chunk counter of work_queue.hpp
+        hipLaunchKernelGGL(kp, dim3(grid), dim3(64 * PAIR_NW), lds_bytes, s, fa, L.trash, reinterpret_cast<unsigned int*>(L.queue));
         HIP_TRY(hipGetLastError());
 #if defined(FX_DBG) && (FX_DBG & 512)
         if (verbose) HIP_TRY(report_wave_lifetimes(L.trash, grid, PAIR_NW));
@@ -811,14 +790,10 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             // one wave (A/B: FIAT_AMD_KERNEL=image|stream|pair)
             // (pair kernel: the tables of each output half must fit half of the column tiles)
             const bool pair_ok = npts <= 32 && (ntab == 1 || (f.nt % 2 == 0 && (f.nt / 2) * 16 >= ((ntab + 1) / 2) * npts));
-            L.fkind = (pair_ok && !verts) ? 2 : 1;
+            L.fkind = pair_ok ? 2 : 1;
             if (kk && !strcmp(kk, "image")) L.fkind = 0;
             if (kk && !strcmp(kk, "stream")) L.fkind = 1;
             if (kk && !strcmp(kk, "pair") && pair_ok) L.fkind = 2;
-            // deferred-output kernel: whole-request image + slab + dump row per wave, two workgroups per CU
-            const long long defer_wave = (((long long)ntab * rows * npts + 1) & ~1LL) + (long long)f.nt * 64 + 64;
-            const bool defer_ok = defer_wave * 8 * 8 + 8 * 1024 <= ctx->lds_per_cu;  // 8 waves + A fragments in one CU
-            if (kk && !strcmp(kk, "defer") && defer_ok) L.fkind = 3;
             L.ncu = ctx->num_cu;
             L.trash = ctx->d_trash;
             L.queue = ctx->d_queue;
@@ -828,10 +803,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             memcpy(fa.b0, e->b0, sizeof fa.b0);
             fa.nreq = nreq;
             fa.npts = npts;
-            // bits 8..12: log2 of the claim chunk of the dynamically scheduled kernels (consecutive
-            // units a workgroup takes before it jumps gridDim.x chunks ahead)
-            static const int chunk_shift = getenv("FIAT_AMD_CHUNK") ? atoi(getenv("FIAT_AMD_CHUNK")) : 3;
-            fa.debug = (a.debug & 0xff) | ((chunk_shift & 31) << 8);
+            fa.debug = a.debug;
             long long need = std::max<long long>((long long)f.nt * e->KS * 64, (long long)ntab * rows * npts);
             need = (need + 1) & ~1LL;
             if (L.fkind >= 1) {
@@ -841,7 +813,6 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     long long per_wave =
                         std::max<long long>((long long)th * rows * npts, (long long)f.nt * 64 * (L.fkind == 2 ? 2 : 1)) + 64;
                     per_wave = (per_wave + 1) & ~1LL;
-                    if (L.fkind == 3) per_wave = defer_wave;
                     fa.lds_doubles = (int)per_wave;
                     int rem = rows % 16;
                     bool split = rem != 0 && rem <= 12;
@@ -914,8 +885,7 @@ int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, in
     if (L.fixed_id >= 0)
         k = L.fkind == 0   ? "fxk::tabulate_simplex_fixed"
             : L.fkind == 1 ? "fxk::tabulate_simplex_stream"
-            : L.fkind == 2 ? "fxk::tabulate_simplex_pair"
-                           : "fxk::tabulate_simplex_defer";
+                           : "fxk::tabulate_simplex_pair";
     else if (L.coop_id >= 0) k = "fxk::tabulate_simplex_coop";
     snprintf(name, (size_t)name_len, "%s", k);
     return FX_OK;

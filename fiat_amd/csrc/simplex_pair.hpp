@@ -13,9 +13,12 @@
 // image, full-line 16-byte stores, exact vmcnt on the prefetched points).
 #pragma once
 #include "simplex_stream.hpp"
+#include "work_queue.hpp"
 
 #ifndef FX_DBG
-#define FX_DBG 0  // ablation builds only (make dbg-libs): 1 skip recurrence, 2 skip MFMA, 8 skip LDS stores of Phi
+// ablation builds only (make dbg-libs): 1 skip recurrence, 2 skip MFMA, 8 skip LDS stores of Phi,
+// 64 L2-resident output window, 512 record wave lifetimes
+#define FX_DBG 0
 #endif
 #ifndef FX_PAIR_WAVES
 #define FX_PAIR_WAVES 2  // waves per SIMD requested from the register allocator (2*NT accumulator tiles)
@@ -25,7 +28,8 @@ namespace fxk {
 
 template <int SD, int N, int ORDER, int ROWS, int NT, int NW, bool UNIFORM>
 __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(const FixedArgs<FixedNC<SD, N>::value> a,
-                                                                                double* __restrict__ trash) {
+                                                                                double* __restrict__ trash,
+                                                                                unsigned int* __restrict__ gqueue) {
     constexpr int NTAB = NTab<SD, ORDER>::value;
     constexpr StepTable<SD, N> TBL{};
     constexpr int NEXP = StepTable<SD, N>::NEXP;
@@ -39,8 +43,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
     // LDS: [A fragments, shared by the workgroup] [per wave: half image of ONE request (the
     // K-step slab of the pair aliases its start) | 64-double dump row for inactive lanes]
     constexpr int NAF = (MT16 + M4) * KS;
-    unsigned int* wq = reinterpret_cast<unsigned int*>(lds);  // work counter of the workgroup (first 16 bytes)
-    double* afr = lds + 2;
+    double* afr = lds + WQ_CTL_DOUBLES;  // the work queue's control block comes first
     double* img = afr + NAF * 64 + (size_t)wave * a.lds_doubles;
     double* slab = img;
     const int dump = a.lds_doubles - 64;
@@ -59,7 +62,9 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
 
     for (int i = lane; i < a.lds_doubles; i += 64) img[i] = 0.0;
     for (int i = threadIdx.x; i < NAF * 64; i += 64 * NW) afr[i] = a.afrag[i];
-    if (threadIdx.x == 0) wq[0] = 0;
+    const long long npairs = (a.nreq + 1) >> 1;
+    WorkQueue wqueue;
+    wqueue.init(lds, gqueue, npairs);  // pairs are handed out dynamically, see work_queue.hpp
     __syncthreads();
 
     const int sub = lane >> 5;  // which request of the pair this lane's point belongs to
@@ -99,27 +104,10 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
         }
     }
 
-    // The waves of a workgroup (NW = 8, the whole CU at two waves per SIMD) claim the
-    // workgroup's pairs one at a time from a counter in LDS (a static split per
-    // wave leaves a tail: the SIMD arbiter favours the older of its two waves, see simplex_defer.hpp).
-    const long long npairs = (a.nreq + 1) >> 1;
-    // claim k of workgroup b is pair b + k*gridDim.x: at any time the whole grid works inside
-    // one moving window of the batch (8 * gridDim.x pairs), so that the concurrent HBM writes
-    // cover a compact address range instead of one distant region per workgroup
     const long long phi = npairs;
-    const int cshift = (a.debug >> 8) & 31;
-    auto claim = [&]() -> long long {
-        unsigned int r = 0;
-        if (lane == 0) r = __hip_atomic_fetch_add(wq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const long long k = (long long)__builtin_amdgcn_readfirstlane(r);
-        if (cshift == 31) {  // one contiguous range per workgroup
-            const long long lo = (long long)blockIdx.x * npairs / gridDim.x, up = (long long)(blockIdx.x + 1) * npairs / gridDim.x;
-            return lo + k < up ? lo + k : npairs;
-        }
-        const long long blk = k >> cshift;  // chunks of 2^cshift consecutive units per workgroup
-        return ((blk * gridDim.x + blockIdx.x) << cshift) + (k & ((1LL << cshift) - 1));
-    };
+    auto claim = [&]() -> long long { return wqueue.claim(); };
     long long pr = claim();
+    wqueue.service();
     if (pr >= phi) return;
     long long pnext = claim();
 #if FX_DBG & 512
@@ -129,7 +117,6 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
     // request: its lanes recompute the first one and the stores are skipped)
     auto lane_req = [&](long long p) -> long long {
         long long r = 2 * p + sub;
-        if (FX_DBG & 128) r &= 1023;  // ablation: cache-resident input window
         return r < a.nreq ? r : a.nreq - 1;
     };
     double xnext[SD];
@@ -262,13 +249,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int mbase = 16 * mt + 4 * jj;  // + (lane >> 4)
-                    if (FX_DBG & 32) {
-                        if (mbase + 3 < ROWS) {
-                            if (mine) img[so + mbase * enpts] = acc16[an][mt][jj];
-                        } else if (mbase < ROWS) {
-                            if (mine && mbase + (elane >> 4) < ROWS) img[so + mbase * enpts] = acc16[an][mt][jj];
-                        }
-                    } else if (mbase + 3 < ROWS) {
+                    if (mbase + 3 < ROWS) {
                         img[mine ? so + mbase * enpts : dsink] = acc16[an][mt][jj];
                     } else if (mbase < ROWS) {
                         img[(mine && mbase + (elane >> 4) < ROWS) ? so + mbase * enpts : dsink] = acc16[an][mt][jj];
@@ -278,9 +259,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
 #pragma unroll
             for (int m4 = 0; m4 < M4; ++m4) {
                 const int mbase = 16 * MT16 + 4 * m4;
-                if (FX_DBG & 32) {
-                    if (mine && mbase + (elane >> 4) < ROWS) img[so + mbase * enpts] = acc4[an][m4];
-                } else if (mbase + 3 < ROWS) {
+                if (mbase + 3 < ROWS) {
                     img[mine ? so + mbase * enpts : dsink] = acc4[an][m4];
                 } else {
                     img[(mine && mbase + (elane >> 4) < ROWS) ? so + mbase * enpts : dsink] = acc4[an][m4];
@@ -345,6 +324,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
         }
 
         // ---------------- D tiles -> half images -> HBM, one request of the pair after the other ----------------
+        wqueue.service();  // the previous pair's stores have drained by now, the points were fetched long ago
         const bool second = 2 * pr + 1 < a.nreq;
         // Everything the epilogue derives from the lane number (image offsets per row block,
         // chunk indices and 64-bit addresses of the stores: ~50 VGPRs) is recomputed here per
@@ -378,7 +358,6 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
             }
             // first use of the prefetched points, in the SAME block as the stores: hipcc places
             // the exact s_waitcnt vmcnt(NSTORE) here (after a control-flow join it gives up: vmcnt(0))
-            if (FX_DBG & 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ablation: drain the stores per pair
 #pragma unroll
             for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
         } else {
@@ -389,6 +368,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
         pr = pnext;
         pnext = claim();
     }
+    wqueue.service();
 #if FX_DBG & 512
     if (lane == 0) {  // ablation build: lifetime of every wave (shader cycles, 100 MHz ticks)
         const long long gw = (long long)blockIdx.x * NW + wave;

@@ -1,0 +1,100 @@
+// Dynamic distribution of work units (requests, pairs of requests) over the persistent waves
+// of the specialised tabulation kernels (gfx950).
+//
+// Measured on MI355X with static, equal shares (tools/placement_probe*.py, FX_DBG=512 builds):
+//   * the SIMD arbiter favours the older of its resident waves: the first workgroup of a CU
+//     finished after 267 us, the second after 336 us;
+//   * under saturated HBM writes the XCDs do not progress at the same rate (odd-numbered XCDs
+//     10-30 % slower, varying from launch to launch): equal shares per XCD end in a tail of up
+//     to a third of the launch.
+// Both are removed by handing out the batch in chunks of 8 consecutive units from ONE counter in
+// global memory (a device-scope atomic costs ~12 ns of serialised time and ~0.5 us of latency,
+// so it is paid once per chunk and two chunks ahead), and the 8 units of a chunk to the waves
+// of the workgroup through a counter in LDS (ds_add_rtn, no vmcnt traffic).
+//
+// LDS control block (64 bytes at the start of dynamic LDS):
+//   ctl[0]            claims of this workgroup so far (k); unit = chunk(k >> 3) * 8 + (k & 7)
+//   slot[4] (u64)     ring of chunk ids, slot[j & 3] = (j << 32) | chunk id of the workgroup's
+//                     j-th chunk, written by the wave that claimed the first unit of chunk j-2
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fxk {
+
+constexpr int WQ_CTL_DOUBLES = 8;  // control block size in doubles
+constexpr unsigned int WQ_END = 0x7fffffffu;
+
+struct WorkQueue {
+    unsigned int* ctl;            // LDS
+    unsigned long long* slot;     // LDS, 4 entries
+    unsigned int* gctr;           // global chunk counter (zeroed before the launch)
+    long long nunits;
+    unsigned int nchunks;
+    bool pending;                 // this wave owes the workgroup the chunk id of ordinal `pord`
+    unsigned int pord;
+
+    // all threads of the workgroup; followed by __syncthreads() in the caller
+    __device__ __forceinline__ void init(double* lds, unsigned int* global_counter, long long units) {
+        ctl = reinterpret_cast<unsigned int*>(lds);
+        slot = reinterpret_cast<unsigned long long*>(lds) + 1;
+        gctr = global_counter;
+        nunits = units;
+        nchunks = (unsigned int)((units + 7) >> 3);
+        pending = false;
+        pord = 0;
+        if (threadIdx.x == 0) {
+            ctl[0] = 0;
+            slot[2] = ~0ULL;
+            slot[3] = ~0ULL;
+            const unsigned int c0 = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int c1 = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            slot[0] = (0ULL << 32) | (c0 < WQ_END ? c0 : WQ_END);
+            slot[1] = (1ULL << 32) | (c1 < WQ_END ? c1 : WQ_END);
+        }
+    }
+
+    // wave-uniform: next unit of this wave, or nunits when the batch is exhausted
+    __device__ __forceinline__ long long claim() {
+        unsigned int r = 0;
+        if ((threadIdx.x & 63) == 0) r = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned int k = __builtin_amdgcn_readfirstlane(r);
+        const unsigned int j = k >> 3, off = k & 7;
+        if (off == 0) {  // first unit of chunk j: this wave fetches the id of chunk j+2 (see service())
+            pending = true;
+            pord = j + 2;
+        }
+        // the id of chunk j was requested two chunks ago; normally it is there.  The wait is
+        // bounded (~1 s): a protocol error must not hang the GPU, it ends the batch early instead
+        // (and the parity tests fail).
+        unsigned long long s = 0;
+        bool ok = false;
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+            s = __hip_atomic_load(&slot[j & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((unsigned int)(s >> 32) == j) {
+                ok = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) return nunits;
+        const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)s);
+        if (lo >= nchunks) return nunits;
+        const long long u = (long long)lo * 8 + off;
+        return u < nunits ? u : nunits;
+    }
+
+    // Executes the fetch this wave owes (one device-scope atomic, its return is waited for:
+    // call it where few vector-memory operations are outstanding).  Must run before the wave
+    // claims again (a second claim would overwrite the debt) or exits.
+    __device__ __forceinline__ void service() {
+        if (!pending) return;
+        pending = false;
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned int c = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&slot[pord & 3], ((unsigned long long)pord << 32) | (c < WQ_END ? c : WQ_END), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+};
+
+}  // namespace fxk

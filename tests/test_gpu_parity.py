@@ -137,6 +137,33 @@ def test_c2_batch_vs_oracle(rt, golden, nreq):
         assert_tables(out[r], ref, 3, f"request {r}")
 
 
+@pytest.mark.parametrize("nreq", [1, 2, 7, 515, 20001])
+@pytest.mark.parametrize("npts", [21, 23, 24])
+def test_c2_batch_physical_cells_vs_oracle(rt, golden, nreq, npts):
+    """Per-request cell geometry (random affine images of the UFC tetrahedron) on the specialised
+    kernel, odd and even batch sizes (two requests share a wave), every table of every request
+    against the C restatement of the oracle."""
+    from oracle import c_oracle
+    g = golden("elements")
+    co = g["c2_p3tet_q6_coeffs"]
+    rng = np.random.default_rng(100 + nreq + npts)
+    ref_pts = rand_points(rng, 3, (nreq, npts))
+    A = np.eye(3) + 0.1 * rng.standard_normal((nreq, 3, 3))   # well-conditioned cells: the bound is on rounding, not on the map
+    b = rng.standard_normal((nreq, 1, 3))
+    verts = np.einsum("vd,red->rve", fo.UFC_SIMPLEX[3], A) + b
+    pts = np.einsum("rpd,red->rpe", ref_pts, A) + b          # points inside the physical cells
+    ps = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=co)
+    if 21 <= npts <= 24:
+        assert ps.kernel_name(1, nreq, npts, has_verts=True) == "fxk::tabulate_simplex_pair"
+    out = ps.tabulate_batch(1, pts, verts=verts).cpu().numpy()
+    ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[3], 3, co, 1, pts, verts=verts, scale=1, variant="bubble")
+    num = np.abs(out - ref).max(axis=(2, 3))
+    den = np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))
+    err = (num / den).max(axis=0)
+    assert err[0] <= TOL_VAL, err
+    assert err[1:].max() <= TOL_DER, err
+
+
 def test_c2_full_baseline_batch(rt, golden):
     """BASELINE config 2 at full size: 100 000 requests x 23 points, every table of every
     request against the C restatement of the oracle (pinned in tests/test_oracle_c.py)."""
@@ -322,7 +349,7 @@ def test_kernel_selection(rt, golden):
     g = golden("elements")
     p3 = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=g["c2_p3tet_q6_coeffs"])
     assert p3.kernel_name(1, 1000, 23) == "fxk::tabulate_simplex_pair"
-    assert p3.kernel_name(1, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_stream"
+    assert p3.kernel_name(1, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_pair"
     assert p3.kernel_name(1, 1000, 40) == "fxk::tabulate_simplex_kernel"     # more points than one tile row
     assert p3.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_kernel"
     dg6 = rt.SimplexPolySet(3, 6, coeffs=g["c4_dg6tet_q6_coeffs"])

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--variants", default="0,1,2,4,3,6,7")
+    ap.add_argument("--verts", action="store_true", help="per-request cell geometry (random affine images of the UFC cell)")
     ap.add_argument("--kernels", default="", help="comma list of FIAT_AMD_KERNEL values to compare (debug=0 only)")
     args = ap.parse_args()
     import torch
@@ -27,6 +28,12 @@ def main():
     ps = el.device_polyset()
     pts = torch.as_tensor(bench.synth_points(sd, args.batch, npts, 2)).cuda()
     out = torch.empty(ps.out_shape(order, args.batch, npts), dtype=torch.float64, device="cuda")
+    verts = None
+    if args.verts:
+        rng = np.random.default_rng(7)
+        ref = np.array(el.get_reference_element().get_vertices(), dtype=float)
+        Aff = np.eye(sd) + 0.2 * rng.standard_normal((args.batch, sd, sd))
+        verts = torch.as_tensor(np.einsum("vd,red->rve", ref, Aff) + rng.standard_normal((args.batch, 1, sd))).cuda()
     def ceiling():
         """HBM write ceiling of THIS box, same bytes as one launch: torch fill_ of the output buffer."""
         torch.cuda.synchronize()
@@ -43,7 +50,7 @@ def main():
     for _ in range(args.rounds):
         for v in variants:
             os.environ["FIAT_AMD_DEBUG"] = str(v)
-            times[v].append(ps.time_tabulate_batch(order, pts, None, out, args.reps))
+            times[v].append(ps.time_tabulate_batch(order, pts, verts, out, args.reps))
     os.environ["FIAT_AMD_DEBUG"] = "0"
     if args.kernels:
         ks = args.kernels.split(",")
@@ -51,7 +58,7 @@ def main():
         for _ in range(args.rounds):
             for k in ks:
                 os.environ["FIAT_AMD_KERNEL"] = k
-                kt[k].append(ps.time_tabulate_batch(order, pts, None, out, args.reps))
+                kt[k].append(ps.time_tabulate_batch(order, pts, verts, out, args.reps))
         os.environ.pop("FIAT_AMD_KERNEL", None)
         cl = statistics.median(ceiling() for _ in range(args.rounds))
         print(f"fill_ of the output buffer on this box: {cl * 1e3:9.1f} us")

@@ -18,4 +18,12 @@ print("kernel:", ps.kernel_name(order, batch, npts), " FIAT_AMD_CHUNK =", os.env
 for rnd in range(2):
     for i, out in enumerate(bufs):
         t = [ps.time_tabulate_batch(order, pts, None, out, int(os.environ.get("REPS", "20"))) for _ in range(int(os.environ.get("ROUNDS", "5")))]
-        print(f"round {rnd} buffer {i} @0x{out.data_ptr():x} (mod 2MB = {out.data_ptr() % (1 << 21):#x}): {statistics.median(t) * 1e3:7.1f} us")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            out.fill_(1.0)
+        e1.record()
+        torch.cuda.synchronize()
+        fill_us = e0.elapsed_time(e1) * 100
+        print(f"[fill_ {fill_us:6.1f} us] round {rnd} buffer {i} @0x{out.data_ptr():x} (mod 2MB = {out.data_ptr() % (1 << 21):#x}): {statistics.median(t) * 1e3:7.1f} us")
