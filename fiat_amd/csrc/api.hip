@@ -103,9 +103,10 @@ struct fx_ctx {
     int lds_per_cu = 0;
     std::string name;
     double* d_trash = nullptr;  // 64 KB scratch (ablation builds: wave lifetimes, FX_DBG & 512)
-    unsigned long long* d_queue = nullptr;  // chunk counter of the dynamically scheduled kernels (work_queue.hpp)
+    unsigned long long* d_queue = nullptr;  // chunk counters of the dynamically scheduled kernels (work_queue.hpp)
+    unsigned int launch_seq = 0;
 };
-constexpr int FX_QUEUE_GROUPS = 256;
+constexpr int FX_QUEUE_SLOTS = 64;  // counters handed to consecutive launches round-robin (128 B apart)
 
 struct fx_element {
     fx_ctx* ctx = nullptr;
@@ -162,7 +163,8 @@ int fx_ctx_create(int device_id, fx_ctx** out) {
     c->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
     if (c->lds_per_cu <= 0) c->lds_per_cu = 160 * 1024;
     c->name = prop.gcnArchName;
-    if (hipMalloc(&c->d_trash, 64 * 1024) != hipSuccess || hipMalloc(&c->d_queue, FX_QUEUE_GROUPS * 128) != hipSuccess) {
+    if (hipMalloc(&c->d_trash, 64 * 1024) != hipSuccess || hipMalloc(&c->d_queue, FX_QUEUE_SLOTS * 128) != hipSuccess ||
+        hipMemset(c->d_queue, 0, FX_QUEUE_SLOTS * 128) != hipSuccess) {
         if (c->d_trash) (void)hipFree(c->d_trash);
         delete c;
         return fail(FX_ENOMEM, "fx_ctx_create: out of device memory");
@@ -540,7 +542,6 @@ int launch_fixed(const Launch& L, hipStream_t s) {
         const int grid = (int)std::max<long long>(1, std::min<long long>(nwg, (long long)L.ncu * std::max(1, occ)));
         static const bool verbose = getenv("FIAT_AMD_VERBOSE") != nullptr;
         if (verbose) fprintf(stderr, "[fiat_amd] pair kernel: occupancy %d WG/CU, grid %d, lds %d B\n", occ, grid, lds_bytes);
-        HIP_TRY(hipMemsetAsync(L.queue, 0, 128, s));  // the chunk counter of work_queue.hpp
         hipLaunchKernelGGL(kp, dim3(grid), dim3(64 * PAIR_NW), lds_bytes, s, fa, L.trash, reinterpret_cast<unsigned int*>(L.queue));
         HIP_TRY(hipGetLastError());
 #if defined(FX_DBG) && (FX_DBG & 512)
@@ -796,7 +797,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             if (kk && !strcmp(kk, "pair") && pair_ok) L.fkind = 2;
             L.ncu = ctx->num_cu;
             L.trash = ctx->d_trash;
-            L.queue = ctx->d_queue;
+            // the kernel leaves its counter zeroed; launches in flight at the same time (other
+            // streams) get different counters
+            L.queue = ctx->d_queue + (size_t)(ctx->launch_seq++ % FX_QUEUE_SLOTS) * 16;
             fa.afrag = L.fkind >= 1 ? e->d_afrag_stream : e->d_afrag_split;
             fa.phi0 = e->prog.phi0;
             memcpy(fa.A0, e->A0, sizeof fa.A0);

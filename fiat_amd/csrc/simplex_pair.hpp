@@ -108,7 +108,10 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
     auto claim = [&]() -> long long { return wqueue.claim(); };
     long long pr = claim();
     wqueue.service();
-    if (pr >= phi) return;
+    if (pr >= phi) {
+        wqueue.finish();
+        return;
+    }
     long long pnext = claim();
 #if FX_DBG & 512
     const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
@@ -369,6 +372,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
         pnext = claim();
     }
     wqueue.service();
+    wqueue.finish();
 #if FX_DBG & 512
     if (lane == 0) {  // ablation build: lifetime of every wave (shader cycles, 100 MHz ticks)
         const long long gw = (long long)blockIdx.x * NW + wave;

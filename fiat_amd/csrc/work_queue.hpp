@@ -12,8 +12,13 @@
 // so it is paid once per chunk and two chunks ahead), and the 8 units of a chunk to the waves
 // of the workgroup through a counter in LDS (ds_add_rtn, no vmcnt traffic).
 //
+// The global counter cleans up after itself: the last wave of the last workgroup to finish sets
+// it back to zero (gctr[0] chunk counter, gctr[1] finished workgroups), so a launch costs no
+// extra memset node; the host hands concurrent launches different counters (api.hip).
+//
 // LDS control block (64 bytes at the start of dynamic LDS):
 //   ctl[0]            claims of this workgroup so far (k); unit = chunk(k >> 3) * 8 + (k & 7)
+//   ctl[1]            waves of this workgroup that have finished
 //   slot[4] (u64)     ring of chunk ids, slot[j & 3] = (j << 32) | chunk id of the workgroup's
 //                     j-th chunk, written by the wave that claimed the first unit of chunk j-2
 #pragma once
@@ -44,6 +49,7 @@ struct WorkQueue {
         pord = 0;
         if (threadIdx.x == 0) {
             ctl[0] = 0;
+            ctl[1] = 0;
             slot[2] = ~0ULL;
             slot[3] = ~0ULL;
             const unsigned int c0 = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -93,6 +99,20 @@ struct WorkQueue {
             const unsigned int c = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&slot[pord & 3], ((unsigned long long)pord << 32) | (c < WQ_END ? c : WQ_END), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+
+    // every wave, once, when it is done (after its last service()): leaves the global counter
+    // zeroed for the next launch
+    __device__ __forceinline__ void finish() {
+        if ((threadIdx.x & 63) == 0) {
+            const unsigned int nw = blockDim.x >> 6;
+            if (__hip_atomic_fetch_add(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == nw - 1) {
+                if (__hip_atomic_fetch_add(gctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+                    __hip_atomic_store(gctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(gctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     }
 };
