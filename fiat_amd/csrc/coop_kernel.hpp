@@ -19,6 +19,7 @@
 // with 16-byte stores of whole lines (direct 8-byte stores double the HBM traffic).
 #pragma once
 #include "simplex_fixed.hpp"
+#include "store.hpp"
 
 namespace fxk {
 
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                 if (((a.TR * table) & 1) == 0 && (reqsize & 1) == 0) {
                     const v2d* s2 = reinterpret_cast<const v2d*>(img);
                     v2d* g2 = reinterpret_cast<v2d*>(g);
-                    for (int i = tid; i < (int)(nd >> 1); i += 512) g2[i] = s2[i];
+                    for (int i = tid; i < (int)(nd >> 1); i += 512) stream_store(&g2[i], s2[i]);
                 } else {
                     for (int i = tid; i < (int)nd; i += 512) g[i] = img[i];
                 }
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                 if (((a.TR * table) & 1) == 0 && (reqsize & 1) == 0) {
                     const v2d* s2 = reinterpret_cast<const v2d*>(img);
                     v2d* g2 = reinterpret_cast<v2d*>(g);
-                    for (int i = tid; i < (int)(nd >> 1); i += 512) g2[i] = s2[i];
+                    for (int i = tid; i < (int)(nd >> 1); i += 512) stream_store(&g2[i], s2[i]);
                 } else {
                     for (int i = tid; i < (int)nd; i += 512) g[i] = img[i];
                 }

@@ -19,27 +19,13 @@
 //     side reads every partially written line back (FETCH_SIZE ~ output size).
 #pragma once
 #include "simplex_fixed.hpp"
+#include "store.hpp"
 
 #ifndef FX_STREAM_WAVES
 #define FX_STREAM_WAVES 2  // minimum waves per SIMD requested from the register allocator
 #endif
 
-#ifndef FX_NT_STORES
-#define FX_NT_STORES 1
-#endif
-
 namespace fxk {
-
-// Output tables are written once and read by later kernels: non-temporal stores let the L2
-// stream them out instead of holding them as dirty lines until an eviction is forced
-// (measured on the P3 tet benchmark: 303 -> 292 us per 100 000 requests, same box and run).
-template <class T> __device__ __forceinline__ void stream_store(T* p, const T& v) {
-#if FX_NT_STORES
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
 
 template <int SD, int N, int ORDER, int ROWS, int NT, int NW, bool UNIFORM>
 __global__ __launch_bounds__(64 * NW, FX_STREAM_WAVES) void tabulate_simplex_stream(const FixedArgs<FixedNC<SD, N>::value> a) {
