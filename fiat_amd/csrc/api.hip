@@ -879,6 +879,34 @@ int fx_tabulate_batch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq,
     return run_tabulate(ctx, e, order, L, (hipStream_t)stream);
 }
 
+int fx_pushforward_batch(fx_ctx* ctx, const fx_element* e, int mapping, int order, int64_t nreq, int npts,
+                         const double* verts, double* out, void* stream) {
+    if (!ctx || !e) return fail(FX_EINVAL, "null context/element");
+    if (mapping < FX_MAP_AFFINE || mapping > FX_MAP_CONTRAVARIANT_PIOLA) return fail(FX_EINVAL, "unknown mapping %d", mapping);
+    if (order < 0) return fail(FX_EINVAL, "negative derivative order");
+    if (order > 2) return fail(FX_ENOTIMPL, "derivative order %d > 2 is not implemented on the device", order);
+    if (nreq < 0 || npts < 0) return fail(FX_EINVAL, "negative batch size");
+    if (mapping == FX_MAP_AFFINE || nreq == 0 || npts == 0) return FX_OK;  // derivatives are w.r.t. physical x already
+    if (e->vdim != e->sd || e->sd < 2)
+        return fail(FX_EINVAL, "Piola maps need vector-valued functions with value shape (%d,), got %d components", e->sd, e->vdim);
+    if (!verts || !out) return fail(FX_EINVAL, "null device pointer");
+    fxk::PiolaArgs pa;
+    pa.verts = verts;
+    pa.out = out;
+    for (int i = 0; i < 9; ++i) pa.G[i] = 0.5 * e->A0[i];
+    pa.ntab = fx::binom(e->sd + order, e->sd);
+    pa.ndof = e->ndof;
+    pa.npts = npts;
+    pa.kind = mapping;
+    if (nreq > 0x7fffffffLL) return fail(FX_EINVAL, "batch too large");
+    if (e->sd == 2)
+        hipLaunchKernelGGL(fxk::piola_apply_kernel<2>, dim3((unsigned)nreq), dim3(256), 0, (hipStream_t)stream, pa);
+    else
+        hipLaunchKernelGGL(fxk::piola_apply_kernel<3>, dim3((unsigned)nreq), dim3(256), 0, (hipStream_t)stream, pa);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
 int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, int has_verts, char* name,
                    int name_len) {
     if (!name || name_len < 1) return fail(FX_EINVAL, "fx_plan_kernel: bad name buffer");

@@ -400,4 +400,86 @@ __global__ __launch_bounds__(256) void tensor_tabulate_kernel(TensorArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Push-forward of vector-valued tables to the requests' physical cells, in place
+// (reference: FiniteElement.mapping(), FIAT/finite_element.py:84-88; the Piola formulas of
+// finat/hdivcurl.py:95-191, checked in test/finat/test_point_evaluation.py:53-70).
+//   covariant:      phi = J^{-T} Phi          contravariant:  phi = J Phi / det J
+// J = dx/dX between the element's own cell and the request's cell = E_req * G with E_req the
+// edge matrix (columns v_i - v_0) and G = A0 / 2 (host constant, A0 = map of the element's
+// cell to the default simplex).  The derivative tables were taken w.r.t. physical x already
+// (fx_tabulate_batch with verts), J is constant per cell: every table gets the same matrix.
+// One workgroup per request; out[t][dof][c][p], vdim == SD.
+struct PiolaArgs {
+    const double* verts;  // [nreq][SD+1][SD]
+    double* out;          // [nreq][ntab][ndof][SD][npts]
+    double G[9];
+    int ntab, ndof, npts, kind;  // kind 1 covariant, 2 contravariant
+};
+
+template <int SD> __global__ __launch_bounds__(256) void piola_apply_kernel(const PiolaArgs a) {
+    __shared__ double M[SD * SD];
+    const size_t req = blockIdx.x;
+    if (threadIdx.x == 0) {
+        const double* v = a.verts + req * (SD + 1) * SD;
+        double E[SD][SD], J[SD][SD];
+        for (int c = 0; c < SD; ++c)
+            for (int r = 0; r < SD; ++r) E[r][c] = v[(c + 1) * SD + r] - v[r];
+        for (int r = 0; r < SD; ++r)
+            for (int c = 0; c < SD; ++c) {
+                double t = 0.0;
+                for (int k = 0; k < SD; ++k) t += E[r][k] * a.G[k * SD + c];
+                J[r][c] = t;
+            }
+        double det, inv[SD][SD];
+        if constexpr (SD == 2) {
+            det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+            inv[0][0] = J[1][1] / det;
+            inv[0][1] = -J[0][1] / det;
+            inv[1][0] = -J[1][0] / det;
+            inv[1][1] = J[0][0] / det;
+        } else {
+            const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+            const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+            const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+            det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+            inv[0][0] = c00 / det;
+            inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+            inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
+            inv[1][0] = c01 / det;
+            inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
+            inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+            inv[2][0] = c02 / det;
+            inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+            inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+        }
+        for (int r = 0; r < SD; ++r)
+            for (int c = 0; c < SD; ++c) M[r * SD + c] = a.kind == 1 ? inv[c][r] : J[r][c] / det;
+    }
+    __syncthreads();
+    double m[SD][SD];
+#pragma unroll
+    for (int r = 0; r < SD; ++r)
+#pragma unroll
+        for (int c = 0; c < SD; ++c) m[r][c] = M[r * SD + c];
+    const int groups = a.ntab * a.ndof;  // (table, dof) pairs: SD rows of npts each
+    double* o = a.out + req * (size_t)groups * SD * a.npts;
+    for (int e = threadIdx.x; e < groups * a.npts; e += blockDim.x) {
+        const int g = e / a.npts, p = e - g * a.npts;
+        double* q = o + (size_t)g * SD * a.npts + p;
+        double x[SD], y[SD];
+#pragma unroll
+        for (int c = 0; c < SD; ++c) x[c] = q[c * a.npts];
+#pragma unroll
+        for (int r = 0; r < SD; ++r) {
+            double t = 0.0;
+#pragma unroll
+            for (int c = 0; c < SD; ++c) t += m[r][c] * x[c];
+            y[r] = t;
+        }
+#pragma unroll
+        for (int c = 0; c < SD; ++c) q[c * a.npts] = y[c];
+    }
+}
+
 }  // namespace fxk

@@ -117,11 +117,14 @@ class CiarletElement(FiniteElement):
         transform = self.ref_el.get_entity_transform(entity_dim, entity_id)
         return self.poly_set.tabulate(transform(numpy.asarray(points, dtype=float)), order)
 
-    def tabulate_batch(self, order, points, verts=None, out=None, stream=None):
+    def tabulate_batch(self, order, points, verts=None, out=None, stream=None, pushforward=False):
         """Batched form of tabulate(): points (nreq, npts, sd) [+ per-request cell
         vertices (nreq, sd+1, sd)] -> device tensor (nreq, ntab, ndof, *value_shape, npts)
-        with tables in mis() order."""
-        return self.device_polyset().tabulate_batch(order, points, verts=verts, out=out, stream=stream)
+        with tables in mis() order.  ``pushforward=True`` (needs ``verts``) applies this element's
+        mapping() -- affine pull-back, covariant or contravariant Piola -- so that the tables are
+        the basis functions ON the physical cells."""
+        mapping = self._mapping if pushforward else None
+        return self.device_polyset().tabulate_batch(order, points, verts=verts, out=out, stream=stream, mapping=mapping)
 
     def value_shape(self):
         return self.poly_set.get_shape()

@@ -112,8 +112,15 @@ class SimplexPolySet:
     def out_shape(self, order, nreq, npts):
         return (nreq, num_tables(self.sd, order), self.ndof) + self.value_shape + (npts,)
 
-    def tabulate_batch(self, order, pts, verts=None, out=None, stream=None):
-        """pts (nreq, npts, sd) -> (nreq, ntab, ndof, *value_shape, npts) on the GPU."""
+    MAPPINGS = {"affine": 0, "covariant piola": 1, "contravariant piola": 2}
+
+    def tabulate_batch(self, order, pts, verts=None, out=None, stream=None, mapping=None):
+        """pts (nreq, npts, sd) -> (nreq, ntab, ndof, *value_shape, npts) on the GPU.
+
+        With per-request cells ``verts`` the derivatives are taken with respect to the physical
+        coordinates; ``mapping`` ("affine", "covariant piola", "contravariant piola": the names
+        of FiniteElement.mapping()) additionally pushes vector-valued functions forward to the
+        physical cells (fx_pushforward_batch)."""
         ctx = self.ctx
         pts = _as_device(pts, ctx)
         if pts.dim() != 3 or pts.shape[2] != self.sd:
@@ -128,8 +135,15 @@ class SimplexPolySet:
             out = torch.empty(shape, dtype=torch.float64, device=ctx.device)
         elif tuple(out.shape) != shape or out.dtype != torch.float64 or not out.is_contiguous():
             raise ValueError("out has the wrong shape/dtype/layout")
+        if mapping is not None and mapping not in self.MAPPINGS:
+            raise ValueError(f"unknown mapping {mapping!r}")
+        if mapping not in (None, "affine") and verts is None:
+            raise ValueError("a Piola push-forward needs the physical cells (verts)")
         check(lib.fx_tabulate_batch(ctx.handle, self.handle, int(order), nreq, npts, _dev_ptr(pts),
                                     None if verts is None else _dev_ptr(verts), _dev_ptr(out), _stream_ptr(stream)))
+        if mapping not in (None, "affine"):
+            check(lib.fx_pushforward_batch(ctx.handle, self.handle, self.MAPPINGS[mapping], int(order), nreq, npts,
+                                           _dev_ptr(verts), _dev_ptr(out), _stream_ptr(stream)))
         return out
 
     def kernel_name(self, order, nreq, npts, has_verts=False):

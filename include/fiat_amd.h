@@ -147,6 +147,23 @@ int fx_plan_steps(int sd, int n, int variant, double scale, int cap, int* nsteps
                   double* phi0, int* ints, double* coefs);
 int fx_plan_c0_transform(int sd, int n, double* T /* host [nexp][nexp] */);
 
+/* ---- push-forward to physical cells ---------------------------
+ * Reference: FiniteElement.mapping() (FIAT/finite_element.py:84-88) names the map, the
+ * consumer applies it (finat/hdivcurl.py:95-191; checked in test/finat/test_point_evaluation.py:53-70).
+ * fx_tabulate_batch with verts != NULL already returns derivatives with respect to the
+ * PHYSICAL coordinates (affine pull-back: nothing left to do for FX_MAP_AFFINE).  For
+ * vector-valued elements (value shape (sd,)) this call applies, in place and to every table,
+ *   FX_MAP_COVARIANT_PIOLA      phi = J^{-T} Phi        (Nedelec)
+ *   FX_MAP_CONTRAVARIANT_PIOLA  phi = J Phi / det J     (Raviart-Thomas)
+ * with J = dx/dX between the element's own cell and the request's cell `verts[r]`.
+ * out: the [nreq][ntab][ndof][sd][npts] device tensor fx_tabulate_batch produced with the
+ * same verts.  (Round 1: a separate pass over the tables, not yet fused into the kernels.) */
+#define FX_MAP_AFFINE 0
+#define FX_MAP_COVARIANT_PIOLA 1
+#define FX_MAP_CONTRAVARIANT_PIOLA 2
+int fx_pushforward_batch(fx_ctx* ctx, const fx_element* elem, int mapping, int order,
+                         int64_t nreq, int npts, const double* verts, double* out, void* stream);
+
 /* Name of the device kernel fx_tabulate_batch would launch for this element and request shape
  * ("fxk::tabulate_simplex_stream", "..._fixed", "..._coop" or the generic "..._kernel"); has_verts != 0
  * stands for per-request cell geometry.  Lets benchmarks and tests name the kernel they measured

@@ -1,0 +1,95 @@
+"""Push-forward of tabulated tables to physical cells through the C ABI.
+
+Golden vectors (tests/golden/piola.npz, made by make_golden_piola.py from the unmodified
+reference): Nedelec / Raviart-Thomas / Lagrange elements constructed DIRECTLY on random
+physical simplices (one of them negatively oriented).  Where every degree of freedom
+transforms with the Piola map (degree 1, and Nedelec degree 2 on tetrahedra: edge and face
+tangent moments only) the pushed-forward reference basis must equal the reference's
+physical-cell basis; elements with interior moments against Cartesian test vectors (N2 on
+triangles, RT2) span the same space with a different interior basis, they are checked against
+the oracle's evaluation of the formula  phi = M Phi(X(x)),  M = J^-T  or  J / det J."""
+import numpy as np
+import pytest
+
+from oracle import fiat_oracle as fo
+
+pytestmark = pytest.mark.gpu
+TOL_VAL, TOL_DER = 1e-12, 1e-10
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from fiat_amd import runtime
+    runtime.Context.get()
+    return runtime
+
+
+def check(got, ref, what):
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    for t in range(ref.shape[0]):
+        err = np.abs(got[t] - ref[t]).max() / max(1.0, np.abs(ref[t]).max())
+        assert err <= (TOL_VAL if t == 0 else TOL_DER), (what, t, err)
+
+
+CASES = [("n1", 1, "covariant piola", True), ("n2", 2, "covariant piola", None), ("rt1", 1, "contravariant piola", True),
+         ("rt2", 2, "contravariant piola", False)]
+
+
+@pytest.mark.parametrize("sd", [2, 3])
+@pytest.mark.parametrize("name,n,mapping,exact", CASES)
+def test_piola_pushforward(rt, golden, sd, name, n, mapping, exact):
+    g = golden("piola")
+    verts, pts = g[f"verts_sd{sd}"], g[f"pts_sd{sd}"]
+    co = g[f"{name}_sd{sd}_refcoeffs"]
+    if exact is None:
+        exact = sd == 3          # N2: tetrahedra have no interior moments at degree 2, triangles do
+    ps = rt.SimplexPolySet(sd, n, coeffs=co, value_shape=(sd,))
+    out = ps.tabulate_batch(1, pts, verts=verts, mapping=mapping).cpu().numpy()
+    ref_cell = fo.UFC_SIMPLEX[sd]
+    for i in range(verts.shape[0]):
+        # the formula, evaluated by the oracle
+        J = (verts[i][1:] - verts[i][0]).T @ np.linalg.inv((ref_cell[1:] - ref_cell[0]).T)
+        M = np.linalg.inv(J).T if mapping.startswith("cov") else J / np.linalg.det(J)
+        tab = fo.element_tabulate(verts[i], n, co, 1, pts[i])
+        raw = np.stack([tab[a] for a in fo.jet_indices(sd, 1)])
+        check(out[i], np.einsum("ce,tdep->tdcp", M, raw), f"{name} sd{sd} cell {i} vs formula")
+        if exact:
+            check(out[i], g[f"{name}_sd{sd}_tab"][i], f"{name} sd{sd} cell {i} vs the reference on the physical cell")
+
+
+@pytest.mark.parametrize("sd", [2, 3])
+def test_affine_pullback_is_the_physical_element(rt, golden, sd):
+    """Lagrange P2: reference coefficients + cell geometry == the reference's element on the physical cell."""
+    g = golden("piola")
+    ps = rt.SimplexPolySet(sd, 2, variant="bubble", scale=1, coeffs=g[f"p2_sd{sd}_refcoeffs"])
+    out = ps.tabulate_batch(1, g[f"pts_sd{sd}"], verts=g[f"verts_sd{sd}"], mapping="affine").cpu().numpy()
+    for i in range(out.shape[0]):
+        check(out[i], g[f"p2_sd{sd}_tab"][i], f"P2 sd{sd} cell {i}")
+
+
+def test_pushforward_errors(rt, golden):
+    g = golden("piola")
+    ps = rt.SimplexPolySet(3, 2, variant="bubble", scale=1, coeffs=g["p2_sd3_refcoeffs"])
+    with pytest.raises(ValueError):          # scalar-valued element: no Piola map
+        ps.tabulate_batch(1, g["pts_sd3"], verts=g["verts_sd3"], mapping="covariant piola")
+    with pytest.raises(ValueError):          # needs the physical cells
+        ps.tabulate_batch(1, g["pts_sd3"], mapping="contravariant piola")
+    with pytest.raises(ValueError):
+        ps.tabulate_batch(1, g["pts_sd3"], verts=g["verts_sd3"], mapping="double covariant piola")
+
+
+def test_facade_pushforward(rt, golden):
+    """Nedelec(ufc tet, 1).tabulate_batch(..., pushforward=True) equals the reference's Nedelec on the physical cell."""
+    import fiat_amd
+    g = golden("piola")
+    el = fiat_amd.Nedelec(fiat_amd.ufc_simplex(3), 1)
+    assert el.mapping()[0] == "covariant piola"
+    out = el.tabulate_batch(1, g["pts_sd3"], verts=g["verts_sd3"], pushforward=True).cpu().numpy()
+    for i in range(out.shape[0]):
+        check(out[i], g["n1_sd3_tab"][i], f"facade N1 cell {i}")
+    rtel = fiat_amd.RaviartThomas(fiat_amd.ufc_simplex(2), 1)
+    out = rtel.tabulate_batch(1, g["pts_sd2"], verts=g["verts_sd2"], pushforward=True).cpu().numpy()
+    for i in range(out.shape[0]):
+        check(out[i], g["rt1_sd2_tab"][i], f"facade RT1 tri cell {i}")
