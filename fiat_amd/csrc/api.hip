@@ -793,7 +793,8 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             // default: K-streamed kernel, two requests per wave when the points of two requests fit
             // one wave (A/B: FIAT_AMD_KERNEL=image|stream|pair)
             // (pair kernel: the tables of each output half must fit half of the column tiles)
-            const bool pair_ok = npts <= 32 && (ntab == 1 || (f.nt % 2 == 0 && (f.nt / 2) * 16 >= ((ntab + 1) / 2) * npts));
+            const bool pair_ok = npts <= 32 && (FX_PAIR_FULLIMG || ntab == 1 ||
+                                                (f.nt % 2 == 0 && (f.nt / 2) * 16 >= ((ntab + 1) / 2) * npts));
             L.fkind = pair_ok ? 2 : 1;
             if (kk && !strcmp(kk, "image")) L.fkind = 0;
             if (kk && !strcmp(kk, "stream")) L.fkind = 1;
@@ -815,7 +816,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             if (L.fkind >= 1) {
                 {
                     // per wave: half image (>= the K-step slab that aliases it) + 64-double dump row
-                    const int th = (ntab + 1) / 2;
+                    const int th = (L.fkind == 2 && FX_PAIR_FULLIMG) ? ntab : (ntab + 1) / 2;
                     long long per_wave =
                         std::max<long long>((long long)th * rows * npts, (long long)f.nt * 64 * (L.fkind == 2 ? 2 : 1)) + 64;
                     per_wave = (per_wave + 1) & ~1LL;

@@ -20,6 +20,9 @@
 // 64 L2-resident output window, 512 record wave lifetimes
 #define FX_DBG 0
 #endif
+#ifndef FX_PAIR_FULLIMG
+#define FX_PAIR_FULLIMG 1  // 1: the LDS image holds a whole request (one write/read-back round per request), 0: half
+#endif
 #ifndef FX_PAIR_WAVES
 #define FX_PAIR_WAVES 2  // waves per SIMD requested from the register allocator (2*NT accumulator tiles)
 #endif
@@ -75,8 +78,8 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
     // h = 1: tables [TH, NTAB)) occupy the column tiles [h*NT/2, (h+1)*NT/2) of their request, so
     // that no tile straddles the two half images (host-checked: (NT/2)*16 >= TH*npts).  The
     // epilogue is then free of branches and masks, which keeps hipcc's vmcnt bookkeeping exact.
-    static_assert(NT % 2 == 0 || NTAB == 1, "half-aligned column tiles need an even tile count");
-    constexpr int TH = (NTAB + 1) / 2;
+    static_assert(FX_PAIR_FULLIMG || NT % 2 == 0 || NTAB == 1, "half-aligned column tiles need an even tile count");
+    constexpr int TH = FX_PAIR_FULLIMG ? NTAB : (NTAB + 1) / 2;  // tables per image round
     constexpr int NTH = NTAB > TH ? NT / 2 : NT;  // tiles per half
     int colbase[NTAB];
 #pragma unroll
@@ -274,16 +277,21 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
             const int nch = (ntab_h * ROWS * enpts) >> 1;
             const v2d* s2 = reinterpret_cast<const v2d*>(img);
             v2d* g2 = reinterpret_cast<v2d*>(a.out + (size_t)req * (NTAB * ROWS * enpts) + (size_t)half * TH * ROWS * enpts);
-            v2d buf[NFL];
+            // in batches of 8 x 16 B per lane (32 VGPRs in flight)
+            constexpr int FB = 8;
 #pragma unroll
-            for (int it = 0; it < NFL; ++it) {
-                const int i = min(it * 64 + elane, nch - 1);
-                buf[it] = s2[i];
-            }
+            for (int b0 = 0; b0 < NFL; b0 += FB) {
+                v2d buf[FB];
 #pragma unroll
-            for (int it = 0; it < NFL; ++it) {
-                const int i = min(it * 64 + elane, nch - 1);
-                stream_store(&g2[i], buf[it]);
+                for (int it = b0; it < NFL && it < b0 + FB; ++it) {
+                    const int i = min(it * 64 + elane, nch - 1);
+                    buf[it - b0] = s2[i];
+                }
+#pragma unroll
+                for (int it = b0; it < NFL && it < b0 + FB; ++it) {
+                    const int i = min(it * 64 + elane, nch - 1);
+                    stream_store(&g2[i], buf[it - b0]);
+                }
             }
         };
 
