@@ -712,7 +712,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 const int table = rows * npts;
                 int TR = std::max(1, (int)((32 * 1024) / ((long long)table * 8)));
                 TR = std::min(TR, ntab);
-                long long img = std::max<long long>(2LL * (nt_need * 64 + 64), (long long)TR * table);
+                long long img = std::max<long long>(2LL * (nt_need * 64 + 128), (long long)TR * table);
                 img = (img + 1) & ~1LL;
                 if (npts > 32) continue;  // LDS-resident chain state holds 32 points
                 long long ldsb = ((long long)(mt16 + m4) * e->coop_KS * 64 + img + 4LL * 4 * ntab * 32) * 8;
@@ -736,7 +736,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 ca.NT = nt_need;
                 ca.emax = e->coop_emax;
                 ca.TR = TR;
-                ca.slab_doubles = nt_need * 64 + 64;
+                ca.slab_doubles = nt_need * 64 + 128;
                 ca.img_doubles = (int)img;
                 ca.debug = a.debug;
                 L.clds_bytes = (int)ldsb;

@@ -37,7 +37,7 @@ struct CoopArgs {
     long long nreq;
     int npts, rows, KS, NT, emax;
     int TR;           // tables per image round
-    int slab_doubles; // NT*64 B-fragment doubles + a 64-double dump row for inactive lanes
+    int slab_doubles; // NT*64 B-fragment doubles + a 128-double dump row for inactive lanes (lane + 16 * K slot)
     int img_doubles;  // >= max(2*slab_doubles, TR*rows*npts)
     int debug;        // measurement only: 1 skip recurrence math, 2 skip MFMAs, 4 skip output rounds
 };
@@ -87,8 +87,9 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
 #pragma unroll
         for (int t = 0; t < NTAB; ++t) {
             const int c = t * npts + pl;
-            // inactive lanes store into the 64-double dump row that closes every slab
-            colbase[t] = active ? (c >> 4) * 64 + w * 16 + (c & 15) : NT * 64 + lane;
+            // (+ 16 * K slot, taken from the entry; inactive lanes store into the 128-double dump
+            // row that closes every slab)
+            colbase[t] = active ? (c >> 4) * 64 + (c & 15) : NT * 64 + lane;
         }
         for (long long req = blockIdx.x; req < a.nreq; req += gridDim.x) {
             double X[SD];
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                 if (level == 0) step(nw, od, 0, d); else step(nw, od, 1, d);
                 par ^= 1;
                 lst(2 * level + par, od);
-                if (publish) put(slab, od);
+                if (publish) put(slab + (publish - 1) * 16, od);
             };
 
             // The entry records are wave uniform and read with scalar loads.  Each record is
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                     const double* d = dreg;
                     if (level < 0) {
                         // zero pad row (seed == -2) or the constant member
-                        if (publish) put_zero(slab, seed == -2 ? 0.0 : phi0);
+                        if (publish) put_zero(slab + (publish - 1) * 16, seed == -2 ? 0.0 : phi0);
                     } else if (level == 0) {
                         lds_level_step(0, par0, seed, publish, slab, d);
                     } else if (level == 1) {
@@ -260,10 +261,10 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                         }
                         if (par2 == 0) {
                             step(a2, b2, 2, d);
-                            if (publish) put(slab, b2);
+                            if (publish) put(slab + (publish - 1) * 16, b2);
                         } else {
                             step(b2, a2, 2, d);
-                            if (publish) put(slab, a2);
+                            if (publish) put(slab + (publish - 1) * 16, a2);
                         }
                         par2 ^= 1;
                     }

@@ -261,7 +261,7 @@ struct CoopEntry {
     int level;    // codimension of the step; -1: the constant member 0
     int seed;     // -2: continue the chain of `level`; -1: chain starts from the constant;
                   // 0/1: chain starts from the current member of that level
-    int publish;  // 1: store the result into this wave's slab row, 0: keep in registers only
+    int publish;  // K slot + 1 (1..4): store the result into that row of the K-step's slab; 0: keep in registers only
     int member;   // member index produced (for the K permutation), -1 for a zero pad
     double A, B, C;
 };
@@ -372,40 +372,67 @@ inline CoopPlan build_coop_plan(const Program& P) {
             for (int r = 1; r <= n - p - q; ++r) emit_step(mid(p, q, r), 1);
         }
     }
-    // K-step boundaries: a K-step ends with the wave's next published entry
-    int KS = 0;
+    // K slots.  The producers meet at a barrier after every K-step, and a K-step of the contraction
+    // takes four published members from whichever producers supply them: all publishes are ordered
+    // by the time their producer reaches them (entries executed so far, steps of the LDS-resident
+    // levels 0/1 weigh 1.5), K-step j takes publishes 4j .. 4j+3 and ends at the time T_j of the
+    // last of them; every producer executes in K-step j whatever it can finish by T_j, published
+    // or not, so that all four stay busy between barriers.  A fixed "one member per producer per K-step" rule made every K-step as slow
+    // as the producer that had a run of unpublished prefix steps in it (DG P6 tet: the sum over
+    // K-steps of the longest producer was 45 entries per request for 29 per producer).
+    // CoopEntry::publish = K slot + 1 (0: not published).
+    auto cost = [](const CoopEntry& e) { return (e.level == 0 || e.level == 1) ? 1.5 : 1.0; };
+    struct Pub { double t; int w, idx; };
+    std::vector<Pub> pubs;
+    std::vector<double> tcum[4];  // time at which producer w has finished entry i
     for (int w = 0; w < 4; ++w) {
-        int pubs = 0;
-        for (const auto& e : C.entries[w]) pubs += e.publish;
-        KS = std::max(KS, pubs);
+        double t = 0.0;
+        for (size_t i = 0; i < C.entries[w].size(); ++i) {
+            t += cost(C.entries[w][i]);
+            tcum[w].push_back(t);
+            if (C.entries[w][i].publish) pubs.push_back({t, w, (int)i});
+        }
     }
+    std::stable_sort(pubs.begin(), pubs.end(), [](const Pub& a, const Pub& b) { return a.t < b.t; });
+    const int total_pubs = (int)pubs.size();
+    const int KS = (total_pubs + 3) / 4;
     C.KS = KS;
     C.kperm.assign((size_t)4 * KS, -1);
+    std::vector<int> group[4];  // K-step of every published entry (-1: not published)
     for (int w = 0; w < 4; ++w) {
-        std::vector<CoopEntry>& E = C.entries[w];
-        std::vector<int>& ks = C.kstart[w];
-        ks.clear();
-        ks.push_back(0);
-        int j = 0;
-        for (size_t i = 0; i < E.size(); ++i) {
-            if (E[i].publish) {
-                C.kperm[(size_t)4 * j + w] = E[i].member;
-                ++j;
-                ks.push_back((int)i + 1);
-            }
+        C.kstart[w].assign(1, 0);
+        group[w].assign(C.entries[w].size(), -1);
+    }
+    for (int k = 0; k < total_pubs; ++k) group[pubs[k].w][pubs[k].idx] = k / 4;
+    for (int j = 0; j < KS; ++j) {
+        double T = 0.0;  // the K-step ends when its last member is published
+        for (int slot = 0; slot < 4 && 4 * j + slot < total_pubs; ++slot) {
+            const Pub& pb = pubs[(size_t)4 * j + slot];
+            CoopEntry& e = C.entries[pb.w][pb.idx];
+            C.kperm[(size_t)4 * j + slot] = e.member;
+            e.publish = slot + 1;
+            T = std::max(T, pb.t);
         }
-        // trailing unpublished entries cannot exist (every list ends with a published chain)
-        while (j < KS) {  // zero pads
-            CoopEntry e;
-            e.level = -1;
-            e.seed = -2;  // marks a zero row
-            e.publish = 1;
-            e.member = -1;
-            e.A = e.B = e.C = 0.0;
-            E.push_back(e);
-            ++j;
-            ks.push_back((int)E.size());
+        for (int w = 0; w < 4; ++w) {
+            // everything this producer can do by then, published or not -- but a member of a
+            // later K-step (ties in time) must wait: it would land in this K-step's slab
+            size_t i = (size_t)C.kstart[w].back();
+            while (i < C.entries[w].size() && tcum[w][i] <= T + 1e-9 && group[w][i] <= j) ++i;
+            if (j == KS - 1) i = C.entries[w].size();
+            C.kstart[w].push_back((int)i);
         }
+    }
+    const int used_last = total_pubs - 4 * (KS - 1);
+    // zero rows for the unused slots of the last K-step (0 x garbage could be NaN): producer 0
+    for (int slot = used_last; slot < 4; ++slot) {
+        CoopEntry e;
+        e.level = -1;
+        e.seed = -2;  // marks a zero row
+        e.publish = slot + 1;
+        e.member = -1;
+        e.A = e.B = e.C = 0.0;
+        C.entries[0].push_back(e);
+        C.kstart[0][KS] = (int)C.entries[0].size();
     }
     return C;
 }
