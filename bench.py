@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--workload", default="p3tet", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="requests per GPU (default: the workload's)")
     ap.add_argument("--allgather", action="store_true", help="also time the RCCL all-gather of the tables")
+    ap.add_argument("--shared-points", action="store_true",
+                    help="variant (SURVEY.md 8d): ONE 23-point rule on the reference cell pushed forward to per-request "
+                         "physical cells (fx_tabulate_batch_shared) instead of per-request random points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", type=int, default=-1,
                     help="requests verified against the CPU oracle after timing (-1: the whole batch, 0: none)")
@@ -143,15 +146,34 @@ def main():
     pts = torch.as_tensor(pts_h).cuda()
     out = torch.empty(ps.out_shape(order, batch, npts), dtype=torch.float64, device="cuda")
     stream = torch.cuda.current_stream()
+    verts_h = None
+    if args.shared_points:
+        # cells: UFC vertices + U(-0.2, 0.2) per coordinate, the rule: 23 fixed points
+        from oracle import fiat_oracle as fo
+        rng = np.random.default_rng(1000 + rank)
+        verts_h = fo.UFC_SIMPLEX[sd][None] + rng.uniform(-0.2, 0.2, size=(batch, sd + 1, sd))
+        ref_pts_h = synth_points(sd, 1, npts, seed=6)[0]
+        bary = np.concatenate([1.0 - ref_pts_h.sum(axis=1, keepdims=True), ref_pts_h], axis=1)
+        pts_h = np.einsum("pv,rvd->rpd", bary, verts_h)          # the same points, per request (for the check)
+        verts = torch.as_tensor(verts_h).cuda()
+        ref_pts = torch.as_tensor(ref_pts_h).cuda()
+        mapping = el.mapping()[0]
+        bytes_per_req = 8 * ((sd + 1) * sd + ntab * rows * npts)
+
+        def step():
+            ps.tabulate_batch_shared(order, ref_pts, verts, mapping=mapping, out=out)
+    else:
+        def step():
+            ps.tabulate_batch(order, pts, out=out)
 
     for _ in range(args.warmup):
-        ps.tabulate_batch(order, pts, out=out)
+        step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ps.tabulate_batch(order, pts, out=out)
+        step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -162,11 +184,21 @@ def main():
         elapsed = float(t.item())
 
     # dominant kernel: average launch duration from HIP events on the launch stream
-    kernel_ms = ps.time_tabulate_batch(order, pts, None, out, max(5, args.steps), stream=stream)
+    if args.shared_points:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nrep = max(5, args.steps)
+        e0.record(stream)
+        for _ in range(nrep):
+            step()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        kernel_ms = e0.elapsed_time(e1) / nrep      # reference tabulation (1 request) + the streaming kernel
+    else:
+        kernel_ms = ps.time_tabulate_batch(order, pts, None, out, max(5, args.steps), stream=stream)
     achieved = bytes_per_req * batch / (kernel_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": ps.kernel_name(order, batch, npts),
+                "kernel": "fxk::shared_points_kernel" if args.shared_points else ps.kernel_name(order, batch, npts),
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_request": bytes_per_req, "requests_per_launch": batch}
     prof = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
@@ -176,7 +208,7 @@ def main():
         try:
             with open(prof) as f:
                 tr = json.load(f)
-            if tr.get("workload") == args.workload and tr.get("batch") == batch:
+            if tr.get("workload") == args.workload and tr.get("batch") == batch and not args.shared_points:
                 roofline["traffic"] = tr["hbm_bytes_per_launch"]
         except Exception:
             pass
@@ -187,7 +219,13 @@ def main():
         from oracle import c_oracle, fiat_oracle as fo
         ncheck = batch if args.check < 0 else min(args.check, batch)
         ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[sd], deg, el.get_coeffs(), order, pts_h[:ncheck],
+                                      verts=None if verts_h is None else verts_h[:ncheck],
                                       scale=el._expansion_scale, variant=el._expansion_variant)
+        if args.shared_points and el.mapping()[0] != "affine":     # Piola: phi = M Phi, evaluated in NumPy
+            E = np.swapaxes(verts_h[:ncheck, 1:] - verts_h[:ncheck, :1], 1, 2)          # J for the UFC reference cell
+            M = np.swapaxes(np.linalg.inv(E), 1, 2) if el.mapping()[0].startswith("cov") else E / np.linalg.det(E)[:, None, None]
+            r5 = ref.reshape(ncheck, ref.shape[1], -1, sd, npts)
+            ref = np.einsum("rce,rtdep->rtdcp", M, r5).reshape(ref.shape)
         got = out[:ncheck].cpu().numpy().reshape(ref.shape)
         num = np.abs(got - ref).max(axis=(2, 3))
         den = np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))
@@ -230,6 +268,8 @@ def main():
                                    f"{'tetrahedron' if sd == 3 else 'triangle'}, order {order}, "
                                    f"{npts} points/request, batch {batch} per GPU",
                        "requests_per_gpu": batch, "points_per_request": npts, "order": order,
+                       "points": "one 23-point rule on the reference cell, per-request physical cells" if args.shared_points
+                                 else "random per request",
                        "sharding": "independent requests, contiguous blocks per rank, no data-path collective"},
             "roofline": roofline,
             "max_rel_err_vs_oracle": max_err,

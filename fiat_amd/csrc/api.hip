@@ -18,6 +18,7 @@
 #include "simplex_stream.hpp"
 #include "simplex_pair.hpp"
 #include "coop_kernel.hpp"
+#include "shared_points.hpp"
 
 namespace {
 
@@ -105,6 +106,8 @@ struct fx_ctx {
     double* d_trash = nullptr;  // 64 KB scratch (ablation builds: wave lifetimes, FX_DBG & 512)
     unsigned long long* d_queue = nullptr;  // chunk counters of the dynamically scheduled kernels (work_queue.hpp)
     unsigned int launch_seq = 0;
+    double* d_ref = nullptr;  // reference-cell tables of fx_tabulate_batch_shared (grown on demand)
+    size_t ref_bytes = 0;
 };
 constexpr int FX_QUEUE_SLOTS = 64;  // counters handed to consecutive launches round-robin (128 B apart)
 
@@ -176,6 +179,7 @@ int fx_ctx_create(int device_id, fx_ctx** out) {
 int fx_ctx_destroy(fx_ctx* ctx) {
     if (ctx && ctx->d_trash) (void)hipFree(ctx->d_trash);
     if (ctx && ctx->d_queue) (void)hipFree(ctx->d_queue);
+    if (ctx && ctx->d_ref) (void)hipFree(ctx->d_ref);
     delete ctx;
     return FX_OK;
 }
@@ -870,6 +874,90 @@ int run_tabulate(fx_ctx* ctx, const fx_element* e, int order, const Launch& L, h
 
 }  // namespace
 
+namespace {
+bool invert_small(int sd, const double* A, double* inv) {
+    if (sd == 1) {
+        if (A[0] == 0.0) return false;
+        inv[0] = 1.0 / A[0];
+        return true;
+    }
+    if (sd == 2) {
+        const double det = A[0] * A[3] - A[1] * A[2];
+        if (det == 0.0) return false;
+        inv[0] = A[3] / det;
+        inv[1] = -A[1] / det;
+        inv[2] = -A[2] / det;
+        inv[3] = A[0] / det;
+        return true;
+    }
+    const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+    const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+    if (det == 0.0) return false;
+    inv[0] = c00 / det;
+    inv[1] = (A[2] * A[7] - A[1] * A[8]) / det;
+    inv[2] = (A[1] * A[5] - A[2] * A[4]) / det;
+    inv[3] = c01 / det;
+    inv[4] = (A[0] * A[8] - A[2] * A[6]) / det;
+    inv[5] = (A[2] * A[3] - A[0] * A[5]) / det;
+    inv[6] = c02 / det;
+    inv[7] = (A[1] * A[6] - A[0] * A[7]) / det;
+    inv[8] = (A[0] * A[4] - A[1] * A[3]) / det;
+    return true;
+}
+
+template <int SD, int ORDER, bool PIOLA>
+bool launch_shared_reg(int np, const fxk::SharedArgs& sa, int grid, hipStream_t s) {
+    switch (np) {
+        case 1: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 1, PIOLA>), dim3(grid), dim3(256), 0, s, sa); return true;
+        case 2: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 2, PIOLA>), dim3(grid), dim3(256), 0, s, sa); return true;
+        case 3: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 3, PIOLA>), dim3(grid), dim3(256), 0, s, sa); return true;
+        case 4: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 4, PIOLA>), dim3(grid), dim3(256), 0, s, sa); return true;
+    }
+    return false;
+}
+
+template <int SD>
+int launch_shared(int order, const fxk::SharedArgs& sa, int grid, hipStream_t s) {
+    const int table = sa.rows * sa.npts;
+    // small affine requests, order <= 1: one wave per request, line-aligned 1 KB stores
+    static const bool nowave = getenv("FIAT_AMD_NO_SHARED_WAVE") != nullptr;
+    if (!nowave && sa.kind == 0 && order == 1 && (table & 1) == 0) {
+        const int npairs = (1 + SD) * table / 2;
+        const int ns = (npairs + 63) / 64;       // 1 KB slots per request
+        const int nwr = ns <= 8 ? 1 : ns <= 16 ? 2 : 4;  // waves per request, 8 slots each
+        const long long teams = (sa.nreq + 63) / 64;     // a team takes 64 requests at a time
+        const int wgrid = (int)std::max<long long>(1, std::min<long long>((teams * nwr + 3) / 4, (long long)grid));
+        bool ok = ns <= 32;
+        if (ok) hipLaunchKernelGGL((fxk::shared_points_wave_kernel<SD, 8>), dim3(wgrid), dim3(256), 0, s, sa, nwr);
+        if (ok) {
+            HIP_TRY(hipGetLastError());
+            return FX_OK;
+        }
+    }
+    // register-resident kernel when a table is even-sized and at most 4 pairs per thread
+    const int np = (table / 2 + 255) / 256;
+    static const bool noreg = getenv("FIAT_AMD_NO_SHARED_REG") != nullptr;
+    if (!noreg && (table & 1) == 0 && np >= 1 && np <= 4 && (sa.kind == 0 || sa.vdim == SD)) {
+        bool ok = false;
+        const bool piola = sa.kind != 0;
+        if (order == 0) ok = piola ? launch_shared_reg<SD, 0, true>(np, sa, grid, s) : launch_shared_reg<SD, 0, false>(np, sa, grid, s);
+        if (order == 1) ok = piola ? launch_shared_reg<SD, 1, true>(np, sa, grid, s) : launch_shared_reg<SD, 1, false>(np, sa, grid, s);
+        if (order == 2) ok = piola ? launch_shared_reg<SD, 2, true>(np, sa, grid, s) : launch_shared_reg<SD, 2, false>(np, sa, grid, s);
+        if (ok) {
+            HIP_TRY(hipGetLastError());
+            return FX_OK;
+        }
+    }
+    switch (order) {
+        case 0: hipLaunchKernelGGL((fxk::shared_points_kernel<SD, 0>), dim3(grid), dim3(256), 0, s, sa); break;
+        case 1: hipLaunchKernelGGL((fxk::shared_points_kernel<SD, 1>), dim3(grid), dim3(256), 0, s, sa); break;
+        default: hipLaunchKernelGGL((fxk::shared_points_kernel<SD, 2>), dim3(grid), dim3(256), 0, s, sa); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int fx_tabulate_batch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, const double* pts,
@@ -906,6 +994,53 @@ int fx_pushforward_batch(fx_ctx* ctx, const fx_element* e, int mapping, int orde
         hipLaunchKernelGGL(fxk::piola_apply_kernel<3>, dim3((unsigned)nreq), dim3(256), 0, (hipStream_t)stream, pa);
     HIP_TRY(hipGetLastError());
     return FX_OK;
+}
+
+int fx_tabulate_batch_shared(fx_ctx* ctx, const fx_element* e, int mapping, int order, int64_t nreq, int npts,
+                             const double* ref_pts, const double* verts, double* out, void* stream) {
+    if (!ctx || !e) return fail(FX_EINVAL, "null context/element");
+    if (mapping < FX_MAP_AFFINE || mapping > FX_MAP_CONTRAVARIANT_PIOLA) return fail(FX_EINVAL, "unknown mapping %d", mapping);
+    if (order < 0) return fail(FX_EINVAL, "negative derivative order");
+    if (order > 2) return fail(FX_ENOTIMPL, "derivative order %d > 2 is not implemented on the device", order);
+    if (nreq < 0 || npts < 0) return fail(FX_EINVAL, "negative batch size");
+    if (nreq == 0 || npts == 0) return FX_OK;
+    if (!ref_pts || !verts || !out) return fail(FX_EINVAL, "null device pointer");
+    if (mapping != FX_MAP_AFFINE && (e->vdim != e->sd || e->sd < 2))
+        return fail(FX_EINVAL, "Piola maps need vector-valued functions with value shape (%d,), got %d components", e->sd, e->vdim);
+    const int ntab = fx::binom(e->sd + order, e->sd);
+    const int rows = e->ndof * e->vdim;
+    const size_t need = (size_t)ntab * rows * npts * sizeof(double);
+    hipStream_t s = (hipStream_t)stream;
+    if (need > ctx->ref_bytes) {  // grow the scratch (rare; the old buffer may still be read by queued work)
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipDeviceSynchronize());
+        if (ctx->d_ref) (void)hipFree(ctx->d_ref);
+        ctx->d_ref = nullptr;
+        ctx->ref_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->d_ref, need));
+        ctx->ref_bytes = need;
+    }
+    // the element on its own cell at the shared points, once
+    int rc = fx_tabulate_batch(ctx, e, order, 1, npts, ref_pts, nullptr, ctx->d_ref, stream);
+    if (rc != FX_OK) return rc;
+    fxk::SharedArgs sa;
+    sa.ref = ctx->d_ref;
+    sa.verts = verts;
+    sa.out = out;
+    if (!invert_small(e->sd, e->A0, sa.A0inv)) return fail(FX_EINVAL, "degenerate cell");
+    sa.nreq = nreq;
+    sa.rows = rows;
+    sa.vdim = e->vdim;
+    sa.npts = npts;
+    sa.kind = mapping;
+    // persistent workgroups; the register-resident kernel takes blocks of 256 requests
+    const int grid = (int)std::max<long long>(1, std::min<long long>((nreq + fxk::SHARED_RB - 1) / fxk::SHARED_RB, (long long)ctx->num_cu * 8));
+    switch (e->sd) {
+        case 1: return launch_shared<1>(order, sa, grid, s);
+        case 2: return launch_shared<2>(order, sa, grid, s);
+        case 3: return launch_shared<3>(order, sa, grid, s);
+    }
+    return fail(FX_EINVAL, "Invalid number of spatial dimensions");
 }
 
 int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, int has_verts, char* name,

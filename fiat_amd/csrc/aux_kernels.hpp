@@ -244,7 +244,6 @@ __global__ __launch_bounds__(256) void tensor_tabulate_kernel(TensorArgs a) {
     const float rinv_nbf = 1.0f / (float)(a.L[0].nn * nn1 * nn2);
     const float rinv_n12 = 1.0f / (float)(nn1 * nn2);
     const float rinv_n2 = 1.0f / (float)nn2;
-    const float rinv_npts = 1.0f / (float)a.npts;
     const float rinv_q = 1.0f / (float)(a.q > 0 ? a.q : 1);
     const float rinv_qq = 1.0f / (float)(a.q > 0 ? a.q * a.q : 1);
     // LDS row table: for every output row (table t, basis function (i0,i1,i2)) the LDS offsets of

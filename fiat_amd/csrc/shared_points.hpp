@@ -1,0 +1,352 @@
+// Tabulation of one reference point set pushed forward to many cells (gfx950).
+#pragma once
+#include "simplex_kernel.hpp"
+#include "store.hpp"
+
+namespace fxk {
+
+// ---------------------------------------------------------------------------------
+// Same reference points in every cell (the quadrature-rule case): the tables of the element on
+// its own cell are computed once (`ref`, [ntab][ndof][vdim][npts], derivatives w.r.t. the own
+// cell's coordinates x^); request r is the affine image of that cell and gets
+//   values        phi            (copied, or mixed by the Piola matrix)
+//   gradients     d/dx_d       = sum_c K[c][d] d/dx^_c
+//   Hessians      d2/dx_d dx_e = sum_{c,c'} K[c][d] K[c'][e] d2/dx^_c dx^_c'
+// with K = dx^/dx = A0^{-1} A_r (A_r: cell map of request r to the default simplex, A0: the own
+// cell's).  Piola maps reuse K: covariant J^{-T} = K^T, contravariant J / det J = adj(K).
+// This is what FIAT's consumers do (tabulate on the reference cell once, FInAT/TSFC push forward
+// per cell); here it is one streaming kernel: reads hit L2 (the reference tables are a few kB),
+// the output is written once.  References: FIAT/finite_element.py:84-88 (mapping),
+// finat/fiat_elements.py:69 (reference tabulation), finat/hdivcurl.py:95-191 (Piola).
+struct SharedArgs {
+    const double* ref;    // [ntab][rows][npts] tables on the element's own cell
+    const double* verts;  // [nreq][SD+1][SD]
+    double* out;          // [nreq][ntab][rows][npts]
+    double A0inv[9];
+    long long nreq;
+    int rows, vdim, npts, kind;  // kind: 0 affine, 1 covariant Piola, 2 contravariant Piola
+};
+
+template <int SD, int ORDER> __global__ __launch_bounds__(256) void shared_points_kernel(const SharedArgs a) {
+    constexpr int NTAB = NTab<SD, ORDER>::value;
+    constexpr int NH = SD * (SD + 1) / 2;
+    __shared__ double sK[SD * SD], sP[SD * SD], sH[NH * NH];
+    const int table = a.rows * a.npts;
+    const int total = NTAB * table;
+    for (long long req = blockIdx.x; req < a.nreq; req += gridDim.x) {
+        __syncthreads();  // the matrices of the previous request are no longer read
+        if (threadIdx.x == 0) {
+            double A[SD][SD], b[SD], K[SD][SD];
+            cell_map<SD>(a.verts + (size_t)req * (SD + 1) * SD, A, b);
+            for (int c = 0; c < SD; ++c)
+                for (int d = 0; d < SD; ++d) {
+                    double t = 0.0;
+                    for (int k = 0; k < SD; ++k) t += a.A0inv[c * SD + k] * A[k][d];
+                    K[c][d] = t;
+                    sK[c * SD + d] = t;
+                }
+            // Piola matrix P[c][c'] (identity for affine elements)
+            for (int c = 0; c < SD; ++c)
+                for (int e = 0; e < SD; ++e) {
+                    double v = c == e ? 1.0 : 0.0;
+                    if (a.kind == 1) v = K[e][c];
+                    if (a.kind == 2) {
+                        if constexpr (SD == 1) v = 1.0;
+                        else if constexpr (SD == 2) v = (c == e ? K[1 - c][1 - e] : -K[c][e]);
+                        else {
+                            const int c1 = (c + 1) % 3, c2 = (c + 2) % 3, e1 = (e + 1) % 3, e2 = (e + 2) % 3;
+                            v = K[e1][c1] * K[e2][c2] - K[e1][c2] * K[e2][c1];  // adj(K)[c][e] = cofactor(K)[e][c]
+                        }
+                    }
+                    sP[c * SD + e] = v;
+                }
+            if constexpr (ORDER >= 2) {
+                // Hessian components in mis() order: (d,e), d <= e  <-  (c,c'), c <= c'
+                int hd = 0;
+                for (int d = 0; d < SD; ++d)
+                    for (int e = d; e < SD; ++e, ++hd) {
+                        int hc = 0;
+                        for (int c = 0; c < SD; ++c)
+                            for (int c2 = c; c2 < SD; ++c2, ++hc)
+                                sH[hd * NH + hc] = c == c2 ? K[c][d] * K[c][e] : K[c][d] * K[c2][e] + K[c2][d] * K[c][e];
+                    }
+            }
+        }
+        __syncthreads();
+        double* o = a.out + (size_t)req * total;
+        for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+            const int t = idx / table, rem = idx - t * table;
+            const int row = rem / a.npts, p = rem - row * a.npts;
+            // source tables and weights of output table t
+            int s0, ns;
+            const double* w;
+            if (t == 0) {
+                s0 = 0; ns = 1; w = nullptr;
+            } else if (t <= SD) {
+                s0 = 1; ns = SD; w = nullptr;
+            } else {
+                s0 = 1 + SD; ns = NH; w = sH + (t - 1 - SD) * NH;
+            }
+            double acc = 0.0;
+            if (a.kind == 0 || a.vdim != SD) {
+                for (int s = 0; s < ns; ++s) {
+                    const double ws = t == 0 ? 1.0 : (t <= SD ? sK[s * SD + (t - 1)] : w[s]);
+                    acc += ws * a.ref[(size_t)(s0 + s) * table + rem];
+                }
+            } else {
+                const int dof = row / SD, c = row - dof * SD;
+                for (int s = 0; s < ns; ++s) {
+                    const double ws = t == 0 ? 1.0 : (t <= SD ? sK[s * SD + (t - 1)] : w[s]);
+                    double v = 0.0;
+                    for (int e = 0; e < SD; ++e) v += sP[c * SD + e] * a.ref[(size_t)(s0 + s) * table + (dof * SD + e) * a.npts + p];
+                    acc += ws * v;
+                }
+            }
+            stream_store(&o[idx], acc);
+        }
+    }
+}
+
+// Register-resident version: every thread of the (persistent) workgroup owns NP fixed pairs of
+// consecutive output positions of a table and keeps the reference values of all source tables for
+// them in registers (for Piola maps: of the SD components of the dof each position belongs to).
+// Per request it takes K from LDS (computed for 256 requests at a time, one per thread), forms
+// adj(K) / sym^2 K in registers and writes its positions with 16-byte non-temporal stores: no
+// reads besides 8*(SD+1)*SD bytes per request.  Needs table = rows*npts even and <= 512*NP.
+constexpr int SHARED_RB = 64;  // requests per block of the register-resident kernel
+
+template <int SD, int ORDER, int NP, bool PIOLA>
+__global__ __launch_bounds__(256) void shared_points_reg_kernel(const SharedArgs a) {
+    constexpr int NTAB = NTab<SD, ORDER>::value;
+    constexpr int NH = SD * (SD + 1) / 2;
+    constexpr int NE = PIOLA ? SD : 1;
+    const int table = a.rows * a.npts;
+    const int npairs = table >> 1;
+    typedef double v2d_t __attribute__((ext_vector_type(2)));
+    // reference values: [slot][element of the pair][source table][component]
+    double rv[NP][2][NTAB][NE];
+    int comp[NP][2];  // component (row % SD) of each element, for the Piola matrix row
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int pr = min((int)threadIdx.x + 256 * i, npairs - 1);
+#pragma unroll
+        for (int el = 0; el < 2; ++el) {
+            const int q = 2 * pr + el;
+            const int row = q / a.npts, p = q - row * a.npts;
+            comp[i][el] = PIOLA ? row % SD : 0;
+            const int dof = PIOLA ? row / SD : 0;
+#pragma unroll
+            for (int s = 0; s < NTAB; ++s)
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    rv[i][el][s][e] = PIOLA ? a.ref[(size_t)s * table + (dof * SD + e) * a.npts + p] : a.ref[(size_t)s * table + q];
+        }
+    }
+    // K of SHARED_RB requests at a time: thread i < SHARED_RB inverts the cell of request base + i
+    // (the divisions and the 3x3 inverse, ~150 fp64 instructions, would otherwise be repeated by
+    // every thread for every request), the workgroup then walks through them reading K from LDS.
+    __shared__ double sK[SHARED_RB][SD * SD];
+    for (long long base = (long long)blockIdx.x * SHARED_RB; base < a.nreq; base += (long long)gridDim.x * SHARED_RB) {
+        __syncthreads();  // sK of the previous block is no longer read
+        if (threadIdx.x < SHARED_RB) {
+            const long long rq = min(base + (long long)threadIdx.x, a.nreq - 1);
+            double A[SD][SD], b[SD];
+            cell_map<SD>(a.verts + (size_t)rq * (SD + 1) * SD, A, b);
+#pragma unroll
+            for (int c = 0; c < SD; ++c)
+#pragma unroll
+                for (int d = 0; d < SD; ++d) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < SD; ++k) t += a.A0inv[c * SD + k] * A[k][d];
+                    sK[threadIdx.x][c * SD + d] = t;
+                }
+        }
+        __syncthreads();
+        const int nblk = (int)min((long long)SHARED_RB, a.nreq - base);
+      for (int rb = 0; rb < nblk; ++rb) {
+        const long long req = base + rb;
+        double K[SD][SD];
+#pragma unroll
+        for (int c = 0; c < SD; ++c)
+#pragma unroll
+            for (int d = 0; d < SD; ++d) K[c][d] = sK[rb][c * SD + d];
+        double P[SD][SD];
+        if constexpr (PIOLA) {
+#pragma unroll
+            for (int c = 0; c < SD; ++c)
+#pragma unroll
+                for (int e = 0; e < SD; ++e) {
+                    double v;
+                    if (a.kind == 1) {
+                        v = K[e][c];
+                    } else if constexpr (SD == 2) {
+                        v = (c == e ? K[1 - c][1 - e] : -K[c][e]);
+                    } else if constexpr (SD == 3) {
+                        constexpr int nx[3] = {1, 2, 0}, nn[3] = {2, 0, 1};
+                        v = K[nx[e]][nx[c]] * K[nn[e]][nn[c]] - K[nx[e]][nn[c]] * K[nn[e]][nx[c]];
+                    } else {
+                        v = 1.0;
+                    }
+                    P[c][e] = v;
+                }
+        }
+        double H[NH][NH];
+        if constexpr (ORDER >= 2) {
+            int hd = 0;
+#pragma unroll
+            for (int d = 0; d < SD; ++d)
+#pragma unroll
+                for (int e = d; e < SD; ++e, ++hd) {
+                    int hc = 0;
+#pragma unroll
+                    for (int c = 0; c < SD; ++c)
+#pragma unroll
+                        for (int c2 = c; c2 < SD; ++c2, ++hc)
+                            H[hd][hc] = c == c2 ? K[c][d] * K[c][e] : K[c][d] * K[c2][e] + K[c2][d] * K[c][e];
+                }
+        }
+        v2d_t* o2 = reinterpret_cast<v2d_t*>(a.out + (size_t)req * NTAB * table);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int pr = (int)threadIdx.x + 256 * i;
+            if (pr < npairs) {
+                // source values after the Piola mix: m[el][s]
+                double m[2][NTAB];
+#pragma unroll
+                for (int el = 0; el < 2; ++el)
+#pragma unroll
+                    for (int s = 0; s < NTAB; ++s) {
+                        if constexpr (PIOLA) {
+                            double v = 0.0;
+#pragma unroll
+                            for (int e = 0; e < SD; ++e) {
+                                // row comp[i][el] of P, selected without dynamic register indexing
+                                double pc = P[0][e];
+#pragma unroll
+                                for (int c = 1; c < SD; ++c) pc = comp[i][el] == c ? P[c][e] : pc;
+                                v += pc * rv[i][el][s][e];
+                            }
+                            m[el][s] = v;
+                        } else {
+                            m[el][s] = rv[i][el][s][0];
+                        }
+                    }
+#pragma unroll
+                for (int t = 0; t < NTAB; ++t) {
+                    v2d_t v;
+#pragma unroll
+                    for (int el = 0; el < 2; ++el) {
+                        double acc;
+                        if (t == 0) {
+                            acc = m[el][0];
+                        } else if (t <= SD) {
+                            acc = 0.0;
+#pragma unroll
+                            for (int c = 0; c < SD; ++c) acc += K[c][t - 1] * m[el][1 + c];
+                        } else {
+                            acc = 0.0;
+                            if constexpr (ORDER >= 2) {
+#pragma unroll
+                                for (int hc = 0; hc < NH; ++hc) acc += H[t - 1 - SD][hc] * m[el][1 + SD + hc];
+                            }
+                        }
+                        if (el == 0) v.x = acc; else v.y = acc;
+                    }
+                    o2[(size_t)t * npairs + pr] = v;  // plain store: chunks are not line-aligned, neighbours complete the lines in L2
+                }
+            }
+        }
+      }
+    }
+}
+
+// Small affine requests (order <= 1, at most 64*NS pairs of doubles per request): one WAVE per
+// request.  Lane l of slot i owns the flat pair 64*i + l of the request, so every store
+// instruction writes 1 KB of consecutive, line-aligned output (requests are multiples of 128 B for
+// the registered shapes) -- the pattern that reaches the write ceiling in tools/ubench3.hip -- and
+// keeps the (at most SD) reference values it needs in registers.  A slot lies inside one table
+// except where a table boundary cuts it; the weights are then selected per lane.
+template <int SD, int NS> __global__ __launch_bounds__(256) void shared_points_wave_kernel(const SharedArgs a, const int nwr) {
+    // nwr (1, 2 or 4) waves share a request, NS slots each
+    constexpr int NTAB = 1 + SD;
+    const int table = a.rows * a.npts;
+    const int npairs = (NTAB * table) >> 1;  // per request; table is even (host-checked)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int part = wave % nwr;                         // which NS slots of the request
+    const int team = (blockIdx.x * 4 + wave) / nwr;      // global index of the wave team
+    const long long nteams = (long long)gridDim.x * 4 / nwr;
+    typedef double v2d_t __attribute__((ext_vector_type(2)));
+    double rv[NS][2][SD];  // value table: rv[..][0]; gradient tables: the SD reference gradients
+    int tsel[NS];          // table of this lane's pair in slot i
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int f0 = 64 * (NS * part + i);
+        const int f = min(f0 + lane, npairs - 1);
+        const int t = (2 * f) / table, q = 2 * f - t * table;
+        tsel[i] = t;
+#pragma unroll
+        for (int el = 0; el < 2; ++el)
+#pragma unroll
+            for (int c = 0; c < SD; ++c) rv[i][el][c] = t == 0 ? (c == 0 ? a.ref[q + el] : 0.0) : a.ref[(size_t)(1 + c) * table + q + el];
+    }
+    __shared__ double sK[4][64][SD * SD];  // per wave: K of its team's next 64 requests
+    for (long long base = (long long)team * 64; base < a.nreq; base += nteams * 64) {
+        {
+            const long long rq = min(base + lane, a.nreq - 1);
+            double A[SD][SD], b[SD];
+            cell_map<SD>(a.verts + (size_t)rq * (SD + 1) * SD, A, b);
+#pragma unroll
+            for (int c = 0; c < SD; ++c)
+#pragma unroll
+                for (int d = 0; d < SD; ++d) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < SD; ++k) t += a.A0inv[c * SD + k] * A[k][d];
+                    sK[wave][lane][c * SD + d] = t;
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        const int nblk = (int)min(64LL, a.nreq - base);
+        for (int rb = 0; rb < nblk; ++rb) {
+            double K[SD][SD];
+#pragma unroll
+            for (int c = 0; c < SD; ++c)
+#pragma unroll
+                for (int d = 0; d < SD; ++d) K[c][d] = sK[wave][rb][c * SD + d];
+            v2d_t* o2 = reinterpret_cast<v2d_t*>(a.out + (size_t)(base + rb) * NTAB * table);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int f = 64 * (NS * part + i) + lane;
+                // weights of this lane's table (value -> (1, 0, 0); gradient d -> column d of K),
+                // selected per lane: a table boundary may cut the slot.  (A wave-uniform fast path
+                // for the slots inside one table, with scalar branches per table, measured slower.)
+                double w[SD];
+#pragma unroll
+                for (int c = 0; c < SD; ++c) {
+                    double x = c == 0 ? 1.0 : 0.0;
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) x = tsel[i] == 1 + d ? K[c][d] : x;
+                    w[c] = x;
+                }
+                v2d_t v;
+                double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                for (int c = 0; c < SD; ++c) {
+                    acc0 += w[c] * rv[i][0][c];
+                    acc1 += w[c] * rv[i][1][c];
+                }
+                v.x = acc0;
+                v.y = acc1;
+                if (f < npairs) stream_store(&o2[f], v);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();  // sK is rewritten for the next 64 requests
+    }
+}
+
+}  // namespace fxk

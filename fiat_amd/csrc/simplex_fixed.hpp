@@ -366,18 +366,6 @@ __global__ __launch_bounds__(64 * NW, 2) void tabulate_simplex_fixed(const Fixed
                 }
             }
         };
-        auto get = [&](int k, Jet<SD, ORDER>& j) {
-            const int kofs = (k >> 2) * 64 + (k & 3) * 16;
-            j.v = phi[colbase[0] + kofs];
-            if constexpr (ORDER >= 1) {
-#pragma unroll
-                for (int d = 0; d < SD; ++d) j.g[d] = phi[colbase[1 + d] + kofs];
-            }
-            if constexpr (ORDER >= 2) {
-#pragma unroll
-                for (int h = 0; h < SD * (SD + 1) / 2; ++h) j.h[h] = phi[colbase[1 + SD + h] + kofs];
-            }
-        };
         if (!(a.debug & 1)) {
             // every member lives in a register array with compile-time indices: the
             // compiler keeps only the seeds still needed by later chains alive, and

@@ -60,8 +60,6 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
 
     const int npts = a.npts;  // <= 32 (host-checked)
     const int table = ROWS * npts;
-    const int reqsize = NTAB * table;
-    const int ncols = NTAB * npts;
 
     for (int i = lane; i < a.lds_doubles; i += 64) img[i] = 0.0;
     for (int i = threadIdx.x; i < NAF * 64; i += 64 * NW) afr[i] = a.afrag[i];

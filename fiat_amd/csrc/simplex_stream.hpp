@@ -35,7 +35,6 @@ __global__ __launch_bounds__(64 * NW, FX_STREAM_WAVES) void tabulate_simplex_str
     constexpr int KS = (NEXP + 3) / 4;
     constexpr int MT16 = rows_full16(ROWS);
     constexpr int M4 = rows_blk4(ROWS);
-    constexpr int SLAB = NT * 64;  // doubles
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63;
     // wave index as a scalar: everything derived from it (request number, output base) stays in SGPRs
@@ -79,7 +78,7 @@ __global__ __launch_bounds__(64 * NW, FX_STREAM_WAVES) void tabulate_simplex_str
     constexpr int TH = (NTAB + 1) / 2;
     // store instructions per half-image flush: NT tiles bound the points (16*NT >= NTAB*npts)
     constexpr int NFL = (TH * ROWS * ((16 * NT) / NTAB) / 2 + 63) / 64;
-    constexpr int NSTORE = NFL * (NTAB > TH ? 2 : 1);  // vector-memory stores per request
+    // (NFL * (NTAB > TH ? 2 : 1) vector-memory stores per request)
     int ioff[NT];   // offset (doubles) inside its half image of this lane's column, row (lane>>4); -1: none
     int ihalf = 0;  // bit nt set: the column of tile nt belongs to half 1
     {

@@ -126,6 +126,14 @@ class CiarletElement(FiniteElement):
         mapping = self._mapping if pushforward else None
         return self.device_polyset().tabulate_batch(order, points, verts=verts, out=out, stream=stream, mapping=mapping)
 
+    def tabulate_cells(self, order, ref_points, verts, out=None, stream=None):
+        """The quadrature-rule case: ONE point set on this element's reference cell, pushed
+        forward (with mapping()) to the physical cells ``verts`` (nreq, sd+1, sd) -> device
+        tensor (nreq, ntab, ndof, *value_shape, npts).  Same result as
+        ``tabulate_batch(order, F_r(ref_points), verts, pushforward=True)``."""
+        return self.device_polyset().tabulate_batch_shared(order, ref_points, verts, mapping=self._mapping, out=out,
+                                                           stream=stream)
+
     def value_shape(self):
         return self.poly_set.get_shape()
 

@@ -146,6 +146,29 @@ class SimplexPolySet:
                                            _dev_ptr(verts), _dev_ptr(out), _stream_ptr(stream)))
         return out
 
+    def tabulate_batch_shared(self, order, ref_pts, verts, mapping="affine", out=None, stream=None):
+        """One point set ``ref_pts`` (npts, sd) on the element's own cell, pushed forward to the
+        cells ``verts`` (nreq, sd+1, sd): (nreq, ntab, ndof, *value_shape, npts) on the GPU, equal to
+        ``tabulate_batch(order, F_r(ref_pts), verts, mapping=mapping)`` (fx_tabulate_batch_shared)."""
+        ctx = self.ctx
+        ref_pts = _as_device(ref_pts, ctx)
+        verts = _as_device(verts, ctx)
+        if ref_pts.dim() != 2 or ref_pts.shape[1] != self.sd:
+            raise ValueError(f"reference points must have shape (npts, {self.sd})")
+        if verts.dim() != 3 or tuple(verts.shape[1:]) != (self.sd + 1, self.sd):
+            raise ValueError("verts must have shape (nreq, sd+1, sd)")
+        if mapping not in self.MAPPINGS:
+            raise ValueError(f"unknown mapping {mapping!r}")
+        nreq, npts = verts.shape[0], ref_pts.shape[0]
+        shape = self.out_shape(order, nreq, npts)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float64, device=ctx.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.float64 or not out.is_contiguous():
+            raise ValueError("out has the wrong shape/dtype/layout")
+        check(lib.fx_tabulate_batch_shared(ctx.handle, self.handle, self.MAPPINGS[mapping], int(order), nreq, npts,
+                                           _dev_ptr(ref_pts), _dev_ptr(verts), _dev_ptr(out), _stream_ptr(stream)))
+        return out
+
     def kernel_name(self, order, nreq, npts, has_verts=False):
         """Device kernel ``tabulate_batch`` launches for this request shape (fx_plan_kernel)."""
         buf = ctypes.create_string_buffer(96)

@@ -164,6 +164,18 @@ int fx_plan_c0_transform(int sd, int n, double* T /* host [nexp][nexp] */);
 int fx_pushforward_batch(fx_ctx* ctx, const fx_element* elem, int mapping, int order,
                          int64_t nreq, int npts, const double* verts, double* out, void* stream);
 
+/* ---- one reference point set in many cells (the quadrature-rule case) ---------------
+ * What FIAT's consumers do around the reference (finat/fiat_elements.py:69: tabulate once on the
+ * reference cell; TSFC-generated code pushes forward per cell) as one call: ref_pts[npts][sd] are
+ * coordinates on the ELEMENT's own cell (device pointer), request r is the affine image of that
+ * cell with vertices verts[r]; out[r] = the element's tables pushed forward to cell r with
+ * `mapping` (FX_MAP_*): exactly what fx_tabulate_batch(points = F_r(ref_pts), verts) followed
+ * by fx_pushforward_batch returns, without the per-request recurrence (second
+ * variant of config 2; 8(f) ranks 1-2).  out: [nreq][ntab][ndof][vdim][npts] device tensor. */
+int fx_tabulate_batch_shared(fx_ctx* ctx, const fx_element* elem, int mapping, int order,
+                             int64_t nreq, int npts, const double* ref_pts, const double* verts,
+                             double* out, void* stream);
+
 /* Name of the device kernel fx_tabulate_batch would launch for this element and request shape
  * ("fxk::tabulate_simplex_stream", "..._fixed", "..._coop" or the generic "..._kernel"); has_verts != 0
  * stands for per-request cell geometry.  Lets benchmarks and tests name the kernel they measured

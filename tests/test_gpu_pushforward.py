@@ -93,3 +93,55 @@ def test_facade_pushforward(rt, golden):
     out = rtel.tabulate_batch(1, g["pts_sd2"], verts=g["verts_sd2"], pushforward=True).cpu().numpy()
     for i in range(out.shape[0]):
         check(out[i], g["rt1_sd2_tab"][i], f"facade RT1 tri cell {i}")
+
+
+# ---- one reference point set in many cells (fx_tabulate_batch_shared) -----------------
+SHARED = [("p2", 2, "affine", "bubble", 1, ()), ("n1", 1, "covariant piola", None, None, "v"),
+          ("n2", 2, "covariant piola", None, None, "v"), ("rt1", 1, "contravariant piola", None, None, "v"),
+          ("rt2", 2, "contravariant piola", None, None, "v")]
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+@pytest.mark.parametrize("sd", [2, 3])
+@pytest.mark.parametrize("name,n,mapping,variant,scale,vs", SHARED)
+def test_shared_points_equal_per_request_points(rt, golden, sd, order, name, n, mapping, variant, scale, vs):
+    """fx_tabulate_batch_shared == fx_tabulate_batch(points = F_r(ref points), verts) + push-forward."""
+    g = golden("piola")
+    co = g[f"{name}_sd{sd}_refcoeffs"]
+    kw = dict(coeffs=co)
+    if variant:
+        kw.update(variant=variant, scale=scale)
+    if vs == "v":
+        kw.update(value_shape=(sd,))
+    ps = rt.SimplexPolySet(sd, n, **kw)
+    rng = np.random.default_rng(31 + sd + order)
+    nreq, npts = 37, 11
+    ref = fo.UFC_SIMPLEX[sd]
+    e = rng.exponential(size=(npts, sd + 1))
+    bary = e / e.sum(axis=1, keepdims=True)
+    ref_pts = bary @ ref
+    A = np.eye(sd) + 0.2 * rng.standard_normal((nreq, sd, sd))
+    A[3, :, 0] *= -1.0                                  # a negatively oriented cell
+    verts = np.einsum("vd,red->rve", ref, A) + rng.standard_normal((nreq, 1, sd))
+    pts = np.einsum("pv,rvd->rpd", bary, verts)
+    want = ps.tabulate_batch(order, pts, verts=verts, mapping=mapping).cpu().numpy()
+    got = ps.tabulate_batch_shared(order, ref_pts, verts, mapping=mapping).cpu().numpy()
+    assert got.shape == want.shape
+    for t in range(want.shape[1]):
+        err = np.abs(got[:, t] - want[:, t]).max() / max(1.0, np.abs(want[:, t]).max())
+        assert err <= (1e-12 if t == 0 else 1e-10), (name, sd, order, t, err)
+
+
+def test_shared_points_against_the_reference_on_physical_cells(rt, golden):
+    """N2 on tetrahedra through the facade: the shared-point path reproduces the reference's Nedelec
+    constructed directly on each physical cell, at that cell's image of the shared points."""
+    import fiat_amd
+    g = golden("piola")
+    el = fiat_amd.Nedelec(fiat_amd.ufc_simplex(3), 2)
+    verts = g["verts_sd3"]
+    ref = fo.UFC_SIMPLEX[3]
+    # the golden points of cell 0, pulled back to the reference cell, serve as the shared set
+    bary0 = np.linalg.solve(np.vstack([verts[0].T, np.ones(4)]), np.vstack([g["pts_sd3"][0].T, np.ones(7)])).T
+    ref_pts = bary0 @ ref
+    out = el.tabulate_cells(1, ref_pts, verts[:1]).cpu().numpy()
+    check(out[0], g["n2_sd3_tab"][0], "shared points, N2 tet, cell 0")
