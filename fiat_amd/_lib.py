@@ -67,6 +67,8 @@ _SIGS = {
     "fx_plan_steps": (c_int, [c_int, c_int, c_int, c_double, c_int, _p_i, _p_d, c_void_p, c_void_p]),
     "fx_plan_c0_transform": (c_int, [c_int, c_int, c_void_p]),
     "fx_pushforward_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "fx_tabulate_batch_mapped": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_void_p]),
     "fx_tabulate_batch_shared": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p]),
     "fx_plan_kernel": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_char_p, c_int]),

@@ -47,6 +47,36 @@ const double UFC[3][12] = {
 };
 
 // host version of the device cell_map (same closed form)
+bool invert_small(int sd, const double* A, double* inv) {
+    if (sd == 1) {
+        if (A[0] == 0.0) return false;
+        inv[0] = 1.0 / A[0];
+        return true;
+    }
+    if (sd == 2) {
+        const double det = A[0] * A[3] - A[1] * A[2];
+        if (det == 0.0) return false;
+        inv[0] = A[3] / det;
+        inv[1] = -A[1] / det;
+        inv[2] = -A[2] / det;
+        inv[3] = A[0] / det;
+        return true;
+    }
+    const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+    const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+    if (det == 0.0) return false;
+    inv[0] = c00 / det;
+    inv[1] = (A[2] * A[7] - A[1] * A[8]) / det;
+    inv[2] = (A[1] * A[5] - A[2] * A[4]) / det;
+    inv[3] = c01 / det;
+    inv[4] = (A[0] * A[8] - A[2] * A[6]) / det;
+    inv[5] = (A[2] * A[3] - A[0] * A[5]) / det;
+    inv[6] = c02 / det;
+    inv[7] = (A[1] * A[6] - A[0] * A[7]) / det;
+    inv[8] = (A[0] * A[4] - A[1] * A[3]) / det;
+    return true;
+}
+
 bool host_cell_map(int sd, const double* v, double* A, double* b) {
     if (sd == 1) {
         double den = v[1] - v[0];
@@ -443,6 +473,7 @@ struct Launch {
     std::vector<double> fcoef;         // [nsteps][3]
     std::vector<double> fucoef;        // [nsteps][12], uniform-cell factor derivatives
     int fgrid = 0, flds_bytes = 0, ncu = 0;
+    bool fused_mapping = false;
     double* trash = nullptr;
     unsigned long long* queue = nullptr;
     // 0: LDS-image kernel (simplex_fixed.hpp), 1: K-streamed kernel (simplex_stream.hpp),
@@ -571,19 +602,26 @@ int launch_fixed(const Launch& L, hipStream_t s) {
 // ---- registry of cooperative (large-shape) kernels: <SD, ORDER, MT16, M4, TPW> ------
 struct CoopShape {
     int sd, order, mt16, m4, tpw;
+    bool can_piola;   // a kernel with the Piola map fused into the output rounds is instantiated
+    bool piola_only;  // registered only for launches that fuse a Piola map (slower than the generic kernel otherwise)
 };
 const CoopShape kCoopShapes[] = {
-    {3, 2, 5, 1, 4},  // DG P6 tetrahedron (84 rows) with Hessians, <= 25 points
-    {3, 1, 5, 1, 2},  // DG P6 tetrahedron, values + gradient, <= 32 points
-    {3, 1, 3, 3, 2},  // N2 tetrahedron (20 x 3 = 60 rows), values + gradient: 319 vs 431 us per 25 000 requests
-                      // (RT2, 45 rows, measured slower here than on the generic kernel: 349 vs 252 us -- not registered)
+    {3, 2, 5, 1, 4, false, false},  // DG P6 tetrahedron (84 rows) with Hessians, <= 25 points
+    {3, 1, 5, 1, 2, false, false},  // DG P6 tetrahedron, values + gradient, <= 32 points
+    {3, 1, 3, 3, 2, true, false},   // N2 tetrahedron (20 x 3 = 60 rows), values + gradient: 319 vs 431 us per 25 000 requests
+    {3, 1, 3, 0, 2, true, true},    // RT2 tetrahedron (15 x 3 = 45 rows): 349 vs 252 us on the generic kernel, but the
+                             // Piola map fuses into this kernel's output rounds (generic + second pass: 616 us)
 };
 
-template <int SD, int ORDER, int MT16, int M4, int TPW>
+template <int SD, int ORDER, int MT16, int M4, int TPW, bool CAN_PIOLA = false>
 int launch_coop(const Launch& L, hipStream_t s) {
     using KernT = void (*)(const fxk::CoopArgs);
     KernT kern = L.cargs.verts ? (KernT)fxk::tabulate_simplex_coop<SD, ORDER, MT16, M4, TPW, false>
                                : (KernT)fxk::tabulate_simplex_coop<SD, ORDER, MT16, M4, TPW, true>;
+    if (L.cargs.piola) {
+        if constexpr (CAN_PIOLA) kern = (KernT)fxk::tabulate_simplex_coop<SD, ORDER, MT16, M4, TPW, false, true>;
+        else return fail(FX_EINVAL, "internal: no fused push-forward for this cooperative shape");
+    }
     if (L.clds_bytes > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     L.clds_bytes));
@@ -596,7 +634,8 @@ int run_coop(const Launch& L, hipStream_t s) {
     switch (L.coop_id) {
         case 0: return launch_coop<3, 2, 5, 1, 4>(L, s);
         case 1: return launch_coop<3, 1, 5, 1, 2>(L, s);
-        case 2: return launch_coop<3, 1, 3, 3, 2>(L, s);
+        case 2: return launch_coop<3, 1, 3, 3, 2, true>(L, s);
+        case 3: return launch_coop<3, 1, 3, 0, 2, true>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown cooperative kernel %d", L.coop_id);
 }
@@ -637,8 +676,10 @@ int launch_sd(int order, const Launch& L, hipStream_t s) {
     return fail(FX_ENOTIMPL, "derivative order %d > 2 is not implemented on the device", order);
 }
 
+// `mapping` != FX_MAP_AFFINE asks for a kernel that fuses the Piola push-forward (L.fused_mapping tells
+// whether one was found; otherwise the caller runs fx_pushforward_batch after the launch)
 int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, const double* pts,
-                const double* verts, double* out, Launch& L) {
+                const double* verts, double* out, Launch& L, int mapping = 0) {
     if (!ctx || !e) return fail(FX_EINVAL, "null context/element");
     if (order < 0) return fail(FX_EINVAL, "negative derivative order");
     if (order > 2) return fail(FX_ENOTIMPL, "derivative order %d > 2 is not implemented on the device", order);
@@ -713,9 +754,16 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             for (size_t i = 0; i < sizeof(kCoopShapes) / sizeof(kCoopShapes[0]); ++i) {
                 const CoopShape& c = kCoopShapes[i];
                 if (c.sd != e->sd || c.order != order || c.mt16 != mt16 || c.m4 != m4 || nt_need > 4 * c.tpw) continue;
+                const bool piola = c.can_piola && mapping != FX_MAP_AFFINE && verts && e->vdim == e->sd;
+                if (c.piola_only && !piola) continue;
                 const int table = rows * npts;
                 int TR = std::max(1, (int)((32 * 1024) / ((long long)table * 8)));
                 TR = std::min(TR, ntab);
+                if (piola) {  // the fused flush writes pairs: every round a whole number of them, <= 4 per thread
+                    if ((table & 1) && (TR & 1)) TR = TR > 1 ? TR - 1 : 0;
+                    if (TR == 0 || (((long long)ntab * table) & 1) || (long long)TR * table > 4096) continue;
+                    if ((table & 1) && (ntab % TR) % 2) continue;  // the last round must be even too
+                }
                 long long img = std::max<long long>(2LL * (nt_need * 64 + 128), (long long)TR * table);
                 img = (img + 1) & ~1LL;
                 if (npts > 32) continue;  // LDS-resident chain state holds 32 points
@@ -743,6 +791,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 ca.slab_doubles = nt_need * 64 + 128;
                 ca.img_doubles = (int)img;
                 ca.debug = a.debug;
+                ca.piola = piola ? mapping : 0;
+                if (piola && !invert_small(e->sd, e->A0, ca.A0inv)) return fail(FX_EINVAL, "degenerate cell");
+                L.fused_mapping = piola;
                 L.clds_bytes = (int)ldsb;
                 int per_cu = std::max(1, std::min(2, ctx->lds_per_cu / L.clds_bytes));
                 L.cgrid = (int)std::max<long long>(1, std::min<long long>(nreq, (long long)ctx->num_cu * per_cu));
@@ -875,36 +926,6 @@ int run_tabulate(fx_ctx* ctx, const fx_element* e, int order, const Launch& L, h
 }  // namespace
 
 namespace {
-bool invert_small(int sd, const double* A, double* inv) {
-    if (sd == 1) {
-        if (A[0] == 0.0) return false;
-        inv[0] = 1.0 / A[0];
-        return true;
-    }
-    if (sd == 2) {
-        const double det = A[0] * A[3] - A[1] * A[2];
-        if (det == 0.0) return false;
-        inv[0] = A[3] / det;
-        inv[1] = -A[1] / det;
-        inv[2] = -A[2] / det;
-        inv[3] = A[0] / det;
-        return true;
-    }
-    const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
-    const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
-    if (det == 0.0) return false;
-    inv[0] = c00 / det;
-    inv[1] = (A[2] * A[7] - A[1] * A[8]) / det;
-    inv[2] = (A[1] * A[5] - A[2] * A[4]) / det;
-    inv[3] = c01 / det;
-    inv[4] = (A[0] * A[8] - A[2] * A[6]) / det;
-    inv[5] = (A[2] * A[3] - A[0] * A[5]) / det;
-    inv[6] = c02 / det;
-    inv[7] = (A[1] * A[6] - A[0] * A[7]) / det;
-    inv[8] = (A[0] * A[4] - A[1] * A[3]) / det;
-    return true;
-}
-
 template <int SD, int ORDER, bool PIOLA>
 bool launch_shared_reg(int np, const fxk::SharedArgs& sa, int grid, hipStream_t s) {
     switch (np) {
@@ -966,6 +987,22 @@ int fx_tabulate_batch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq,
     int rc = plan_launch(ctx, e, order, nreq, npts, pts, verts, out, L);
     if (rc != FX_OK) return rc;
     return run_tabulate(ctx, e, order, L, (hipStream_t)stream);
+}
+
+int fx_tabulate_batch_mapped(fx_ctx* ctx, const fx_element* e, int mapping, int order, int64_t nreq, int npts,
+                             const double* pts, const double* verts, double* out, void* stream) {
+    if (mapping < FX_MAP_AFFINE || mapping > FX_MAP_CONTRAVARIANT_PIOLA) return fail(FX_EINVAL, "unknown mapping %d", mapping);
+    if (mapping == FX_MAP_AFFINE) return fx_tabulate_batch(ctx, e, order, nreq, npts, pts, verts, out, stream);
+    if (!e) return fail(FX_EINVAL, "null context/element");
+    if (e->vdim != e->sd || e->sd < 2)
+        return fail(FX_EINVAL, "Piola maps need vector-valued functions with value shape (%d,), got %d components", e->sd, e->vdim);
+    if (!verts && nreq > 0 && npts > 0) return fail(FX_EINVAL, "a Piola push-forward needs the physical cells (verts)");
+    Launch L;
+    int rc = plan_launch(ctx, e, order, nreq, npts, pts, verts, out, L, mapping);
+    if (rc != FX_OK) return rc;
+    rc = run_tabulate(ctx, e, order, L, (hipStream_t)stream);
+    if (rc != FX_OK || L.fused_mapping) return rc;
+    return fx_pushforward_batch(ctx, e, mapping, order, nreq, npts, verts, out, stream);
 }
 
 int fx_pushforward_batch(fx_ctx* ctx, const fx_element* e, int mapping, int order, int64_t nreq, int npts,

@@ -40,7 +40,62 @@ struct CoopArgs {
     int slab_doubles; // NT*64 B-fragment doubles + a 128-double dump row for inactive lanes (lane + 16 * K slot)
     int img_doubles;  // >= max(2*slab_doubles, TR*rows*npts)
     int debug;        // measurement only: 1 skip recurrence math, 2 skip MFMAs, 4 skip output rounds
+    // Piola push-forward fused into the output rounds (vector-valued elements with vdim == SD,
+    // per-request cells): 0 none, 1 covariant (M = K^T), 2 contravariant (M = adj K), K = A0inv * A_req
+    int piola;
+    double A0inv[9];
 };
+
+// One output round: the image of nd doubles (whole tables of rows x npts) -> HBM.  With a Piola map
+// every output element (dof, c, p) is the M-combination of the SD components (dof, ., p) of the
+// image; which image offsets and which row of M a thread's elements need does not change from
+// round to round or request to request and is precomputed (PiolaSlots).
+struct PiolaSlots {
+    int base[4][2];  // image offset of component 0 of the element's dof at its point
+    int comp[4][2];  // its component
+};
+
+template <int SD, bool PIOLA>
+__device__ __forceinline__ void coop_flush(const double* img, double* g, long long nd, bool pairs, int tid, int npts,
+                                           const PiolaSlots& ps, const double* sM) {
+    if constexpr (!PIOLA) {
+        if (pairs) {
+            const v2d* s2 = reinterpret_cast<const v2d*>(img);
+            v2d* g2 = reinterpret_cast<v2d*>(g);
+            for (int i = tid; i < (int)(nd >> 1); i += 512) stream_store(&g2[i], s2[i]);
+        } else {
+            for (int i = tid; i < (int)nd; i += 512) g[i] = img[i];
+        }
+        return;
+    } else {
+    double M[SD][SD];
+#pragma unroll
+    for (int r = 0; r < SD; ++r)
+#pragma unroll
+        for (int c = 0; c < SD; ++c) M[r][c] = sM[r * SD + c];
+    v2d* g2 = reinterpret_cast<v2d*>(g);  // (host: Piola rounds are whole pairs)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = tid + 512 * k;
+        if (i < (int)(nd >> 1)) {
+            v2d v;
+#pragma unroll
+            for (int el = 0; el < 2; ++el) {
+                double acc = 0.0;
+#pragma unroll
+                for (int c = 0; c < SD; ++c) {
+                    double m = M[0][c];
+#pragma unroll
+                    for (int r = 1; r < SD; ++r) m = ps.comp[k][el] == r ? M[r][c] : m;
+                    acc += m * img[ps.base[k][el] + c * npts];
+                }
+                if (el == 0) v.x = acc; else v.y = acc;
+            }
+            stream_store(&g2[i], v);
+        }
+    }
+    }
+}
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a full
 // workgroup-scope fence, for which hipcc emits s_waitcnt vmcnt(0): every barrier after a
@@ -51,8 +106,9 @@ __device__ __forceinline__ void wg_lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <int SD, int ORDER, int MT16, int M4, int TPW, bool UNIFORM>
+template <int SD, int ORDER, int MT16, int M4, int TPW, bool UNIFORM, bool PIOLA = false>
 __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a) {
+    static_assert(!PIOLA || !UNIFORM, "a Piola push-forward needs per-request cells");
     constexpr int NTAB = NTab<SD, ORDER>::value;
     constexpr int NAFT = MT16 + M4;
     typedef const __attribute__((address_space(4))) int CInt;
@@ -74,6 +130,22 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
     __syncthreads();
 
     const int nrounds = (a.debug & 4) ? 0 : (NTAB + a.TR - 1) / a.TR;
+    __shared__ double sM[9];  // Piola matrix of the current request (written by producer 0 before the K loop)
+    PiolaSlots pslots;
+    if constexpr (PIOLA) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int el = 0; el < 2; ++el) {
+                const int e = 2 * (tid + 512 * k) + el;
+                const int tt = e / table, rem = e - tt * table;
+                const int row = rem / npts, p = rem - row * npts;
+                const int dof = row / SD;
+                pslots.comp[k][el] = row - dof * SD;
+                // (positions past the image belong to no round: clamped so that the reads stay inside it)
+                pslots.base[k][el] = min(tt * table + dof * SD * npts + p, a.img_doubles - (SD - 1) * npts - 1);
+            }
+    }
 
     if (wave < 4) {
         // =========================== producer ===========================
@@ -102,6 +174,29 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                 double bb[SD];
                 if constexpr (!UNIFORM) {
                     cell_map<SD>(a.verts + (size_t)req * (SD + 1) * SD, J, bb);
+                    if (PIOLA && w == 0 && lane == 0) {
+                        // K = A0inv * A_req = d(own cell coordinates)/dx; read after the K loop's barriers.
+                        // (The previous request's last output round ended with a barrier.)
+                        double K[SD][SD];
+                        for (int c = 0; c < SD; ++c)
+                            for (int d = 0; d < SD; ++d) {
+                                double t = 0.0;
+                                for (int k = 0; k < SD; ++k) t += a.A0inv[c * SD + k] * J[k][d];
+                                K[c][d] = t;
+                            }
+                        for (int c = 0; c < SD; ++c)
+                            for (int e = 0; e < SD; ++e) {
+                                double v = K[e][c];  // covariant: J^{-T} = K^T
+                                if (a.piola == 2) {  // contravariant: J / det J = adj(K)
+                                    if constexpr (SD == 2) v = (c == e ? K[1 - c][1 - e] : -K[c][e]);
+                                    else if constexpr (SD == 3) {
+                                        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3, e1 = (e + 1) % 3, e2 = (e + 2) % 3;
+                                        v = K[e1][c1] * K[e2][c2] - K[e1][c2] * K[e2][c1];
+                                    } else v = 1.0;
+                                }
+                                sM[c * SD + e] = v;
+                            }
+                    }
                 } else {
 #pragma unroll
                     for (int i = 0; i < SD; ++i) {
@@ -282,13 +377,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                 const int nt_r = min(a.TR, NTAB - t0);
                 const long long nd = (long long)nt_r * table;
                 double* g = a.out + (size_t)req * reqsize + (size_t)t0 * table;
-                if (((a.TR * table) & 1) == 0 && (reqsize & 1) == 0) {
-                    const v2d* s2 = reinterpret_cast<const v2d*>(img);
-                    v2d* g2 = reinterpret_cast<v2d*>(g);
-                    for (int i = tid; i < (int)(nd >> 1); i += 512) stream_store(&g2[i], s2[i]);
-                } else {
-                    for (int i = tid; i < (int)nd; i += 512) g[i] = img[i];
-                }
+                coop_flush<SD, PIOLA>(img, g, nd, ((a.TR * table) & 1) == 0 && (reqsize & 1) == 0, tid, npts, pslots, sM);
                 wg_lds_barrier();  // image may be overwritten
             }
         }
@@ -385,13 +474,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                 const int nt_r = min(a.TR, NTAB - t0);
                 const long long nd = (long long)nt_r * table;
                 double* g = a.out + (size_t)req * reqsize + (size_t)t0 * table;
-                if (((a.TR * table) & 1) == 0 && (reqsize & 1) == 0) {
-                    const v2d* s2 = reinterpret_cast<const v2d*>(img);
-                    v2d* g2 = reinterpret_cast<v2d*>(g);
-                    for (int i = tid; i < (int)(nd >> 1); i += 512) stream_store(&g2[i], s2[i]);
-                } else {
-                    for (int i = tid; i < (int)nd; i += 512) g[i] = img[i];
-                }
+                coop_flush<SD, PIOLA>(img, g, nd, ((a.TR * table) & 1) == 0 && (reqsize & 1) == 0, tid, npts, pslots, sM);
                 wg_lds_barrier();  // image may be overwritten
             }
         }

@@ -139,11 +139,23 @@ class SimplexPolySet:
             raise ValueError(f"unknown mapping {mapping!r}")
         if mapping not in (None, "affine") and verts is None:
             raise ValueError("a Piola push-forward needs the physical cells (verts)")
-        check(lib.fx_tabulate_batch(ctx.handle, self.handle, int(order), nreq, npts, _dev_ptr(pts),
-                                    None if verts is None else _dev_ptr(verts), _dev_ptr(out), _stream_ptr(stream)))
-        if mapping not in (None, "affine"):
-            check(lib.fx_pushforward_batch(ctx.handle, self.handle, self.MAPPINGS[mapping], int(order), nreq, npts,
-                                           _dev_ptr(verts), _dev_ptr(out), _stream_ptr(stream)))
+        if mapping in (None, "affine"):
+            check(lib.fx_tabulate_batch(ctx.handle, self.handle, int(order), nreq, npts, _dev_ptr(pts),
+                                        None if verts is None else _dev_ptr(verts), _dev_ptr(out), _stream_ptr(stream)))
+        else:   # fused into the kernel's output stage where the shape allows, else a second pass
+            check(lib.fx_tabulate_batch_mapped(ctx.handle, self.handle, self.MAPPINGS[mapping], int(order), nreq, npts,
+                                               _dev_ptr(pts), _dev_ptr(verts), _dev_ptr(out), _stream_ptr(stream)))
+        return out
+
+    def pushforward_batch(self, order, out, verts, mapping):
+        """In-place push-forward of tables produced by ``tabulate_batch(order, pts, verts=verts)``
+        (fx_pushforward_batch: the separate pass; ``tabulate_batch(..., mapping=...)`` fuses it where it can)."""
+        if mapping not in self.MAPPINGS:
+            raise ValueError(f"unknown mapping {mapping!r}")
+        verts = _as_device(verts, self.ctx)
+        nreq, npts = out.shape[0], out.shape[-1]
+        check(lib.fx_pushforward_batch(self.ctx.handle, self.handle, self.MAPPINGS[mapping], int(order), nreq, npts,
+                                       _dev_ptr(verts), _dev_ptr(out), _stream_ptr(None)))
         return out
 
     def tabulate_batch_shared(self, order, ref_pts, verts, mapping="affine", out=None, stream=None):

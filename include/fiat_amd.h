@@ -163,6 +163,11 @@ int fx_plan_c0_transform(int sd, int n, double* T /* host [nexp][nexp] */);
 #define FX_MAP_CONTRAVARIANT_PIOLA 2
 int fx_pushforward_batch(fx_ctx* ctx, const fx_element* elem, int mapping, int order,
                          int64_t nreq, int npts, const double* verts, double* out, void* stream);
+/* fx_tabulate_batch followed by the push-forward `mapping`, in ONE kernel where the shape's kernel
+ * fuses it into its output stage (N2 / RT2 tetrahedra, order 1), otherwise as two launches. */
+int fx_tabulate_batch_mapped(fx_ctx* ctx, const fx_element* elem, int mapping, int order,
+                             int64_t nreq, int npts, const double* pts, const double* verts,
+                             double* out, void* stream);
 
 /* ---- one reference point set in many cells (the quadrature-rule case) ---------------
  * What FIAT's consumers do around the reference (finat/fiat_elements.py:69: tabulate once on the

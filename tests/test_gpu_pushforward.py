@@ -145,3 +145,33 @@ def test_shared_points_against_the_reference_on_physical_cells(rt, golden):
     ref_pts = bary0 @ ref
     out = el.tabulate_cells(1, ref_pts, verts[:1]).cpu().numpy()
     check(out[0], g["n2_sd3_tab"][0], "shared points, N2 tet, cell 0")
+
+
+@pytest.mark.parametrize("name,n,mapping", [("n2", 2, "covariant piola"), ("rt2", 2, "contravariant piola")])
+@pytest.mark.parametrize("npts", [22, 23, 24])
+def test_fused_pushforward_equals_second_pass(rt, golden, name, n, mapping, npts):
+    """N2 / RT2 tetrahedra at benchmark-like sizes: the push-forward fused into the kernel's output
+    rounds (several rounds per request, odd table sizes for RT2 at 23 points) against tabulation
+    followed by the separate pass, and both against the oracle's evaluation of the formula."""
+    g = golden("piola")
+    co = g[f"{name}_sd3_refcoeffs"]
+    ps = rt.SimplexPolySet(3, n, coeffs=co, value_shape=(3,))
+    rng = np.random.default_rng(77 + npts)
+    nreq = 301
+    ref = fo.UFC_SIMPLEX[3]
+    A = np.eye(3) + 0.15 * rng.standard_normal((nreq, 3, 3))
+    A[5, :, 0] *= -1.0
+    verts = np.einsum("vd,red->rve", ref, A) + rng.standard_normal((nreq, 1, 3))
+    e = rng.exponential(size=(nreq, npts, 4))
+    pts = np.einsum("rpv,rvd->rpd", e / e.sum(axis=-1, keepdims=True), verts)
+    fused = ps.tabulate_batch(1, pts, verts=verts, mapping=mapping).cpu().numpy()
+    two = ps.pushforward_batch(1, ps.tabulate_batch(1, pts, verts=verts), verts, mapping).cpu().numpy()
+    for t in range(4):
+        err = np.abs(fused[:, t] - two[:, t]).max() / max(1.0, np.abs(two[:, t]).max())
+        assert err <= 1e-13, (name, npts, t, err)
+    for i in (0, 5, 150, 300):
+        J = (verts[i][1:] - verts[i][0]).T @ np.linalg.inv((ref[1:] - ref[0]).T)
+        M = np.linalg.inv(J).T if mapping.startswith("cov") else J / np.linalg.det(J)
+        tab = fo.element_tabulate(verts[i], n, co, 1, pts[i])
+        raw = np.stack([tab[a] for a in fo.jet_indices(3, 1)])
+        check(fused[i], np.einsum("ce,tdep->tdcp", M, raw), f"{name} fused, cell {i}")
