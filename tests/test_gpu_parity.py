@@ -355,3 +355,32 @@ def test_kernel_selection(rt, golden):
     dg6 = rt.SimplexPolySet(3, 6, coeffs=g["c4_dg6tet_q6_coeffs"])
     assert dg6.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_coop"
     assert dg6.kernel_name(2, 1000, 122) == "fxk::tabulate_simplex_kernel"
+
+
+def test_concurrent_streams(rt, golden):
+    """Launches of the dynamically scheduled kernel in flight on two streams at once: every launch
+    gets its own work counter (the counter resets itself when the launch ends)."""
+    import torch
+    from oracle import c_oracle
+    g = golden("elements")
+    co = g["c2_p3tet_q6_coeffs"]
+    ps = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=co)
+    rng = np.random.default_rng(11)
+    nreq = 6001
+    pts = [rand_points(rng, 3, (nreq, 23)) for _ in range(2)]
+    dpts = [torch.as_tensor(p).cuda() for p in pts]
+    outs = [torch.empty(ps.out_shape(1, nreq, 23), dtype=torch.float64, device="cuda") for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for rep in range(20):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                ps.tabulate_batch(1, dpts[k], out=outs[k], stream=streams[k])
+    torch.cuda.synchronize()
+    for k in range(2):
+        ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[3], 3, co, 1, pts[k], scale=1, variant="bubble")
+        got = outs[k].cpu().numpy()
+        num = np.abs(got - ref).max(axis=(2, 3))
+        den = np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))
+        err = (num / den).max(axis=0)
+        assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, (k, err)
