@@ -17,6 +17,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -27,6 +28,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# fp64 MFMA: 32 FLOP/clk/SIMD measured (v_mfma_f64_16x16x4 = 64 cycles, tools/ubench2.hip; the fp64 FMA rate)
+# x 1024 SIMDs x 2.4 GHz.  The guide's peak table has no fp64 row.
+F64_PEAK_TFLOPS = 32 * 1024 * 2.4e9 / 1e12
 
 WORKLOADS = {
     # name: (family, sd, degree, order, npts, default batch)
@@ -201,6 +205,15 @@ def main():
                 "kernel": "fxk::shared_points_kernel" if args.shared_points else ps.kernel_name(order, batch, npts),
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_request": bytes_per_req, "requests_per_launch": batch}
+    # algorithmic flops: contraction + recurrence; the binding roofline of the large
+    # shapes (DG P6 with Hessians: 21 flop/B) is the fp64 pipe, not HBM
+    nexp = math.comb(deg + sd, sd)
+    flops_per_req = 2 * rows * nexp * npts * ntab + nexp * npts * (5 + 21 * (order >= 1) + 60 * (order >= 2))
+    if flops_per_req / bytes_per_req > F64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS:
+        tf = flops_per_req * batch / (kernel_ms * 1e-3) / 1e12
+        roofline = dict(roofline, bound="mfma", achieved=tf, peak=F64_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / F64_PEAK_TFLOPS,
+                        algorithmic_flops_per_request=flops_per_req,
+                        hbm={"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS})
     prof = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
     if not os.path.exists(prof):
         prof = os.path.join(ROOT, "profiles", "traffic_latest.json")
