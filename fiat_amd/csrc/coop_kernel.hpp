@@ -39,7 +39,7 @@ struct CoopArgs {
     int TR;           // tables per image round
     int slab_doubles; // NT*64 B-fragment doubles + a 128-double dump row for inactive lanes (lane + 16 * K slot)
     int img_doubles;  // >= max(2*slab_doubles, TR*rows*npts)
-    int debug;        // measurement only: 1 skip recurrence math, 2 skip MFMAs, 4 skip output rounds
+    int debug;        // measurement only: 1 skip recurrence math, 2 skip MFMAs, 4 skip output rounds, 8 no LDS chain state
     // Piola push-forward fused into the output rounds (vector-valued elements with vdim == SD,
     // per-request cells): 0 none, 1 covariant (M = K^T), 2 contravariant (M = adj K), K = A0inv * A_req
     int piola;
@@ -293,6 +293,13 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
             // one step of an LDS-resident level (0 or 1)
             auto lds_level_step = [&](int level, int& par, int seed, int publish, double* slab, const double* d) {
                 Jet<SD, ORDER> nw, od;
+                if (a.debug & 8) {  // ablation: no LDS chain state (wrong results)
+                    nw = a2;
+                    od = b2;
+                    if (level == 0) step(nw, od, 0, d); else step(nw, od, 1, d);
+                    if (publish) put(slab + (publish - 1) * 16, od);
+                    return;
+                }
                 if (seed != -2) {  // chain start: newer = seed, older = 0
                     if (seed == -1) set_const(nw); else lld(0 + par0, nw);  // only level 1 has a level-0 seed
                     jet_zero(od);
