@@ -205,6 +205,20 @@ def main():
                 "kernel": "fxk::shared_points_kernel" if args.shared_points else ps.kernel_name(order, batch, npts),
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_request": bytes_per_req, "requests_per_launch": batch}
+    # context: what this box writes with a plain fill of the same buffer (the attainable write rate
+    # varies between boxes and over time by +-10 %)
+    if rank == 0:
+        scratch = torch.empty_like(out)
+        for _ in range(3):
+            scratch.fill_(1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            scratch.fill_(1.0)
+        e1.record()
+        torch.cuda.synchronize()
+        roofline["fill_same_bytes_gbs"] = scratch.numel() * 8 / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e9
+        del scratch
     # algorithmic flops: contraction + recurrence; the binding roofline of the large
     # shapes (DG P6 with Hessians: 21 flop/B) is the fp64 pipe, not HBM
     nexp = math.comb(deg + sd, sd)
