@@ -153,7 +153,6 @@ struct fx_element {
     double* d_afrag = nullptr;
     double* d_afrag_split = nullptr;  // layout of the shape-specialised kernels
     double* d_afrag_stream = nullptr; // same, K in production order (K-streamed kernel)
-    double* d_coef = nullptr;         // [nsteps][3]
     // cooperative (large-shape) plan
     int coop_KS = 0, coop_emax = 0;
     int* d_coop_eint = nullptr;
@@ -405,20 +404,6 @@ int fx_element_create(fx_ctx* ctx, int sd, int n, int variant, double scale, con
         fx_element_destroy(e);
         return fail(FX_EHIP, "fx_element_create: %s", hipGetErrorString(he));
     }
-    {
-        std::vector<double> cf(std::max<size_t>(1, e->prog.steps.size()) * 3, 0.0);
-        for (size_t i = 0; i < e->prog.steps.size(); ++i) {
-            cf[3 * i + 0] = e->prog.steps[i].A;
-            cf[3 * i + 1] = e->prog.steps[i].B;
-            cf[3 * i + 2] = e->prog.steps[i].C;
-        }
-        he = hipMalloc(&e->d_coef, cf.size() * sizeof(double));
-        if (he == hipSuccess) he = hipMemcpy(e->d_coef, cf.data(), cf.size() * sizeof(double), hipMemcpyHostToDevice);
-        if (he != hipSuccess) {
-            fx_element_destroy(e);
-            return fail(FX_EHIP, "fx_element_create: %s", hipGetErrorString(he));
-        }
-    }
     int rc = upload_coeffs(e, ndof, vdim, coeffs);
     if (rc != FX_OK) {
         fx_element_destroy(e);
@@ -434,7 +419,6 @@ int fx_element_destroy(fx_element* e) {
     if (e->d_afrag) (void)hipFree(e->d_afrag);
     if (e->d_afrag_split) (void)hipFree(e->d_afrag_split);
     if (e->d_afrag_stream) (void)hipFree(e->d_afrag_stream);
-    if (e->d_coef) (void)hipFree(e->d_coef);
     if (e->d_coop_eint) (void)hipFree(e->d_coop_eint);
     if (e->d_coop_edbl) (void)hipFree(e->d_coop_edbl);
     if (e->d_coop_kstart) (void)hipFree(e->d_coop_kstart);
