@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """C5 timing: P4 x P4 x P4 hexahedron, order 1, 5^3 tensor grid per request (measurement tooling)."""
-import sys, os, time
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import fiat_amd
