@@ -19,6 +19,7 @@
 #include "simplex_pair.hpp"
 #include "coop_kernel.hpp"
 #include "shared_points.hpp"
+#include "quadrature.hpp"
 
 namespace {
 
@@ -1062,6 +1063,47 @@ int fx_tabulate_batch_shared(fx_ctx* ctx, const fx_element* e, int mapping, int 
         case 3: return launch_shared<3>(order, sa, grid, s);
     }
     return fail(FX_EINVAL, "Invalid number of spatial dimensions");
+}
+
+int fx_collapsed_quadrature(fx_ctx* ctx, int sd, int m, const double* verts, double* pts, double* wts, void* stream) {
+    if (!ctx) return fail(FX_EINVAL, "null context");
+    if (sd < 1 || sd > 3) return fail(FX_EINVAL, "Invalid number of spatial dimensions");
+    if (m < 1 || m > fxk::GJ_MAX) return fail(FX_EINVAL, "points per direction must be in [1, %d]", fxk::GJ_MAX);
+    if (!pts || !wts) return fail(FX_EINVAL, "null device pointer");
+    static const double UFC[3][12] = {{0, 1}, {0, 0, 1, 0, 0, 1}, {0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1}};
+    fxk::RuleArgs ra;
+    double A[9], b[3];
+    if (!host_cell_map(sd, verts ? verts : UFC[sd - 1], A, b) || !invert_small(sd, A, ra.Ainv)) return fail(FX_EINVAL, "degenerate cell");
+    for (int i = 0; i < 3; ++i) ra.b[i] = i < sd ? b[i] : 0.0;
+    double det = sd == 1 ? ra.Ainv[0]
+                 : sd == 2 ? ra.Ainv[0] * ra.Ainv[3] - ra.Ainv[1] * ra.Ainv[2]
+                           : ra.Ainv[0] * (ra.Ainv[4] * ra.Ainv[8] - ra.Ainv[5] * ra.Ainv[7]) -
+                                 ra.Ainv[1] * (ra.Ainv[3] * ra.Ainv[8] - ra.Ainv[5] * ra.Ainv[6]) +
+                                 ra.Ainv[2] * (ra.Ainv[3] * ra.Ainv[7] - ra.Ainv[4] * ra.Ainv[6]);
+    ra.jac = std::fabs(det);
+    ra.m = m;
+    const size_t need = (size_t)2 * 3 * fxk::GJ_MAX * sizeof(double);
+    hipStream_t s = (hipStream_t)stream;
+    if (need > ctx->ref_bytes) {  // the 1-D rules live in the context's scratch buffer
+        HIP_TRY(hipDeviceSynchronize());
+        if (ctx->d_ref) (void)hipFree(ctx->d_ref);
+        ctx->d_ref = nullptr;
+        ctx->ref_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->d_ref, need));
+        ctx->ref_bytes = need;
+    }
+    ra.rules = ctx->d_ref;
+    ra.pts = pts;
+    ra.wts = wts;
+    hipLaunchKernelGGL(fxk::gauss_jacobi_kernel, dim3(1), dim3(64), 0, s, m, sd, ctx->d_ref);
+    int total = 1;
+    for (int d = 0; d < sd; ++d) total *= m;
+    const int grid = (total + 255) / 256;
+    if (sd == 1) hipLaunchKernelGGL(fxk::collapsed_rule_kernel<1>, dim3(grid), dim3(256), 0, s, ra);
+    if (sd == 2) hipLaunchKernelGGL(fxk::collapsed_rule_kernel<2>, dim3(grid), dim3(256), 0, s, ra);
+    if (sd == 3) hipLaunchKernelGGL(fxk::collapsed_rule_kernel<3>, dim3(grid), dim3(256), 0, s, ra);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
 }
 
 int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, int has_verts, char* name,

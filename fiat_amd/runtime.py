@@ -197,6 +197,24 @@ class SimplexPolySet:
         return ms.value
 
 
+def collapsed_quadrature(sd, m, verts=None, ctx=None, stream=None):
+    """Collapsed Gauss-Jacobi rule with ``m`` points per direction on the simplex ``verts``
+    ((sd+1, sd) array, default: the UFC simplex), produced on the device:
+    (points (m**sd, sd), weights (m**sd,)) as CUDA tensors (fx_collapsed_quadrature)."""
+    ctx = ctx or Context.get()
+    n = int(m) ** int(sd)
+    pts = torch.empty((n, sd), dtype=torch.float64, device=ctx.device)
+    wts = torch.empty((n,), dtype=torch.float64, device=ctx.device)
+    hv = None
+    if verts is not None:
+        hv = np.ascontiguousarray(verts, dtype=np.float64)
+        if hv.shape != (sd + 1, sd):
+            raise ValueError("verts must have shape (sd+1, sd)")
+    check(lib.fx_collapsed_quadrature(ctx.handle, int(sd), int(m), None if hv is None else host_ptr(hv), _dev_ptr(pts),
+                                      _dev_ptr(wts), _stream_ptr(stream)))
+    return pts, wts
+
+
 def riesz_assemble(wts, expvals, ctx=None):
     """mat[i, k] = sum_q wts[i, q] expvals[k, q] on the device."""
     ctx = ctx or Context.get()

@@ -181,6 +181,17 @@ int fx_tabulate_batch_shared(fx_ctx* ctx, const fx_element* elem, int mapping, i
                              int64_t nreq, int npts, const double* ref_pts, const double* verts,
                              double* out, void* stream);
 
+/* ---- point production on the device ---------------------------
+ * Collapsed Gauss-Jacobi rule with m points per direction on the simplex `verts`
+ * ((sd+1) x sd HOST doubles; NULL = the UFC simplex): FIAT/quadrature.py
+ * CollapsedQuadratureSimplexRule (:171-181) / GaussJacobiQuadratureLineRule (:96-110) =
+ * create_quadrature(ref_el, 2m-1, "collapsed").  pts[m^sd][sd] and wts[m^sd] are DEVICE
+ * buffers, points ordered with the last direction fastest; the points can be handed to
+ * fx_tabulate_batch_shared as they are.  The Gauss-Jacobi nodes are Newton roots of the Jacobi
+ * recurrence of FIAT/jacobi.py:47-74. */
+int fx_collapsed_quadrature(fx_ctx* ctx, int sd, int m, const double* verts, double* pts,
+                            double* wts, void* stream);
+
 /* Name of the device kernel fx_tabulate_batch would launch for this element and request shape
  * ("fxk::tabulate_simplex_stream", "..._fixed", "..._coop" or the generic "..._kernel"); has_verts != 0
  * stands for per-request cell geometry.  Lets benchmarks and tests name the kernel they measured
