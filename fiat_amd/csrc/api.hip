@@ -554,10 +554,19 @@ int launch_fixed(const Launch& L, hipStream_t s) {
         KernP kp = L.fhead.verts ? (KernP)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, PAIR_NW, false>
                                  : (KernP)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, PAIR_NW, true>;
         const int lds_bytes = fxk::WQ_CTL_DOUBLES * 8 + (L.flds_bytes - (int)(fa.lds_doubles * 8) * FIXED_NW) + (int)(fa.lds_doubles * 8) * PAIR_NW;
-        if (lds_bytes > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        int occ = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(kp), 64 * PAIR_NW, (size_t)lds_bytes));
+        // attribute and occupancy are properties of (kernel, LDS size): asked once, not per launch
+        static thread_local const void* cached_kp = nullptr;
+        static thread_local int cached_lds = -1, cached_occ = 0;
+        if (cached_kp != reinterpret_cast<const void*>(kp) || cached_lds != lds_bytes) {
+            if (lds_bytes > 48 * 1024)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            int q = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(kp), 64 * PAIR_NW, (size_t)lds_bytes));
+            cached_kp = reinterpret_cast<const void*>(kp);
+            cached_lds = lds_bytes;
+            cached_occ = q;
+        }
+        const int occ = cached_occ;
         const long long nwg = ((L.fhead.nreq + 1) / 2 + PAIR_NW - 1) / PAIR_NW;
         const int grid = (int)std::max<long long>(1, std::min<long long>(nwg, (long long)L.ncu * std::max(1, occ)));
         static const bool verbose = getenv("FIAT_AMD_VERBOSE") != nullptr;
