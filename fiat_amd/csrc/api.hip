@@ -751,11 +751,18 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 const bool piola = c.can_piola && mapping != FX_MAP_AFFINE && verts && e->vdim == e->sd;
                 if (c.piola_only && !piola) continue;
                 const int table = rows * npts;
-                int TR = std::max(1, (int)((32 * 1024) / ((long long)table * 8)));
+                // tables per output round: as many as LDS holds next to the A fragments and the chain
+                // state while two workgroups still fit a CU (fewer rounds = fewer workgroup barriers per
+                // request); when one workgroup fills the CU anyway, whatever is left of its LDS
+                const long long other = ((long long)(mt16 + m4) * e->coop_KS * 64 + 4LL * 4 * ntab * 32) * 8;
+                long long img_budget = ctx->lds_per_cu / 2 - other - 1024;
+                if (img_budget < 16 * 1024) img_budget = std::min<long long>(ctx->lds_per_cu - other - 1024, 56 * 1024);
+                int TR = std::max(1, (int)(img_budget / ((long long)table * 8)));
                 TR = std::min(TR, ntab);
                 if (piola) {  // the fused flush writes pairs: every round a whole number of them, <= 4 per thread
                     if ((table & 1) && (TR & 1)) TR = TR > 1 ? TR - 1 : 0;
-                    if (TR == 0 || (((long long)ntab * table) & 1) || (long long)TR * table > 4096) continue;
+                    while (TR > 0 && (long long)TR * table > 2 * 512 * fxk::PIOLA_SLOTS) TR -= (table & 1) ? 2 : 1;
+                    if (TR <= 0 || (((long long)ntab * table) & 1)) continue;
                     if ((table & 1) && (ntab % TR) % 2) continue;  // the last round must be even too
                 }
                 long long img = std::max<long long>(2LL * (nt_need * 64 + 128), (long long)TR * table);

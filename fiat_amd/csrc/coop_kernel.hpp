@@ -50,9 +50,10 @@ struct CoopArgs {
 // every output element (dof, c, p) is the M-combination of the SD components (dof, ., p) of the
 // image; which image offsets and which row of M a thread's elements need does not change from
 // round to round or request to request and is precomputed (PiolaSlots).
+constexpr int PIOLA_SLOTS = 6;  // pairs of output doubles per thread and round (512 threads)
 struct PiolaSlots {
-    int base[4][2];  // image offset of component 0 of the element's dof at its point
-    int comp[4][2];  // its component
+    int base[PIOLA_SLOTS][2];  // image offset of component 0 of the element's dof at its point
+    int comp[PIOLA_SLOTS][2];  // its component
 };
 
 template <int SD, bool PIOLA>
@@ -75,7 +76,7 @@ __device__ __forceinline__ void coop_flush(const double* img, double* g, long lo
         for (int c = 0; c < SD; ++c) M[r][c] = sM[r * SD + c];
     v2d* g2 = reinterpret_cast<v2d*>(g);  // (host: Piola rounds are whole pairs)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < PIOLA_SLOTS; ++k) {
         const int i = tid + 512 * k;
         if (i < (int)(nd >> 1)) {
             v2d v;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
     PiolaSlots pslots;
     if constexpr (PIOLA) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < PIOLA_SLOTS; ++k)
 #pragma unroll
             for (int el = 0; el < 2; ++el) {
                 const int e = 2 * (tid + 512 * k) + el;
