@@ -66,6 +66,7 @@ _SIGS = {
                                               c_void_p, c_void_p]),
     "fx_plan_steps": (c_int, [c_int, c_int, c_int, c_double, c_int, _p_i, _p_d, c_void_p, c_void_p]),
     "fx_plan_c0_transform": (c_int, [c_int, c_int, c_void_p]),
+    "fx_plan_coop": (c_int, [c_int, c_int, c_int, c_double, c_int, _p_i, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "fx_pushforward_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "fx_tabulate_batch_mapped": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p]),
@@ -114,6 +115,22 @@ def plan_steps(sd, n, variant=None, scale=0.0):
                             host_ptr(ints), host_ptr(coefs)))
     k = nsteps.value
     return phi0.value, ints[:k].copy(), coefs[:k].copy()
+
+
+def plan_coop(sd, n, variant=None, scale=0.0):
+    """Schedule of the cooperative kernel (host computation only): dict with KS, per-producer
+    entries (level, seed, publish, member), kstart and kperm."""
+    cap, cap_k = 512, 128
+    ks = c_int(0)
+    nent = np.zeros(4, dtype=np.int32)
+    ints = np.zeros((4, cap, 5), dtype=np.int32)
+    kstart = np.zeros((4, cap_k), dtype=np.int32)
+    kperm = np.full(4 * cap_k, -2, dtype=np.int32)
+    check(lib.fx_plan_coop(sd, n, VARIANTS[variant], float(scale), cap, ctypes.byref(ks), host_ptr(nent), host_ptr(ints),
+                           host_ptr(kstart), cap_k, host_ptr(kperm)))
+    K = ks.value
+    return {"KS": K, "entries": [ints[w, :nent[w], :4].copy() for w in range(4)],
+            "kstart": [kstart[w, :K + 1].copy() for w in range(4)], "kperm": kperm[:4 * K].copy()}
 
 
 def plan_c0_transform(sd, n):

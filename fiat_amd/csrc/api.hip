@@ -253,6 +253,32 @@ int fx_plan_steps(int sd, int n, int variant, double scale, int cap, int* nsteps
     return FX_OK;
 }
 
+int fx_plan_coop(int sd, int n, int variant, double scale, int cap, int* KS, int* nentries /* [4] */,
+                 int* ints /* [4][cap][5] */, int* kstart /* [4][cap_k] */, int cap_k, int* kperm /* [4*cap_k] */) {
+    if (sd < 1 || sd > 3 || n < 0 || variant < 0 || variant > 2) return fail(FX_EINVAL, "fx_plan_coop: bad arguments");
+    if (variant == FX_VARIANT_BUBBLE && n < 1) return fail(FX_EINVAL, "bubble variant needs degree >= 1");
+    if (scale <= 0.0) scale = std::sqrt(1.0 / default_simplex_volume(sd));
+    fx::Program P = fx::build_program(sd, n, variant, scale);
+    fx::CoopPlan C = fx::build_coop_plan(P);
+    if (KS) *KS = C.KS;
+    for (int w = 0; w < 4; ++w) {
+        if (nentries) nentries[w] = (int)C.entries[w].size();
+        const int m = std::min<int>(cap, (int)C.entries[w].size());
+        for (int i = 0; i < m && ints; ++i) {
+            const fx::CoopEntry& e = C.entries[w][i];
+            int* q = ints + ((size_t)w * cap + i) * 5;
+            q[0] = e.level;
+            q[1] = e.seed;
+            q[2] = e.publish;
+            q[3] = e.member;
+            q[4] = 0;
+        }
+        for (int j = 0; j <= C.KS && j < cap_k && kstart; ++j) kstart[(size_t)w * cap_k + j] = C.kstart[w][j];
+    }
+    for (int k = 0; k < 4 * C.KS && k < 4 * cap_k && kperm; ++k) kperm[k] = C.kperm[k];
+    return FX_OK;
+}
+
 int fx_plan_c0_transform(int sd, int n, double* T /* [nexp][nexp] */) {
     if (sd < 1 || sd > 3 || n < 1 || !T) return fail(FX_EINVAL, "fx_plan_c0_transform: bad arguments");
     std::vector<double> M = fx::c0_transform(sd, n);

@@ -146,6 +146,12 @@ int fx_tensor_tabulate_grid_batch(fx_ctx* ctx, int nf, const fx_line_element* co
 int fx_plan_steps(int sd, int n, int variant, double scale, int cap, int* nsteps,
                   double* phi0, int* ints, double* coefs);
 int fx_plan_c0_transform(int sd, int n, double* T /* host [nexp][nexp] */);
+/* The cooperative kernel's schedule of the same recurrence (plan.hpp build_coop_plan): per
+ * producer w its entries ints[w][i] = {level (-1: constant / zero row), seed, publish (K slot + 1,
+ * 0: none), member, 0}, the entry ranges of the K-steps kstart[w][0..KS] and the K order
+ * kperm[4*j + slot] = member (-1: zero row).  Host only, for the CPU test-suite. */
+int fx_plan_coop(int sd, int n, int variant, double scale, int cap, int* KS, int* nentries,
+                 int* ints, int* kstart, int cap_k, int* kperm);
 
 /* ---- push-forward to physical cells ---------------------------
  * Reference: FiniteElement.mapping() (FIAT/finite_element.py:84-88) names the map, the

@@ -105,3 +105,45 @@ def test_a_fragment_layout_doc():
     for sd in (2, 3):
         T = _lib.plan_c0_transform(sd, 4)
         assert abs(np.linalg.det(T)) > 0.5
+
+
+# ---- schedule of the cooperative (producer / consumer) kernel -------------------------
+@pytest.mark.parametrize("sd,n", [(1, 1), (1, 6), (2, 1), (2, 3), (2, 6), (3, 1), (3, 2), (3, 3), (3, 6), (3, 8)])
+@pytest.mark.parametrize("variant", [None, "bubble"])
+def test_coop_schedule_invariants(sd, n, variant):
+    """plan.hpp build_coop_plan: every member is published exactly once, in the K slot the
+    coefficient fragments expect; K-step ranges are contiguous; every step finds its inputs in the
+    producer's own chain state (interpreted here exactly as the device does)."""
+    from fiat_amd import _lib
+    C = _lib.plan_coop(sd, n, variant)
+    phi0, ints, coefs = _lib.plan_steps(sd, n, variant)
+    nexp = math.comb(n + sd, sd)
+    producer = {int(d): (int(c), int(p), int(cd)) for d, c, p, cd in ints}     # member -> (cur, prv, codim)
+    KS = C["KS"]
+    kperm = C["kperm"]
+    assert KS == (nexp + 3) // 4
+    assert sorted(int(m) for m in kperm if m >= 0) == list(range(nexp))
+    assert all(int(m) == -1 for m in kperm[nexp - 4 * KS:]) if nexp % 4 else True
+    for w in range(4):
+        E, ks = C["entries"][w], C["kstart"][w]
+        assert ks[0] == 0 and ks[-1] == len(E) and np.all(np.diff(ks) >= 0)
+        # chain state as in the kernel: per level the newest two members
+        state = {0: [None, None], 1: [None, None], 2: [None, None]}
+        for j in range(KS):
+            for i in range(ks[j], ks[j + 1]):
+                level, seed, publish, member = (int(v) for v in E[i])
+                if level < 0:
+                    assert publish >= 1
+                    assert kperm[4 * j + publish - 1] == (member if seed == -1 else -1)
+                    continue
+                cur, prv, codim = producer[member]
+                assert codim == level
+                if seed != -2:                                  # chain start: newer = seed member, older = 0
+                    seed_member = 0 if seed == -1 else state[seed][0]
+                    assert prv == -1 and cur == seed_member, (w, i, member, cur, seed_member)
+                    state[level] = [member, cur]
+                else:
+                    assert state[level][0] == cur and state[level][1] == prv, (w, i, member)
+                    state[level] = [member, cur]
+                if publish:
+                    assert 1 <= publish <= 4 and kperm[4 * j + publish - 1] == member
