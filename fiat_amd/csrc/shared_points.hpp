@@ -341,7 +341,7 @@ template <int SD, int NS> __global__ __launch_bounds__(256) void shared_points_w
                 }
                 v.x = acc0;
                 v.y = acc1;
-                if (f < npairs) stream_store(&o2[f], v);
+                if (f < npairs) o2[f] = v;  // plain store: measured 3 % faster than non-temporal for this store-only kernel
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
