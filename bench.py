@@ -129,10 +129,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the tabulate path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU over RCCL; FIAT_AMD_BENCH_BACKEND=gloo lets several ranks share a GPU to
+    # rehearse the multi-rank path on a one-GPU box (timings are then meaningless)
+    backend = os.environ.get("FIAT_AMD_BENCH_BACKEND", "nccl")
+    ngpu = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ngpu:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ngpu} GPUs visible")
+    device_index = local_rank % max(1, ngpu)
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -183,7 +193,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
