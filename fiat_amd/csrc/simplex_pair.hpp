@@ -167,13 +167,6 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
 
         v4d acc16[NT2][MT16 > 0 ? MT16 : 1];
         double acc4[NT2][M4 > 0 ? M4 : 1];
-#pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) {
-#pragma unroll
-            for (int mt = 0; mt < MT16; ++mt) acc16[nt][mt] = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int m4 = 0; m4 < M4; ++m4) acc4[nt][m4] = 0.0;
-        }
 
         Jet<SD, ORDER> mem[NEXP];
         Jet<SD, ORDER> zero;
@@ -321,12 +314,13 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
                         acc4[an][0] += b[nt] * a4[0];
                         continue;
                     }
+                    // (the first K-step starts from the constant 0: no accumulator clearing per pair)
 #pragma unroll
                     for (int mt = 0; mt < MT16; ++mt)
-                        acc16[an][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a16[mt], b[nt], acc16[an][mt], 0, 0, 0);
+                        acc16[an][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a16[mt], b[nt], j == 0 ? v4d{0.0, 0.0, 0.0, 0.0} : acc16[an][mt], 0, 0, 0);
 #pragma unroll
                     for (int m4 = 0; m4 < M4; ++m4)
-                        acc4[an][m4] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[m4], b[nt], acc4[an][m4], 0, 0, 0);
+                        acc4[an][m4] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[m4], b[nt], j == 0 ? 0.0 : acc4[an][m4], 0, 0, 0);
                 }
             }
             wave_lds_fence();  // fragments read before the next K-step overwrites the slab
