@@ -954,6 +954,19 @@ int run_tabulate(fx_ctx* ctx, const fx_element* e, int order, const Launch& L, h
 
 namespace {
 template <int SD, int ORDER, bool PIOLA>
+bool launch_shared_reg1(int np, const fxk::SharedArgs& sa, int grid, hipStream_t s) {  // single doubles (odd tables)
+    switch (np) {
+        case 1: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 1, PIOLA, 1>), dim3(grid), dim3(256), 0, s, sa); return true;
+        case 2: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 2, PIOLA, 1>), dim3(grid), dim3(256), 0, s, sa); return true;
+        case 3: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 3, PIOLA, 1>), dim3(grid), dim3(256), 0, s, sa); return true;
+        case 4: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 4, PIOLA, 1>), dim3(grid), dim3(256), 0, s, sa); return true;
+        case 5: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 5, PIOLA, 1>), dim3(grid), dim3(256), 0, s, sa); return true;
+        case 6: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 6, PIOLA, 1>), dim3(grid), dim3(256), 0, s, sa); return true;
+    }
+    return false;
+}
+
+template <int SD, int ORDER, bool PIOLA>
 bool launch_shared_reg(int np, const fxk::SharedArgs& sa, int grid, hipStream_t s) {
     switch (np) {
         case 1: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 1, PIOLA>), dim3(grid), dim3(256), 0, s, sa); return true;
@@ -982,9 +995,21 @@ int launch_shared(int order, const fxk::SharedArgs& sa, int grid, hipStream_t s)
             return FX_OK;
         }
     }
+    static const bool noreg = getenv("FIAT_AMD_NO_SHARED_REG") != nullptr;
+    // odd tables: register-resident kernel with one double per slot (order <= 1: NTAB sources per slot)
+    if (!noreg && (table & 1) && order <= 1 && (sa.kind == 0 || sa.vdim == SD)) {
+        const int np1 = (table + 255) / 256;
+        const bool piola = sa.kind != 0;
+        bool ok = false;
+        if (order == 0) ok = piola ? launch_shared_reg1<SD, 0, true>(np1, sa, grid, s) : launch_shared_reg1<SD, 0, false>(np1, sa, grid, s);
+        if (order == 1) ok = piola ? launch_shared_reg1<SD, 1, true>(np1, sa, grid, s) : launch_shared_reg1<SD, 1, false>(np1, sa, grid, s);
+        if (ok) {
+            HIP_TRY(hipGetLastError());
+            return FX_OK;
+        }
+    }
     // register-resident kernel when a table is even-sized and at most 4 pairs per thread
     const int np = (table / 2 + 255) / 256;
-    static const bool noreg = getenv("FIAT_AMD_NO_SHARED_REG") != nullptr;
     if (!noreg && (table & 1) == 0 && np >= 1 && np <= 4 && (sa.kind == 0 || sa.vdim == SD)) {
         bool ok = false;
         const bool piola = sa.kind != 0;

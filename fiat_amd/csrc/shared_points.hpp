@@ -112,26 +112,28 @@ template <int SD, int ORDER> __global__ __launch_bounds__(256) void shared_point
 // them in registers (for Piola maps: of the SD components of the dof each position belongs to).
 // Per request it takes K from LDS (computed for 256 requests at a time, one per thread), forms
 // adj(K) / sym^2 K in registers and writes its positions with 16-byte non-temporal stores: no
-// reads besides 8*(SD+1)*SD bytes per request.  Needs table = rows*npts even and <= 512*NP.
+// reads besides 8*(SD+1)*SD bytes per request.  Needs table = rows*npts <= 256*EL*NP.
 constexpr int SHARED_RB = 64;  // requests per block of the register-resident kernel
 
-template <int SD, int ORDER, int NP, bool PIOLA>
+// EL = 2: a thread owns pairs of consecutive doubles (16-byte stores, table even); EL = 1: single
+// doubles (odd tables, e.g. RT2 with 23 points: 45 x 23)
+template <int SD, int ORDER, int NP, bool PIOLA, int EL = 2>
 __global__ __launch_bounds__(256) void shared_points_reg_kernel(const SharedArgs a) {
     constexpr int NTAB = NTab<SD, ORDER>::value;
     constexpr int NH = SD * (SD + 1) / 2;
     constexpr int NE = PIOLA ? SD : 1;
     const int table = a.rows * a.npts;
-    const int npairs = table >> 1;
+    const int npairs = EL == 2 ? table >> 1 : table;  // units (pairs or single doubles) per table
     typedef double v2d_t __attribute__((ext_vector_type(2)));
     // reference values: [slot][element of the pair][source table][component]
-    double rv[NP][2][NTAB][NE];
-    int comp[NP][2];  // component (row % SD) of each element, for the Piola matrix row
+    double rv[NP][EL][NTAB][NE];
+    int comp[NP][EL];  // component (row % SD) of each element, for the Piola matrix row
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int pr = min((int)threadIdx.x + 256 * i, npairs - 1);
 #pragma unroll
-        for (int el = 0; el < 2; ++el) {
-            const int q = 2 * pr + el;
+        for (int el = 0; el < EL; ++el) {
+            const int q = EL * pr + el;
             const int row = q / a.npts, p = q - row * a.npts;
             comp[i][el] = PIOLA ? row % SD : 0;
             const int dof = PIOLA ? row / SD : 0;
@@ -206,15 +208,17 @@ __global__ __launch_bounds__(256) void shared_points_reg_kernel(const SharedArgs
                             H[hd][hc] = c == c2 ? K[c][d] * K[c][e] : K[c][d] * K[c2][e] + K[c2][d] * K[c][e];
                 }
         }
-        v2d_t* o2 = reinterpret_cast<v2d_t*>(a.out + (size_t)req * NTAB * table);
+        double* o1 = a.out + (size_t)req * NTAB * table;
+        v2d_t* o2 = reinterpret_cast<v2d_t*>(o1);
+        (void)o2;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int pr = (int)threadIdx.x + 256 * i;
             if (pr < npairs) {
                 // source values after the Piola mix: m[el][s]
-                double m[2][NTAB];
+                double m[EL][NTAB];
 #pragma unroll
-                for (int el = 0; el < 2; ++el)
+                for (int el = 0; el < EL; ++el)
 #pragma unroll
                     for (int s = 0; s < NTAB; ++s) {
                         if constexpr (PIOLA) {
@@ -234,9 +238,9 @@ __global__ __launch_bounds__(256) void shared_points_reg_kernel(const SharedArgs
                     }
 #pragma unroll
                 for (int t = 0; t < NTAB; ++t) {
-                    v2d_t v;
+                    double vv[2] = {0.0, 0.0};
 #pragma unroll
-                    for (int el = 0; el < 2; ++el) {
+                    for (int el = 0; el < EL; ++el) {
                         double acc;
                         if (t == 0) {
                             acc = m[el][0];
@@ -251,9 +255,11 @@ __global__ __launch_bounds__(256) void shared_points_reg_kernel(const SharedArgs
                                 for (int hc = 0; hc < NH; ++hc) acc += H[t - 1 - SD][hc] * m[el][1 + SD + hc];
                             }
                         }
-                        if (el == 0) v.x = acc; else v.y = acc;
+                        vv[el] = acc;
                     }
-                    o2[(size_t)t * npairs + pr] = v;  // plain store: chunks are not line-aligned, neighbours complete the lines in L2
+                    // plain stores: chunks are not line-aligned, neighbours complete the lines in L2
+                    if constexpr (EL == 2) o2[(size_t)t * npairs + pr] = v2d_t{vv[0], vv[1]};
+                    else o1[(size_t)t * npairs + pr] = vv[0];
                 }
             }
         }
