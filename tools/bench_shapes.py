@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""HBM fraction of tabulate_batch for a range of common element shapes (measurement tooling)."""
+import os, sys, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import fiat_amd, bench
+
+CASES = [("Lagrange", 2, 1, 3), ("Lagrange", 2, 2, 6), ("Lagrange", 2, 3, 12), ("Lagrange", 3, 1, 4), ("Lagrange", 3, 2, 11),
+         ("Lagrange", 3, 2, 14), ("Lagrange", 3, 3, 23), ("Lagrange", 3, 4, 23), ("DiscontinuousLagrange", 3, 1, 4),
+         ("Nedelec", 3, 1, 4), ("RaviartThomas", 3, 1, 4), ("Nedelec", 2, 1, 3)]
+for fam, sd, deg, npts in CASES:
+    el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg)
+    ps = el.device_polyset()
+    order = 1
+    shape1 = ps.out_shape(order, 1, npts)
+    per_req = 8 * (npts * sd + int(np.prod(shape1[1:])))
+    nreq = int(min(4_000_000, 1.2e9 // per_req))
+    pts = torch.as_tensor(bench.synth_points(sd, nreq, npts, 1)).cuda()
+    out = torch.empty(ps.out_shape(order, nreq, npts), dtype=torch.float64, device="cuda")
+    t = statistics.median(ps.time_tabulate_batch(order, pts, None, out, 10) for _ in range(3))
+    print(f"{fam:22s} sd{sd} P{deg} npts {npts:3d}: {nreq:8d} requests, {t*1e3:8.1f} us, {nreq/t/1e3:8.1f} M req/s, "
+          f"{per_req*nreq/t/1e6:6.0f} GB/s ({per_req*nreq/t/1e6/80:.0f} %)  {ps.kernel_name(order, nreq, npts)}")
+    del pts, out
