@@ -20,6 +20,7 @@
 #include "coop_kernel.hpp"
 #include "shared_points.hpp"
 #include "quadrature.hpp"
+#include "simplex_small.hpp"
 
 namespace {
 
@@ -152,6 +153,7 @@ struct fx_element {
     int KS = 0, MT = 0;
     fxk::Step* d_steps = nullptr;
     double* d_afrag = nullptr;
+    double* d_cmat = nullptr;          // plain coefficient matrix [rows][nexp] (C0 transform folded in)
     double* d_afrag_split = nullptr;  // layout of the shape-specialised kernels
     double* d_afrag_stream = nullptr; // same, K in production order (K-streamed kernel)
     // cooperative (large-shape) plan
@@ -307,6 +309,12 @@ static int upload_coeffs(fx_element* e, int ndof, int vdim, const double* coeffs
             }
         C.swap(CT);
     }
+    if (e->d_cmat) {
+        HIP_TRY(hipFree(e->d_cmat));
+        e->d_cmat = nullptr;
+    }
+    HIP_TRY(hipMalloc(&e->d_cmat, C.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(e->d_cmat, C.data(), C.size() * sizeof(double), hipMemcpyHostToDevice));
     std::vector<double> F = fx::pack_a_fragments(C, rows, nexp);
     if (e->d_afrag) {
         HIP_TRY(hipFree(e->d_afrag));
@@ -443,6 +451,7 @@ int fx_element_create(fx_ctx* ctx, int sd, int n, int variant, double scale, con
 int fx_element_destroy(fx_element* e) {
     if (!e) return FX_OK;
     if (e->d_steps) (void)hipFree(e->d_steps);
+    if (e->d_cmat) (void)hipFree(e->d_cmat);
     if (e->d_afrag) (void)hipFree(e->d_afrag);
     if (e->d_afrag_split) (void)hipFree(e->d_afrag_split);
     if (e->d_afrag_stream) (void)hipFree(e->d_afrag_stream);
@@ -490,6 +499,10 @@ struct Launch {
     // 0: LDS-image kernel (simplex_fixed.hpp), 1: K-streamed kernel (simplex_stream.hpp),
     // 2: K-streamed, two requests per wave (simplex_pair.hpp)
     int fkind = 0;
+    // low-order lane-local kernel (simplex_small.hpp)
+    int small_id = -1;
+    fxk::SmallArgs sargs;
+    int sgrid = 0, slds_bytes = 0;
     // cooperative large-shape kernel
     int coop_id = -1;
     fxk::CoopArgs cargs;
@@ -658,6 +671,45 @@ int run_coop(const Launch& L, hipStream_t s) {
         case 3: return launch_coop<3, 1, 3, 0, 2, true>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown cooperative kernel %d", L.coop_id);
+}
+
+// ---- registry of the low-order lane-local kernel: (sd, n), orders 0 and 1 -----------------
+struct SmallShape {
+    int sd, n;
+};
+const SmallShape kSmallShapes[] = {{2, 1}, {2, 2}, {2, 3}, {3, 1}, {3, 2}};
+constexpr int SMALL_NW = 4;
+
+template <int SD, int N>
+int launch_small(int order, const Launch& L, hipStream_t s) {
+    if (order == 0)
+        hipLaunchKernelGGL((fxk::tabulate_simplex_small<SD, N, 0, SMALL_NW>), dim3(L.sgrid), dim3(64 * SMALL_NW), L.slds_bytes, s, L.sargs);
+    else
+        hipLaunchKernelGGL((fxk::tabulate_simplex_small<SD, N, 1, SMALL_NW>), dim3(L.sgrid), dim3(64 * SMALL_NW), L.slds_bytes, s, L.sargs);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+int run_small(int order, const Launch& L, hipStream_t s) {
+    switch (L.small_id) {
+        case 0: return launch_small<2, 1>(order, L, s);
+        case 1: return launch_small<2, 2>(order, L, s);
+        case 2: return launch_small<2, 3>(order, L, s);
+        case 3: return launch_small<3, 1>(order, L, s);
+        case 4: return launch_small<3, 2>(order, L, s);
+    }
+    return fail(FX_EINVAL, "internal: unknown small kernel %d", L.small_id);
+}
+
+bool small_table_matches(int id, const fx::Program& P) {
+    switch (id) {
+        case 0: return table_matches<2, 1>(P);
+        case 1: return table_matches<2, 2>(P);
+        case 2: return table_matches<2, 3>(P);
+        case 3: return table_matches<3, 1>(P);
+        case 4: return table_matches<3, 2>(P);
+    }
+    return false;
 }
 
 int run_fixed(const Launch& L, hipStream_t s) {
@@ -932,6 +984,47 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             break;
         }
     }
+    // ---- low-order lane-local kernel? ----
+    L.small_id = -1;
+    {
+        static const bool nosmall = getenv("FIAT_AMD_NO_SMALL") != nullptr;
+        const long long reqbytes8 = (long long)ntab * rows * npts * 8;
+        if (!nosmall && order <= 1 && npts <= 64 && rows <= 96 && reqbytes8 <= 16 * 1024 && e->d_cmat) {
+            for (size_t i = 0; i < sizeof(kSmallShapes) / sizeof(kSmallShapes[0]); ++i) {
+                if (kSmallShapes[i].sd != e->sd || kSmallShapes[i].n != e->n) continue;
+                if (!small_table_matches((int)i, e->prog) || (int)e->prog.steps.size() > fxk::SMALL_MAXSTEPS) continue;
+                int P = std::max(1, 64 / npts);
+                while (P > 1 && P * reqbytes8 > 12 * 1024) --P;  // per-wave image: several workgroups per CU
+                fxk::SmallArgs& sa = L.sargs;
+                memset(&sa, 0, sizeof sa);
+                sa.pts = pts;
+                sa.verts = verts;
+                sa.out = out;
+                sa.cmat = e->d_cmat;
+                for (size_t k = 0; k < e->prog.steps.size(); ++k) {
+                    sa.coef[3 * k + 0] = e->prog.steps[k].A;
+                    sa.coef[3 * k + 1] = e->prog.steps[k].B;
+                    sa.coef[3 * k + 2] = e->prog.steps[k].C;
+                }
+                sa.phi0 = e->prog.phi0;
+                memcpy(sa.A0, e->A0, sizeof sa.A0);
+                memcpy(sa.b0, e->b0, sizeof sa.b0);
+                sa.nreq = nreq;
+                sa.nitems = (nreq + P - 1) / P;
+                sa.npts = npts;
+                sa.rows = rows;
+                sa.P = P;
+                sa.stage_doubles = (int)(((long long)P * ntab * rows * npts + 1) & ~1LL);
+                sa.debug = a.debug;
+                L.slds_bytes = sa.stage_doubles * 8 * SMALL_NW;
+                const int wg_per_cu = std::max(1, std::min(8, ctx->lds_per_cu / std::max(1, L.slds_bytes)));
+                const long long nwg = (sa.nitems + SMALL_NW - 1) / SMALL_NW;
+                L.sgrid = (int)std::max<long long>(1, std::min<long long>(nwg, (long long)ctx->num_cu * wg_per_cu * 4));
+                L.small_id = (int)i;
+                break;
+            }
+        }
+    }
     int per_cu = std::max(1, std::min(16, ctx->lds_per_cu / std::max(1, L.lds_bytes)));
     long long want = (long long)ctx->num_cu * per_cu * 4;
     L.grid = (int)std::max<long long>(1, std::min<long long>(a.nitems, want));
@@ -942,6 +1035,7 @@ int run_tabulate(fx_ctx* ctx, const fx_element* e, int order, const Launch& L, h
     if (L.args.nitems == 0 || L.args.npts == 0) return FX_OK;
     if (L.fixed_id >= 0) return run_fixed(L, s);
     if (L.coop_id >= 0) return run_coop(L, s);
+    if (L.small_id >= 0) return run_small(order, L, s);
     switch (e->sd) {
         case 1: return launch_sd<1>(order, L, s);
         case 2: return launch_sd<2>(order, L, s);
@@ -1187,6 +1281,7 @@ int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, in
             : L.fkind == 1 ? "fxk::tabulate_simplex_stream"
                            : "fxk::tabulate_simplex_pair";
     else if (L.coop_id >= 0) k = "fxk::tabulate_simplex_coop";
+    else if (L.small_id >= 0) k = "fxk::tabulate_simplex_small";
     snprintf(name, (size_t)name_len, "%s", k);
     return FX_OK;
 }
