@@ -677,7 +677,8 @@ int run_coop(const Launch& L, hipStream_t s) {
 struct SmallShape {
     int sd, n;
 };
-const SmallShape kSmallShapes[] = {{2, 1}, {2, 2}, {2, 3}, {3, 1}, {3, 2}};
+// (measured against the generic kernel: (2,5) and (3,3) are slower lane-local -- 1600+ FMAs per lane -- and stay generic)
+const SmallShape kSmallShapes[] = {{2, 1}, {2, 2}, {2, 3}, {3, 1}, {3, 2}, {2, 4}};
 constexpr int SMALL_NW = 4;
 
 template <int SD, int N>
@@ -697,6 +698,7 @@ int run_small(int order, const Launch& L, hipStream_t s) {
         case 2: return launch_small<2, 3>(order, L, s);
         case 3: return launch_small<3, 1>(order, L, s);
         case 4: return launch_small<3, 2>(order, L, s);
+        case 5: return launch_small<2, 4>(order, L, s);
     }
     return fail(FX_EINVAL, "internal: unknown small kernel %d", L.small_id);
 }
@@ -708,6 +710,7 @@ bool small_table_matches(int id, const fx::Program& P) {
         case 2: return table_matches<2, 3>(P);
         case 3: return table_matches<3, 1>(P);
         case 4: return table_matches<3, 2>(P);
+        case 5: return table_matches<2, 4>(P);
     }
     return false;
 }

@@ -1,4 +1,4 @@
-// Low-order simplex elements (degree <= 3 on triangles, <= 2 on tetrahedra; gfx950).
+// Low-order simplex elements (degree <= 4 on triangles, <= 2 on tetrahedra; gfx950).
 //
 // For these shapes the MFMA path of the generic kernel spends most of its time around the matrix
 // instruction (a 16x16x4 tile of which 3-10 rows are used, column decoding, the LDS round trip of
@@ -14,7 +14,7 @@
 
 namespace fxk {
 
-constexpr int SMALL_MAXSTEPS = 9;  // (sd, n) = (2, 3) and (3, 2): 10 members
+constexpr int SMALL_MAXSTEPS = 14;  // (sd, n) = (2, 4): 15 members
 
 struct SmallArgs {
     const double* pts;    // [nreq][npts][SD]

@@ -7,7 +7,7 @@ import pytest
 from oracle import fiat_oracle as fo
 
 pytestmark = pytest.mark.gpu
-SHAPES = [(2, 1), (2, 2), (2, 3), (3, 1), (3, 2)]
+SHAPES = [(2, 1), (2, 2), (2, 3), (3, 1), (3, 2), (2, 4)]
 
 
 @pytest.fixture(scope="module")

@@ -6,7 +6,7 @@ import numpy as np, torch
 import fiat_amd, bench
 
 CASES = [("Lagrange", 2, 1, 3), ("Lagrange", 2, 2, 6), ("Lagrange", 2, 3, 12), ("Lagrange", 3, 1, 4), ("Lagrange", 3, 2, 11),
-         ("Lagrange", 3, 2, 14), ("Lagrange", 3, 3, 23), ("Lagrange", 3, 4, 23), ("DiscontinuousLagrange", 3, 1, 4),
+         ("Lagrange", 3, 2, 14), ("Lagrange", 3, 3, 23), ("Lagrange", 3, 3, 14), ("Lagrange", 2, 4, 12), ("Lagrange", 2, 5, 16), ("Lagrange", 3, 4, 23), ("DiscontinuousLagrange", 3, 1, 4),
          ("Nedelec", 3, 1, 4), ("RaviartThomas", 3, 1, 4), ("Nedelec", 2, 1, 3)]
 for fam, sd, deg, npts in CASES:
     el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg)
