@@ -1289,6 +1289,21 @@ int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, in
     return FX_OK;
 }
 
+namespace {
+// after a synchronisation point: did a dynamically scheduled kernel give up waiting for a chunk id
+// (work_queue.hpp)?  Its output is then incomplete.
+int check_work_queues(fx_ctx* ctx) {
+    unsigned int flags[FX_QUEUE_SLOTS * 32];
+    HIP_TRY(hipMemcpy(flags, ctx->d_queue, sizeof flags, hipMemcpyDeviceToHost));
+    for (int i = 0; i < FX_QUEUE_SLOTS; ++i)
+        if (flags[i * 32 + 2]) {
+            (void)hipMemset(ctx->d_queue, 0, FX_QUEUE_SLOTS * 128);
+            return fail(FX_EHIP, "work queue protocol error in a tabulation kernel: the output is incomplete");
+        }
+    return FX_OK;
+}
+}  // namespace
+
 int fx_time_tabulate_batch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, const double* pts,
                            const double* verts, double* out, void* stream, int reps, float* ms) {
     if (reps < 1 || !ms) return fail(FX_EINVAL, "fx_time_tabulate_batch: bad reps/ms");
@@ -1311,6 +1326,7 @@ int fx_time_tabulate_batch(fx_ctx* ctx, const fx_element* e, int order, int64_t 
     (void)hipEventDestroy(t0);
     (void)hipEventDestroy(t1);
     *ms = total / reps;
+    if (rc == FX_OK) rc = check_work_queues(ctx);
     return rc;
 }
 
@@ -1336,6 +1352,7 @@ int fx_tabulate_batch_host(fx_ctx* ctx, const fx_element* e, int order, int64_t 
         hipError_t he = hipDeviceSynchronize();
         if (he != hipSuccess) rc = fail(FX_EHIP, "tabulate kernel: %s", hipGetErrorString(he));
     }
+    if (rc == FX_OK) rc = check_work_queues(ctx);
     if (rc == FX_OK) {
         hipError_t he = hipMemcpy(out, dout, obytes, hipMemcpyDeviceToHost);
         if (he != hipSuccess) rc = fail(FX_EHIP, "copy back: %s", hipGetErrorString(he));

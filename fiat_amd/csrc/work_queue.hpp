@@ -13,7 +13,7 @@
 // of the workgroup through a counter in LDS (ds_add_rtn, no vmcnt traffic).
 //
 // The global counter cleans up after itself: the last wave of the last workgroup to finish sets
-// it back to zero (gctr[0] chunk counter, gctr[1] finished workgroups), so a launch costs no
+// it back to zero (gctr[0] chunk counter, gctr[1] finished workgroups; gctr[2] = protocol-error mark), so a launch costs no
 // extra memset node; the host hands concurrent launches different counters (api.hip).
 //
 // LDS control block (64 bytes at the start of dynamic LDS):
@@ -82,7 +82,10 @@ struct WorkQueue {
             }
             __builtin_amdgcn_s_sleep(2);
         }
-        if (!ok) return nunits;
+        if (!ok) {  // leave a mark the host finds at its next synchronisation point (gctr[2], never reset by kernels)
+            if ((threadIdx.x & 63) == 0) __hip_atomic_store(gctr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return nunits;
+        }
         const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)s);
         if (lo >= nchunks) return nunits;
         const long long u = (long long)lo * 8 + off;
