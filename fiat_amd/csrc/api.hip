@@ -685,8 +685,10 @@ template <int SD, int N>
 int launch_small(int order, const Launch& L, hipStream_t s) {
     if (order == 0)
         hipLaunchKernelGGL((fxk::tabulate_simplex_small<SD, N, 0, SMALL_NW>), dim3(L.sgrid), dim3(64 * SMALL_NW), L.slds_bytes, s, L.sargs);
-    else
+    else if (order == 1)
         hipLaunchKernelGGL((fxk::tabulate_simplex_small<SD, N, 1, SMALL_NW>), dim3(L.sgrid), dim3(64 * SMALL_NW), L.slds_bytes, s, L.sargs);
+    else
+        hipLaunchKernelGGL((fxk::tabulate_simplex_small<SD, N, 2, SMALL_NW>), dim3(L.sgrid), dim3(64 * SMALL_NW), L.slds_bytes, s, L.sargs);
     HIP_TRY(hipGetLastError());
     return FX_OK;
 }
@@ -992,7 +994,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     {
         static const bool nosmall = getenv("FIAT_AMD_NO_SMALL") != nullptr;
         const long long reqbytes8 = (long long)ntab * rows * npts * 8;
-        if (!nosmall && order <= 1 && npts <= 64 && rows <= 96 && reqbytes8 <= 16 * 1024 && e->d_cmat) {
+        if (!nosmall && order <= 2 && npts <= 64 && rows <= 96 && reqbytes8 <= 16 * 1024 && e->d_cmat) {
             for (size_t i = 0; i < sizeof(kSmallShapes) / sizeof(kSmallShapes[0]); ++i) {
                 if (kSmallShapes[i].sd != e->sd || kSmallShapes[i].n != e->n) continue;
                 if (!small_table_matches((int)i, e->prog) || (int)e->prog.steps.size() > fxk::SMALL_MAXSTEPS) continue;

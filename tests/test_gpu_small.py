@@ -32,11 +32,11 @@ def compare(out, ref, order):
     err = (num / den).max(axis=0)
     assert err[0] <= 1e-12, err
     if order:
-        assert err[1:].max() <= 1e-10, err
+        assert err[1:].max() <= 1e-10, err   # (first and second derivatives)
 
 
 @pytest.mark.parametrize("sd,n", SHAPES)
-@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("order", [0, 1, 2])
 @pytest.mark.parametrize("nreq,npts", [(1, 1), (7, 3), (1000, 4), (333, 11), (129, 17), (65, 64), (4097, 6)])
 @pytest.mark.parametrize("cells", [False, True])
 def test_small_kernel_vs_c_oracle(rt, sd, n, order, nreq, npts, cells):
@@ -69,7 +69,8 @@ def test_small_kernel_is_selected(rt, sd, n):
     ps = rt.SimplexPolySet(sd, n, coeffs=np.eye(nexp))
     assert ps.kernel_name(1, 1000, 4) == "fxk::tabulate_simplex_small"
     assert ps.kernel_name(0, 1000, 11, has_verts=True) == "fxk::tabulate_simplex_small"
-    assert ps.kernel_name(2, 1000, 4) == "fxk::tabulate_simplex_kernel"       # Hessians: generic kernel
+    assert ps.kernel_name(2, 1000, 4) == "fxk::tabulate_simplex_small"        # Hessians too
+    assert ps.kernel_name(1, 1000, 65) == "fxk::tabulate_simplex_kernel"      # more points than lanes: generic kernel
 
 
 def test_small_kernel_vector_valued_and_bubble(rt, golden):
