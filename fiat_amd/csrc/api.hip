@@ -514,9 +514,13 @@ struct Launch {
 constexpr int FIXED_NW = 4;  // 256-thread workgroups: one wave per SIMD, 2 workgroups per CU
 struct FixedShape {
     int sd, n, order, rows, nt;
+    bool pair_only;
 };
 const FixedShape kFixedShapes[] = {
-    {3, 3, 1, 20, 6},  // Lagrange P3 tetrahedron, values + gradient, 21..24 points
+    {3, 3, 1, 20, 6, false},  // Lagrange P3 tetrahedron, values + gradient, 21..24 points (the benchmark shape)
+    {3, 3, 1, 20, 5, true},   // ... 17..20 points
+    {3, 3, 1, 20, 4, true},   // ... 13..16 points
+    {3, 3, 1, 20, 3, true},   // ... 9..12 points
 };
 
 template <int SD, int N>
@@ -567,7 +571,9 @@ hipError_t report_wave_lifetimes(const double* trash, int grid, int wg_waves) {
 }
 #endif
 
-template <int SD, int N, int ORDER, int ROWS, int NT>
+// PAIR_ONLY: only the paired kernel is instantiated for this shape (the A/B partners
+// `stream` and `image` exist for the benchmark shape)
+template <int SD, int N, int ORDER, int ROWS, int NT, bool PAIR_ONLY = false>
 int launch_fixed(const Launch& L, hipStream_t s) {
     using KernT = void (*)(const fxk::FixedArgs<fxk::FixedNC<SD, N>::value>);
     constexpr int NC = fxk::FixedNC<SD, N>::value;
@@ -617,19 +623,23 @@ int launch_fixed(const Launch& L, hipStream_t s) {
 #endif
         return FX_OK;
     }
-    KernT kern;
-    if (L.fkind == 1)
-        kern = L.fhead.verts ? (KernT)fxk::tabulate_simplex_stream<SD, N, ORDER, ROWS, NT, FIXED_NW, false>
-                             : (KernT)fxk::tabulate_simplex_stream<SD, N, ORDER, ROWS, NT, FIXED_NW, true>;
-    else
-        kern = (KernT)fxk::tabulate_simplex_fixed<SD, N, ORDER, ROWS, NT, FIXED_NW>;
-    if (L.flds_bytes > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    L.flds_bytes));
-    const int grid = L.fgrid;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FIXED_NW), L.flds_bytes, s, fa);
-    HIP_TRY(hipGetLastError());
-    return FX_OK;
+    if constexpr (PAIR_ONLY) {
+        return fail(FX_EINVAL, "internal: only the paired kernel exists for this shape");
+    } else {
+        KernT kern;
+        if (L.fkind == 1)
+            kern = L.fhead.verts ? (KernT)fxk::tabulate_simplex_stream<SD, N, ORDER, ROWS, NT, FIXED_NW, false>
+                                 : (KernT)fxk::tabulate_simplex_stream<SD, N, ORDER, ROWS, NT, FIXED_NW, true>;
+        else
+            kern = (KernT)fxk::tabulate_simplex_fixed<SD, N, ORDER, ROWS, NT, FIXED_NW>;
+        if (L.flds_bytes > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        L.flds_bytes));
+        const int grid = L.fgrid;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * FIXED_NW), L.flds_bytes, s, fa);
+        HIP_TRY(hipGetLastError());
+        return FX_OK;
+    }
 }
 
 // ---- registry of cooperative (large-shape) kernels: <SD, ORDER, MT16, M4, TPW> ------
@@ -720,6 +730,9 @@ bool small_table_matches(int id, const fx::Program& P) {
 int run_fixed(const Launch& L, hipStream_t s) {
     switch (L.fixed_id) {
         case 0: return launch_fixed<3, 3, 1, 20, 6>(L, s);
+        case 1: return launch_fixed<3, 3, 1, 20, 5, true>(L, s);
+        case 2: return launch_fixed<3, 3, 1, 20, 4, true>(L, s);
+        case 3: return launch_fixed<3, 3, 1, 20, 3, true>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown fixed kernel %d", L.fixed_id);
 }
@@ -935,8 +948,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             const bool pair_ok = npts <= 32 && (FX_PAIR_FULLIMG || ntab == 1 ||
                                                 (f.nt % 2 == 0 && (f.nt / 2) * 16 >= ((ntab + 1) / 2) * npts));
             L.fkind = pair_ok ? 2 : 1;
-            if (kk && !strcmp(kk, "image")) L.fkind = 0;
-            if (kk && !strcmp(kk, "stream")) L.fkind = 1;
+            if (kk && !strcmp(kk, "image") && !f.pair_only) L.fkind = 0;
+            if (kk && !strcmp(kk, "stream") && !f.pair_only) L.fkind = 1;
+            if (f.pair_only && L.fkind != 2) continue;
             if (kk && !strcmp(kk, "pair") && pair_ok) L.fkind = 2;
             L.ncu = ctx->num_cu;
             L.trash = ctx->d_trash;

@@ -384,3 +384,27 @@ def test_concurrent_streams(rt, golden):
         den = np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))
         err = (num / den).max(axis=0)
         assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, (k, err)
+
+
+@pytest.mark.parametrize("npts", [9, 11, 12, 13, 14, 16, 17, 19, 20])
+@pytest.mark.parametrize("nreq,cells", [(1, False), (2, True), (515, False), (1030, True)])
+def test_p3_tet_paired_kernel_point_counts(rt, golden, npts, nreq, cells):
+    """The paired kernel is instantiated for 3..6 column tiles: P3 tetrahedra with 9..24 points."""
+    from oracle import c_oracle
+    co = golden("elements")["c2_p3tet_q6_coeffs"]
+    ps = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=co)
+    assert ps.kernel_name(1, nreq, npts, has_verts=cells) == "fxk::tabulate_simplex_pair"
+    rng = np.random.default_rng(3000 + 10 * npts + nreq)
+    pts = rand_points(rng, 3, (nreq, npts))
+    verts = None
+    if cells:
+        A = np.eye(3) + 0.1 * rng.standard_normal((nreq, 3, 3))
+        b = rng.standard_normal((nreq, 1, 3))
+        verts = np.einsum("vd,red->rve", fo.UFC_SIMPLEX[3], A) + b
+        pts = np.einsum("rpd,red->rpe", pts, A) + b
+    out = ps.tabulate_batch(1, pts, verts=verts).cpu().numpy()
+    ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[3], 3, co, 1, pts, verts=verts, scale=1, variant="bubble")
+    num = np.abs(out - ref).max(axis=(2, 3))
+    den = np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))
+    err = (num / den).max(axis=0)
+    assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
