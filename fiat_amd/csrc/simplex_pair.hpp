@@ -9,8 +9,9 @@
 // here lanes 0..31 carry the points of request 2i and lanes 32..63 those of request 2i+1,
 // so every recurrence instruction, coordinate map and LDS store of expansion values serves
 // two requests.  The contraction runs over 2*NT column tiles (same MFMA count per request);
-// everything else follows simplex_stream.hpp (K-streamed slab aliasing a half-request output
-// image, full-line 16-byte stores, exact vmcnt on the prefetched points).
+// the K-streamed slab aliases a whole-request output image in LDS, the output leaves as full-line
+// 16-byte stores with an exact vmcnt on the prefetched points (as in simplex_stream.hpp), and the
+// pairs are handed to the waves dynamically (work_queue.hpp).
 #pragma once
 #include "simplex_stream.hpp"
 #include "work_queue.hpp"
