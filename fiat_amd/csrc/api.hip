@@ -514,13 +514,17 @@ struct Launch {
 constexpr int FIXED_NW = 4;  // 256-thread workgroups: one wave per SIMD, 2 workgroups per CU
 struct FixedShape {
     int sd, n, order, rows, nt;
-    bool pair_only;
+    bool pair_only;  // only the paired kernel is instantiated (no A/B partners)
+    int rpw;         // requests per wave of the paired kernel: 2, or 1 for shapes with many rows / > 32 points
+    bool fullimg;    // LDS image of a whole request (false: half of its tables)
 };
 const FixedShape kFixedShapes[] = {
-    {3, 3, 1, 20, 6, false},  // Lagrange P3 tetrahedron, values + gradient, 21..24 points (the benchmark shape)
-    {3, 3, 1, 20, 5, true},   // ... 17..20 points
-    {3, 3, 1, 20, 4, true},   // ... 13..16 points
-    {3, 3, 1, 20, 3, true},   // ... 9..12 points
+    {3, 3, 1, 20, 6, false, 2, true},  // Lagrange P3 tetrahedron, values + gradient, 21..24 points (the benchmark shape)
+    {3, 3, 1, 20, 5, true, 2, true},   // ... 17..20 points
+    {3, 3, 1, 20, 4, true, 2, true},   // ... 13..16 points
+    {3, 3, 1, 20, 3, true, 2, true},   // ... 9..12 points
+    {3, 2, 1, 45, 6, true, 1, false},  // RT2 tetrahedron (15 x 3 rows), 21..24 points: one request per wave, half image
+    {3, 4, 1, 35, 6, true, 1, false},  // Lagrange P4 tetrahedron, 21..24 points
 };
 
 template <int SD, int N>
@@ -573,7 +577,7 @@ hipError_t report_wave_lifetimes(const double* trash, int grid, int wg_waves) {
 
 // PAIR_ONLY: only the paired kernel is instantiated for this shape (the A/B partners
 // `stream` and `image` exist for the benchmark shape)
-template <int SD, int N, int ORDER, int ROWS, int NT, bool PAIR_ONLY = false>
+template <int SD, int N, int ORDER, int ROWS, int NT, bool PAIR_ONLY = false, int RPW = 2, bool FULLIMG = true>
 int launch_fixed(const Launch& L, hipStream_t s) {
     using KernT = void (*)(const fxk::FixedArgs<fxk::FixedNC<SD, N>::value>);
     constexpr int NC = fxk::FixedNC<SD, N>::value;
@@ -596,8 +600,8 @@ int launch_fixed(const Launch& L, hipStream_t s) {
     if (L.fkind == 2) {
         constexpr int PAIR_NW = 8;  // one 512-thread workgroup per CU, two waves per SIMD, LDS work counter
         using KernP = void (*)(const fxk::FixedArgs<NC>, double*, unsigned int*);
-        KernP kp = L.fhead.verts ? (KernP)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, PAIR_NW, false>
-                                 : (KernP)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, PAIR_NW, true>;
+        KernP kp = L.fhead.verts ? (KernP)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, PAIR_NW, false, RPW, FULLIMG>
+                                 : (KernP)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, PAIR_NW, true, RPW, FULLIMG>;
         const int lds_bytes = fxk::WQ_CTL_DOUBLES * 8 + (L.flds_bytes - (int)(fa.lds_doubles * 8) * FIXED_NW) + (int)(fa.lds_doubles * 8) * PAIR_NW;
         // attribute and occupancy are properties of (kernel, LDS size): asked once, not per launch
         static thread_local const void* cached_kp = nullptr;
@@ -612,7 +616,7 @@ int launch_fixed(const Launch& L, hipStream_t s) {
             cached_occ = q;
         }
         const int occ = cached_occ;
-        const long long nwg = ((L.fhead.nreq + 1) / 2 + PAIR_NW - 1) / PAIR_NW;
+        const long long nwg = ((L.fhead.nreq + RPW - 1) / RPW + PAIR_NW - 1) / PAIR_NW;
         const int grid = (int)std::max<long long>(1, std::min<long long>(nwg, (long long)L.ncu * std::max(1, occ)));
         static const bool verbose = getenv("FIAT_AMD_VERBOSE") != nullptr;
         if (verbose) fprintf(stderr, "[fiat_amd] pair kernel: occupancy %d WG/CU, grid %d, lds %d B\n", occ, grid, lds_bytes);
@@ -733,6 +737,8 @@ int run_fixed(const Launch& L, hipStream_t s) {
         case 1: return launch_fixed<3, 3, 1, 20, 5, true>(L, s);
         case 2: return launch_fixed<3, 3, 1, 20, 4, true>(L, s);
         case 3: return launch_fixed<3, 3, 1, 20, 3, true>(L, s);
+        case 4: return launch_fixed<3, 2, 1, 45, 6, true, 1, false>(L, s);
+        case 5: return launch_fixed<3, 4, 1, 35, 6, true, 1, false>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown fixed kernel %d", L.fixed_id);
 }
@@ -902,12 +908,15 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     // ---- shape-specialised kernel available? ----
     L.fixed_id = -1;
     const char* nofixed = getenv("FIAT_AMD_NO_FIXED");
-    if (!(nofixed && atoi(nofixed)) && npts <= 64) {
+    if (!(nofixed && atoi(nofixed)) && npts <= 64 && !L.fused_mapping) {  // (a fused push-forward lives in the cooperative kernel)
         const int nt_need = (ntab * npts + 15) / 16;
         for (size_t i = 0; i < sizeof(kFixedShapes) / sizeof(kFixedShapes[0]); ++i) {
             const FixedShape& f = kFixedShapes[i];
             if (f.sd != e->sd || f.n != e->n || f.order != order || f.rows != rows || f.nt != nt_need) continue;
-            bool ok = (e->sd == 3 && e->n == 3) ? table_matches<3, 3>(e->prog) : false;
+            bool ok = false;
+            if (e->sd == 3 && e->n == 2) ok = table_matches<3, 2>(e->prog);
+            if (e->sd == 3 && e->n == 3) ok = table_matches<3, 3>(e->prog);
+            if (e->sd == 3 && e->n == 4) ok = table_matches<3, 4>(e->prog);
             if (!ok) continue;
             fxk::FixedArgs<0>& fa = L.fhead;
             memset(&fa, 0, sizeof fa);
@@ -945,8 +954,8 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             // default: K-streamed kernel, two requests per wave when the points of two requests fit
             // one wave (A/B: FIAT_AMD_KERNEL=image|stream|pair)
             // (pair kernel: the tables of each output half must fit half of the column tiles)
-            const bool pair_ok = npts <= 32 && (FX_PAIR_FULLIMG || ntab == 1 ||
-                                                (f.nt % 2 == 0 && (f.nt / 2) * 16 >= ((ntab + 1) / 2) * npts));
+            const bool pair_ok = npts <= 32 * (3 - f.rpw) && (f.fullimg || ntab == 1 ||
+                                                              (f.nt % 2 == 0 && (f.nt / 2) * 16 >= ((ntab + 1) / 2) * npts));
             L.fkind = pair_ok ? 2 : 1;
             if (kk && !strcmp(kk, "image") && !f.pair_only) L.fkind = 0;
             if (kk && !strcmp(kk, "stream") && !f.pair_only) L.fkind = 1;
@@ -969,9 +978,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             if (L.fkind >= 1) {
                 {
                     // per wave: half image (>= the K-step slab that aliases it) + 64-double dump row
-                    const int th = (L.fkind == 2 && FX_PAIR_FULLIMG) ? ntab : (ntab + 1) / 2;
+                    const int th = (L.fkind == 2 && f.fullimg) ? ntab : (ntab + 1) / 2;
                     long long per_wave =
-                        std::max<long long>((long long)th * rows * npts, (long long)f.nt * 64 * (L.fkind == 2 ? 2 : 1)) + 64;
+                        std::max<long long>((long long)th * rows * npts, (long long)f.nt * 64 * (L.fkind == 2 ? f.rpw : 1)) + 64;
                     per_wave = (per_wave + 1) & ~1LL;
                     fa.lds_doubles = (int)per_wave;
                     int rem = rows % 16;
@@ -981,7 +990,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 }
                 // registers bound the occupancy: ask for every workgroup the CU can hold
                 long long want = (long long)ctx->num_cu * 4;
-                const long long units = L.fkind == 2 ? (nreq + 1) / 2 : nreq;  // requests or pairs, one per wave
+                const long long units = L.fkind == 2 ? (nreq + f.rpw - 1) / f.rpw : nreq;  // requests or pairs, one per wave
                 long long nwg = (units + FIXED_NW - 1) / FIXED_NW;
                 L.fgrid = (int)std::max<long long>(1, std::min<long long>(nwg, L.fkind >= 2 ? nwg : want));
                 if (L.flds_bytes > ctx->lds_per_cu) continue;

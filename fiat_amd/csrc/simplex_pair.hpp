@@ -30,7 +30,11 @@
 
 namespace fxk {
 
-template <int SD, int N, int ORDER, int ROWS, int NT, int NW, bool UNIFORM>
+// RPW: requests per wave.  2 (the default): two requests of <= 32 points share a wave.  1: one request
+// of <= 64 points per wave -- shapes whose accumulators leave no room for a second request (many rows)
+// or with more than 32 points; everything else is the same kernel.  FULLIMG: the LDS image holds a
+// whole request (one write / read-back round per request) or half of its tables (large requests).
+template <int SD, int N, int ORDER, int ROWS, int NT, int NW, bool UNIFORM, int RPW = 2, bool FULLIMG = (FX_PAIR_FULLIMG != 0)>
 __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(const FixedArgs<FixedNC<SD, N>::value> a,
                                                                                 double* __restrict__ trash,
                                                                                 unsigned int* __restrict__ gqueue) {
@@ -40,7 +44,8 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
     constexpr int KS = (NEXP + 3) / 4;
     constexpr int MT16 = rows_full16(ROWS);
     constexpr int M4 = rows_blk4(ROWS);
-    constexpr int NT2 = 2 * NT;  // column tiles of the pair: [0, NT) request 2i, [NT, 2NT) request 2i+1
+    static_assert(RPW == 1 || RPW == 2, "one or two requests per wave");
+    constexpr int NT2 = RPW * NT;  // column tiles of the unit: [0, NT) request RPW*i, [NT, 2NT) request 2i+1
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -64,21 +69,21 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
 
     for (int i = lane; i < a.lds_doubles; i += 64) img[i] = 0.0;
     for (int i = threadIdx.x; i < NAF * 64; i += 64 * NW) afr[i] = a.afrag[i];
-    const long long npairs = (a.nreq + 1) >> 1;
+    const long long npairs = (a.nreq + RPW - 1) / RPW;  // units (pairs or single requests)
     WorkQueue wqueue;
     wqueue.init(lds, gqueue, npairs);  // pairs are handed out dynamically, see work_queue.hpp
     __syncthreads();
 
-    const int sub = lane >> 5;  // which request of the pair this lane's point belongs to
-    const int lp = lane & 31;
+    const int sub = RPW == 2 ? lane >> 5 : 0;  // which request of the pair this lane's point belongs to
+    const int lp = RPW == 2 ? lane & 31 : lane;
     const bool active = lp < npts;
     const int pl = active ? lp : 0;
     // Column order of the contraction: the tables of output half h (h = 0: tables [0, TH),
     // h = 1: tables [TH, NTAB)) occupy the column tiles [h*NT/2, (h+1)*NT/2) of their request, so
     // that no tile straddles the two half images (host-checked: (NT/2)*16 >= TH*npts).  The
     // epilogue is then free of branches and masks, which keeps hipcc's vmcnt bookkeeping exact.
-    static_assert(FX_PAIR_FULLIMG || NT % 2 == 0 || NTAB == 1, "half-aligned column tiles need an even tile count");
-    constexpr int TH = FX_PAIR_FULLIMG ? NTAB : (NTAB + 1) / 2;  // tables per image round
+    static_assert(FULLIMG || NT % 2 == 0 || NTAB == 1, "half-aligned column tiles need an even tile count");
+    constexpr int TH = FULLIMG ? NTAB : (NTAB + 1) / 2;  // tables per image round
     constexpr int NTH = NTAB > TH ? NT / 2 : NT;  // tiles per half
     int colbase[NTAB];
 #pragma unroll
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
         colbase[t] = active ? (sub * NT + h * NTH + (c >> 4)) * 64 + (c & 15) : dump + (lane & 15);
     }
     constexpr int NFL = (TH * ROWS * ((16 * NTH) / TH) / 2 + 63) / 64;
-    constexpr int NSTORE = 2 * NFL * (NTAB > TH ? 2 : 1);  // vector-memory stores per pair
+    constexpr int NSTORE = RPW * NFL * (NTAB > TH ? 2 : 1);  // vector-memory stores per unit
     (void)NSTORE;
     // image offset (inside its half image) of this lane's column of tile nt, row (lane >> 4);
     // padding columns go to the dump row
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
     // request of this lane's half of the pair (the last pair of an odd batch has no second
     // request: its lanes recompute the first one and the stores are skipped)
     auto lane_req = [&](long long p) -> long long {
-        long long r = 2 * p + sub;
+        long long r = RPW * p + sub;
         return r < a.nreq ? r : a.nreq - 1;
     };
     double xnext[SD];
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
 #pragma unroll
             for (int m4 = 0; m4 < M4; ++m4) a4[m4] = afr[((MT16 + m4) * KS + j) * 64 + lane];
 #pragma unroll
-            for (int rq = 0; rq < 2; ++rq) {
+            for (int rq = 0; rq < RPW; ++rq) {
                 double b[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) b[nt] = slab[(rq * NT + nt) * 64 + lane];
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
 
         // ---------------- D tiles -> half images -> HBM, one request of the pair after the other ----------------
         wqueue.service();  // the previous pair's stores have drained by now, the points were fetched long ago
-        const bool second = 2 * pr + 1 < a.nreq;
+        const bool second = RPW * pr + 1 < a.nreq;
         // Everything the epilogue derives from the lane number (image offsets per row block,
         // chunk indices and 64-bit addresses of the stores: ~50 VGPRs) is recomputed here per
         // pair: left to itself hipcc hoists it out of the request loop and the K loop then
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
         if (!(a.debug & 4)) {
             wave_lds_fence();
 #pragma unroll
-            for (int rq = 0; rq < 2; ++rq) {
+            for (int rq = 0; rq < RPW; ++rq) {
 #pragma unroll
                 for (int half = 0; half < (NTAB > TH ? 2 : 1); ++half) {
 #pragma unroll
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
                     wave_lds_fence();
                     // the missing second request of an odd batch is written onto the first
                     // (same values), which keeps the store count per pair constant
-                    long long oreq = rq == 0 || second ? 2 * pr + rq : 2 * pr;
+                    long long oreq = rq == 0 || second ? RPW * pr + rq : RPW * pr;
                     if (FX_DBG & 64) oreq &= 1023;  // ablation: L2-resident output window
                     flush_half(oreq, half);
                     wave_lds_fence();

@@ -408,3 +408,32 @@ def test_p3_tet_paired_kernel_point_counts(rt, golden, npts, nreq, cells):
     den = np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))
     err = (num / den).max(axis=0)
     assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
+
+
+@pytest.mark.parametrize("fam,deg", [("Lagrange", 4), ("RaviartThomas", 2), ("DiscontinuousLagrange", 4)])
+@pytest.mark.parametrize("npts", [21, 23, 24])
+@pytest.mark.parametrize("nreq,cells", [(1, False), (3, True), (2049, False), (1500, True)])
+def test_one_request_per_wave_instances(rt, fam, deg, npts, nreq, cells):
+    """P4 / RT2 tetrahedra: the K-streamed kernel with one request per wave and a half-request image."""
+    import fiat_amd
+    from oracle import c_oracle
+    el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(3), deg)
+    ps = el.device_polyset()
+    assert ps.kernel_name(1, nreq, npts, has_verts=cells) == "fxk::tabulate_simplex_pair"
+    rng = np.random.default_rng(7000 + 10 * npts + nreq + deg)
+    pts = rand_points(rng, 3, (nreq, npts))
+    verts = None
+    if cells:
+        A = np.eye(3) + 0.1 * rng.standard_normal((nreq, 3, 3))
+        b = rng.standard_normal((nreq, 1, 3))
+        verts = np.einsum("vd,red->rve", fo.UFC_SIMPLEX[3], A) + b
+        pts = np.einsum("rpd,red->rpe", pts, A) + b
+    out = ps.tabulate_batch(1, pts, verts=verts).cpu().numpy()
+    n = deg if fam != "RaviartThomas" else 2
+    ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[3], n, el.get_coeffs(), 1, pts, verts=verts, scale=el._expansion_scale,
+                                  variant=el._expansion_variant).reshape(out.shape)
+    axes = tuple(range(2, out.ndim))
+    num = np.abs(out - ref).max(axis=axes)
+    den = np.maximum(1.0, np.abs(ref).max(axis=axes))
+    err = (num / den).max(axis=0)
+    assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
