@@ -523,6 +523,8 @@ const FixedShape kFixedShapes[] = {
     {3, 3, 1, 20, 5, true, 2, true},   // ... 17..20 points
     {3, 3, 1, 20, 4, true, 2, true},   // ... 13..16 points
     {3, 3, 1, 20, 3, true, 2, true},   // ... 9..12 points
+    {3, 3, 1, 20, 8, true, 1, false},  // P3 tetrahedron, 29..32 points: one request per wave, half image
+    {3, 3, 1, 20, 12, true, 1, false}, // ... 41..48 points
     {3, 2, 1, 45, 6, true, 1, false},  // RT2 tetrahedron (15 x 3 rows), 21..24 points: one request per wave, half image
     {3, 4, 1, 35, 6, true, 1, false},  // Lagrange P4 tetrahedron, 21..24 points
 };
@@ -737,8 +739,10 @@ int run_fixed(const Launch& L, hipStream_t s) {
         case 1: return launch_fixed<3, 3, 1, 20, 5, true>(L, s);
         case 2: return launch_fixed<3, 3, 1, 20, 4, true>(L, s);
         case 3: return launch_fixed<3, 3, 1, 20, 3, true>(L, s);
-        case 4: return launch_fixed<3, 2, 1, 45, 6, true, 1, false>(L, s);
-        case 5: return launch_fixed<3, 4, 1, 35, 6, true, 1, false>(L, s);
+        case 4: return launch_fixed<3, 3, 1, 20, 8, true, 1, false>(L, s);
+        case 5: return launch_fixed<3, 3, 1, 20, 12, true, 1, false>(L, s);
+        case 6: return launch_fixed<3, 2, 1, 45, 6, true, 1, false>(L, s);
+        case 7: return launch_fixed<3, 4, 1, 35, 6, true, 1, false>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown fixed kernel %d", L.fixed_id);
 }
@@ -912,7 +916,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
         const int nt_need = (ntab * npts + 15) / 16;
         for (size_t i = 0; i < sizeof(kFixedShapes) / sizeof(kFixedShapes[0]); ++i) {
             const FixedShape& f = kFixedShapes[i];
-            if (f.sd != e->sd || f.n != e->n || f.order != order || f.rows != rows || f.nt != nt_need) continue;
+            // (half-image shapes keep the tables of each half in their own tiles: one spare tile is fine)
+            const bool nt_ok = f.nt == nt_need || (!f.fullimg && f.nt == nt_need + 1);
+            if (f.sd != e->sd || f.n != e->n || f.order != order || f.rows != rows || !nt_ok) continue;
             bool ok = false;
             if (e->sd == 3 && e->n == 2) ok = table_matches<3, 2>(e->prog);
             if (e->sd == 3 && e->n == 3) ok = table_matches<3, 3>(e->prog);
