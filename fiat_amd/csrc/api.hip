@@ -523,7 +523,8 @@ const FixedShape kFixedShapes[] = {
     {3, 3, 1, 20, 5, true, 2, true},   // ... 17..20 points
     {3, 3, 1, 20, 4, true, 2, true},   // ... 13..16 points
     {3, 3, 1, 20, 3, true, 2, true},   // ... 9..12 points
-    {3, 3, 1, 20, 8, true, 1, false},  // P3 tetrahedron, 29..32 points: one request per wave, half image
+    {3, 3, 1, 20, 8, true, 1, false},  // P3 tetrahedron, 25..32 points: one request per wave, half image
+    {3, 3, 1, 20, 10, true, 1, false}, // ... 33..40 points
     {3, 3, 1, 20, 12, true, 1, false}, // ... 41..48 points
     {3, 2, 1, 45, 6, true, 1, false},  // RT2 tetrahedron (15 x 3 rows), 21..24 points: one request per wave, half image
     {3, 4, 1, 35, 6, true, 1, false},  // Lagrange P4 tetrahedron, 21..24 points
@@ -740,9 +741,10 @@ int run_fixed(const Launch& L, hipStream_t s) {
         case 2: return launch_fixed<3, 3, 1, 20, 4, true>(L, s);
         case 3: return launch_fixed<3, 3, 1, 20, 3, true>(L, s);
         case 4: return launch_fixed<3, 3, 1, 20, 8, true, 1, false>(L, s);
-        case 5: return launch_fixed<3, 3, 1, 20, 12, true, 1, false>(L, s);
-        case 6: return launch_fixed<3, 2, 1, 45, 6, true, 1, false>(L, s);
-        case 7: return launch_fixed<3, 4, 1, 35, 6, true, 1, false>(L, s);
+        case 5: return launch_fixed<3, 3, 1, 20, 10, true, 1, false>(L, s);
+        case 6: return launch_fixed<3, 3, 1, 20, 12, true, 1, false>(L, s);
+        case 7: return launch_fixed<3, 2, 1, 45, 6, true, 1, false>(L, s);
+        case 8: return launch_fixed<3, 4, 1, 35, 6, true, 1, false>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown fixed kernel %d", L.fixed_id);
 }
