@@ -517,17 +517,19 @@ struct FixedShape {
     bool pair_only;  // only the paired kernel is instantiated (no A/B partners)
     int rpw;         // requests per wave of the paired kernel: 2, or 1 for shapes with many rows / > 32 points
     bool fullimg;    // LDS image of a whole request (false: half of its tables)
+    int nw;          // waves per workgroup of the paired kernel (8 = a whole CU; fewer when the images are large)
 };
 const FixedShape kFixedShapes[] = {
-    {3, 3, 1, 20, 6, false, 2, true},  // Lagrange P3 tetrahedron, values + gradient, 21..24 points (the benchmark shape)
-    {3, 3, 1, 20, 5, true, 2, true},   // ... 17..20 points
-    {3, 3, 1, 20, 4, true, 2, true},   // ... 13..16 points
-    {3, 3, 1, 20, 3, true, 2, true},   // ... 9..12 points
-    {3, 3, 1, 20, 8, true, 1, false},  // P3 tetrahedron, 25..32 points: one request per wave, half image
-    {3, 3, 1, 20, 10, true, 1, false}, // ... 33..40 points
-    {3, 3, 1, 20, 12, true, 1, false}, // ... 41..48 points
-    {3, 2, 1, 45, 6, true, 1, false},  // RT2 tetrahedron (15 x 3 rows), 21..24 points: one request per wave, half image
-    {3, 4, 1, 35, 6, true, 1, false},  // Lagrange P4 tetrahedron, 21..24 points
+    {3, 3, 1, 20, 6, false, 2, true, 8},  // Lagrange P3 tetrahedron, values + gradient, 21..24 points (the benchmark shape)
+    {3, 3, 1, 20, 5, true, 2, true, 8},   // ... 17..20 points
+    {3, 3, 1, 20, 4, true, 2, true, 8},   // ... 13..16 points
+    {3, 3, 1, 20, 3, true, 2, true, 8},   // ... 9..12 points
+    {3, 3, 1, 20, 8, true, 1, false, 8},  // P3 tetrahedron, 25..32 points: one request per wave, half image
+    {3, 3, 1, 20, 10, true, 1, false, 8}, // ... 33..40 points
+    {3, 3, 1, 20, 12, true, 1, false, 8}, // ... 41..48 points
+    {3, 2, 1, 45, 6, true, 1, false, 8},  // RT2 tetrahedron (15 x 3 rows), 21..24 points: one request per wave, half image
+    {3, 4, 1, 35, 6, true, 1, false, 8},  // Lagrange P4 tetrahedron, 21..24 points
+    {3, 2, 1, 60, 6, true, 1, false, 6},  // N2 tetrahedron (20 x 3 rows), 21..24 points: 22 KB half images, six waves
 };
 
 template <int SD, int N>
@@ -580,7 +582,7 @@ hipError_t report_wave_lifetimes(const double* trash, int grid, int wg_waves) {
 
 // PAIR_ONLY: only the paired kernel is instantiated for this shape (the A/B partners
 // `stream` and `image` exist for the benchmark shape)
-template <int SD, int N, int ORDER, int ROWS, int NT, bool PAIR_ONLY = false, int RPW = 2, bool FULLIMG = true>
+template <int SD, int N, int ORDER, int ROWS, int NT, bool PAIR_ONLY = false, int RPW = 2, bool FULLIMG = true, int PAIR_NW = 8>
 int launch_fixed(const Launch& L, hipStream_t s) {
     using KernT = void (*)(const fxk::FixedArgs<fxk::FixedNC<SD, N>::value>);
     constexpr int NC = fxk::FixedNC<SD, N>::value;
@@ -601,7 +603,7 @@ int launch_fixed(const Launch& L, hipStream_t s) {
     memcpy(fa.coef, L.fcoef.data(), NC * sizeof(double));
     memcpy(fa.ucoef, L.fucoef.data(), 4 * NC * sizeof(double));
     if (L.fkind == 2) {
-        constexpr int PAIR_NW = 8;  // one 512-thread workgroup per CU, two waves per SIMD, LDS work counter
+        // PAIR_NW = 8: one 512-thread workgroup per CU, two waves per SIMD; LDS work counter
         using KernP = void (*)(const fxk::FixedArgs<NC>, double*, unsigned int*);
         KernP kp = L.fhead.verts ? (KernP)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, PAIR_NW, false, RPW, FULLIMG>
                                  : (KernP)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, PAIR_NW, true, RPW, FULLIMG>;
@@ -745,6 +747,7 @@ int run_fixed(const Launch& L, hipStream_t s) {
         case 6: return launch_fixed<3, 3, 1, 20, 12, true, 1, false>(L, s);
         case 7: return launch_fixed<3, 2, 1, 45, 6, true, 1, false>(L, s);
         case 8: return launch_fixed<3, 4, 1, 35, 6, true, 1, false>(L, s);
+        case 9: return launch_fixed<3, 2, 1, 60, 6, true, 1, false, 6>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown fixed kernel %d", L.fixed_id);
 }
