@@ -518,18 +518,19 @@ struct FixedShape {
     int rpw;         // requests per wave of the paired kernel: 2, or 1 for shapes with many rows / > 32 points
     bool fullimg;    // LDS image of a whole request (false: half of its tables)
     int nw;          // waves per workgroup of the paired kernel (8 = a whole CU; fewer when the images are large)
+    bool can_piola;  // an instance with the Piola map applied to the LDS image exists (vector-valued, per-request cells)
 };
 const FixedShape kFixedShapes[] = {
-    {3, 3, 1, 20, 6, false, 2, true, 8},  // Lagrange P3 tetrahedron, values + gradient, 21..24 points (the benchmark shape)
-    {3, 3, 1, 20, 5, true, 2, true, 8},   // ... 17..20 points
-    {3, 3, 1, 20, 4, true, 2, true, 8},   // ... 13..16 points
-    {3, 3, 1, 20, 3, true, 2, true, 8},   // ... 9..12 points
-    {3, 3, 1, 20, 8, true, 1, false, 8},  // P3 tetrahedron, 25..32 points: one request per wave, half image
-    {3, 3, 1, 20, 10, true, 1, false, 8}, // ... 33..40 points
-    {3, 3, 1, 20, 12, true, 1, false, 8}, // ... 41..48 points
-    {3, 2, 1, 45, 6, true, 1, false, 8},  // RT2 tetrahedron (15 x 3 rows), 21..24 points: one request per wave, half image
-    {3, 4, 1, 35, 6, true, 1, false, 8},  // Lagrange P4 tetrahedron, 21..24 points
-    {3, 2, 1, 60, 6, true, 1, false, 6},  // N2 tetrahedron (20 x 3 rows), 21..24 points: 22 KB half images, six waves
+    {3, 3, 1, 20, 6, false, 2, true, 8, false},  // Lagrange P3 tetrahedron, values + gradient, 21..24 points (the benchmark shape)
+    {3, 3, 1, 20, 5, true, 2, true, 8, false},   // ... 17..20 points
+    {3, 3, 1, 20, 4, true, 2, true, 8, false},   // ... 13..16 points
+    {3, 3, 1, 20, 3, true, 2, true, 8, false},   // ... 9..12 points
+    {3, 3, 1, 20, 8, true, 1, false, 8, false},  // P3 tetrahedron, 25..32 points: one request per wave, half image
+    {3, 3, 1, 20, 10, true, 1, false, 8, false}, // ... 33..40 points
+    {3, 3, 1, 20, 12, true, 1, false, 8, false}, // ... 41..48 points
+    {3, 2, 1, 45, 6, true, 1, false, 8, true},   // RT2 tetrahedron (15 x 3 rows), 21..24 points: one request per wave, half image
+    {3, 4, 1, 35, 6, true, 1, false, 8, false},  // Lagrange P4 tetrahedron, 21..24 points
+    {3, 2, 1, 60, 6, true, 1, false, 6, true},   // N2 tetrahedron (20 x 3 rows), 21..24 points: 22 KB half images, six waves
 };
 
 template <int SD, int N>
@@ -582,7 +583,8 @@ hipError_t report_wave_lifetimes(const double* trash, int grid, int wg_waves) {
 
 // PAIR_ONLY: only the paired kernel is instantiated for this shape (the A/B partners
 // `stream` and `image` exist for the benchmark shape)
-template <int SD, int N, int ORDER, int ROWS, int NT, bool PAIR_ONLY = false, int RPW = 2, bool FULLIMG = true, int PAIR_NW = 8>
+template <int SD, int N, int ORDER, int ROWS, int NT, bool PAIR_ONLY = false, int RPW = 2, bool FULLIMG = true, int PAIR_NW = 8,
+          bool CAN_PIOLA = false>
 int launch_fixed(const Launch& L, hipStream_t s) {
     using KernT = void (*)(const fxk::FixedArgs<fxk::FixedNC<SD, N>::value>);
     constexpr int NC = fxk::FixedNC<SD, N>::value;
@@ -607,6 +609,10 @@ int launch_fixed(const Launch& L, hipStream_t s) {
         using KernP = void (*)(const fxk::FixedArgs<NC>, double*, unsigned int*);
         KernP kp = L.fhead.verts ? (KernP)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, PAIR_NW, false, RPW, FULLIMG>
                                  : (KernP)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, PAIR_NW, true, RPW, FULLIMG>;
+        if ((fa.debug >> 16) & 3) {  // fused Piola push-forward
+            if constexpr (CAN_PIOLA) kp = (KernP)fxk::tabulate_simplex_pair<SD, N, ORDER, ROWS, NT, PAIR_NW, false, RPW, FULLIMG, true>;
+            else return fail(FX_EINVAL, "internal: no fused push-forward for this shape");
+        }
         const int lds_bytes = fxk::WQ_CTL_DOUBLES * 8 + (L.flds_bytes - (int)(fa.lds_doubles * 8) * FIXED_NW) + (int)(fa.lds_doubles * 8) * PAIR_NW;
         // attribute and occupancy are properties of (kernel, LDS size): asked once, not per launch
         static thread_local const void* cached_kp = nullptr;
@@ -745,9 +751,9 @@ int run_fixed(const Launch& L, hipStream_t s) {
         case 4: return launch_fixed<3, 3, 1, 20, 8, true, 1, false>(L, s);
         case 5: return launch_fixed<3, 3, 1, 20, 10, true, 1, false>(L, s);
         case 6: return launch_fixed<3, 3, 1, 20, 12, true, 1, false>(L, s);
-        case 7: return launch_fixed<3, 2, 1, 45, 6, true, 1, false>(L, s);
+        case 7: return launch_fixed<3, 2, 1, 45, 6, true, 1, false, 8, true>(L, s);
         case 8: return launch_fixed<3, 4, 1, 35, 6, true, 1, false>(L, s);
-        case 9: return launch_fixed<3, 2, 1, 60, 6, true, 1, false, 6>(L, s);
+        case 9: return launch_fixed<3, 2, 1, 60, 6, true, 1, false, 6, true>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown fixed kernel %d", L.fixed_id);
 }
@@ -917,13 +923,16 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     // ---- shape-specialised kernel available? ----
     L.fixed_id = -1;
     const char* nofixed = getenv("FIAT_AMD_NO_FIXED");
-    if (!(nofixed && atoi(nofixed)) && npts <= 64 && !L.fused_mapping) {  // (a fused push-forward lives in the cooperative kernel)
+    if (!(nofixed && atoi(nofixed)) && npts <= 64) {
         const int nt_need = (ntab * npts + 15) / 16;
         for (size_t i = 0; i < sizeof(kFixedShapes) / sizeof(kFixedShapes[0]); ++i) {
             const FixedShape& f = kFixedShapes[i];
             // (half-image shapes keep the tables of each half in their own tiles: one spare tile is fine)
             const bool nt_ok = f.nt == nt_need || (!f.fullimg && f.nt == nt_need + 1);
             if (f.sd != e->sd || f.n != e->n || f.order != order || f.rows != rows || !nt_ok) continue;
+            const bool want_piola = mapping != FX_MAP_AFFINE;
+            const bool fuse_here = want_piola && f.can_piola && verts && e->vdim == e->sd;
+            if (L.fused_mapping && !fuse_here) continue;  // the cooperative kernel fuses the map, this one cannot
             bool ok = false;
             if (e->sd == 3 && e->n == 2) ok = table_matches<3, 2>(e->prog);
             if (e->sd == 3 && e->n == 3) ok = table_matches<3, 3>(e->prog);
@@ -983,7 +992,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             memcpy(fa.b0, e->b0, sizeof fa.b0);
             fa.nreq = nreq;
             fa.npts = npts;
-            fa.debug = a.debug;
+            fa.debug = (a.debug & 0xffff) | (fuse_here ? (mapping << 16) : 0);
             long long need = std::max<long long>((long long)f.nt * e->KS * 64, (long long)ntab * rows * npts);
             need = (need + 1) & ~1LL;
             if (L.fkind >= 1) {
@@ -1005,9 +1014,12 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 long long nwg = (units + FIXED_NW - 1) / FIXED_NW;
                 L.fgrid = (int)std::max<long long>(1, std::min<long long>(nwg, L.fkind >= 2 ? nwg : want));
                 if (L.flds_bytes > ctx->lds_per_cu) continue;
+                if (fuse_here && L.fkind != 2) continue;
+                if (fuse_here) L.fused_mapping = true;
                 L.fixed_id = (int)i;
                 break;
             }
+            if (fuse_here) continue;
             // 8 waves per CU (2 workgroups of 4 waves): pad the request to 1/2 of the CU's LDS
             long long per_wave = std::max<long long>(need * 8, (long long)(ctx->lds_per_cu / 8));
             per_wave &= ~15LL;

@@ -34,7 +34,11 @@ namespace fxk {
 // of <= 64 points per wave -- shapes whose accumulators leave no room for a second request (many rows)
 // or with more than 32 points; everything else is the same kernel.  FULLIMG: the LDS image holds a
 // whole request (one write / read-back round per request) or half of its tables (large requests).
-template <int SD, int N, int ORDER, int ROWS, int NT, int NW, bool UNIFORM, int RPW = 2, bool FULLIMG = (FX_PAIR_FULLIMG != 0)>
+// PIOLA: vector-valued elements (ROWS = ndof * SD, per-request cells): the covariant / contravariant
+// Piola map of the request (kind in bits 16-17 of a.debug) is applied to the LDS image in place before it
+// is copied out -- lane <-> (dof, point), the SD components of a dof are SD rows of the image.
+template <int SD, int N, int ORDER, int ROWS, int NT, int NW, bool UNIFORM, int RPW = 2, bool FULLIMG = (FX_PAIR_FULLIMG != 0),
+          bool PIOLA = false>
 __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(const FixedArgs<FixedNC<SD, N>::value> a,
                                                                                 double* __restrict__ trash,
                                                                                 unsigned int* __restrict__ gqueue) {
@@ -45,6 +49,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
     constexpr int MT16 = rows_full16(ROWS);
     constexpr int M4 = rows_blk4(ROWS);
     static_assert(RPW == 1 || RPW == 2, "one or two requests per wave");
+    static_assert(!PIOLA || (!UNIFORM && ROWS % SD == 0), "the Piola map needs per-request cells and SD components per dof");
     constexpr int NT2 = RPW * NT;  // column tiles of the unit: [0, NT) request RPW*i, [NT, 2NT) request 2i+1
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63;
@@ -64,7 +69,30 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
     CDouble* kcoef = (CDouble*)(kargs + __builtin_offsetof(ArgsT, coef));
     CDouble* kucoef = (CDouble*)(kargs + __builtin_offsetof(ArgsT, ucoef));
 
-    const int npts = a.npts;  // <= 32 (host-checked)
+    const int npts = a.npts;  // <= 32 * (3 - RPW) (host-checked)
+    double a0inv[SD][SD];  // inverse of the element's own cell map (Piola: K = A0inv * A_req)
+    if constexpr (PIOLA) {
+        if constexpr (SD == 2) {
+            const double det = a.A0[0] * a.A0[3] - a.A0[1] * a.A0[2];
+            a0inv[0][0] = a.A0[3] / det;
+            a0inv[0][1] = -a.A0[1] / det;
+            a0inv[1][0] = -a.A0[2] / det;
+            a0inv[1][1] = a.A0[0] / det;
+        } else {
+            const double* A = a.A0;
+            const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+            const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+            a0inv[0][0] = c00 / det;
+            a0inv[0][1] = (A[2] * A[7] - A[1] * A[8]) / det;
+            a0inv[0][2] = (A[1] * A[5] - A[2] * A[4]) / det;
+            a0inv[1][0] = c01 / det;
+            a0inv[1][1] = (A[0] * A[8] - A[2] * A[6]) / det;
+            a0inv[1][2] = (A[2] * A[3] - A[0] * A[5]) / det;
+            a0inv[2][0] = c02 / det;
+            a0inv[2][1] = (A[1] * A[6] - A[0] * A[7]) / det;
+            a0inv[2][2] = (A[0] * A[4] - A[1] * A[3]) / det;
+        }
+    }
     const int table = ROWS * npts;
 
     for (int i = lane; i < a.lds_doubles; i += 64) img[i] = 0.0;
@@ -140,6 +168,7 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
     while (true) {
         double X[SD];
         double J[SD][SD];
+        double Mreq[RPW][SD][SD];  // (PIOLA only)
         {
             double x[SD];
 #pragma unroll
@@ -153,6 +182,43 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
             double bb[SD];
             if constexpr (!UNIFORM) {
                 cell_map<SD>(a.verts + (size_t)lane_req(pr) * (SD + 1) * SD, J, bb);  // per lane: two cells per wave
+                if constexpr (PIOLA) {
+                    // Piola matrix of each request of the unit, wave uniform (scalar registers): K = A0inv * A_req
+                    // read from a lane of that request; covariant J^{-T} = K^T, contravariant J / det J = adj(K)
+                    const int kind = (a.debug >> 16) & 3;
+#pragma unroll
+                    for (int rq = 0; rq < RPW; ++rq) {
+                        double Km[SD][SD];
+#pragma unroll
+                        for (int c = 0; c < SD; ++c)
+#pragma unroll
+                            for (int d = 0; d < SD; ++d) {
+                                double t = 0.0;
+#pragma unroll
+                                for (int k = 0; k < SD; ++k) {
+                                    const int lo = __builtin_amdgcn_readlane(__double2loint(J[k][d]), 32 * rq);
+                                    const int hi = __builtin_amdgcn_readlane(__double2hiint(J[k][d]), 32 * rq);
+                                    t += a0inv[c][k] * __hiloint2double(hi, lo);
+                                }
+                                Km[c][d] = t;
+                            }
+#pragma unroll
+                        for (int c = 0; c < SD; ++c)
+#pragma unroll
+                            for (int e = 0; e < SD; ++e) {
+                                double v = Km[e][c];
+                                if (kind == 2) {
+                                    if constexpr (SD == 2) v = (c == e ? Km[1 - c][1 - e] : -Km[c][e]);
+                                    else if constexpr (SD == 3) {
+                                        constexpr int nx[3] = {1, 2, 0}, nn[3] = {2, 0, 1};
+                                        v = Km[nx[e]][nx[c]] * Km[nn[e]][nn[c]] - Km[nx[e]][nn[c]] * Km[nn[e]][nx[c]];
+                                    }
+                                }
+                                Mreq[rq][c][e] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                                                                  __builtin_amdgcn_readfirstlane(__double2loint(v)));
+                            }
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < SD; ++i) {
                     double t = bb[i];
@@ -357,6 +423,34 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
 #pragma unroll
                     for (int nt = 0; nt < NTH; ++nt) image_tile(rq, half * NTH + nt);
                     wave_lds_fence();
+                    if constexpr (PIOLA) {
+                        double Mp[SD][SD];
+#pragma unroll
+                        for (int c = 0; c < SD; ++c)
+#pragma unroll
+                            for (int e = 0; e < SD; ++e) Mp[c][e] = Mreq[rq][c][e];
+                        // blocks of SD rows = one dof of one table of this image
+                        const float prinv = 1.0f / (float)enpts;
+                        const int lb = idiv_small(elane, prinv), lq = elane - lb * enpts;
+                        const int per = idiv_small(64, prinv);
+                        const int nblk = (half == 0 ? TH : NTAB - TH) * (ROWS / SD);
+                        for (int b0 = 0; b0 < nblk; b0 += per) {
+                            const int b = b0 + lb;
+                            const bool on = lb < per && b < nblk;
+                            double* q = img + (on ? b * SD * enpts + lq : dump + elane);
+                            double xin[SD];
+#pragma unroll
+                            for (int c = 0; c < SD; ++c) xin[c] = on ? q[c * enpts] : 0.0;
+#pragma unroll
+                            for (int c = 0; c < SD; ++c) {
+                                double y = 0.0;
+#pragma unroll
+                                for (int e = 0; e < SD; ++e) y += Mp[c][e] * xin[e];
+                                if (on) q[c * enpts] = y;
+                            }
+                        }
+                        wave_lds_fence();
+                    }
                     // the missing second request of an odd batch is written onto the first
                     // (same values), which keeps the store count per pair constant
                     long long oreq = rq == 0 || second ? RPW * pr + rq : RPW * pr;
