@@ -21,6 +21,7 @@
 #include "shared_points.hpp"
 #include "quadrature.hpp"
 #include "simplex_small.hpp"
+#include "table_kernels.hpp"
 
 namespace {
 
@@ -1314,6 +1315,33 @@ int fx_collapsed_quadrature(fx_ctx* ctx, int sd, int m, const double* verts, dou
     if (sd == 1) hipLaunchKernelGGL(fxk::collapsed_rule_kernel<1>, dim3(grid), dim3(256), 0, s, ra);
     if (sd == 2) hipLaunchKernelGGL(fxk::collapsed_rule_kernel<2>, dim3(grid), dim3(256), 0, s, ra);
     if (sd == 3) hipLaunchKernelGGL(fxk::collapsed_rule_kernel<3>, dim3(grid), dim3(256), 0, s, ra);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+int fx_classify_tables(fx_ctx* ctx, int64_t ntables, int rows, int npts, double rtol, const double* tables, double* stats,
+                       void* stream) {
+    if (!ctx) return fail(FX_EINVAL, "null context");
+    if (ntables < 0 || rows < 1 || npts < 1) return fail(FX_EINVAL, "bad table shape (%lld, %d, %d)", (long long)ntables, rows, npts);
+    if (ntables > 0x7fffffffLL) return fail(FX_EINVAL, "too many tables for one launch");
+    if ((long long)rows * npts > 0x7fffffffLL) return fail(FX_EINVAL, "table too large");
+    if (ntables == 0) return FX_OK;
+    if (!tables || !stats) return fail(FX_EINVAL, "null device pointer");
+    fxk::ClassifyArgs ca{tables, stats, rows, npts, rtol};
+    hipLaunchKernelGGL(fxk::classify_tables_kernel, dim3((unsigned)ntables), dim3(256), 0, (hipStream_t)stream, ca);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+int fx_tables_point_major(fx_ctx* ctx, int64_t ntables, int rows, int npts, const double* in, double* out, void* stream) {
+    if (!ctx) return fail(FX_EINVAL, "null context");
+    if (ntables < 0 || rows < 1 || npts < 1) return fail(FX_EINVAL, "bad table shape (%lld, %d, %d)", (long long)ntables, rows, npts);
+    if (ntables == 0) return FX_OK;
+    if (!in || !out || in == out) return fail(FX_EINVAL, "null or aliased device pointers");
+    const long long tiles = (long long)((rows + 31) / 32) * ((npts + 31) / 32);
+    if (ntables * tiles > 0x7fffffffLL) return fail(FX_EINVAL, "too many tiles for one launch");
+    fxk::PointMajorArgs pa{in, out, rows, npts};
+    hipLaunchKernelGGL(fxk::point_major_kernel, dim3((unsigned)(ntables * tiles)), dim3(256), 0, (hipStream_t)stream, pa);
     HIP_TRY(hipGetLastError());
     return FX_OK;
 }

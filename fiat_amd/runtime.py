@@ -215,6 +215,38 @@ def collapsed_quadrature(sd, m, verts=None, ctx=None, stream=None):
     return pts, wts
 
 
+def classify_tables(tables, rtol=1e-5, ctx=None, stream=None):
+    """Per table of a device tensor ``tables[..., rows, npts]``: (max |x|, max(|x - x[..., :1]| - rtol |x[..., :1]|))
+    as a device tensor ``[..., 2]`` (fx_classify_tables; what finat/fiat_elements.py:92-111 asserts)."""
+    ctx = ctx or Context.get()
+    tables = _as_device(tables, ctx)
+    if tables.dim() < 2:
+        raise ValueError("tables must have shape (..., rows, npts)")
+    rows, npts = tables.shape[-2:]
+    lead = tuple(tables.shape[:-2])
+    ntables = int(np.prod(lead, dtype=np.int64)) if lead else 1
+    stats = torch.empty(lead + (2,), dtype=torch.float64, device=ctx.device)
+    check(lib.fx_classify_tables(ctx.handle, ntables, int(rows), int(npts), float(rtol), _dev_ptr(tables), _dev_ptr(stats),
+                                 _stream_ptr(stream)))
+    return stats
+
+
+def tables_point_major(tables, out=None, ctx=None, stream=None):
+    """``tables[..., rows, npts]`` -> a new contiguous device tensor ``[..., npts, rows]`` (fx_tables_point_major)."""
+    ctx = ctx or Context.get()
+    tables = _as_device(tables, ctx)
+    if tables.dim() < 2:
+        raise ValueError("tables must have shape (..., rows, npts)")
+    rows, npts = tables.shape[-2:]
+    lead = tuple(tables.shape[:-2])
+    ntables = int(np.prod(lead, dtype=np.int64)) if lead else 1
+    if out is None:
+        out = torch.empty(lead + (npts, rows), dtype=torch.float64, device=ctx.device)
+    check(lib.fx_tables_point_major(ctx.handle, ntables, int(rows), int(npts), _dev_ptr(tables), _dev_ptr(out),
+                                    _stream_ptr(stream)))
+    return out
+
+
 def riesz_assemble(wts, expvals, ctx=None):
     """mat[i, k] = sum_q wts[i, q] expvals[k, q] on the device."""
     ctx = ctx or Context.get()

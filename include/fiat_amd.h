@@ -198,6 +198,20 @@ int fx_tabulate_batch_shared(fx_ctx* ctx, const fx_element* elem, int mapping, i
 int fx_collapsed_quadrature(fx_ctx* ctx, int sd, int m, const double* verts, double* pts,
                             double* wts, void* stream);
 
+/* ---- the FInAT side of the boundary ---------------------------
+ * What finat/fiat_elements.py:92-111 (FiatElement.basis_evaluation) checks about each FIAT table
+ * before it becomes a GEM literal, for `ntables` device-resident tables [rows][npts] at once:
+ * stats[t][0] = max |x| (a table of derivative order > degree must be zero, :104-108),
+ * stats[t][1] = max (|x - x[.., 0]| - rtol |x[.., 0]|) (derivative order == degree on a simplex:
+ * constant over the points, numpy.allclose(table, table[..., 0, None]), :96-103; compare with
+ * numpy's atol).  NaN entries give NaN stats.  tables, stats[ntables][2]: device pointers. */
+int fx_classify_tables(fx_ctx* ctx, int64_t ntables, int rows, int npts, double rtol,
+                       const double* tables, double* stats, void* stream);
+/* [ntables][rows][npts] -> [ntables][npts][rows]: the layout FInAT hands tables to generated kernels
+ * in (finat/runtime_tabulated.py:79: point extents, then index_shape + value_shape).  in != out. */
+int fx_tables_point_major(fx_ctx* ctx, int64_t ntables, int rows, int npts, const double* in,
+                          double* out, void* stream);
+
 /* Name of the device kernel fx_tabulate_batch would launch for this element and request shape
  * ("fxk::tabulate_simplex_stream", "..._fixed", "..._coop" or the generic "..._kernel"); has_verts != 0
  * stands for per-request cell geometry.  Lets benchmarks and tests name the kernel they measured

@@ -1,0 +1,171 @@
+"""FInAT-side adapter: the arrays finat/fiat_elements.py:60-123 would wrap in GEM
+literals, the run-time-tabulated arguments (finat/runtime_tabulated.py:68-95) and the factor tables of
+finat/tensor_product.py:103-144, served from device tables.  finat itself is not importable in the build
+container (needs ufl): the expected values restate the cited lines on top of FIAT-parity tabulations."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import fiat_amd
+    from fiat_amd import finat_adapter
+    return fiat_amd, finat_adapter
+
+
+def simplex_points(sd, n, seed):
+    e = np.random.default_rng(seed).exponential(size=(n, sd + 1))
+    return (e / e.sum(axis=1, keepdims=True))[:, 1:]
+
+
+@pytest.mark.parametrize("family,sd,degree,order", [("Lagrange", 2, 1, 2), ("Lagrange", 3, 2, 2), ("Lagrange", 3, 3, 1),
+                                                    ("DiscontinuousLagrange", 3, 1, 2), ("Nedelec", 3, 2, 2),
+                                                    ("RaviartThomas", 2, 1, 2)])
+def test_basis_evaluation_kinds(fa, family, sd, degree, order):
+    fiat_amd, ad = fa
+    el = getattr(fiat_amd, family)(fiat_amd.ufc_simplex(sd), degree)
+    fe = ad.FiatElement(el)
+    ps = ad.PointSet(simplex_points(sd, 7, 3))
+    res = fe.basis_evaluation(order, ps)
+    raw = el.tabulate(order, ps.points)
+    assert set(res) == set(raw)
+    shape = (el.space_dimension(),) + tuple(el.value_shape())
+    for alpha, tab in res.items():
+        d = sum(alpha)
+        if d == el.degree():
+            assert tab.kind == ad.CELLWISE_CONSTANT and tab.shape == shape
+            np.testing.assert_allclose(tab.array, raw[alpha][..., 0], atol=1e-12)
+        elif d > el.degree():
+            assert tab.kind == ad.ZERO and tab.shape == shape and not tab.array.any()
+        else:
+            assert tab.kind == ad.POINTWISE and tab.shape == shape + (7,)
+            np.testing.assert_array_equal(tab.array, raw[alpha])
+    assert fe.index_shape == (el.space_dimension(),) and fe.degree == el.degree()
+    assert fe.mapping == el.mapping()[0] and fe.fiat_equivalent is el
+
+
+@pytest.mark.parametrize("family,degree,order,physical", [("Lagrange", 1, 2, True), ("Lagrange", 2, 2, False),
+                                                          ("Lagrange", 3, 1, True), ("Nedelec", 2, 2, True)])
+def test_basis_evaluation_batch(fa, family, degree, order, physical):
+    fiat_amd, ad = fa
+    sd, nreq, npts = 3, 64, 11
+    el = getattr(fiat_amd, family)(fiat_amd.ufc_simplex(sd), degree)
+    fe = ad.FiatElement(el)
+    rng = np.random.default_rng(5)
+    ref = np.array(fiat_amd.ufc_simplex(sd).get_vertices(), dtype=float)
+    pts = np.stack([simplex_points(sd, npts, 10 + r) for r in range(nreq)])
+    verts = None
+    if physical:
+        A = np.eye(sd) + 0.1 * rng.standard_normal((nreq, sd, sd))
+        b = rng.standard_normal((nreq, 1, sd))
+        verts = np.einsum("vd,red->rve", ref, A) + b
+        pts = np.einsum("rpd,red->rpe", pts, A) + b
+    res = fe.basis_evaluation_batch(order, pts, verts=verts)
+    full = el.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    alphas = [a for k in range(order + 1) for a in fiat_amd.mis(sd, k)]
+    assert list(res) == alphas
+    for t, alpha in enumerate(alphas):
+        tab, d = res[alpha], sum(alpha)
+        if d == el.degree():
+            assert tab.kind == ad.CELLWISE_CONSTANT
+            np.testing.assert_array_equal(tab.array.cpu().numpy(), full[:, t, ..., 0])
+            # constant on each cell, different between cells when the cells differ
+            assert np.abs(full[:, t] - full[:, t, ..., :1]).max() < 1e-9
+        elif d > el.degree():
+            assert tab.kind == ad.ZERO and not tab.array.cpu().numpy().any()
+            assert np.abs(full[:, t]).max() < 1e-9
+        else:
+            assert tab.kind == ad.POINTWISE
+            np.testing.assert_array_equal(tab.array.cpu().numpy(), full[:, t])
+
+
+def test_batch_check_raises_on_wrong_degree(fa):
+    """The device-side check is the reference's assertion: claim a lower degree and it must fire."""
+    fiat_amd, ad = fa
+    el = fiat_amd.Lagrange(fiat_amd.ufc_simplex(2), 3)
+
+    class Wrong(ad.FiatElement):
+        degree = 1
+
+    pts = np.stack([simplex_points(2, 6, r) for r in range(8)])
+    with pytest.raises(AssertionError):
+        Wrong(el).basis_evaluation_batch(2, pts)
+    with pytest.raises(AssertionError):
+        Wrong(el).basis_evaluation(2, ad.PointSet(pts[0]))
+
+
+@pytest.mark.parametrize("shape", [(5, 3, 20, 23), (2, 60, 23), (1, 1, 1), (3, 33, 65), (4, 7, 1)])
+def test_classify_and_point_major_kernels(fa, shape):
+    fiat_amd, ad = fa
+    from fiat_amd import runtime
+    rng = np.random.default_rng(sum(shape))
+    x = rng.standard_normal(shape)
+    x.reshape(-1, *shape[-2:])[0] = 0.0                                   # a zero table
+    if np.prod(shape[:-2]) > 1:
+        x.reshape(-1, *shape[-2:])[1] = rng.standard_normal(shape[-2])[:, None]  # constant along the points
+    stats = runtime.classify_tables(x, rtol=1e-5).cpu().numpy()
+    assert stats.shape == shape[:-2] + (2,)
+    np.testing.assert_array_equal(stats[..., 0], np.abs(x).max(axis=(-2, -1)))
+    expect = (np.abs(x - x[..., :1]) - 1e-5 * np.abs(x[..., :1])).max(axis=(-2, -1))
+    np.testing.assert_allclose(stats[..., 1], expect, rtol=0, atol=1e-15)
+    flat = stats.reshape(-1, 2)
+    assert flat[0, 0] == 0.0 and flat[0, 1] == 0.0
+    if len(flat) > 1:
+        assert flat[1, 1] <= 0.0
+    t = runtime.tables_point_major(x).cpu().numpy()
+    np.testing.assert_array_equal(t, np.swapaxes(x, -1, -2))
+    x.reshape(-1)[-1] = np.nan
+    assert np.isnan(runtime.classify_tables(x).cpu().numpy().reshape(-1, 2)[-1]).all()
+
+
+def test_runtime_tabulated_arguments(fa):
+    fiat_amd, ad = fa
+    cell = fiat_amd.ufc_simplex(1)
+    rt = ad.RuntimeTabulated(cell, 3, variant="equispaced", shift_axes=1, restriction='+', continuous=True)
+    ps = ad.PointSet(np.linspace(0.1, 0.9, 5)[:, None])
+    args = rt.basis_evaluation(2, ps)
+    assert [a.name for a in args.values()] == ["rt_equispaced_3_0_1_c_p", "rt_equispaced_3_1_1_c_p", "rt_equispaced_3_2_1_c_p"]
+    assert all(a.shape == (5, 4) for a in args.values())
+    assert rt.formdegree == 0 and rt.space_dimension() == 4
+    with pytest.raises(NotImplementedError):
+        rt.entity_dofs()
+    with pytest.raises(NotImplementedError):
+        ad.RuntimeTabulated(fiat_amd.ufc_simplex(2), 1, variant="x")
+    el = fiat_amd.Lagrange(cell, 3)
+    pts = np.sort(np.random.default_rng(1).uniform(size=(6, 5)), axis=1)
+    dev = rt.tabulate_arguments(2, pts, el)
+    assert sorted(dev) == sorted(a.name for a in args.values())
+    for k in range(3):
+        got = dev[rt.argument_name((k,))].cpu().numpy()
+        assert got.shape == (6, 5, 4)
+        for r in range(6):
+            np.testing.assert_allclose(got[r], el.tabulate(2, pts[r][:, None])[(k,)].T, rtol=0, atol=1e-11)
+    assert ad.RuntimeTabulated(cell, 2, variant="gll", continuous=False).argument_name((1,)) == "rt_gll_2_1_0_d_"
+
+
+def test_tensor_product_factor_tables(fa):
+    fiat_amd, ad = fa
+    cell = fiat_amd.ufc_simplex(1)
+    fes = [ad.FiatElement(fiat_amd.Lagrange(cell, 2)), ad.FiatElement(fiat_amd.Lagrange(cell, 3)),
+           ad.FiatElement(fiat_amd.DiscontinuousLagrange(cell, 1))]
+    tp = ad.TensorProductElement(fes)
+    assert tp.index_shape == (3, 4, 2)
+    pss = [ad.PointSet(np.linspace(0.05, 0.95, n)[:, None]) for n in (4, 5, 3)]
+    factor_results, deltas = tp.basis_evaluation(1, pss)
+    assert list(deltas) == [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)]
+    assert deltas[(0, 1, 0)] == ((0,), (1,), (0,))
+    # the product over factors reproduces the tensor-product element's own tabulation on the grid
+    T = fiat_amd.TensorProductElement(fiat_amd.TensorProductElement(fes[0].fiat_equivalent, fes[1].fiat_equivalent),
+                                      fes[2].fiat_equivalent)
+    grid = np.stack(np.meshgrid(*[ps.points[:, 0] for ps in pss], indexing="ij"), axis=-1).reshape(-1, 3)
+    full = T.tabulate(1, grid)
+    for Delta, ds in deltas.items():
+        arrs = []
+        for fr, d in zip(factor_results, ds):
+            tab = fr[d]
+            a = tab.array if tab.kind == ad.POINTWISE else tab.array[..., None] * np.ones(len(pss[len(arrs)].points))
+            arrs.append(a)
+        prod = np.einsum("ai,bj,ck->abcijk", *arrs).reshape(24, -1)
+        np.testing.assert_allclose(prod, full[Delta], rtol=0, atol=1e-11)
