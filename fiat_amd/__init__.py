@@ -22,6 +22,8 @@ from .lagrange import Lagrange  # noqa: F401
 from .discontinuous_lagrange import P0, DiscontinuousLagrange  # noqa: F401
 from .nedelec import Nedelec  # noqa: F401
 from .raviart_thomas import RaviartThomas  # noqa: F401
+from .brezzi_douglas_marini import BrezziDouglasMarini  # noqa: F401
+from .nedelec_second_kind import NedelecSecondKind  # noqa: F401
 from .tensor_product import FlattenedDimensions, TensorProductElement  # noqa: F401
 
 # the element registry of the reference (FIAT/__init__.py:72-131), in-scope subset
@@ -30,6 +32,8 @@ supported_elements = {
     "Discontinuous Lagrange": DiscontinuousLagrange,
     "Nedelec 1st kind H(curl)": Nedelec,
     "Raviart-Thomas": RaviartThomas,
+    "Brezzi-Douglas-Marini": BrezziDouglasMarini,
+    "Nedelec 2nd kind H(curl)": NedelecSecondKind,
     "TensorProductElement": TensorProductElement,
     "FlattenedDimensions": FlattenedDimensions,
 }

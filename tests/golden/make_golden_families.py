@@ -1,0 +1,44 @@
+"""Golden vectors for the wider-families row, generated from the
+*unmodified reference* in the build container:
+
+    PYTHONPATH=oracle/restated_deps:/root/reference OMP_NUM_THREADS=1 \
+        python -B tests/golden/make_golden_families.py
+
+Brezzi-Douglas-Marini and second-kind Nedelec elements on the UFC triangle / tetrahedron:
+nodal coefficients, entity -> dof map, the tables of tabulate(1, points) at seeded points.
+Plain numbers only."""
+import json
+import os
+
+import numpy as np
+
+from FIAT import BrezziDouglasMarini, NedelecSecondKind, ufc_simplex
+from FIAT.polynomial_set import mis
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = [("bdm", BrezziDouglasMarini, 2, (1, 2, 3)), ("bdm", BrezziDouglasMarini, 3, (1, 2)),
+         ("n2curl", NedelecSecondKind, 2, (1, 2, 3)), ("n2curl", NedelecSecondKind, 3, (1, 2))]
+
+
+def main():
+    rng = np.random.default_rng(424)
+    out = {}
+    for sd in (2, 3):
+        e = rng.exponential(size=(6, sd + 1))
+        out[f"pts_sd{sd}"] = (e / e.sum(axis=1, keepdims=True))[:, 1:]
+    for name, cls, sd, degrees in CASES:
+        for k in degrees:
+            el = cls(ufc_simplex(sd), k)
+            key = f"{name}{k}_sd{sd}"
+            out[key + "_coeffs"] = np.asarray(el.get_coeffs())
+            tab = el.tabulate(1, out[f"pts_sd{sd}"])
+            out[key + "_tab"] = np.stack([np.asarray(tab[a]) for j in range(2) for a in mis(sd, j)])
+            out[key + "_entity_dofs"] = np.array(json.dumps({str(d): {str(i): v for i, v in ents.items()}
+                                                             for d, ents in el.entity_dofs().items()}))
+            out[key + "_mapping"] = np.array(el.mapping()[0])
+    np.savez_compressed(os.path.join(HERE, "families.npz"), **out)
+    print("wrote families.npz:", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,84 @@
+"""Wider families on the same coeffs x Dubiner kernels: Brezzi-Douglas-Marini
+(FIAT/brezzi_douglas_marini.py) and second-kind Nedelec (FIAT/nedelec_second_kind.py) against golden
+vectors produced by the reference itself (tests/golden/make_golden_families.py)."""
+import json
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("bdm", "BrezziDouglasMarini", 2, 1), ("bdm", "BrezziDouglasMarini", 2, 2), ("bdm", "BrezziDouglasMarini", 2, 3),
+         ("bdm", "BrezziDouglasMarini", 3, 1), ("bdm", "BrezziDouglasMarini", 3, 2),
+         ("n2curl", "NedelecSecondKind", 2, 1), ("n2curl", "NedelecSecondKind", 2, 2), ("n2curl", "NedelecSecondKind", 2, 3),
+         ("n2curl", "NedelecSecondKind", 3, 1), ("n2curl", "NedelecSecondKind", 3, 2)]
+
+
+def rel(x, ref):
+    return np.abs(x - ref).max() / max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("name,cls,sd,k", CASES)
+def test_family_against_the_reference(golden, name, cls, sd, k):
+    import fiat_amd
+    g = golden("families")
+    key = f"{name}{k}_sd{sd}"
+    el = getattr(fiat_amd, cls)(fiat_amd.ufc_simplex(sd), k)
+    co = g[key + "_coeffs"]
+    assert el.get_coeffs().shape == co.shape
+    assert rel(el.get_coeffs(), co) <= 1e-12, rel(el.get_coeffs(), co)
+    assert el.mapping()[0] == str(g[key + "_mapping"]) and len(el.mapping()) == el.space_dimension()
+    want = json.loads(str(g[key + "_entity_dofs"]))
+    got = {str(d): {str(i): list(v) for i, v in ents.items()} for d, ents in el.entity_dofs().items()}
+    assert got == want
+    pts = g[f"pts_sd{sd}"]
+    tab = el.tabulate(1, pts)
+    alphas = [a for j in range(2) for a in fiat_amd.mis(sd, j)]
+    assert list(tab) == alphas
+    for t, a in enumerate(alphas):
+        assert tab[a].shape == g[key + "_tab"][t].shape
+        assert rel(tab[a], g[key + "_tab"][t]) <= (1e-12 if t == 0 else 1e-10), (a, rel(tab[a], g[key + "_tab"][t]))
+    # batched path, the same points as two requests
+    dev = el.tabulate_batch(1, np.stack([pts, pts[::-1]])).cpu().numpy()
+    assert rel(dev[0], g[key + "_tab"]) <= 1e-10
+    assert rel(dev[1][..., ::-1], g[key + "_tab"]) <= 1e-10
+    assert el.value_shape() == (sd,) and el.get_formdegree() == (sd - 1 if name == "bdm" else 1)
+
+
+def test_family_errors():
+    import fiat_amd
+    with pytest.raises(Exception):
+        fiat_amd.BrezziDouglasMarini(fiat_amd.ufc_simplex(2), 0)
+    with pytest.raises(NotImplementedError):
+        fiat_amd.BrezziDouglasMarini(fiat_amd.ufc_simplex(2), 1, variant="point")
+    with pytest.raises(NotImplementedError):
+        fiat_amd.NedelecSecondKind(fiat_amd.ufc_simplex(3), 1, variant="point")
+    assert fiat_amd.supported_elements["Brezzi-Douglas-Marini"] is fiat_amd.BrezziDouglasMarini
+    assert fiat_amd.supported_elements["Nedelec 2nd kind H(curl)"] is fiat_amd.NedelecSecondKind
+
+
+def test_pushforward_of_the_new_families(golden):
+    """BDM / N2curl with their Piola maps on physical cells: fused or second-pass result == formula on
+    the reference tables (the maps themselves are pinned in test_gpu_pushforward.py)."""
+    import fiat_amd
+    rng = np.random.default_rng(3)
+    sd, nreq, npts = 3, 40, 9
+    ref = np.array(fiat_amd.ufc_simplex(sd).get_vertices(), dtype=float)
+    A = np.eye(sd) + 0.15 * rng.standard_normal((nreq, sd, sd))
+    verts = np.einsum("vd,red->rve", ref, A) + rng.standard_normal((nreq, 1, sd))
+    e = rng.exponential(size=(nreq, npts, sd + 1))
+    bary = e / e.sum(axis=-1, keepdims=True)
+    pts = np.einsum("rpv,rvd->rpd", bary, verts)
+    ref_pts = np.einsum("rpv,vd->rpd", bary, ref)
+    for cls in (fiat_amd.BrezziDouglasMarini, fiat_amd.NedelecSecondKind):
+        el = cls(fiat_amd.ufc_simplex(sd), 2)
+        got = el.tabulate_batch(1, pts, verts=verts, pushforward=True).cpu().numpy()
+        raw = el.tabulate_batch(1, ref_pts).cpu().numpy()  # reference cell: (nreq, 4, ndof, sd, npts)
+        for i in (0, 17, 39):
+            J = (verts[i][1:] - verts[i][0]).T @ np.linalg.inv((ref[1:] - ref[0]).T)
+            Jinv = np.linalg.inv(J)
+            M = Jinv.T if el.mapping()[0].startswith("cov") else J / np.linalg.det(J)
+            vals = np.einsum("ce,dep->dcp", M, raw[i, 0])
+            grads = np.einsum("ce,gdep,gh->hdcp", M, raw[i, 1:], Jinv)
+            assert rel(got[i, 0], vals) <= 1e-12
+            assert rel(got[i, 1:], grads) <= 1e-10
