@@ -24,6 +24,9 @@ from .nedelec import Nedelec  # noqa: F401
 from .raviart_thomas import RaviartThomas  # noqa: F401
 from .brezzi_douglas_marini import BrezziDouglasMarini  # noqa: F401
 from .nedelec_second_kind import NedelecSecondKind  # noqa: F401
+from .hermite import CubicHermite  # noqa: F401
+from .morley import Morley  # noqa: F401
+from .crouzeix_raviart import CrouzeixRaviart  # noqa: F401
 from .tensor_product import FlattenedDimensions, TensorProductElement  # noqa: F401
 
 # the element registry of the reference (FIAT/__init__.py:72-131), in-scope subset
@@ -34,6 +37,9 @@ supported_elements = {
     "Raviart-Thomas": RaviartThomas,
     "Brezzi-Douglas-Marini": BrezziDouglasMarini,
     "Nedelec 2nd kind H(curl)": NedelecSecondKind,
+    "Hermite": CubicHermite,
+    "Morley": Morley,
+    "Crouzeix-Raviart": CrouzeixRaviart,
     "TensorProductElement": TensorProductElement,
     "FlattenedDimensions": FlattenedDimensions,
 }

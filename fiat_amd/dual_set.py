@@ -50,11 +50,12 @@ class DualSet:
 
     def riesz_weights(self):
         """(points, W): sorted unique functional points and the dense weight tensor
-        W[node, *target_shape, point] such that node(f) = sum W . f(points)."""
-        if any(len(ell.deriv_dict) for ell in self.nodes):
-            raise NotImplementedError("derivative functionals are not supported by fiat_amd yet")
+        W[node, *target_shape, point] such that the value part of node(f) = sum W . f(points);
+        (None, None) when no functional evaluates function values."""
         tshape = self.nodes[0].target_shape
         pts = sorted({pt for ell in self.nodes for pt in ell.pt_dict})
+        if not pts:
+            return None, None
         index = {pt: j for j, pt in enumerate(pts)}
         W = numpy.zeros((len(self.nodes), *tshape, len(pts)))
         for i, ell in enumerate(self.nodes):
@@ -64,18 +65,55 @@ class DualSet:
                     W[(i, *c, j)] += w
         return numpy.array(pts, dtype=float), W
 
+    def riesz_derivative_weights(self):
+        """(points, order, D): the derivative part (FIAT/dual_set.py:175-205).  D[node, *target_shape, t, point]
+        weights the t-th derivative table (mis() order over all orders <= ``order``; t = 0, the values, stays
+        zero) at the sorted unique derivative points; (None, 0, None) without derivative functionals."""
+        order = max(ell.max_deriv_order for ell in self.nodes)
+        if order == 0:
+            return None, 0, None
+        from .polynomial_set import mis
+        sd = self.ref_el.get_spatial_dimension()
+        tshape = self.nodes[0].target_shape
+        alphas = [a for k in range(order + 1) for a in mis(sd, k)]
+        slot = {a: t for t, a in enumerate(alphas)}
+        pts = sorted({pt for ell in self.nodes for pt in ell.deriv_dict})
+        index = {pt: j for j, pt in enumerate(pts)}
+        D = numpy.zeros((len(self.nodes), *tshape, len(alphas), len(pts)))
+        for i, ell in enumerate(self.nodes):
+            for pt, wac_list in ell.deriv_dict.items():
+                j = index[pt]
+                for w, alpha, c in wac_list:
+                    D[(i, *c, slot[tuple(alpha)], j)] += w
+        return numpy.array(pts, dtype=float), order, D
+
+    def _expansion_tables(self, es, ed, pts, order):
+        """Device tensor (ntab, nexp, npts): the expansion set and its derivatives <= order at pts."""
+        if hasattr(es, "_device_set"):
+            return es._device_set(ed).tabulate_batch(order, pts[None])[0]
+        return es.device_line().tabulate_batch(order, pts.reshape(1, -1))[0]  # 1-D Lagrange expansion set
+
     def to_riesz(self, poly_set):
         """R[i, *shape, k] = node_i(e_shape phi_k) for the expansion set of poly_set."""
         es = poly_set.get_expansion_set()
         ed = poly_set.get_embedded_degree()
         nexp = es.get_num_members(ed)
-        pts, W = self.riesz_weights()
-        tshape = W.shape[1:-1]
+        tshape = self.nodes[0].target_shape
         ctx = runtime.Context.get()
-        if hasattr(es, "_device_set"):
-            ev = es._device_set(ed).tabulate_batch(0, pts[None])[0, 0]      # (nexp, npts) on device
-        else:  # 1-D Lagrange expansion set
-            ev = es.device_line().tabulate_batch(0, pts.reshape(1, -1))[0, 0]
-        Wd = torch.as_tensor(W.reshape(-1, W.shape[-1])).to(ctx.device)
-        mat = runtime.riesz_assemble(Wd, ev, ctx)
+        mat = torch.zeros((len(self.nodes) * int(numpy.prod(tshape, dtype=int)), nexp), dtype=torch.float64, device=ctx.device)
+        pts, W = self.riesz_weights()
+        if pts is not None:
+            ev = self._expansion_tables(es, ed, pts, 0)[0]                          # (nexp, npts) on device
+            Wd = torch.as_tensor(W.reshape(-1, W.shape[-1])).to(ctx.device)
+            mat += runtime.riesz_assemble(Wd, ev, ctx)
+        dpts, order, D = self.riesz_derivative_weights()
+        if dpts is not None:
+            if order > 2:
+                raise NotImplementedError("derivative functionals of order > 2 are not supported on the device")
+            tabs = self._expansion_tables(es, ed, dpts, order)                      # (ntab, nexp, npts)
+            ntab, _, npts = tabs.shape
+            # the (table, point) pairs play the role of quadrature points
+            ev = tabs.permute(1, 0, 2).reshape(nexp, ntab * npts).contiguous()
+            Dd = torch.as_tensor(D.reshape(-1, ntab * npts)).to(ctx.device)
+            mat += runtime.riesz_assemble(Dd, ev, ctx)
         return mat.cpu().numpy().reshape((len(self.nodes), *tshape, nexp))

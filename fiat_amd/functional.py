@@ -2,11 +2,30 @@
 
 Only the kinds the in-scope families need (FIAT/functional.py: Functional
 :22-153, PointEvaluation :156-170, ComponentPointEvaluation :173-190,
-IntegralMoment :286-315, FrobeniusIntegralMoment :369-385).  A functional is
-data: ``pt_dict = {point: [(weight, component), ...]}``; the arithmetic of
+point derivatives :193-271, IntegralMoment :286-315, IntegralMomentOf(Normal)Derivative
+:318-366, FrobeniusIntegralMoment :369-385).  A functional is data:
+``pt_dict = {point: [(weight, component), ...]}`` and
+``deriv_dict = {point: [(weight, alpha, component), ...]}``; the arithmetic of
 applying it to an expansion set happens on the device (dual_set.to_riesz).
 """
+from collections import defaultdict
+
 import numpy
+
+
+def _derivative_multiindices(sd, *directions):
+    """{alpha: weight} of the directional derivative d/ds_1 ... d/ds_m: the tensor product of
+    the directions, entries summed per multi-index."""
+    S = numpy.asarray(directions[0], dtype=float)
+    for s in directions[1:]:
+        S = numpy.multiply.outer(S, numpy.asarray(s, dtype=float))
+    tau = defaultdict(float)
+    for index in numpy.ndindex(S.shape):
+        alpha = [0] * sd
+        for axis in index:
+            alpha[axis] += 1
+        tau[tuple(alpha)] += float(S[index])
+    return dict(tau)
 
 
 class Functional:
@@ -84,3 +103,78 @@ class FrobeniusIntegralMoment(IntegralMoment):
         pt_dict = {tuple(pt): [(wt[alpha], alpha) for alpha in alphas]
                    for pt, wt in zip(Q.get_points(), weights)}
         Functional.__init__(self, ref_el, shp, pt_dict, {}, nm or "FrobeniusIntegralMoment")
+
+
+class PointDerivative(Functional):
+    """f -> D^alpha f(x) for scalar f."""
+
+    def __init__(self, ref_el, x, alpha):
+        self.alpha = tuple(alpha)
+        self.order = sum(self.alpha)
+        super().__init__(ref_el, (), {}, {tuple(x): [(1.0, self.alpha, ())]}, "PointDeriv")
+
+
+class PointDirectionalDerivative(Functional):
+    """f -> d f_comp / ds (x)."""
+
+    def __init__(self, ref_el, s, pt, comp=(), shp=(), nm=None):
+        sd = ref_el.get_spatial_dimension()
+        unit = numpy.eye(sd, dtype=int)
+        wacs = [(s[i], tuple(int(a) for a in unit[i]), comp) for i in range(sd)]
+        super().__init__(ref_el, shp, {}, {tuple(pt): wacs}, nm or "PointDirectionalDeriv")
+
+
+class PointNormalDerivative(PointDirectionalDerivative):
+    def __init__(self, ref_el, facet_no, pt, comp=(), shp=()):
+        super().__init__(ref_el, ref_el.compute_normal(facet_no), pt, comp=comp, shp=shp, nm="PointNormalDeriv")
+
+
+class PointTangentialDerivative(PointDirectionalDerivative):
+    def __init__(self, ref_el, edge_no, pt, comp=(), shp=()):
+        super().__init__(ref_el, ref_el.compute_edge_tangent(edge_no), pt, comp=comp, shp=shp, nm="PointTangentialDeriv")
+
+
+class PointSecondDerivative(Functional):
+    """f -> d/ds1 d/ds2 f_comp (x)."""
+
+    def __init__(self, ref_el, s1, s2, pt, comp=(), shp=(), nm=None):
+        tau = _derivative_multiindices(ref_el.get_spatial_dimension(), s1, s2)
+        super().__init__(ref_el, shp, {}, {tuple(pt): [(w, alpha, comp) for alpha, w in tau.items()]},
+                         nm or "PointSecondDeriv")
+
+
+class PointNormalSecondDerivative(PointSecondDerivative):
+    def __init__(self, ref_el, facet_no, pt, comp=(), shp=()):
+        n = ref_el.compute_normal(facet_no)
+        super().__init__(ref_el, n, n, pt, comp=comp, shp=shp, nm="PointNormalSecondDeriv")
+
+
+class PointTangentialSecondDerivative(PointSecondDerivative):
+    def __init__(self, ref_el, edge_no, pt, comp=(), shp=()):
+        t = ref_el.compute_edge_tangent(edge_no)
+        super().__init__(ref_el, t, t, pt, comp=comp, shp=shp, nm="PointTangentialSecondDeriv")
+
+
+class IntegralMomentOfDerivative(Functional):
+    """f -> sum_q w_q g(x_q) (d/ds_1 ... d/ds_m f_comp)(x_q)."""
+
+    def __init__(self, ref_el, Q, f_at_qpts, *directions, comp=(), shp=(), nm=""):
+        self.Q = Q
+        self.f_at_qpts = numpy.asarray(f_at_qpts)
+        self.comp = comp
+        tau = _derivative_multiindices(ref_el.get_spatial_dimension(), *directions)
+        weights = numpy.multiply(self.f_at_qpts, Q.get_weights())
+        self.weights = {alpha: weights * t for alpha, t in tau.items()}
+        dpt_dict = {tuple(pt): [(wt * t, alpha, comp) for alpha, t in tau.items()]
+                    for pt, wt in zip(Q.get_points(), weights)}
+        super().__init__(ref_el, shp, {}, dpt_dict, nm or "IntegralMomentOfDerivative")
+
+
+class IntegralMomentOfNormalDerivative(IntegralMomentOfDerivative):
+    """Average over a facet of g times the normal derivative."""
+
+    def __init__(self, ref_el, facet_no, Q_face, f_at_qpts):
+        from .quadrature import FacetQuadratureRule
+        sd = ref_el.get_spatial_dimension()
+        Q = FacetQuadratureRule(ref_el, sd - 1, facet_no, Q_face, avg=True)
+        super().__init__(ref_el, Q, f_at_qpts, ref_el.compute_normal(facet_no), nm="IntegralMomentOfNormalDerivative")

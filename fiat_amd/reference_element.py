@@ -217,6 +217,24 @@ class UFCSimplex(Simplex):
         return ufc_simplex(dimension)
 
 
+class _UFCTriangleCell(UFCSimplex):
+    def compute_normal(self, facet_i):
+        """UFC-consistent unit normal: the rotated edge tangent, not always outward
+        (FIAT/reference_element.py:1044-1048)."""
+        t = self.compute_tangents(1, facet_i)[0]
+        n = numpy.array((t[1], -t[0]))
+        return n / numpy.linalg.norm(n)
+
+
+class _UFCTetrahedronCell(UFCSimplex):
+    def compute_normal(self, facet_i):
+        """UFC-consistent normal of length 2: minus twice the normalised cross product of the
+        face tangents (FIAT/reference_element.py:1148-1152; not a unit vector)."""
+        t = self.compute_tangents(2, facet_i)
+        n = numpy.cross(t[0], t[1])
+        return -2.0 * n / numpy.linalg.norm(n)
+
+
 class DefaultSimplex(Simplex):
     def construct_subelement(self, dimension):
         return default_simplex(dimension)
@@ -277,7 +295,8 @@ def ufc_simplex(spatial_dim):
         return Point()
     if spatial_dim not in (1, 2, 3):
         raise RuntimeError(f"Can't create UFC simplex of dimension {spatial_dim}.")
-    return UFCSimplex(_SHAPES[spatial_dim], _unit_vertices(spatial_dim, 0.0, 1.0), _UFC_TOPOLOGY[spatial_dim])
+    cls = {1: UFCSimplex, 2: _UFCTriangleCell, 3: _UFCTetrahedronCell}[spatial_dim]
+    return cls(_SHAPES[spatial_dim], _unit_vertices(spatial_dim, 0.0, 1.0), _UFC_TOPOLOGY[spatial_dim])
 
 
 def default_simplex(spatial_dim):

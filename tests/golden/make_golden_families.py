@@ -4,7 +4,8 @@
     PYTHONPATH=oracle/restated_deps:/root/reference OMP_NUM_THREADS=1 \
         python -B tests/golden/make_golden_families.py
 
-Brezzi-Douglas-Marini and second-kind Nedelec elements on the UFC triangle / tetrahedron:
+Brezzi-Douglas-Marini, second-kind Nedelec, cubic Hermite, Morley and Crouzeix-Raviart elements on
+the UFC interval / triangle / tetrahedron:
 nodal coefficients, entity -> dof map, the tables of tabulate(1, points) at seeded points.
 Plain numbers only."""
 import json
@@ -12,18 +13,22 @@ import os
 
 import numpy as np
 
-from FIAT import BrezziDouglasMarini, NedelecSecondKind, ufc_simplex
+from FIAT import BrezziDouglasMarini, CrouzeixRaviart, CubicHermite, Morley, NedelecSecondKind, ufc_simplex
 from FIAT.polynomial_set import mis
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = [("bdm", BrezziDouglasMarini, 2, (1, 2, 3)), ("bdm", BrezziDouglasMarini, 3, (1, 2)),
-         ("n2curl", NedelecSecondKind, 2, (1, 2, 3)), ("n2curl", NedelecSecondKind, 3, (1, 2))]
+         ("n2curl", NedelecSecondKind, 2, (1, 2, 3)), ("n2curl", NedelecSecondKind, 3, (1, 2)),
+         # derivative functionals in the dual set (FIAT/dual_set.py:175-205)
+         ("hermite", CubicHermite, 1, (3,)), ("hermite", CubicHermite, 2, (3,)), ("hermite", CubicHermite, 3, (3,)),
+         ("morley", Morley, 2, (2,)), ("morley", Morley, 3, (2,)),
+         ("cr", CrouzeixRaviart, 2, (1, 3)), ("cr", CrouzeixRaviart, 3, (1,))]
 
 
 def main():
     rng = np.random.default_rng(424)
     out = {}
-    for sd in (2, 3):
+    for sd in (2, 3, 1):
         e = rng.exponential(size=(6, sd + 1))
         out[f"pts_sd{sd}"] = (e / e.sum(axis=1, keepdims=True))[:, 1:]
     for name, cls, sd, degrees in CASES:

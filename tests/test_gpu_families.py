@@ -1,5 +1,6 @@
 """Wider families on the same coeffs x Dubiner kernels: Brezzi-Douglas-Marini
-(FIAT/brezzi_douglas_marini.py) and second-kind Nedelec (FIAT/nedelec_second_kind.py) against golden
+(FIAT/brezzi_douglas_marini.py), second-kind Nedelec (FIAT/nedelec_second_kind.py), cubic Hermite
+(FIAT/hermite.py), Morley (FIAT/morley.py) and Crouzeix-Raviart (FIAT/crouzeix_raviart.py) against golden
 vectors produced by the reference itself (tests/golden/make_golden_families.py)."""
 import json
 
@@ -11,7 +12,12 @@ pytestmark = pytest.mark.gpu
 CASES = [("bdm", "BrezziDouglasMarini", 2, 1), ("bdm", "BrezziDouglasMarini", 2, 2), ("bdm", "BrezziDouglasMarini", 2, 3),
          ("bdm", "BrezziDouglasMarini", 3, 1), ("bdm", "BrezziDouglasMarini", 3, 2),
          ("n2curl", "NedelecSecondKind", 2, 1), ("n2curl", "NedelecSecondKind", 2, 2), ("n2curl", "NedelecSecondKind", 2, 3),
-         ("n2curl", "NedelecSecondKind", 3, 1), ("n2curl", "NedelecSecondKind", 3, 2)]
+         ("n2curl", "NedelecSecondKind", 3, 1), ("n2curl", "NedelecSecondKind", 3, 2),
+         # dual sets with derivative functionals (FIAT/dual_set.py:175-205) and facet-moment scalar elements
+         ("hermite", "CubicHermite", 1, 3), ("hermite", "CubicHermite", 2, 3), ("hermite", "CubicHermite", 3, 3),
+         ("morley", "Morley", 2, 2), ("morley", "Morley", 3, 2),
+         ("cr", "CrouzeixRaviart", 2, 1), ("cr", "CrouzeixRaviart", 2, 3), ("cr", "CrouzeixRaviart", 3, 1)]
+VECTOR = ("bdm", "n2curl")
 
 
 def rel(x, ref):
@@ -42,7 +48,10 @@ def test_family_against_the_reference(golden, name, cls, sd, k):
     dev = el.tabulate_batch(1, np.stack([pts, pts[::-1]])).cpu().numpy()
     assert rel(dev[0], g[key + "_tab"]) <= 1e-10
     assert rel(dev[1][..., ::-1], g[key + "_tab"]) <= 1e-10
-    assert el.value_shape() == (sd,) and el.get_formdegree() == (sd - 1 if name == "bdm" else 1)
+    if name in VECTOR:
+        assert el.value_shape() == (sd,) and el.get_formdegree() == (sd - 1 if name == "bdm" else 1)
+    else:
+        assert el.value_shape() == ()
 
 
 def test_family_errors():
@@ -55,6 +64,14 @@ def test_family_errors():
         fiat_amd.NedelecSecondKind(fiat_amd.ufc_simplex(3), 1, variant="point")
     assert fiat_amd.supported_elements["Brezzi-Douglas-Marini"] is fiat_amd.BrezziDouglasMarini
     assert fiat_amd.supported_elements["Nedelec 2nd kind H(curl)"] is fiat_amd.NedelecSecondKind
+    with pytest.raises(ValueError):
+        fiat_amd.CrouzeixRaviart(fiat_amd.ufc_simplex(2), 2)
+    with pytest.raises(NotImplementedError):
+        fiat_amd.CrouzeixRaviart(fiat_amd.ufc_simplex(3), 3)
+    with pytest.raises(ValueError):
+        fiat_amd.Morley(fiat_amd.ufc_simplex(2), 3)
+    with pytest.raises(ValueError):
+        fiat_amd.Morley(fiat_amd.ufc_simplex(1))
 
 
 def test_pushforward_of_the_new_families(golden):

@@ -350,7 +350,8 @@ def test_kernel_selection(rt, golden):
     p3 = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=g["c2_p3tet_q6_coeffs"])
     assert p3.kernel_name(1, 1000, 23) == "fxk::tabulate_simplex_pair"
     assert p3.kernel_name(1, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_pair"
-    assert p3.kernel_name(1, 1000, 40) == "fxk::tabulate_simplex_kernel"     # more points than one tile row
+    assert p3.kernel_name(1, 1000, 40) == "fxk::tabulate_simplex_pair"       # one request per wave, 10 column tiles
+    assert p3.kernel_name(1, 1000, 50) == "fxk::tabulate_simplex_kernel"     # more points than the registered tilings
     assert p3.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_kernel"
     dg6 = rt.SimplexPolySet(3, 6, coeffs=g["c4_dg6tet_q6_coeffs"])
     assert dg6.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_coop"
