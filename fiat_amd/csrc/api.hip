@@ -22,6 +22,7 @@
 #include "quadrature.hpp"
 #include "simplex_small.hpp"
 #include "table_kernels.hpp"
+#include "simplex_stacked.hpp"
 
 namespace {
 
@@ -163,6 +164,12 @@ struct fx_element {
     double* d_coop_edbl = nullptr;
     int* d_coop_kstart = nullptr;
     double* d_afrag_coop = nullptr;
+    // stacked-matrix kernel (simplex_stacked.hpp): effective coefficients on the host, A fragments of
+    // [C; C D^alpha ...] per derivative order (built at first use, ensure_stacked)
+    std::vector<double> hC;
+    double* d_astack[3] = {nullptr, nullptr, nullptr};
+    int stack_state[3] = {0, 0, 0};  // 0 not built, 1 built, -1 failed
+    bool raw_expansion = false;      // internal helper element (identity coefficients): never takes the stacked path
 };
 
 struct fx_line_element {
@@ -309,6 +316,12 @@ static int upload_coeffs(fx_element* e, int ndof, int vdim, const double* coeffs
                 for (int k = 0; k < nexp; ++k) CT[(size_t)i * nexp + k] += cij * trow[k];
             }
         C.swap(CT);
+    }
+    e->hC = C;
+    for (int o = 0; o < 3; ++o) {
+        if (e->d_astack[o]) (void)hipFree(e->d_astack[o]);
+        e->d_astack[o] = nullptr;
+        e->stack_state[o] = 0;
     }
     if (e->d_cmat) {
         HIP_TRY(hipFree(e->d_cmat));
@@ -460,6 +473,8 @@ int fx_element_destroy(fx_element* e) {
     if (e->d_coop_edbl) (void)hipFree(e->d_coop_edbl);
     if (e->d_coop_kstart) (void)hipFree(e->d_coop_kstart);
     if (e->d_afrag_coop) (void)hipFree(e->d_afrag_coop);
+    for (int o = 0; o < 3; ++o)
+        if (e->d_astack[o]) (void)hipFree(e->d_astack[o]);
     delete e;
     return FX_OK;
 }
@@ -504,6 +519,10 @@ struct Launch {
     int small_id = -1;
     fxk::SmallArgs sargs;
     int sgrid = 0, slds_bytes = 0;
+    // stacked-matrix kernel (simplex_stacked.hpp)
+    int stacked_id = -1;
+    fxk::StackedArgs<0> khead;
+    int kgrid = 0, klds_bytes = 0;
     // cooperative large-shape kernel
     int coop_id = -1;
     fxk::CoopArgs cargs;
@@ -657,6 +676,53 @@ int launch_fixed(const Launch& L, hipStream_t s) {
         return FX_OK;
     }
 }
+
+// ---- registry of the stacked-matrix kernel: <SD, N, CT, G> ----------------------------------
+// (sd, n) of the expansion set, CT column tiles per group of G requests: npts <= 16 CT / G
+struct StackedShape {
+    int sd, n, ct, g;
+};
+const StackedShape kStackedShapes[] = {
+    {3, 6, 3, 2},  // degree-6 tetrahedron (DG P6 with Hessians: C4), 17..24 points
+    {3, 6, 2, 1},  // ... 25..32 points
+    {3, 6, 3, 1},  // ... 33..48 points
+};
+constexpr int STACKED_NW = 4;  // one wave per SIMD
+
+template <int SD, int N, int CT, int G>
+int launch_stacked(const Launch& L, hipStream_t s) {
+    constexpr int NC = fxk::FixedNC<SD, N>::value;
+    fxk::StackedArgs<NC> ka;
+    ka.pts = L.khead.pts;
+    ka.out = L.khead.out;
+    ka.afrag = L.khead.afrag;
+    ka.phi0 = L.khead.phi0;
+    memcpy(ka.A0, L.khead.A0, sizeof ka.A0);
+    memcpy(ka.b0, L.khead.b0, sizeof ka.b0);
+    ka.nreq = L.khead.nreq;
+    ka.npts = L.khead.npts;
+    ka.R = L.khead.R;
+    ka.RT = L.khead.RT;
+    ka.debug = L.khead.debug;
+    if ((int)L.fcoef.size() != NC) return fail(FX_EINVAL, "internal: coefficient table size mismatch");
+    memcpy(ka.coef, L.fcoef.data(), NC * sizeof(double));
+    auto kern = fxk::tabulate_simplex_stacked<SD, N, CT, G>;
+    hipLaunchKernelGGL(kern, dim3(L.kgrid), dim3(64 * STACKED_NW), L.klds_bytes, s, ka, L.trash,
+                       reinterpret_cast<unsigned int*>(L.queue));
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+int run_stacked(const Launch& L, hipStream_t s) {
+    switch (L.stacked_id) {
+        case 0: return launch_stacked<3, 6, 3, 2>(L, s);
+        case 1: return launch_stacked<3, 6, 2, 1>(L, s);
+        case 2: return launch_stacked<3, 6, 3, 1>(L, s);
+    }
+    return fail(FX_EINVAL, "internal: unknown stacked kernel %d", L.stacked_id);
+}
+
+int ensure_stacked(fx_ctx* ctx, fx_element* e, int order);  // defined after the C entry points it uses
 
 // ---- registry of cooperative (large-shape) kernels: <SD, ORDER, MT16, M4, TPW> ------
 struct CoopShape {
@@ -854,6 +920,59 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     a.stage_doubles = (int)((stage / 8 + 1) & ~1LL);
     if (stage == 0) a.stage_doubles = 0;
     L.lds_bytes = (a.phi_doubles + a.stage_doubles) * 8;
+    // ---- stacked-matrix kernel (requests on the element's own cell, large shapes)? ----
+    L.stacked_id = -1;
+    {
+        static const bool nostacked = getenv("FIAT_AMD_NO_STACKED") != nullptr;
+        const long long R = (long long)ntab * rows;
+        const int RT = (int)((R + 15) / 16);
+        const bool even = ((R * npts) % 2 == 0) && (((R - 16LL * (RT - 1)) * npts) % 2 == 0);
+        if (!nostacked && !verts && mapping == FX_MAP_AFFINE && !e->raw_expansion && order <= 2 && even && R >= 256) {
+            for (size_t i = 0; i < sizeof(kStackedShapes) / sizeof(kStackedShapes[0]); ++i) {
+                const StackedShape& k = kStackedShapes[i];
+                if (k.sd != e->sd || k.n != e->n) continue;
+                const int cap = 16 * k.ct / k.g;              // points one request may have
+                const int lo = 16 * k.ct / (k.g + 1);         // below: one more request fits the tiles
+                if (npts > cap || npts <= lo) continue;
+                bool ok = false;
+                if (e->sd == 3 && e->n == 6) ok = table_matches<3, 6>(e->prog);
+                if (!ok) continue;
+                int rc = ensure_stacked(ctx, const_cast<fx_element*>(e), order);
+                if (rc != FX_OK) return rc;
+                if (e->stack_state[order] != 1) continue;
+                fxk::StackedArgs<0>& ka = L.khead;
+                memset(&ka, 0, sizeof ka);
+                L.fcoef.resize(e->prog.steps.size() * 3);
+                for (size_t q = 0; q < e->prog.steps.size(); ++q) {
+                    L.fcoef[3 * q + 0] = e->prog.steps[q].A;
+                    L.fcoef[3 * q + 1] = e->prog.steps[q].B;
+                    L.fcoef[3 * q + 2] = e->prog.steps[q].C;
+                }
+                ka.pts = pts;
+                ka.out = out;
+                ka.afrag = e->d_astack[order];
+                ka.phi0 = e->prog.phi0;
+                memcpy(ka.A0, e->A0, sizeof ka.A0);
+                memcpy(ka.b0, e->b0, sizeof ka.b0);
+                ka.nreq = nreq;
+                ka.npts = npts;
+                ka.R = (int)R;
+                ka.RT = RT;
+                ka.debug = a.debug;
+                L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * fxk::stacked_image_doubles(k.ct)) * 8;
+                const long long groups = (nreq + k.g - 1) / k.g;
+                // one workgroup per CU = one wave per SIMD (measured: a second wave per SIMD at half the registers
+                // spills in the production phase and gains nothing, 1.45 -> 1.48 ms: the kernel is bound by the
+                // shared fp64 MFMA/VALU pipe, not by latencies)
+                L.kgrid = (int)std::max<long long>(1, std::min<long long>((groups + STACKED_NW - 1) / STACKED_NW, ctx->num_cu));
+                L.ncu = ctx->num_cu;
+                L.trash = ctx->d_trash;
+                L.queue = ctx->d_queue + (size_t)(ctx->launch_seq++ % FX_QUEUE_SLOTS) * 16;
+                L.stacked_id = (int)i;
+                break;
+            }
+        }
+    }
     // ---- cooperative kernel for large shapes? ----
     L.coop_id = -1;
     {
@@ -1085,6 +1204,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
 
 int run_tabulate(fx_ctx* ctx, const fx_element* e, int order, const Launch& L, hipStream_t s) {
     if (L.args.nitems == 0 || L.args.npts == 0) return FX_OK;
+    if (L.stacked_id >= 0) return run_stacked(L, s);
     if (L.fixed_id >= 0) return run_fixed(L, s);
     if (L.coop_id >= 0) return run_coop(L, s);
     if (L.small_id >= 0) return run_small(order, L, s);
@@ -1355,7 +1475,9 @@ int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, in
     int rc = plan_launch(ctx, e, order, nreq, npts, &dummy, has_verts ? &dummy : nullptr, &dummy, L);
     if (rc != FX_OK) return rc;
     const char* k = "fxk::tabulate_simplex_kernel";
-    if (L.fixed_id >= 0)
+    if (L.stacked_id >= 0)
+        k = "fxk::tabulate_simplex_stacked";
+    else if (L.fixed_id >= 0)
         k = L.fkind == 0   ? "fxk::tabulate_simplex_fixed"
             : L.fkind == 1 ? "fxk::tabulate_simplex_stream"
                            : "fxk::tabulate_simplex_pair";
@@ -1625,3 +1747,155 @@ int fx_tensor_tabulate_grid_batch(fx_ctx* ctx, int nf, const fx_line_element* co
 }
 
 }  // extern "C"
+
+namespace {
+// Solve M Y = B in place (B: n x nrhs, row-major) by Gaussian elimination with partial pivoting.
+bool solve_dense(int n, std::vector<double> M, int nrhs, std::vector<double>& B) {
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < n; ++r)
+            if (std::fabs(M[(size_t)r * n + c]) > std::fabs(M[(size_t)piv * n + c])) piv = r;
+        if (M[(size_t)piv * n + c] == 0.0) return false;
+        if (piv != c) {
+            for (int k = 0; k < n; ++k) std::swap(M[(size_t)c * n + k], M[(size_t)piv * n + k]);
+            for (int k = 0; k < nrhs; ++k) std::swap(B[(size_t)c * nrhs + k], B[(size_t)piv * nrhs + k]);
+        }
+        const double d = 1.0 / M[(size_t)c * n + c];
+        for (int r = c + 1; r < n; ++r) {
+            const double f = M[(size_t)r * n + c] * d;
+            if (f == 0.0) continue;
+            for (int k = c + 1; k < n; ++k) M[(size_t)r * n + k] -= f * M[(size_t)c * n + k];
+            for (int k = 0; k < nrhs; ++k) B[(size_t)r * nrhs + k] -= f * B[(size_t)c * nrhs + k];
+        }
+    }
+    for (int c = n - 1; c >= 0; --c) {
+        const double d = 1.0 / M[(size_t)c * n + c];
+        for (int k = 0; k < nrhs; ++k) {
+            double t = B[(size_t)c * nrhs + k];
+            for (int j = c + 1; j < n; ++j) t -= M[(size_t)c * n + j] * B[(size_t)j * nrhs + k];
+            B[(size_t)c * nrhs + k] = t * d;
+        }
+    }
+    return true;
+}
+
+// A fragments of the stacked matrix [C; C D^alpha ...] of derivative order `order` for the stacked-matrix
+// kernel.  The derivative matrices D^alpha (d^alpha phi_j = sum_k D^alpha[j][k] phi_k on the element's cell:
+// what FIAT's dmats hold, FIAT/expansions.py:438-446) are obtained by L2 projection: the raw expansion set
+// and its derivatives are tabulated ON THE DEVICE (the parity-checked recurrence kernels) at a collapsed
+// Gauss-Jacobi rule of n + 1 points per direction (exact for the degree-2n products), D^alpha = R_alpha M^-1
+// with the mass matrix M = sum w phi phi^T and R_alpha = sum w (d^alpha phi) phi^T.
+int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
+    if (order < 0 || order > 2) return FX_OK;
+    if (e->stack_state[order] != 0) return FX_OK;
+    e->stack_state[order] = -1;
+    const int sd = e->sd, nexp = e->nexp;
+    const int rows = (int)(e->hC.size() / (size_t)nexp);
+    const int ntab = fx::binom(sd + order, sd);
+    const long long R = (long long)ntab * rows;
+    std::vector<double> S((size_t)R * nexp, 0.0);  // stacked matrix
+    std::copy(e->hC.begin(), e->hC.end(), S.begin());
+    if (ntab > 1) {
+        // vertices of the element's cell: preimages of the default simplex's vertices under x -> A0 x + b0
+        double inv[9], verts[12];
+        if (!invert_small(sd, e->A0, inv)) return FX_OK;
+        for (int v = 0; v <= sd; ++v)
+            for (int i = 0; i < sd; ++i) {
+                double t = 0.0;
+                for (int d = 0; d < sd; ++d) t += inv[i * sd + d] * ((v == d + 1 ? 1.0 : -1.0) - e->b0[d]);
+                verts[v * sd + i] = t;
+            }
+        const int m = e->n + 1;
+        int nq = 1;
+        for (int d = 0; d < sd; ++d) nq *= m;
+        double *d_pts = nullptr, *d_wts = nullptr, *d_tab = nullptr;
+        fx_element* raw = new fx_element;
+        raw->ctx = ctx;
+        raw->sd = sd;
+        raw->n = e->n;
+        raw->variant = e->variant;
+        raw->nexp = nexp;
+        raw->scale = e->scale;
+        memcpy(raw->A0, e->A0, sizeof raw->A0);
+        memcpy(raw->b0, e->b0, sizeof raw->b0);
+        raw->prog = e->prog;
+        raw->raw_expansion = true;  // (no C0 transform: the projection is onto the raw recurrence basis)
+        std::vector<double> tab((size_t)ntab * nexp * nq), wts(nq);
+        auto cleanup = [&]() {
+            if (d_pts) (void)hipFree(d_pts);
+            if (d_wts) (void)hipFree(d_wts);
+            if (d_tab) (void)hipFree(d_tab);
+            fx_element_destroy(raw);
+        };
+        int rc = FX_OK;
+        hipError_t he = hipMalloc(&raw->d_steps, std::max<size_t>(1, raw->prog.steps.size()) * sizeof(fxk::Step));
+        if (he == hipSuccess && !raw->prog.steps.empty())
+            he = hipMemcpy(raw->d_steps, raw->prog.steps.data(), raw->prog.steps.size() * sizeof(fxk::Step), hipMemcpyHostToDevice);
+        if (he == hipSuccess) he = hipMalloc(&d_pts, (size_t)nq * sd * sizeof(double));
+        if (he == hipSuccess) he = hipMalloc(&d_wts, (size_t)nq * sizeof(double));
+        if (he == hipSuccess) he = hipMalloc(&d_tab, tab.size() * sizeof(double));
+        if (he != hipSuccess) {
+            cleanup();
+            return fail(FX_EHIP, "stacked matrix: %s", hipGetErrorString(he));
+        }
+        rc = upload_coeffs(raw, nexp, 1, nullptr);
+        if (rc == FX_OK) rc = fx_collapsed_quadrature(ctx, sd, m, verts, d_pts, d_wts, nullptr);
+        if (rc == FX_OK) rc = fx_tabulate_batch(ctx, raw, order, 1, nq, d_pts, nullptr, d_tab, nullptr);
+        if (rc == FX_OK) {
+            he = hipMemcpy(tab.data(), d_tab, tab.size() * sizeof(double), hipMemcpyDeviceToHost);
+            if (he == hipSuccess) he = hipMemcpy(wts.data(), d_wts, wts.size() * sizeof(double), hipMemcpyDeviceToHost);
+            if (he != hipSuccess) rc = fail(FX_EHIP, "stacked matrix: %s", hipGetErrorString(he));
+        }
+        cleanup();
+        if (rc != FX_OK) return rc;
+        // M (symmetric) and the right-hand sides R_alpha^T, side by side
+        const int nrhs = (ntab - 1) * nexp;
+        std::vector<double> M((size_t)nexp * nexp, 0.0), B((size_t)nexp * nrhs, 0.0), wphi((size_t)nexp * nq);
+        for (int k = 0; k < nexp; ++k)
+            for (int q = 0; q < nq; ++q) wphi[(size_t)k * nq + q] = wts[q] * tab[(size_t)k * nq + q];
+        for (int k = 0; k < nexp; ++k)
+            for (int l = 0; l < nexp; ++l) {
+                double t = 0.0;
+                for (int q = 0; q < nq; ++q) t += wphi[(size_t)k * nq + q] * tab[(size_t)l * nq + q];
+                M[(size_t)k * nexp + l] = t;
+            }
+        for (int t = 1; t < ntab; ++t)
+            for (int j = 0; j < nexp; ++j) {
+                const double* dj = &tab[((size_t)t * nexp + j) * nq];
+                for (int k = 0; k < nexp; ++k) {
+                    double acc = 0.0;
+                    for (int q = 0; q < nq; ++q) acc += dj[q] * wphi[(size_t)k * nq + q];
+                    B[(size_t)k * nrhs + (size_t)(t - 1) * nexp + j] = acc;  // R_t^T[k][j]
+                }
+            }
+        if (!solve_dense(nexp, M, nrhs, B)) return FX_OK;  // (state stays -1: other kernels serve the element)
+        // B[k][(t-1) nexp + j] = D_t[j][k];  rows of table t: C D_t
+        for (int t = 1; t < ntab; ++t)
+            for (int r = 0; r < rows; ++r) {
+                double* srow = &S[((size_t)t * rows + r) * nexp];
+                for (int j = 0; j < nexp; ++j) {
+                    const double c = e->hC[(size_t)r * nexp + j];
+                    if (c == 0.0) continue;
+                    for (int k = 0; k < nexp; ++k) srow[k] += c * B[(size_t)k * nrhs + (size_t)(t - 1) * nexp + j];
+                }
+            }
+    }
+    // 16x16x4 A fragments, K in production order (slot 0 = member 0, slot s = destination of step s-1)
+    const int KS = (nexp + 3) / 4, RT = (int)((R + 15) / 16);
+    std::vector<int> member(4 * KS, -1);
+    member[0] = 0;
+    for (size_t i = 0; i < e->prog.steps.size() && (int)i + 1 < nexp; ++i) member[i + 1] = e->prog.steps[i].dst;
+    std::vector<double> F((size_t)(RT + 1) * KS * 64, 0.0);
+    for (int rt = 0; rt < RT; ++rt)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const long long row = 16LL * rt + (lane & 15);
+                const int mem = member[4 * ks + (lane >> 4)];
+                if (row < R && mem >= 0) F[((size_t)rt * KS + ks) * 64 + lane] = S[(size_t)row * nexp + mem];
+            }
+    HIP_TRY(hipMalloc(&e->d_astack[order], F.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(e->d_astack[order], F.data(), F.size() * sizeof(double), hipMemcpyHostToDevice));
+    e->stack_state[order] = 1;
+    return FX_OK;
+}
+}  // namespace

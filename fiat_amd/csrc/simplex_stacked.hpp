@@ -1,0 +1,210 @@
+// Stacked-matrix simplex tabulation kernel (gfx950): large shapes, requests on the element's own cell.
+//
+// All tables of a request at once as ONE matrix product:
+//     out[req][(table, row)][point] = A_stack[(table, row)][k] * Phi_k(point),
+//     A_stack = [C; C D^(1,0,0); C D^(0,1,0); ...]   (R = ntab * rows stacked rows, host: api.hip)
+// where D^alpha are the derivative matrices of the expansion set on the element's cell
+// (d^alpha phi_j = sum_k D^alpha[j][k] phi_k: the route FIAT itself takes above its recurrence order,
+// FIAT/expansions.py:438-446), so the recurrence runs for the VALUES only (order 0: ~6 flop per member and
+// point instead of ~86 with Hessians) and everything else is fp64 MFMA work.  The cooperative kernel
+// (coop_kernel.hpp) spends 2/3 of its time in the order-2 recurrence of DG P6; here it is ~5 %.
+//
+// One wave per SIMD, every wave on its own: a wave takes a group of G requests (G * npts <= 16 CT
+// columns = CT column tiles), produces Phi directly in MFMA B-fragment layout in registers (lane
+// (kk, col) runs the recurrence of column col and keeps member 4 ks + kk of every K-step: 4x redundant,
+// on lanes that would idle otherwise, and no LDS round trip), then sweeps the R / 16 row tiles of
+// A_stack: A fragments stream from L2 one row tile ahead (A_stack is 0.5 MB for DG P6 with Hessians,
+// far beyond LDS), CT MFMAs per K-step, the 16 x (16 CT) result goes through a per-wave LDS image and
+// leaves as 16-byte stores of 16 * npts contiguous doubles per request.  No workgroup barriers;
+// groups are handed out dynamically (work_queue.hpp).
+#pragma once
+#include "simplex_stream.hpp"
+#include "store.hpp"
+#include "work_queue.hpp"
+
+namespace fxk {
+
+template <int NC> struct StackedArgs {
+    const double* pts;    // [nreq][npts][SD]
+    double* out;          // [nreq][R][npts]
+    const double* afrag;  // [RT + 1][KS][64]: 16x16x4 A fragments of A_stack, K in production order; last tile zero
+    double coef[NC > 0 ? NC : 1];  // [nsteps][3] = A, B, C
+    double phi0;
+    double A0[9];
+    double b0[3];
+    long long nreq;
+    int npts;
+    int R;   // stacked rows = ntab * rows
+    int RT;  // row tiles = ceil(R / 16)
+    int debug;
+};
+
+constexpr int stacked_image_doubles(int CT) { return 16 * 16 * CT + 128; }  // + dump row (64) + read slack
+
+// G requests of <= (16 CT / G) points per group
+template <int SD, int N, int CT, int G>
+__global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const StackedArgs<FixedNC<SD, N>::value> a,
+                                                                   double* __restrict__ trash,
+                                                                   unsigned int* __restrict__ gqueue) {
+    constexpr StepTable<SD, N> TBL{};
+    constexpr int NEXP = StepTable<SD, N>::NEXP;
+    constexpr int KS = (NEXP + 3) / 4;
+    constexpr int CPR = 16 * CT / G;                // column budget of one request
+    constexpr int NST = (16 * CPR / 2 + 63) / 64;   // 16-byte stores per lane and request chunk
+    constexpr int IMG = stacked_image_doubles(CT);
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    double* img = lds + WQ_CTL_DOUBLES + (size_t)wave * IMG;
+    constexpr int DUMP = 16 * 16 * CT;
+
+    typedef const __attribute__((address_space(4))) double CDouble;
+    typedef StackedArgs<FixedNC<SD, N>::value> ArgsT;
+    const __attribute__((address_space(4))) char* kargs =
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    CDouble* kcoef = (CDouble*)(kargs + __builtin_offsetof(ArgsT, coef));
+
+    const int npts = a.npts;
+    const int chunk = 16 * npts;  // doubles one request contributes to a row tile
+    const long long ngroups = (a.nreq + G - 1) / G;
+    WorkQueue wqueue;
+    wqueue.init(lds, gqueue, ngroups);
+    __syncthreads();
+
+    // column of this lane in column tile c: (request of the group, point); padding columns recompute
+    // a valid point and drop their results in the dump row
+    const int kk = lane >> 4;
+    int cg[CT], cp[CT], ioff[CT];
+    {
+        const float rinv = 1.0f / (float)npts;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int j = 16 * c + (lane & 15);
+            const int g = idiv_small(j, rinv);
+            const bool valid = g < G;
+            cg[c] = valid ? g : 0;
+            cp[c] = valid ? j - g * npts : 0;
+            ioff[c] = valid ? g * chunk + kk * npts + (j - g * npts) : -1;
+        }
+    }
+
+    long long grp = wqueue.claim();
+    wqueue.service();
+    while (grp < ngroups) {
+        // ---------------- expansion values, straight into B-fragment layout ----------------
+        double bf[KS][CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            long long req = grp * G + cg[c];
+            req = req < a.nreq ? req : a.nreq - 1;
+            const double* pp = a.pts + ((size_t)req * npts + cp[c]) * SD;
+            double X[SD];
+            {
+                double x[SD];
+#pragma unroll
+                for (int d = 0; d < SD; ++d) x[d] = pp[d];
+#pragma unroll
+                for (int i = 0; i < SD; ++i) {
+                    double t = a.b0[i];
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) t += a.A0[i * SD + d] * x[d];
+                    X[i] = t;
+                }
+            }
+            double mem[NEXP];
+            double ufa = 0.0, ufb = 0.0, ufc = 0.0;
+            int fcodim = -1;
+            auto produce = [&](int slot) -> double {
+                if (slot == 0) {
+                    mem[0] = a.phi0;
+                    return mem[0];
+                }
+                if (slot >= NEXP) return 0.0;
+                const int s = slot - 1;
+                const CDouble* cb = kcoef;
+                // opaque base, immediate offsets (see simplex_pair.hpp); tied to the step's input so that the
+                // 83 pointer copies are not all made (and spilled) ahead of the recurrence
+                asm volatile("" : "+s"(cb) : "v"(mem[TBL.cur[s]]));
+                const CDouble* cq = cb + 3 * s;
+                const double cA = cq[0], cB = cq[1], cC = cq[2];
+                if (TBL.codim[s] != fcodim) {
+                    fcodim = TBL.codim[s];
+                    point_factors<SD>(fcodim, X, ufa, ufb, ufc);
+                }
+                const double f = cA * ufa - cB * ufb;
+                double v = mem[TBL.cur[s]] * f;
+                if (TBL.prv[s] >= 0) v -= cC * ufc * mem[TBL.prv[s]];
+                mem[TBL.dst[s]] = v;
+                return v;
+            };
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const double v0 = produce(4 * ks), v1 = produce(4 * ks + 1), v2 = produce(4 * ks + 2), v3 = produce(4 * ks + 3);
+                bf[ks][c] = kk == 0 ? v0 : kk == 1 ? v1 : kk == 2 ? v2 : v3;
+                // keep the scheduler from gathering the scalar coefficient loads of all 83 steps at the top
+                // of the block (498 SGPRs, spilled to VGPR lanes)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // ---------------- sweep the row tiles of A_stack ----------------
+        const double* ap = a.afrag + lane;
+        double acur[KS], anext[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acur[ks] = ap[ks * 64];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(acur[ks]));
+        long long oreq[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) oreq[g] = grp * G + g;
+        for (int rt = 0; rt < a.RT; ++rt) {
+            {
+                const double* an = ap + (size_t)(rt + 1) * KS * 64;  // (the buffer ends with a zero tile)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) anext[ks] = an[ks * 64];
+            }
+            v4d acc[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[c] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(acur[ks], bf[ks][c], acc[c], 0, 0, 0);
+            // D tile: element jj of lane (kk, col) is row 4 jj + kk -> image [request][row][point]
+            const int nrows = min(16, a.R - 16 * rt);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const bool ok = ioff[c] >= 0 && 4 * jj + kk < nrows;
+                    img[ok ? ioff[c] + 4 * jj * npts : DUMP + lane] = acc[c][jj];
+                }
+            wave_lds_fence();
+            const int nch = (nrows * npts) >> 1;  // 16-byte pieces of a request's chunk (host: even)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const v2d* s2 = reinterpret_cast<const v2d*>(img + g * chunk);
+                v2d* g2 = oreq[g] < a.nreq
+                              ? reinterpret_cast<v2d*>(a.out + ((size_t)oreq[g] * a.R + (size_t)16 * rt) * npts)
+                              : reinterpret_cast<v2d*>(trash);
+                v2d buf[NST];
+#pragma unroll
+                for (int it = 0; it < NST; ++it) buf[it] = s2[min(it * 64 + lane, nch - 1)];
+#pragma unroll
+                for (int it = 0; it < NST; ++it) stream_store(&g2[min(it * 64 + lane, nch - 1)], buf[it]);
+            }
+            wave_lds_fence();
+            // first use of the prefetched fragments in the same block as the stores: exact vmcnt
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(anext[ks]));
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) acur[ks] = anext[ks];
+        }
+        grp = wqueue.claim();
+        wqueue.service();
+    }
+    wqueue.finish();
+}
+
+}  // namespace fxk

@@ -53,7 +53,7 @@ def test_c4_full_size(rt, golden):
     pts = simplex_points(rng, 3, (nreq, 23))
     ps = rt.SimplexPolySet(3, 6, coeffs=co)
     out = ps.tabulate_batch(2, pts)                       # (nreq, 10, 84, 23): 19.3 GB, stays on the device
-    assert ps.kernel_name(2, nreq, 23) == "fxk::tabulate_simplex_coop"
+    assert ps.kernel_name(2, nreq, 23) == "fxk::tabulate_simplex_stacked"
     s = out.sum(dim=2)                                    # sum over the basis: 1 for the values, 0 for every derivative
     assert float((s[:, 0] - 1.0).abs().max()) <= 1e-11
     assert float(s[:, 1:4].abs().max()) <= 1e-9          # gradients (entries up to ~1e2)

@@ -354,7 +354,8 @@ def test_kernel_selection(rt, golden):
     assert p3.kernel_name(1, 1000, 50) == "fxk::tabulate_simplex_kernel"     # more points than the registered tilings
     assert p3.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_kernel"
     dg6 = rt.SimplexPolySet(3, 6, coeffs=g["c4_dg6tet_q6_coeffs"])
-    assert dg6.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_coop"
+    assert dg6.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_stacked"          # requests on the element's cell
+    assert dg6.kernel_name(2, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_coop"  # per-request cells
     assert dg6.kernel_name(2, 1000, 122) == "fxk::tabulate_simplex_kernel"
 
 
