@@ -148,30 +148,22 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
         }
 
         // ---------------- sweep the row tiles of A_stack ----------------
+        // Software pipeline over the row tiles: while the MFMAs of tile rt run, the finished tile rt-1 goes
+        // through the LDS image to HBM (LDS and vector-memory instructions issue under the 64-cycle MFMAs;
+        // two accumulator sets, the loop is unrolled by two so that they swap roles without copies).
         const double* ap = a.afrag + lane;
-        double acur[KS], anext[KS];
+        double fa0[KS], fa1[KS];  // A fragments of the even / odd row tiles (loaded one tile ahead)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acur[ks] = ap[ks * 64];
+        for (int ks = 0; ks < KS; ++ks) fa0[ks] = ap[ks * 64];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(acur[ks]));
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa0[ks]));
         long long oreq[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) oreq[g] = grp * G + g;
-        for (int rt = 0; rt < a.RT; ++rt) {
-            {
-                const double* an = ap + (size_t)(rt + 1) * KS * 64;  // (the buffer ends with a zero tile)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) anext[ks] = an[ks * 64];
-            }
-            v4d acc[CT];
-#pragma unroll
-            for (int c = 0; c < CT; ++c) acc[c] = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int c = 0; c < CT; ++c)
-                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(acur[ks], bf[ks][c], acc[c], 0, 0, 0);
-            // D tile: element jj of lane (kk, col) is row 4 jj + kk -> image [request][row][point]
+        const int RTn = a.RT;
+
+        // D tile: element jj of lane (kk, col) is row 4 jj + kk -> image [request][row][point]
+        auto image_tile = [&](const v4d (&acc)[CT], int rt) {
             const int nrows = min(16, a.R - 16 * rt);
 #pragma unroll
             for (int c = 0; c < CT; ++c)
@@ -180,27 +172,83 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
                     const bool ok = ioff[c] >= 0 && 4 * jj + kk < nrows;
                     img[ok ? ioff[c] + 4 * jj * npts : DUMP + lane] = acc[c][jj];
                 }
-            wave_lds_fence();
-            const int nch = (nrows * npts) >> 1;  // 16-byte pieces of a request's chunk (host: even)
+        };
+        v2d fbuf[G][NST];
+        auto image_read = [&](int rt) {
+            const int nch = (min(16, a.R - 16 * rt) * npts) >> 1;  // 16-byte pieces of a request's chunk (host: even)
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const v2d* s2 = reinterpret_cast<const v2d*>(img + g * chunk);
+#pragma unroll
+                for (int it = 0; it < NST; ++it) fbuf[g][it] = s2[min(it * 64 + lane, nch - 1)];
+            }
+        };
+        auto image_store = [&](int rt) {
+            const int nch = (min(16, a.R - 16 * rt) * npts) >> 1;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
                 v2d* g2 = oreq[g] < a.nreq
                               ? reinterpret_cast<v2d*>(a.out + ((size_t)oreq[g] * a.R + (size_t)16 * rt) * npts)
                               : reinterpret_cast<v2d*>(trash);
-                v2d buf[NST];
 #pragma unroll
-                for (int it = 0; it < NST; ++it) buf[it] = s2[min(it * 64 + lane, nch - 1)];
-#pragma unroll
-                for (int it = 0; it < NST; ++it) stream_store(&g2[min(it * 64 + lane, nch - 1)], buf[it]);
+                for (int it = 0; it < NST; ++it) stream_store(&g2[min(it * 64 + lane, nch - 1)], fbuf[g][it]);
             }
+        };
+        auto mfma_steps = [&](v4d (&acc)[CT], const double (&af)[KS], int k0, int k1) {
+#pragma unroll
+            for (int ks = k0; ks < k1; ++ks)
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], bf[ks][c], acc[c], 0, 0, 0);
+        };
+        // one pipeline stage: MFMAs of tile rt (fragments `af`) into `cur`, tile rt-1 (in `prev`) out, fragments
+        // of tile rt+1 into `an`
+        auto stage = [&](v4d (&cur)[CT], const v4d (&prev)[CT], int rt, const double (&af)[KS], double (&an)[KS]) {
+            {
+                const double* anp = ap + (size_t)(rt + 1) * KS * 64;  // (the buffer ends with a zero tile)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) an[ks] = anp[ks * 64];
+            }
+            image_tile(prev, rt - 1);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) cur[c] = v4d{0.0, 0.0, 0.0, 0.0};
+            mfma_steps(cur, af, 0, KS / 3);
             wave_lds_fence();
+            image_read(rt - 1);
+            mfma_steps(cur, af, KS / 3, 2 * KS / 3);
+            image_store(rt - 1);
+            wave_lds_fence();
+            mfma_steps(cur, af, 2 * KS / 3, KS);
             // first use of the prefetched fragments in the same block as the stores: exact vmcnt
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(anext[ks]));
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(an[ks]));
+        };
+        v4d accA[CT], accB[CT];
+        {   // tile 0: nothing to flush yet
+            const double* anp = ap + (size_t)KS * 64;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acur[ks] = anext[ks];
+            for (int ks = 0; ks < KS; ++ks) fa1[ks] = anp[ks * 64];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) accA[c] = v4d{0.0, 0.0, 0.0, 0.0};
+            mfma_steps(accA, fa0, 0, KS);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa1[ks]));
         }
+        int rt = 1;
+        for (; rt + 1 < RTn; rt += 2) {  // odd tiles: fragments fa1 -> accB, even tiles: fa0 -> accA
+            stage(accB, accA, rt, fa1, fa0);
+            stage(accA, accB, rt + 1, fa0, fa1);
+        }
+        if (rt < RTn) {  // odd number of remaining tiles: one more stage, the last tile ends up in accB
+            stage(accB, accA, rt, fa1, fa0);
+            image_tile(accB, rt);
+        } else {
+            image_tile(accA, RTn - 1);
+        }
+        wave_lds_fence();
+        image_read(RTn - 1);
+        image_store(RTn - 1);
+        wave_lds_fence();
         grp = wqueue.claim();
         wqueue.service();
     }
