@@ -161,10 +161,12 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
 #pragma unroll
         for (int g = 0; g < G; ++g) oreq[g] = grp * G + g;
         const int RTn = a.RT;
+        const int last_rows = a.R - 16 * (RTn - 1);
 
         // D tile: element jj of lane (kk, col) is row 4 jj + kk -> image [request][row][point]
-        auto image_tile = [&](const v4d (&acc)[CT], int rt) {
-            const int nrows = min(16, a.R - 16 * rt);
+        // (`nrows`: 16 for every tile but possibly the last one -- the pipelined stages only ever flush full
+        // tiles, which makes all their LDS and output offsets loop invariants)
+        auto image_tile = [&](const v4d (&acc)[CT], int nrows) {
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -174,8 +176,8 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
                 }
         };
         v2d fbuf[G][NST];
-        auto image_read = [&](int rt) {
-            const int nch = (min(16, a.R - 16 * rt) * npts) >> 1;  // 16-byte pieces of a request's chunk (host: even)
+        auto image_read = [&](int nrows) {
+            const int nch = (nrows * npts) >> 1;  // 16-byte pieces of a request's chunk (host: even)
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const v2d* s2 = reinterpret_cast<const v2d*>(img + g * chunk);
@@ -183,8 +185,8 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
                 for (int it = 0; it < NST; ++it) fbuf[g][it] = s2[min(it * 64 + lane, nch - 1)];
             }
         };
-        auto image_store = [&](int rt) {
-            const int nch = (min(16, a.R - 16 * rt) * npts) >> 1;
+        auto image_store = [&](int rt, int nrows) {
+            const int nch = (nrows * npts) >> 1;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 v2d* g2 = oreq[g] < a.nreq
@@ -209,14 +211,14 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) an[ks] = anp[ks * 64];
             }
-            image_tile(prev, rt - 1);
+            image_tile(prev, 16);
 #pragma unroll
             for (int c = 0; c < CT; ++c) cur[c] = v4d{0.0, 0.0, 0.0, 0.0};
             mfma_steps(cur, af, 0, KS / 3);
             wave_lds_fence();
-            image_read(rt - 1);
+            image_read(16);
             mfma_steps(cur, af, KS / 3, 2 * KS / 3);
-            image_store(rt - 1);
+            image_store(rt - 1, 16);
             wave_lds_fence();
             mfma_steps(cur, af, 2 * KS / 3, KS);
             // first use of the prefetched fragments in the same block as the stores: exact vmcnt
@@ -241,13 +243,13 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
         }
         if (rt < RTn) {  // odd number of remaining tiles: one more stage, the last tile ends up in accB
             stage(accB, accA, rt, fa1, fa0);
-            image_tile(accB, rt);
+            image_tile(accB, last_rows);
         } else {
-            image_tile(accA, RTn - 1);
+            image_tile(accA, last_rows);
         }
         wave_lds_fence();
-        image_read(RTn - 1);
-        image_store(RTn - 1);
+        image_read(last_rows);
+        image_store(RTn - 1, last_rows);
         wave_lds_fence();
         grp = wqueue.claim();
         wqueue.service();
