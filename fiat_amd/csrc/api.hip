@@ -707,6 +707,8 @@ int launch_stacked(const Launch& L, hipStream_t s) {
     if ((int)L.fcoef.size() != NC) return fail(FX_EINVAL, "internal: coefficient table size mismatch");
     memcpy(ka.coef, L.fcoef.data(), NC * sizeof(double));
     auto kern = fxk::tabulate_simplex_stacked<SD, N, CT, G>;
+    if (L.klds_bytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L.klds_bytes));
     hipLaunchKernelGGL(kern, dim3(L.kgrid), dim3(64 * STACKED_NW), L.klds_bytes, s, ka, L.trash,
                        reinterpret_cast<unsigned int*>(L.queue));
     HIP_TRY(hipGetLastError());
@@ -959,7 +961,8 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 ka.R = (int)R;
                 ka.RT = RT;
                 ka.debug = a.debug;
-                L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * fxk::stacked_image_doubles(k.ct)) * 8;
+                L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * fxk::stacked_image_doubles(k.ct, (e->nexp + 3) / 4)) * 8;
+                if (L.klds_bytes > ctx->lds_per_cu) continue;
                 const long long groups = (nreq + k.g - 1) / k.g;
                 // one workgroup per CU = one wave per SIMD (measured: a second wave per SIMD at half the registers
                 // spills in the production phase and gains nothing, 1.45 -> 1.48 ms: the kernel is bound by the

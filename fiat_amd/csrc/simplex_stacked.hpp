@@ -10,9 +10,8 @@
 // (coop_kernel.hpp) spends 2/3 of its time in the order-2 recurrence of DG P6; here it is ~5 %.
 //
 // One wave per SIMD, every wave on its own: a wave takes a group of G requests (G * npts <= 16 CT
-// columns = CT column tiles), produces Phi directly in MFMA B-fragment layout in registers (lane
-// (kk, col) runs the recurrence of column col and keeps member 4 ks + kk of every K-step: 4x redundant,
-// on lanes that would idle otherwise, and no LDS round trip), then sweeps the R / 16 row tiles of
+// columns = CT column tiles), runs the order-0 recurrence with lane <-> column, turns the members into MFMA
+// B fragments through LDS ONCE per group and keeps them in registers, then sweeps the R / 16 row tiles of
 // A_stack: A fragments stream from L2 one row tile ahead (A_stack is 0.5 MB for DG P6 with Hessians,
 // far beyond LDS), CT MFMAs per K-step, the 16 x (16 CT) result goes through a per-wave LDS image and
 // leaves as 16-byte stores of 16 * npts contiguous doubles per request.  No workgroup barriers;
@@ -39,7 +38,11 @@ template <int NC> struct StackedArgs {
     int debug;
 };
 
-constexpr int stacked_image_doubles(int CT) { return 16 * 16 * CT + 128; }  // + dump row (64) + read slack
+// per-wave LDS: the output image of a row tile (16 x 16 CT doubles + dump row + read slack); the expansion
+// values of a group ([4 KS slots][16 CT columns]) alias it while they are produced
+constexpr int stacked_image_doubles(int CT, int KS) {
+    return (4 * KS * 16 * CT > 16 * 16 * CT + 128) ? 4 * KS * 16 * CT : 16 * 16 * CT + 128;
+}
 
 // G requests of <= (16 CT / G) points per group
 template <int SD, int N, int CT, int G>
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
     constexpr int KS = (NEXP + 3) / 4;
     constexpr int CPR = 16 * CT / G;                // column budget of one request
     constexpr int NST = (16 * CPR / 2 + 63) / 64;   // 16-byte stores per lane and request chunk
-    constexpr int IMG = stacked_image_doubles(CT);
+    constexpr int IMG = stacked_image_doubles(CT, KS);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
     // column of this lane in column tile c: (request of the group, point); padding columns recompute
     // a valid point and drop their results in the dump row
     const int kk = lane >> 4;
-    int cg[CT], cp[CT], ioff[CT];
+    int ioff[CT];
     {
         const float rinv = 1.0f / (float)npts;
 #pragma unroll
@@ -82,69 +85,82 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
             const int j = 16 * c + (lane & 15);
             const int g = idiv_small(j, rinv);
             const bool valid = g < G;
-            cg[c] = valid ? g : 0;
-            cp[c] = valid ? j - g * npts : 0;
             ioff[c] = valid ? g * chunk + kk * npts + (j - g * npts) : -1;
         }
+    }
+
+    // production: lane <-> column `lane` of the group (lanes < 16 CT)
+    int pg, ppt;
+    {
+        const int g = idiv_small(lane, 1.0f / (float)npts);
+        const bool valid = g < G;
+        pg = valid ? g : 0;
+        ppt = valid ? lane - g * npts : 0;
     }
 
     long long grp = wqueue.claim();
     wqueue.service();
     while (grp < ngroups) {
-        // ---------------- expansion values, straight into B-fragment layout ----------------
+        // ---------------- expansion values -> B fragments ----------------
+        // lane <-> column (request of the group, point): the order-0 recurrence once per column, every member to
+        // a [slot][column] slab in LDS (it aliases the output image, which is idle until the sweep starts), then
+        // each lane (kk, col) picks the members 4 ks + kk of its columns: the MFMA B fragments, kept in registers.
         double bf[KS][CT];
+        {
+            constexpr int PW = 16 * CT;
+            double* phi = img;
+            if (lane < PW) {
+                long long req = grp * G + pg;
+                req = req < a.nreq ? req : a.nreq - 1;
+                const double* pp = a.pts + ((size_t)req * npts + ppt) * SD;
+                double X[SD];
+                {
+                    double x[SD];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            long long req = grp * G + cg[c];
-            req = req < a.nreq ? req : a.nreq - 1;
-            const double* pp = a.pts + ((size_t)req * npts + cp[c]) * SD;
-            double X[SD];
-            {
-                double x[SD];
+                    for (int d = 0; d < SD; ++d) x[d] = pp[d];
 #pragma unroll
-                for (int d = 0; d < SD; ++d) x[d] = pp[d];
+                    for (int i = 0; i < SD; ++i) {
+                        double t = a.b0[i];
 #pragma unroll
-                for (int i = 0; i < SD; ++i) {
-                    double t = a.b0[i];
-#pragma unroll
-                    for (int d = 0; d < SD; ++d) t += a.A0[i * SD + d] * x[d];
-                    X[i] = t;
+                        for (int d = 0; d < SD; ++d) t += a.A0[i * SD + d] * x[d];
+                        X[i] = t;
+                    }
                 }
+                double mem[NEXP];
+                double ufa = 0.0, ufb = 0.0, ufc = 0.0;
+                int fcodim = -1;
+                auto produce = [&](int slot) -> double {
+                    if (slot == 0) {
+                        mem[0] = a.phi0;
+                        return mem[0];
+                    }
+                    if (slot >= NEXP) return 0.0;
+                    const int s = slot - 1;
+                    const CDouble* cb = kcoef;
+                    // opaque base, immediate offsets (see simplex_pair.hpp); tied to the step's input so that the
+                    // 83 pointer copies are not all made (and spilled) ahead of the recurrence
+                    asm volatile("" : "+s"(cb) : "v"(mem[TBL.cur[s]]));
+                    const CDouble* cq = cb + 3 * s;
+                    const double cA = cq[0], cB = cq[1], cC = cq[2];
+                    if (TBL.codim[s] != fcodim) {
+                        fcodim = TBL.codim[s];
+                        point_factors<SD>(fcodim, X, ufa, ufb, ufc);
+                    }
+                    const double f = cA * ufa - cB * ufb;
+                    double v = mem[TBL.cur[s]] * f;
+                    if (TBL.prv[s] >= 0) v -= cC * ufc * mem[TBL.prv[s]];
+                    mem[TBL.dst[s]] = v;
+                    return v;
+                };
+#pragma unroll
+                for (int slot = 0; slot < 4 * KS; ++slot) phi[slot * PW + lane] = produce(slot);
             }
-            double mem[NEXP];
-            double ufa = 0.0, ufb = 0.0, ufc = 0.0;
-            int fcodim = -1;
-            auto produce = [&](int slot) -> double {
-                if (slot == 0) {
-                    mem[0] = a.phi0;
-                    return mem[0];
-                }
-                if (slot >= NEXP) return 0.0;
-                const int s = slot - 1;
-                const CDouble* cb = kcoef;
-                // opaque base, immediate offsets (see simplex_pair.hpp); tied to the step's input so that the
-                // 83 pointer copies are not all made (and spilled) ahead of the recurrence
-                asm volatile("" : "+s"(cb) : "v"(mem[TBL.cur[s]]));
-                const CDouble* cq = cb + 3 * s;
-                const double cA = cq[0], cB = cq[1], cC = cq[2];
-                if (TBL.codim[s] != fcodim) {
-                    fcodim = TBL.codim[s];
-                    point_factors<SD>(fcodim, X, ufa, ufb, ufc);
-                }
-                const double f = cA * ufa - cB * ufb;
-                double v = mem[TBL.cur[s]] * f;
-                if (TBL.prv[s] >= 0) v -= cC * ufc * mem[TBL.prv[s]];
-                mem[TBL.dst[s]] = v;
-                return v;
-            };
+            wave_lds_fence();
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const double v0 = produce(4 * ks), v1 = produce(4 * ks + 1), v2 = produce(4 * ks + 2), v3 = produce(4 * ks + 3);
-                bf[ks][c] = kk == 0 ? v0 : kk == 1 ? v1 : kk == 2 ? v2 : v3;
-                // keep the scheduler from gathering the scalar coefficient loads of all 83 steps at the top
-                // of the block (498 SGPRs, spilled to VGPR lanes)
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) bf[ks][c] = phi[(4 * ks + kk) * PW + 16 * c + (lane & 15)];
+            wave_lds_fence();
         }
 
         // ---------------- sweep the row tiles of A_stack ----------------

@@ -440,3 +440,44 @@ def test_one_request_per_wave_instances(rt, fam, deg, npts, nreq, cells):
     den = np.maximum(1.0, np.abs(ref).max(axis=axes))
     err = (num / den).max(axis=0)
     assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
+
+
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("npts,nreq", [(17, 5), (23, 1), (23, 2050), (24, 333), (25, 64), (32, 129), (33, 7), (40, 100), (48, 65)])
+def test_stacked_matrix_kernel(rt, golden, order, npts, nreq):
+    """Degree-6 tetrahedron on the element's own cell: all derivative tables as rows of ONE stacked matrix
+    [C; C D^alpha] (simplex_stacked.hpp), every (column tiles, requests per group) instance, odd batch sizes
+    (a last group with a missing request), against the C oracle's recurrence derivatives; and a physical
+    element cell (the derivative matrices are taken on the element's cell, not the UFC one)."""
+    from oracle import c_oracle
+    g = golden("elements")
+    co = g["c4_dg6tet_q6_coeffs"]
+    ps = rt.SimplexPolySet(3, 6, coeffs=co)
+    assert ps.kernel_name(order, nreq, npts) == "fxk::tabulate_simplex_stacked"
+    rng = np.random.default_rng(100 * npts + nreq + order)
+    pts = rand_points(rng, 3, (nreq, npts))
+    out = ps.tabulate_batch(order, pts).cpu().numpy()
+    ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[3], 6, co, order, pts).reshape(out.shape)
+    axes = tuple(range(2, out.ndim))
+    err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)
+    assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
+
+
+def test_stacked_matrix_kernel_on_a_physical_element_cell(rt):
+    import fiat_amd
+    from oracle import c_oracle
+    rng = np.random.default_rng(99)
+    A = np.eye(3) + 0.2 * rng.standard_normal((3, 3))
+    verts = fo.UFC_SIMPLEX[3] @ A.T + rng.standard_normal(3)
+    el = fiat_amd.DiscontinuousLagrange(fiat_amd.physical_simplex(verts), 6)
+    ps = el.device_polyset()
+    nreq, npts = 37, 23
+    assert ps.kernel_name(2, nreq, npts) == "fxk::tabulate_simplex_stacked"
+    e = rng.exponential(size=(nreq, npts, 4))
+    pts = (e / e.sum(axis=-1, keepdims=True)) @ verts
+    out = ps.tabulate_batch(2, pts).cpu().numpy()
+    ref = c_oracle.tabulate_batch(verts, 6, el.get_coeffs(), 2, pts, scale=el._expansion_scale,
+                                  variant=el._expansion_variant).reshape(out.shape)
+    axes = tuple(range(2, out.ndim))
+    err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)
+    assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
