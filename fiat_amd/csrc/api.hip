@@ -712,6 +712,9 @@ int launch_stacked(const Launch& L, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(L.kgrid), dim3(64 * STACKED_NW), L.klds_bytes, s, ka, L.trash,
                        reinterpret_cast<unsigned int*>(L.queue));
     HIP_TRY(hipGetLastError());
+#if defined(FX_DBG) && (FX_DBG & 512)
+    if (getenv("FIAT_AMD_VERBOSE")) HIP_TRY(report_wave_lifetimes(L.trash, L.kgrid, STACKED_NW));
+#endif
     return FX_OK;
 }
 

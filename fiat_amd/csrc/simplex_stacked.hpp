@@ -98,6 +98,9 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
         ppt = valid ? lane - g * npts : 0;
     }
 
+#if FX_DBG & 512
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     long long grp = wqueue.claim();
     wqueue.service();
     while (grp < ngroups) {
@@ -182,35 +185,24 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
         // D tile: element jj of lane (kk, col) is row 4 jj + kk -> image [request][row][point]
         // (`nrows`: 16 for every tile but possibly the last one -- the pipelined stages only ever flush full
         // tiles, which makes all their LDS and output offsets loop invariants)
-        auto image_tile = [&](const v4d (&acc)[CT], int nrows) {
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const bool ok = ioff[c] >= 0 && 4 * jj + kk < nrows;
-                    img[ok ? ioff[c] + 4 * jj * npts : DUMP + lane] = acc[c][jj];
-                }
+        // D tile: element jj of lane (kk, col) is row 4 jj + kk -> image [request][row][point]
+        auto image_put = [&](const v4d (&acc)[CT], int w, int nrows) {  // w-th of the 4 CT image stores
+            const int c = w >> 2, jj = w & 3;
+            const bool ok = ioff[c] >= 0 && 4 * jj + kk < nrows;
+            img[ok ? ioff[c] + 4 * jj * npts : DUMP + lane] = acc[c][jj];
         };
-        v2d fbuf[G][NST];
-        auto image_read = [&](int nrows) {
+        v2d fbuf[G * NST];
+        auto image_get = [&](int r, int nrows) {  // r-th of the G NST 16-byte image reads
+            const int g = r / NST, it = r % NST;
             const int nch = (nrows * npts) >> 1;  // 16-byte pieces of a request's chunk (host: even)
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const v2d* s2 = reinterpret_cast<const v2d*>(img + g * chunk);
-#pragma unroll
-                for (int it = 0; it < NST; ++it) fbuf[g][it] = s2[min(it * 64 + lane, nch - 1)];
-            }
+            fbuf[r] = reinterpret_cast<const v2d*>(img + g * chunk)[min(it * 64 + lane, nch - 1)];
         };
-        auto image_store = [&](int rt, int nrows) {
+        auto image_out = [&](int r, int rt, int nrows) {  // r-th output store of row tile rt
+            const int g = r / NST, it = r % NST;
             const int nch = (nrows * npts) >> 1;
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                v2d* g2 = oreq[g] < a.nreq
-                              ? reinterpret_cast<v2d*>(a.out + ((size_t)oreq[g] * a.R + (size_t)16 * rt) * npts)
-                              : reinterpret_cast<v2d*>(trash);
-#pragma unroll
-                for (int it = 0; it < NST; ++it) stream_store(&g2[min(it * 64 + lane, nch - 1)], fbuf[g][it]);
-            }
+            v2d* g2 = oreq[g] < a.nreq ? reinterpret_cast<v2d*>(a.out + ((size_t)oreq[g] * a.R + (size_t)16 * rt) * npts)
+                                       : reinterpret_cast<v2d*>(trash);
+            stream_store(&g2[min(it * 64 + lane, nch - 1)], fbuf[r]);
         };
         auto mfma_steps = [&](v4d (&acc)[CT], const double (&af)[KS], int k0, int k1) {
 #pragma unroll
@@ -219,24 +211,41 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
                 for (int c = 0; c < CT; ++c)
                     acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], bf[ks][c], acc[c], 0, 0, 0);
         };
-        // one pipeline stage: MFMAs of tile rt (fragments `af`) into `cur`, tile rt-1 (in `prev`) out, fragments
-        // of tile rt+1 into `an`
+        // One pipeline stage: MFMAs of tile rt (fragments `af`) into `cur`, tile rt-1 (in `prev`) out, fragments
+        // of tile rt+1 into `an`.  The memory instructions are spread over the K-steps (a wave issues in order:
+        // a burst of 17 loads or 18 LDS operations between two MFMAs leaves the matrix pipe idle): every K-step
+        // CT MFMAs + its share of the fragment loads (first two thirds), image stores (first third), image
+        // reads (second third) or output stores (last third); the scheduler may not move anything across a K-step.
+        constexpr int NWR = 4 * CT, NRD = G * NST, T3 = KS / 3;
+        constexpr int LPK = (KS + 2 * T3 - 1) / (2 * T3);
+        constexpr int WPK = (NWR + T3 - 1) / T3, RPK = (NRD + T3 - 1) / T3, SPK = (NRD + (KS - 2 * T3) - 1) / (KS - 2 * T3);
         auto stage = [&](v4d (&cur)[CT], const v4d (&prev)[CT], int rt, const double (&af)[KS], double (&an)[KS]) {
-            {
-                const double* anp = ap + (size_t)(rt + 1) * KS * 64;  // (the buffer ends with a zero tile)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) an[ks] = anp[ks * 64];
-            }
-            image_tile(prev, 16);
+            const double* anp = ap + (size_t)(rt + 1) * KS * 64;  // (the buffer ends with a zero tile)
 #pragma unroll
             for (int c = 0; c < CT; ++c) cur[c] = v4d{0.0, 0.0, 0.0, 0.0};
-            mfma_steps(cur, af, 0, KS / 3);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                mfma_steps(cur, af, ks, ks + 1);
+                // fragment loads in the first two thirds only: at the end of the stage they are older than every
+                // output store, so the wait for them is an exact vmcnt(#stores), not a wait for the stores
+                if (ks < 2 * T3) {
+#pragma unroll
+                    for (int q = ks * LPK; q < (ks + 1) * LPK && q < KS; ++q) an[q] = anp[q * 64];
+                }
+                if (ks < T3) {
+#pragma unroll
+                    for (int w = ks * WPK; w < (ks + 1) * WPK && w < NWR; ++w) image_put(prev, w, 16);
+                } else if (ks < 2 * T3) {
+                    if (ks == T3) wave_lds_fence();
+#pragma unroll
+                    for (int r = (ks - T3) * RPK; r < (ks - T3 + 1) * RPK && r < NRD; ++r) image_get(r, 16);
+                } else {
+#pragma unroll
+                    for (int r = (ks - 2 * T3) * SPK; r < (ks - 2 * T3 + 1) * SPK && r < NRD; ++r) image_out(r, rt - 1, 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             wave_lds_fence();
-            image_read(16);
-            mfma_steps(cur, af, KS / 3, 2 * KS / 3);
-            image_store(rt - 1, 16);
-            wave_lds_fence();
-            mfma_steps(cur, af, 2 * KS / 3, KS);
             // first use of the prefetched fragments in the same block as the stores: exact vmcnt
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(an[ks]));
@@ -257,20 +266,35 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
             stage(accB, accA, rt, fa1, fa0);
             stage(accA, accB, rt + 1, fa0, fa1);
         }
+        auto flush_last = [&](const v4d (&acc)[CT]) {
+#pragma unroll
+            for (int w = 0; w < NWR; ++w) image_put(acc, w, last_rows);
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < NRD; ++r) image_get(r, last_rows);
+#pragma unroll
+            for (int r = 0; r < NRD; ++r) image_out(r, RTn - 1, last_rows);
+            wave_lds_fence();
+        };
         if (rt < RTn) {  // odd number of remaining tiles: one more stage, the last tile ends up in accB
             stage(accB, accA, rt, fa1, fa0);
-            image_tile(accB, last_rows);
+            flush_last(accB);
         } else {
-            image_tile(accA, last_rows);
+            flush_last(accA);
         }
-        wave_lds_fence();
-        image_read(last_rows);
-        image_store(RTn - 1, last_rows);
-        wave_lds_fence();
         grp = wqueue.claim();
         wqueue.service();
     }
     wqueue.finish();
+#if FX_DBG & 512
+    if (lane == 0) {  // ablation build: lifetime of every wave (shader cycles, 100 MHz ticks)
+        const long long gw = (long long)blockIdx.x * 4 + wave;
+        if (gw < 3000) {
+            trash[2048 + 2 * gw] = (double)(__builtin_readcyclecounter() - clk0);
+            trash[2049 + 2 * gw] = (double)(__builtin_amdgcn_s_memrealtime() - rt0);
+        }
+    }
+#endif
 }
 
 }  // namespace fxk
