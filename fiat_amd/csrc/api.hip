@@ -686,6 +686,15 @@ const StackedShape kStackedShapes[] = {
     {3, 6, 3, 2},  // degree-6 tetrahedron (DG P6 with Hessians: C4), 17..24 points
     {3, 6, 2, 1},  // ... 25..32 points
     {3, 6, 3, 1},  // ... 33..48 points
+    {3, 5, 3, 2},  // degree-5 tetrahedron
+    {3, 5, 2, 1},
+    {3, 5, 3, 1},
+    {3, 4, 3, 2},  // degree-4 tetrahedron (with Hessians: 350 stacked rows)
+    {3, 4, 2, 1},
+    {3, 4, 3, 1},
+    {3, 3, 3, 2},  // degree-3 tetrahedron (vector-valued elements, Hessians of P3)
+    {3, 3, 2, 1},
+    {3, 3, 3, 1},
 };
 constexpr int STACKED_NW = 4;  // one wave per SIMD
 
@@ -723,6 +732,15 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 0: return launch_stacked<3, 6, 3, 2>(L, s);
         case 1: return launch_stacked<3, 6, 2, 1>(L, s);
         case 2: return launch_stacked<3, 6, 3, 1>(L, s);
+        case 3: return launch_stacked<3, 5, 3, 2>(L, s);
+        case 4: return launch_stacked<3, 5, 2, 1>(L, s);
+        case 5: return launch_stacked<3, 5, 3, 1>(L, s);
+        case 6: return launch_stacked<3, 4, 3, 2>(L, s);
+        case 7: return launch_stacked<3, 4, 2, 1>(L, s);
+        case 8: return launch_stacked<3, 4, 3, 1>(L, s);
+        case 9: return launch_stacked<3, 3, 3, 2>(L, s);
+        case 10: return launch_stacked<3, 3, 2, 1>(L, s);
+        case 11: return launch_stacked<3, 3, 3, 1>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown stacked kernel %d", L.stacked_id);
 }
@@ -929,10 +947,12 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     L.stacked_id = -1;
     {
         static const bool nostacked = getenv("FIAT_AMD_NO_STACKED") != nullptr;
+        // (fewer stacked rows: the production of the B fragments is no longer amortised over enough row tiles)
+        static const long long stacked_min_rows = getenv("FIAT_AMD_STACKED_MIN_ROWS") ? atoll(getenv("FIAT_AMD_STACKED_MIN_ROWS")) : 200;
         const long long R = (long long)ntab * rows;
         const int RT = (int)((R + 15) / 16);
         const bool even = ((R * npts) % 2 == 0) && (((R - 16LL * (RT - 1)) * npts) % 2 == 0);
-        if (!nostacked && !verts && mapping == FX_MAP_AFFINE && !e->raw_expansion && order <= 2 && even && R >= 256) {
+        if (!nostacked && !verts && mapping == FX_MAP_AFFINE && !e->raw_expansion && order <= 2 && even && R >= stacked_min_rows) {
             for (size_t i = 0; i < sizeof(kStackedShapes) / sizeof(kStackedShapes[0]); ++i) {
                 const StackedShape& k = kStackedShapes[i];
                 if (k.sd != e->sd || k.n != e->n) continue;
@@ -941,6 +961,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 if (npts > cap || npts <= lo) continue;
                 bool ok = false;
                 if (e->sd == 3 && e->n == 6) ok = table_matches<3, 6>(e->prog);
+                if (e->sd == 3 && e->n == 5) ok = table_matches<3, 5>(e->prog);
+                if (e->sd == 3 && e->n == 4) ok = table_matches<3, 4>(e->prog);
+                if (e->sd == 3 && e->n == 3) ok = table_matches<3, 3>(e->prog);
                 if (!ok) continue;
                 int rc = ensure_stacked(ctx, const_cast<fx_element*>(e), order);
                 if (rc != FX_OK) return rc;

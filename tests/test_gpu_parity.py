@@ -352,7 +352,8 @@ def test_kernel_selection(rt, golden):
     assert p3.kernel_name(1, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_pair"
     assert p3.kernel_name(1, 1000, 40) == "fxk::tabulate_simplex_pair"       # one request per wave, 10 column tiles
     assert p3.kernel_name(1, 1000, 50) == "fxk::tabulate_simplex_kernel"     # more points than the registered tilings
-    assert p3.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_kernel"
+    assert p3.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_stacked"    # Hessians: 200 stacked rows
+    assert p3.kernel_name(2, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_kernel"
     dg6 = rt.SimplexPolySet(3, 6, coeffs=g["c4_dg6tet_q6_coeffs"])
     assert dg6.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_stacked"          # requests on the element's cell
     assert dg6.kernel_name(2, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_coop"  # per-request cells
@@ -477,6 +478,31 @@ def test_stacked_matrix_kernel_on_a_physical_element_cell(rt):
     pts = (e / e.sum(axis=-1, keepdims=True)) @ verts
     out = ps.tabulate_batch(2, pts).cpu().numpy()
     ref = c_oracle.tabulate_batch(verts, 6, el.get_coeffs(), 2, pts, scale=el._expansion_scale,
+                                  variant=el._expansion_variant).reshape(out.shape)
+    axes = tuple(range(2, out.ndim))
+    err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)
+    assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
+
+
+@pytest.mark.parametrize("fam,deg,order,npts", [
+    ("Lagrange", 3, 2, 23), ("Lagrange", 4, 2, 23), ("Lagrange", 5, 1, 23), ("Lagrange", 5, 2, 30), ("Lagrange", 6, 2, 23),
+    ("DiscontinuousLagrange", 5, 1, 40), ("DiscontinuousLagrange", 4, 2, 19), ("Nedelec", 3, 1, 23), ("Nedelec", 4, 1, 23),
+    ("Nedelec", 4, 2, 17), ("RaviartThomas", 3, 1, 28), ("BrezziDouglasMarini", 3, 1, 23), ("NedelecSecondKind", 3, 2, 23)])
+def test_stacked_matrix_kernel_families(fam, deg, order, npts):
+    """The stacked-matrix kernel across expansion degrees 3-6, bubble (Lagrange: the C0 transform is folded
+    into the coefficients, the derivative matrices are those of the raw hierarchy) and orthonormal variants,
+    scalar and vector-valued elements, against the C oracle's recurrence derivatives."""
+    import fiat_amd
+    from oracle import c_oracle
+    el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(3), deg)
+    ps = el.device_polyset()
+    nreq = 211
+    assert ps.kernel_name(order, nreq, npts) == "fxk::tabulate_simplex_stacked"
+    rng = np.random.default_rng(17 * deg + npts + order)
+    pts = rand_points(rng, 3, (nreq, npts))
+    out = ps.tabulate_batch(order, pts).cpu().numpy()
+    n = el.get_nodal_basis().get_embedded_degree()
+    ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[3], n, el.get_coeffs(), order, pts, scale=el._expansion_scale,
                                   variant=el._expansion_variant).reshape(out.shape)
     axes = tuple(range(2, out.ndim))
     err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)

@@ -8,10 +8,17 @@ import fiat_amd, bench
 CASES = [("Lagrange", 2, 1, 3), ("Lagrange", 2, 2, 6), ("Lagrange", 2, 3, 12), ("Lagrange", 3, 1, 4), ("Lagrange", 3, 2, 11),
          ("Lagrange", 3, 2, 14), ("Lagrange", 3, 3, 23), ("Lagrange", 3, 3, 14), ("Lagrange", 2, 4, 12), ("Lagrange", 2, 5, 16), ("Lagrange", 3, 4, 23), ("DiscontinuousLagrange", 3, 1, 4),
          ("Nedelec", 3, 1, 4), ("RaviartThomas", 3, 1, 4), ("Nedelec", 2, 1, 3)]
-for fam, sd, deg, npts in CASES:
+# (family, sd, degree, points, order): larger shapes, FIAT_AMD_NO_STACKED=1 for the A/B partner
+BIG = [("Lagrange", 3, 4, 23, 2), ("Lagrange", 3, 5, 23, 1), ("Lagrange", 3, 5, 23, 2), ("DiscontinuousLagrange", 3, 5, 30, 1),
+       ("DiscontinuousLagrange", 3, 6, 23, 1), ("DiscontinuousLagrange", 3, 6, 40, 2), ("Lagrange", 3, 6, 23, 2),
+       ("Nedelec", 3, 4, 23, 1), ("Nedelec", 3, 3, 23, 1), ("BrezziDouglasMarini", 3, 3, 23, 1)]
+if "--big" in sys.argv:
+    CASES = BIG
+for case in CASES:
+    fam, sd, deg, npts = case[:4]
     el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg)
     ps = el.device_polyset()
-    order = 1
+    order = case[4] if len(case) > 4 else 1
     shape1 = ps.out_shape(order, 1, npts)
     per_req = 8 * (npts * sd + int(np.prod(shape1[1:])))
     nreq = int(min(4_000_000, 1.2e9 // per_req))
