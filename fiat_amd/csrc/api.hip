@@ -681,24 +681,28 @@ int launch_fixed(const Launch& L, hipStream_t s) {
 // (sd, n) of the expansion set, CT column tiles per group of G requests: npts <= 16 CT / G
 struct StackedShape {
     int sd, n, ct, g;
+    int rtc;  // > 0: instance for exactly rtc row tiles with register-resident A fragments (small shapes); 0: any
 };
 const StackedShape kStackedShapes[] = {
-    {3, 6, 3, 2},  // degree-6 tetrahedron (DG P6 with Hessians: C4), 17..24 points
-    {3, 6, 2, 1},  // ... 25..32 points
-    {3, 6, 3, 1},  // ... 33..48 points
-    {3, 5, 3, 2},  // degree-5 tetrahedron
-    {3, 5, 2, 1},
-    {3, 5, 3, 1},
-    {3, 4, 3, 2},  // degree-4 tetrahedron (with Hessians: 350 stacked rows)
-    {3, 4, 2, 1},
-    {3, 4, 3, 1},
-    {3, 3, 3, 2},  // degree-3 tetrahedron (vector-valued elements, Hessians of P3)
-    {3, 3, 2, 1},
-    {3, 3, 3, 1},
+    {3, 6, 3, 2, 0},  // degree-6 tetrahedron (DG P6 with Hessians: C4), 17..24 points
+    {3, 6, 2, 1, 0},  // ... 25..32 points
+    {3, 6, 3, 1, 0},  // ... 33..48 points
+    {3, 5, 3, 2, 0},  // degree-5 tetrahedron
+    {3, 5, 2, 1, 0},
+    {3, 5, 3, 1, 0},
+    {3, 4, 3, 2, 0},  // degree-4 tetrahedron (with Hessians: 350 stacked rows)
+    {3, 4, 2, 1, 0},
+    {3, 4, 3, 1, 0},
+    {3, 3, 3, 2, 0},  // degree-3 tetrahedron (vector-valued elements, Hessians of P3)
+    {3, 3, 2, 1, 0},
+    {3, 3, 3, 1, 0},
+    {3, 3, 3, 2, 5},  // Lagrange P3 tetrahedron, values + gradient (80 stacked rows): the benchmark shape C2, 17..24 points
+    {3, 3, 2, 1, 5},  // ... 25..32 points
+    {3, 3, 3, 1, 5},  // ... 33..48 points
 };
 constexpr int STACKED_NW = 4;  // one wave per SIMD
 
-template <int SD, int N, int CT, int G>
+template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1>
 int launch_stacked(const Launch& L, hipStream_t s) {
     constexpr int NC = fxk::FixedNC<SD, N>::value;
     fxk::StackedArgs<NC> ka;
@@ -715,14 +719,27 @@ int launch_stacked(const Launch& L, hipStream_t s) {
     ka.debug = L.khead.debug;
     if ((int)L.fcoef.size() != NC) return fail(FX_EINVAL, "internal: coefficient table size mismatch");
     memcpy(ka.coef, L.fcoef.data(), NC * sizeof(double));
-    auto kern = fxk::tabulate_simplex_stacked<SD, N, CT, G>;
-    if (L.klds_bytes > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L.klds_bytes));
-    hipLaunchKernelGGL(kern, dim3(L.kgrid), dim3(64 * STACKED_NW), L.klds_bytes, s, ka, L.trash,
+    auto kern = fxk::tabulate_simplex_stacked<SD, N, CT, G, RTC, WPS>;
+    // as many workgroups per CU as registers and LDS allow (low degrees need few registers: their short
+    // row sweeps rely on other waves to cover the production phase); asked once per kernel
+    static thread_local int occ = 0;
+    if (occ == 0) {
+        if (L.klds_bytes > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, L.klds_bytes));
+        int q = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(kern), 64 * STACKED_NW, (size_t)L.klds_bytes));
+        occ = std::max(1, q);
+        static const int cap = getenv("FIAT_AMD_STACKED_WPS") ? atoi(getenv("FIAT_AMD_STACKED_WPS")) : 8;
+        occ = std::min(occ, std::max(1, cap));
+        if (getenv("FIAT_AMD_VERBOSE")) fprintf(stderr, "[fiat_amd] stacked kernel <%d,%d,%d,%d>: %d workgroups per CU, lds %d B\n", SD, N, CT, G, occ, L.klds_bytes);
+    }
+    const long long groups = (L.khead.nreq + G - 1) / G;
+    const int grid = (int)std::max<long long>(1, std::min<long long>((groups + STACKED_NW - 1) / STACKED_NW, (long long)L.ncu * occ));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * STACKED_NW), L.klds_bytes, s, ka, L.trash,
                        reinterpret_cast<unsigned int*>(L.queue));
     HIP_TRY(hipGetLastError());
 #if defined(FX_DBG) && (FX_DBG & 512)
-    if (getenv("FIAT_AMD_VERBOSE")) HIP_TRY(report_wave_lifetimes(L.trash, L.kgrid, STACKED_NW));
+    if (getenv("FIAT_AMD_VERBOSE")) HIP_TRY(report_wave_lifetimes(L.trash, grid, STACKED_NW));
 #endif
     return FX_OK;
 }
@@ -741,6 +758,9 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 9: return launch_stacked<3, 3, 3, 2>(L, s);
         case 10: return launch_stacked<3, 3, 2, 1>(L, s);
         case 11: return launch_stacked<3, 3, 3, 1>(L, s);
+        case 12: return launch_stacked<3, 3, 3, 2, 5, 3>(L, s);
+        case 13: return launch_stacked<3, 3, 2, 1, 5, 3>(L, s);
+        case 14: return launch_stacked<3, 3, 3, 1, 5, 3>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown stacked kernel %d", L.stacked_id);
 }
@@ -952,10 +972,15 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
         const long long R = (long long)ntab * rows;
         const int RT = (int)((R + 15) / 16);
         const bool even = ((R * npts) % 2 == 0) && (((R - 16LL * (RT - 1)) * npts) % 2 == 0);
-        if (!nostacked && !verts && mapping == FX_MAP_AFFINE && !e->raw_expansion && order <= 2 && even && R >= stacked_min_rows) {
+        if (!nostacked && !verts && mapping == FX_MAP_AFFINE && !e->raw_expansion && order <= 2 && even) {
             for (size_t i = 0; i < sizeof(kStackedShapes) / sizeof(kStackedShapes[0]); ++i) {
                 const StackedShape& k = kStackedShapes[i];
                 if (k.sd != e->sd || k.n != e->n) continue;
+                // small shapes with register-resident fragments: A/B partner of the paired kernel only (measured
+                // equal on C2, 302 vs 303 us -- both sit on the store-path plateau -- and the paired kernel's
+                // recurrence derivatives are two digits more accurate), opt-in with FIAT_AMD_STACKED_SMALL=1
+                const char* small = getenv("FIAT_AMD_STACKED_SMALL");
+                if (k.rtc > 0 ? (RT != k.rtc || !(small && atoi(small))) : R < stacked_min_rows) continue;
                 const int cap = 16 * k.ct / k.g;              // points one request may have
                 const int lo = 16 * k.ct / (k.g + 1);         // below: one more request fits the tiles
                 if (npts > cap || npts <= lo) continue;

@@ -44,9 +44,13 @@ constexpr int stacked_image_doubles(int CT, int KS) {
     return (4 * KS * 16 * CT > 16 * 16 * CT + 128) ? 4 * KS * 16 * CT : 16 * 16 * CT + 128;
 }
 
-// G requests of <= (16 CT / G) points per group
-template <int SD, int N, int CT, int G>
-__global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const StackedArgs<FixedNC<SD, N>::value> a,
+// G requests of <= (16 CT / G) points per group.  RTC > 0: the stacked matrix has exactly RTC row tiles and
+// all of its A fragments stay in registers for the whole launch (small shapes: nothing is loaded in the
+// sweep, which is fully unrolled); RTC == 0: any number of row tiles, fragments streamed from L2.
+// WPS: waves per SIMD the register allocation aims for (short sweeps need other waves to cover the
+// production phase of a group).
+template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1>
+__global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const StackedArgs<FixedNC<SD, N>::value> a,
                                                                    double* __restrict__ trash,
                                                                    unsigned int* __restrict__ gqueue) {
     constexpr StepTable<SD, N> TBL{};
@@ -103,7 +107,28 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
 #endif
     long long grp = wqueue.claim();
     wqueue.service();
+    // points of the wave's next group, one group ahead (their latency would otherwise be paid per group)
+    auto load_points = [&](long long g_, double (&x)[SD]) {
+        long long req = (g_ < ngroups ? g_ : ngroups - 1) * G + pg;
+        req = req < a.nreq ? req : a.nreq - 1;
+        const double* pp = a.pts + ((size_t)req * npts + ppt) * SD;
+#pragma unroll
+        for (int d = 0; d < SD; ++d) x[d] = pp[d];
+    };
+    double xnext[SD];
+    load_points(grp, xnext);
+    double areg[RTC > 0 ? RTC : 1][KS];
+    if constexpr (RTC > 0) {
+#pragma unroll
+        for (int t = 0; t < RTC; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) areg[t][ks] = a.afrag[((size_t)t * KS + ks) * 64 + lane];
+    }
+#pragma unroll
+    for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
     while (grp < ngroups) {
+        const long long gnext = wqueue.claim();
+        wqueue.service();
         // ---------------- expansion values -> B fragments ----------------
         // lane <-> column (request of the group, point): the order-0 recurrence once per column, every member to
         // a [slot][column] slab in LDS (it aliases the output image, which is idle until the sweep starts), then
@@ -112,15 +137,16 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
         {
             constexpr int PW = 16 * CT;
             double* phi = img;
+            double xcur[SD];
+#pragma unroll
+            for (int d = 0; d < SD; ++d) xcur[d] = xnext[d];
+            load_points(gnext, xnext);
             if (lane < PW) {
-                long long req = grp * G + pg;
-                req = req < a.nreq ? req : a.nreq - 1;
-                const double* pp = a.pts + ((size_t)req * npts + ppt) * SD;
                 double X[SD];
                 {
                     double x[SD];
 #pragma unroll
-                    for (int d = 0; d < SD; ++d) x[d] = pp[d];
+                    for (int d = 0; d < SD; ++d) x[d] = xcur[d];
 #pragma unroll
                     for (int i = 0; i < SD; ++i) {
                         double t = a.b0[i];
@@ -172,14 +198,28 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
         // two accumulator sets, the loop is unrolled by two so that they swap roles without copies).
         const double* ap = a.afrag + lane;
         double fa0[KS], fa1[KS];  // A fragments of the even / odd row tiles (loaded one tile ahead)
+        if constexpr (RTC == 0) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) fa0[ks] = ap[ks * 64];
+            for (int ks = 0; ks < KS; ++ks) fa0[ks] = ap[ks * 64];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa0[ks]));
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa0[ks]));
+        }
         long long oreq[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) oreq[g] = grp * G + g;
-        const int RTn = a.RT;
+        const int RTn = RTC > 0 ? RTC : a.RT;
+        // opaque per-group copies of the lane-derived offsets: otherwise every (tile, store) address of the
+        // unrolled sweep is precomputed outside the group loop and spilled (see simplex_pair.hpp)
+        int elane = lane, ekk = kk, enpts = npts;
+        int eoff[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) eoff[c] = ioff[c];
+        if constexpr (RTC > 0) {
+            asm volatile("" : "+v"(elane), "+v"(ekk), "+s"(enpts));
+#pragma unroll
+            for (int c = 0; c < CT; ++c) asm volatile("" : "+v"(eoff[c]));
+        }
+        const int echunk = 16 * enpts;
         const int last_rows = a.R - 16 * (RTn - 1);
 
         // D tile: element jj of lane (kk, col) is row 4 jj + kk -> image [request][row][point]
@@ -188,21 +228,21 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
         // D tile: element jj of lane (kk, col) is row 4 jj + kk -> image [request][row][point]
         auto image_put = [&](const v4d (&acc)[CT], int w, int nrows) {  // w-th of the 4 CT image stores
             const int c = w >> 2, jj = w & 3;
-            const bool ok = ioff[c] >= 0 && 4 * jj + kk < nrows;
-            img[ok ? ioff[c] + 4 * jj * npts : DUMP + lane] = acc[c][jj];
+            const bool ok = eoff[c] >= 0 && 4 * jj + ekk < nrows;
+            img[ok ? eoff[c] + 4 * jj * enpts : DUMP + elane] = acc[c][jj];
         };
         v2d fbuf[G * NST];
         auto image_get = [&](int r, int nrows) {  // r-th of the G NST 16-byte image reads
             const int g = r / NST, it = r % NST;
-            const int nch = (nrows * npts) >> 1;  // 16-byte pieces of a request's chunk (host: even)
-            fbuf[r] = reinterpret_cast<const v2d*>(img + g * chunk)[min(it * 64 + lane, nch - 1)];
+            const int nch = (nrows * enpts) >> 1;  // 16-byte pieces of a request's chunk (host: even)
+            fbuf[r] = reinterpret_cast<const v2d*>(img + g * echunk)[min(it * 64 + elane, nch - 1)];
         };
         auto image_out = [&](int r, int rt, int nrows) {  // r-th output store of row tile rt
             const int g = r / NST, it = r % NST;
-            const int nch = (nrows * npts) >> 1;
-            v2d* g2 = oreq[g] < a.nreq ? reinterpret_cast<v2d*>(a.out + ((size_t)oreq[g] * a.R + (size_t)16 * rt) * npts)
+            const int nch = (nrows * enpts) >> 1;
+            v2d* g2 = oreq[g] < a.nreq ? reinterpret_cast<v2d*>(a.out + ((size_t)oreq[g] * a.R + (size_t)16 * rt) * enpts)
                                        : reinterpret_cast<v2d*>(trash);
-            stream_store(&g2[min(it * 64 + lane, nch - 1)], fbuf[r]);
+            stream_store(&g2[min(it * 64 + elane, nch - 1)], fbuf[r]);
         };
         auto mfma_steps = [&](v4d (&acc)[CT], const double (&af)[KS], int k0, int k1) {
 #pragma unroll
@@ -228,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
                 mfma_steps(cur, af, ks, ks + 1);
                 // fragment loads in the first two thirds only: at the end of the stage they are older than every
                 // output store, so the wait for them is an exact vmcnt(#stores), not a wait for the stores
-                if (ks < 2 * T3) {
+                if (RTC == 0 && ks < 2 * T3) {
 #pragma unroll
                     for (int q = ks * LPK; q < (ks + 1) * LPK && q < KS; ++q) an[q] = anp[q * 64];
                 }
@@ -247,25 +287,11 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
             }
             wave_lds_fence();
             // first use of the prefetched fragments in the same block as the stores: exact vmcnt
+            if constexpr (RTC == 0) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(an[ks]));
+                for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(an[ks]));
+            }
         };
-        v4d accA[CT], accB[CT];
-        {   // tile 0: nothing to flush yet
-            const double* anp = ap + (size_t)KS * 64;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) fa1[ks] = anp[ks * 64];
-#pragma unroll
-            for (int c = 0; c < CT; ++c) accA[c] = v4d{0.0, 0.0, 0.0, 0.0};
-            mfma_steps(accA, fa0, 0, KS);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa1[ks]));
-        }
-        int rt = 1;
-        for (; rt + 1 < RTn; rt += 2) {  // odd tiles: fragments fa1 -> accB, even tiles: fa0 -> accA
-            stage(accB, accA, rt, fa1, fa0);
-            stage(accA, accB, rt + 1, fa0, fa1);
-        }
         auto flush_last = [&](const v4d (&acc)[CT]) {
 #pragma unroll
             for (int w = 0; w < NWR; ++w) image_put(acc, w, last_rows);
@@ -276,14 +302,53 @@ __global__ __launch_bounds__(256, 1) void tabulate_simplex_stacked(const Stacked
             for (int r = 0; r < NRD; ++r) image_out(r, RTn - 1, last_rows);
             wave_lds_fence();
         };
-        if (rt < RTn) {  // odd number of remaining tiles: one more stage, the last tile ends up in accB
-            stage(accB, accA, rt, fa1, fa0);
-            flush_last(accB);
+        if constexpr (RTC > 0) {
+            // register-resident fragments, fully unrolled; one accumulator set and no pipelining inside the wave:
+            // these shapes run several waves per SIMD, which overlap each other's flushes
+            v4d acc[CT];
+#pragma unroll
+            for (int t = 0; t < RTC; ++t) {
+                const int nrows = t == RTC - 1 ? last_rows : 16;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c] = v4d{0.0, 0.0, 0.0, 0.0};
+                mfma_steps(acc, areg[t], 0, KS);
+#pragma unroll
+                for (int w = 0; w < NWR; ++w) image_put(acc, w, nrows);
+                wave_lds_fence();
+#pragma unroll
+                for (int r = 0; r < NRD; ++r) image_get(r, nrows);
+#pragma unroll
+                for (int r = 0; r < NRD; ++r) image_out(r, t, nrows);
+                wave_lds_fence();
+            }
         } else {
-            flush_last(accA);
+            v4d accA[CT], accB[CT];
+            {   // tile 0: nothing to flush yet
+                const double* anp = ap + (size_t)KS * 64;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) fa1[ks] = anp[ks * 64];
+#pragma unroll
+                for (int c = 0; c < CT; ++c) accA[c] = v4d{0.0, 0.0, 0.0, 0.0};
+                mfma_steps(accA, fa0, 0, KS);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa1[ks]));
+            }
+            int rt = 1;
+            for (; rt + 1 < RTn; rt += 2) {  // odd tiles: fragments fa1 -> accB, even tiles: fa0 -> accA
+                stage(accB, accA, rt, fa1, fa0);
+                stage(accA, accB, rt + 1, fa0, fa1);
+            }
+            if (rt < RTn) {  // odd number of remaining tiles: one more stage, the last tile ends up in accB
+                stage(accB, accA, rt, fa1, fa0);
+                flush_last(accB);
+            } else {
+                flush_last(accA);
+            }
         }
-        grp = wqueue.claim();
-        wqueue.service();
+        // first use of the prefetched points in the same block as the last stores: exact vmcnt
+#pragma unroll
+        for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
+        grp = gnext;
     }
     wqueue.finish();
 #if FX_DBG & 512

@@ -507,3 +507,24 @@ def test_stacked_matrix_kernel_families(fam, deg, order, npts):
     axes = tuple(range(2, out.ndim))
     err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)
     assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
+
+
+@pytest.mark.parametrize("npts,nreq", [(23, 4001), (17, 3), (28, 500), (40, 77)])
+def test_stacked_matrix_kernel_small_shape_ab(rt, golden, monkeypatch, npts, nreq):
+    """The register-resident instances of the stacked-matrix kernel (P3 tetrahedron, values + gradient: the A/B
+    partner of the paired kernel on the benchmark shape, FIAT_AMD_STACKED_SMALL=1) against the C oracle."""
+    from oracle import c_oracle
+    monkeypatch.setenv("FIAT_AMD_STACKED_SMALL", "1")  # (read at every launch)
+    g = golden("elements")
+    co = g["c2_p3tet_q6_coeffs"]
+    ps = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=co)
+    assert ps.kernel_name(1, nreq, npts) == "fxk::tabulate_simplex_stacked"
+    rng = np.random.default_rng(npts + nreq)
+    pts = rand_points(rng, 3, (nreq, npts))
+    out = ps.tabulate_batch(1, pts).cpu().numpy()
+    ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[3], 3, co, 1, pts, scale=1.0, variant="bubble").reshape(out.shape)
+    axes = tuple(range(2, out.ndim))
+    err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)
+    assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
+    monkeypatch.delenv("FIAT_AMD_STACKED_SMALL")
+    assert ps.kernel_name(1, nreq, npts) == "fxk::tabulate_simplex_pair"
