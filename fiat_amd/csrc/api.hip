@@ -1633,11 +1633,24 @@ int fx_vandermonde_solve_batch(fx_ctx* ctx, int64_t nsys, int ndof, int m, const
     if (!ctx || nsys < 0 || ndof < 1 || m < 1 || !info) return fail(FX_EINVAL, "fx_vandermonde_solve_batch: bad argument");
     if (nsys == 0) return FX_OK;
     size_t lds = ((size_t)ndof * ndof + (size_t)ndof * m) * 8;
-    if (lds > 150 * 1024) return fail(FX_ENOTIMPL, "system too large for the LDS-resident solver (ndof=%d, m=%d)", ndof, m);
-    auto kern = fxk::vandermonde_solve_kernel;
+    if (lds > 150 * 1024) {
+        // beyond the LDS: the same elimination with M and the right-hand sides in a global workspace
+        if (nsys > 65535) return fail(FX_EINVAL, "fx_vandermonde_solve_batch: too many large systems in one call");
+        double* ws = nullptr;
+        HIP_TRY(hipMalloc(&ws, (size_t)nsys * lds));
+        hipLaunchKernelGGL(fxk::vandermonde_solve_kernel<true>, dim3((unsigned)nsys), dim3(256), 0, (hipStream_t)stream, ndof, m,
+                           A, B, X, Vout, info, ws);
+        hipError_t he = hipGetLastError();
+        if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream);
+        (void)hipFree(ws);
+        if (he != hipSuccess) return fail(FX_EHIP, "fx_vandermonde_solve_batch: %s", hipGetErrorString(he));
+        return FX_OK;
+    }
+    auto kern = fxk::vandermonde_solve_kernel<false>;
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)nsys), dim3(256), lds, (hipStream_t)stream, ndof, m, A, B, X, Vout, info);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nsys), dim3(256), lds, (hipStream_t)stream, ndof, m, A, B, X, Vout, info,
+                       (double*)nullptr);
     HIP_TRY(hipGetLastError());
     return FX_OK;
 }

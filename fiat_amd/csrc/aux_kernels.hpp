@@ -28,14 +28,17 @@ __global__ void riesz_assemble_kernel(int nrows, int nq, int nexp, const double*
 // pivoting (finite_element.py:141-159; scipy.linalg.solve(V, B, transposed=True)
 // is LAPACK gesv, the same elimination order).  LDS: M = V^T (n x n) followed
 // by the right-hand sides / solution (n x m).
+// GLOBAL: systems beyond the LDS (n^2 + n m doubles > 150 kB, e.g. 105 dofs of BDM4 or 120 of P7 on a
+// tetrahedron) keep M and R in a global workspace `ws` (L2-resident; construction only).
+template <bool GLOBAL>
 __global__ __launch_bounds__(256) void vandermonde_solve_kernel(int n, int m, const double* __restrict__ Aall,
                                                                const double* __restrict__ Ball,
                                                                double* __restrict__ Xall,
                                                                double* __restrict__ Vall,
-                                                               int* __restrict__ info_all) {
+                                                               int* __restrict__ info_all, double* ws) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double* M = sm;                    // n x n, M[r][c] = V[c][r]
-    double* R = sm + (size_t)n * n;    // n x m
+    double* M = GLOBAL ? ws + (size_t)blockIdx.x * ((size_t)n * n + (size_t)n * m) : sm;  // n x n, M[r][c] = V[c][r]
+    double* R = M + (size_t)n * n;     // n x m
     __shared__ int s_piv;
     __shared__ int s_info;
     __shared__ double s_anorm;

@@ -99,3 +99,16 @@ def test_pushforward_of_the_new_families(golden):
             grads = np.einsum("ce,gdep,gh->hdcp", M, raw[i, 1:], Jinv)
             assert rel(got[i, 0], vals) <= 1e-12
             assert rel(got[i, 1:], grads) <= 1e-10
+
+
+@pytest.mark.parametrize("cls,degree", [("Lagrange", 7), ("DiscontinuousLagrange", 7)])
+def test_large_vandermonde_systems_nodality(cls, degree):
+    """120 dofs on a tetrahedron: V and the right-hand sides exceed the LDS, the solver works in a global
+    workspace (vandermonde_solve_kernel<true>).  Nodal basis: phi_j(x_i) = delta_ij
+    (test/FIAT/unit/test_fiat.py:76-117, test_nodality)."""
+    import fiat_amd
+    el = getattr(fiat_amd, cls)(fiat_amd.ufc_simplex(3), degree)
+    assert el.space_dimension() == 120
+    nodes = np.array([list(ell.get_point_dict().keys())[0] for ell in el.dual_basis()])
+    tab = el.tabulate(0, nodes)[(0, 0, 0)]
+    assert np.abs(tab - np.eye(120)).max() < 1e-9
