@@ -684,6 +684,9 @@ struct StackedShape {
     int rtc;  // > 0: instance for exactly rtc row tiles with register-resident A fragments (small shapes); 0: any
 };
 const StackedShape kStackedShapes[] = {
+    {3, 3, 3, 2, 5},  // Lagrange P3 tetrahedron, values + gradient (80 stacked rows): the benchmark shape C2, 17..24 points
+    {3, 3, 2, 1, 5},  // ... 25..32 points
+    {3, 3, 3, 1, 5},  // ... 33..48 points
     {3, 6, 3, 2, 0},  // degree-6 tetrahedron (DG P6 with Hessians: C4), 17..24 points
     {3, 6, 2, 1, 0},  // ... 25..32 points
     {3, 6, 3, 1, 0},  // ... 33..48 points
@@ -696,9 +699,18 @@ const StackedShape kStackedShapes[] = {
     {3, 3, 3, 2, 0},  // degree-3 tetrahedron (vector-valued elements, Hessians of P3)
     {3, 3, 2, 1, 0},
     {3, 3, 3, 1, 0},
-    {3, 3, 3, 2, 5},  // Lagrange P3 tetrahedron, values + gradient (80 stacked rows): the benchmark shape C2, 17..24 points
-    {3, 3, 2, 1, 5},  // ... 25..32 points
-    {3, 3, 3, 1, 5},  // ... 33..48 points
+    {2, 6, 3, 2, 0},  // degree-5 / 6 triangles
+    {2, 6, 2, 1, 0},
+    {2, 6, 3, 1, 0},
+    {2, 5, 3, 2, 0},
+    {2, 5, 2, 1, 0},
+    {2, 5, 3, 1, 0},
+    {3, 6, 3, 3, 0}, {3, 6, 4, 1, 0},  // 13..16 and 49..64 points
+    {3, 5, 3, 3, 0}, {3, 5, 4, 1, 0},
+    {3, 4, 3, 3, 0}, {3, 4, 4, 1, 0},
+    {3, 3, 3, 3, 0}, {3, 3, 4, 1, 0},
+    {2, 6, 3, 3, 0}, {2, 6, 4, 1, 0},
+    {2, 5, 3, 3, 0}, {2, 5, 4, 1, 0},
 };
 constexpr int STACKED_NW = 4;  // one wave per SIMD
 
@@ -745,22 +757,40 @@ int launch_stacked(const Launch& L, hipStream_t s) {
 }
 
 int run_stacked(const Launch& L, hipStream_t s) {
-    switch (L.stacked_id) {
-        case 0: return launch_stacked<3, 6, 3, 2>(L, s);
-        case 1: return launch_stacked<3, 6, 2, 1>(L, s);
-        case 2: return launch_stacked<3, 6, 3, 1>(L, s);
-        case 3: return launch_stacked<3, 5, 3, 2>(L, s);
-        case 4: return launch_stacked<3, 5, 2, 1>(L, s);
-        case 5: return launch_stacked<3, 5, 3, 1>(L, s);
-        case 6: return launch_stacked<3, 4, 3, 2>(L, s);
-        case 7: return launch_stacked<3, 4, 2, 1>(L, s);
-        case 8: return launch_stacked<3, 4, 3, 1>(L, s);
-        case 9: return launch_stacked<3, 3, 3, 2>(L, s);
-        case 10: return launch_stacked<3, 3, 2, 1>(L, s);
-        case 11: return launch_stacked<3, 3, 3, 1>(L, s);
-        case 12: return launch_stacked<3, 3, 3, 2, 5, 3>(L, s);
-        case 13: return launch_stacked<3, 3, 2, 1, 5, 3>(L, s);
-        case 14: return launch_stacked<3, 3, 3, 1, 5, 3>(L, s);
+    switch (L.stacked_id) {  // (same order as kStackedShapes)
+        case 0: return launch_stacked<3, 3, 3, 2, 5, 3>(L, s);
+        case 1: return launch_stacked<3, 3, 2, 1, 5, 3>(L, s);
+        case 2: return launch_stacked<3, 3, 3, 1, 5, 3>(L, s);
+        case 3: return launch_stacked<3, 6, 3, 2>(L, s);
+        case 4: return launch_stacked<3, 6, 2, 1>(L, s);
+        case 5: return launch_stacked<3, 6, 3, 1>(L, s);
+        case 6: return launch_stacked<3, 5, 3, 2>(L, s);
+        case 7: return launch_stacked<3, 5, 2, 1>(L, s);
+        case 8: return launch_stacked<3, 5, 3, 1>(L, s);
+        case 9: return launch_stacked<3, 4, 3, 2>(L, s);
+        case 10: return launch_stacked<3, 4, 2, 1>(L, s);
+        case 11: return launch_stacked<3, 4, 3, 1>(L, s);
+        case 12: return launch_stacked<3, 3, 3, 2>(L, s);
+        case 13: return launch_stacked<3, 3, 2, 1>(L, s);
+        case 14: return launch_stacked<3, 3, 3, 1>(L, s);
+        case 15: return launch_stacked<2, 6, 3, 2>(L, s);
+        case 16: return launch_stacked<2, 6, 2, 1>(L, s);
+        case 17: return launch_stacked<2, 6, 3, 1>(L, s);
+        case 18: return launch_stacked<2, 5, 3, 2>(L, s);
+        case 19: return launch_stacked<2, 5, 2, 1>(L, s);
+        case 20: return launch_stacked<2, 5, 3, 1>(L, s);
+        case 21: return launch_stacked<3, 6, 3, 3>(L, s);
+        case 22: return launch_stacked<3, 6, 4, 1>(L, s);
+        case 23: return launch_stacked<3, 5, 3, 3>(L, s);
+        case 24: return launch_stacked<3, 5, 4, 1>(L, s);
+        case 25: return launch_stacked<3, 4, 3, 3>(L, s);
+        case 26: return launch_stacked<3, 4, 4, 1>(L, s);
+        case 27: return launch_stacked<3, 3, 3, 3>(L, s);
+        case 28: return launch_stacked<3, 3, 4, 1>(L, s);
+        case 29: return launch_stacked<2, 6, 3, 3>(L, s);
+        case 30: return launch_stacked<2, 6, 4, 1>(L, s);
+        case 31: return launch_stacked<2, 5, 3, 3>(L, s);
+        case 32: return launch_stacked<2, 5, 4, 1>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown stacked kernel %d", L.stacked_id);
 }
@@ -963,70 +993,6 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     a.stage_doubles = (int)((stage / 8 + 1) & ~1LL);
     if (stage == 0) a.stage_doubles = 0;
     L.lds_bytes = (a.phi_doubles + a.stage_doubles) * 8;
-    // ---- stacked-matrix kernel (requests on the element's own cell, large shapes)? ----
-    L.stacked_id = -1;
-    {
-        static const bool nostacked = getenv("FIAT_AMD_NO_STACKED") != nullptr;
-        // (fewer stacked rows: the production of the B fragments is no longer amortised over enough row tiles)
-        static const long long stacked_min_rows = getenv("FIAT_AMD_STACKED_MIN_ROWS") ? atoll(getenv("FIAT_AMD_STACKED_MIN_ROWS")) : 200;
-        const long long R = (long long)ntab * rows;
-        const int RT = (int)((R + 15) / 16);
-        const bool even = ((R * npts) % 2 == 0) && (((R - 16LL * (RT - 1)) * npts) % 2 == 0);
-        if (!nostacked && !verts && mapping == FX_MAP_AFFINE && !e->raw_expansion && order <= 2 && even) {
-            for (size_t i = 0; i < sizeof(kStackedShapes) / sizeof(kStackedShapes[0]); ++i) {
-                const StackedShape& k = kStackedShapes[i];
-                if (k.sd != e->sd || k.n != e->n) continue;
-                // small shapes with register-resident fragments: A/B partner of the paired kernel only (measured
-                // equal on C2, 302 vs 303 us -- both sit on the store-path plateau -- and the paired kernel's
-                // recurrence derivatives are two digits more accurate), opt-in with FIAT_AMD_STACKED_SMALL=1
-                const char* small = getenv("FIAT_AMD_STACKED_SMALL");
-                if (k.rtc > 0 ? (RT != k.rtc || !(small && atoi(small))) : R < stacked_min_rows) continue;
-                const int cap = 16 * k.ct / k.g;              // points one request may have
-                const int lo = 16 * k.ct / (k.g + 1);         // below: one more request fits the tiles
-                if (npts > cap || npts <= lo) continue;
-                bool ok = false;
-                if (e->sd == 3 && e->n == 6) ok = table_matches<3, 6>(e->prog);
-                if (e->sd == 3 && e->n == 5) ok = table_matches<3, 5>(e->prog);
-                if (e->sd == 3 && e->n == 4) ok = table_matches<3, 4>(e->prog);
-                if (e->sd == 3 && e->n == 3) ok = table_matches<3, 3>(e->prog);
-                if (!ok) continue;
-                int rc = ensure_stacked(ctx, const_cast<fx_element*>(e), order);
-                if (rc != FX_OK) return rc;
-                if (e->stack_state[order] != 1) continue;
-                fxk::StackedArgs<0>& ka = L.khead;
-                memset(&ka, 0, sizeof ka);
-                L.fcoef.resize(e->prog.steps.size() * 3);
-                for (size_t q = 0; q < e->prog.steps.size(); ++q) {
-                    L.fcoef[3 * q + 0] = e->prog.steps[q].A;
-                    L.fcoef[3 * q + 1] = e->prog.steps[q].B;
-                    L.fcoef[3 * q + 2] = e->prog.steps[q].C;
-                }
-                ka.pts = pts;
-                ka.out = out;
-                ka.afrag = e->d_astack[order];
-                ka.phi0 = e->prog.phi0;
-                memcpy(ka.A0, e->A0, sizeof ka.A0);
-                memcpy(ka.b0, e->b0, sizeof ka.b0);
-                ka.nreq = nreq;
-                ka.npts = npts;
-                ka.R = (int)R;
-                ka.RT = RT;
-                ka.debug = a.debug;
-                L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * fxk::stacked_image_doubles(k.ct, (e->nexp + 3) / 4)) * 8;
-                if (L.klds_bytes > ctx->lds_per_cu) continue;
-                const long long groups = (nreq + k.g - 1) / k.g;
-                // one workgroup per CU = one wave per SIMD (measured: a second wave per SIMD at half the registers
-                // spills in the production phase and gains nothing, 1.45 -> 1.48 ms: the kernel is bound by the
-                // shared fp64 MFMA/VALU pipe, not by latencies)
-                L.kgrid = (int)std::max<long long>(1, std::min<long long>((groups + STACKED_NW - 1) / STACKED_NW, ctx->num_cu));
-                L.ncu = ctx->num_cu;
-                L.trash = ctx->d_trash;
-                L.queue = ctx->d_queue + (size_t)(ctx->launch_seq++ % FX_QUEUE_SLOTS) * 16;
-                L.stacked_id = (int)i;
-                break;
-            }
-        }
-    }
     // ---- cooperative kernel for large shapes? ----
     L.coop_id = -1;
     {
@@ -1097,7 +1063,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     // ---- shape-specialised kernel available? ----
     L.fixed_id = -1;
     const char* nofixed = getenv("FIAT_AMD_NO_FIXED");
-    if (!(nofixed && atoi(nofixed)) && npts <= 64) {
+    const char* stacked_small = getenv("FIAT_AMD_STACKED_SMALL");  // A/B: the stacked kernel's small-shape instances instead
+    const bool ab_small = stacked_small && atoi(stacked_small) && !verts && mapping == FX_MAP_AFFINE;
+    if (!(nofixed && atoi(nofixed)) && !ab_small && npts <= 64) {
         const int nt_need = (ntab * npts + 15) / 16;
         for (size_t i = 0; i < sizeof(kFixedShapes) / sizeof(kFixedShapes[0]); ++i) {
             const FixedShape& f = kFixedShapes[i];
@@ -1209,6 +1177,73 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             break;
         }
     }
+    // ---- stacked-matrix kernel (requests on the element's own cell, large shapes)? ----
+    L.stacked_id = -1;
+    {
+        static const bool nostacked = getenv("FIAT_AMD_NO_STACKED") != nullptr;
+        // (fewer stacked rows: the production of the B fragments is no longer amortised over enough row tiles)
+        static const long long stacked_min_rows = getenv("FIAT_AMD_STACKED_MIN_ROWS") ? atoll(getenv("FIAT_AMD_STACKED_MIN_ROWS")) : 48;
+        const long long R = (long long)ntab * rows;
+        const int RT = (int)((R + 15) / 16);
+        const bool even = ((R * npts) % 2 == 0) && (((R - 16LL * (RT - 1)) * npts) % 2 == 0);
+        // (after the shape-specialised registry: its tuned paired instances keep their shapes)
+        if (!nostacked && L.fixed_id < 0 && !verts && mapping == FX_MAP_AFFINE && !e->raw_expansion && order <= 2 && even) {
+            for (size_t i = 0; i < sizeof(kStackedShapes) / sizeof(kStackedShapes[0]); ++i) {
+                const StackedShape& k = kStackedShapes[i];
+                if (k.sd != e->sd || k.n != e->n) continue;
+                // small shapes with register-resident fragments: A/B partner of the paired kernel only (measured
+                // equal on C2, 302 vs 303 us -- both sit on the store-path plateau -- and the paired kernel's
+                // recurrence derivatives are two digits more accurate), opt-in with FIAT_AMD_STACKED_SMALL=1
+                const char* small = getenv("FIAT_AMD_STACKED_SMALL");
+                if (k.rtc > 0 ? (RT != k.rtc || !(small && atoi(small))) : R < stacked_min_rows) continue;
+                const int cap = 16 * k.ct / k.g;              // points one request may have
+                const int lo = 16 * k.ct / (k.g + 1);         // below: one more request fits the tiles
+                if (npts > cap || npts <= lo) continue;
+                bool ok = false;
+                if (e->sd == 3 && e->n == 6) ok = table_matches<3, 6>(e->prog);
+                if (e->sd == 3 && e->n == 5) ok = table_matches<3, 5>(e->prog);
+                if (e->sd == 3 && e->n == 4) ok = table_matches<3, 4>(e->prog);
+                if (e->sd == 3 && e->n == 3) ok = table_matches<3, 3>(e->prog);
+                if (e->sd == 2 && e->n == 6) ok = table_matches<2, 6>(e->prog);
+                if (e->sd == 2 && e->n == 5) ok = table_matches<2, 5>(e->prog);
+                if (!ok) continue;
+                int rc = ensure_stacked(ctx, const_cast<fx_element*>(e), order);
+                if (rc != FX_OK) return rc;
+                if (e->stack_state[order] != 1) continue;
+                fxk::StackedArgs<0>& ka = L.khead;
+                memset(&ka, 0, sizeof ka);
+                L.fcoef.resize(e->prog.steps.size() * 3);
+                for (size_t q = 0; q < e->prog.steps.size(); ++q) {
+                    L.fcoef[3 * q + 0] = e->prog.steps[q].A;
+                    L.fcoef[3 * q + 1] = e->prog.steps[q].B;
+                    L.fcoef[3 * q + 2] = e->prog.steps[q].C;
+                }
+                ka.pts = pts;
+                ka.out = out;
+                ka.afrag = e->d_astack[order];
+                ka.phi0 = e->prog.phi0;
+                memcpy(ka.A0, e->A0, sizeof ka.A0);
+                memcpy(ka.b0, e->b0, sizeof ka.b0);
+                ka.nreq = nreq;
+                ka.npts = npts;
+                ka.R = (int)R;
+                ka.RT = RT;
+                ka.debug = a.debug;
+                L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * fxk::stacked_image_doubles(k.ct, (e->nexp + 3) / 4)) * 8;
+                if (L.klds_bytes > ctx->lds_per_cu) continue;
+                const long long groups = (nreq + k.g - 1) / k.g;
+                // one workgroup per CU = one wave per SIMD (measured: a second wave per SIMD at half the registers
+                // spills in the production phase and gains nothing, 1.45 -> 1.48 ms: the kernel is bound by the
+                // shared fp64 MFMA/VALU pipe, not by latencies)
+                L.kgrid = (int)std::max<long long>(1, std::min<long long>((groups + STACKED_NW - 1) / STACKED_NW, ctx->num_cu));
+                L.ncu = ctx->num_cu;
+                L.trash = ctx->d_trash;
+                L.queue = ctx->d_queue + (size_t)(ctx->launch_seq++ % FX_QUEUE_SLOTS) * 16;
+                L.stacked_id = (int)i;
+                break;
+            }
+        }
+    }
     // ---- low-order lane-local kernel? ----
     L.small_id = -1;
     {
@@ -1258,8 +1293,8 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
 
 int run_tabulate(fx_ctx* ctx, const fx_element* e, int order, const Launch& L, hipStream_t s) {
     if (L.args.nitems == 0 || L.args.npts == 0) return FX_OK;
-    if (L.stacked_id >= 0) return run_stacked(L, s);
     if (L.fixed_id >= 0) return run_fixed(L, s);
+    if (L.stacked_id >= 0) return run_stacked(L, s);
     if (L.coop_id >= 0) return run_coop(L, s);
     if (L.small_id >= 0) return run_small(order, L, s);
     switch (e->sd) {
@@ -1529,12 +1564,12 @@ int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, in
     int rc = plan_launch(ctx, e, order, nreq, npts, &dummy, has_verts ? &dummy : nullptr, &dummy, L);
     if (rc != FX_OK) return rc;
     const char* k = "fxk::tabulate_simplex_kernel";
-    if (L.stacked_id >= 0)
-        k = "fxk::tabulate_simplex_stacked";
-    else if (L.fixed_id >= 0)
+    if (L.fixed_id >= 0)
         k = L.fkind == 0   ? "fxk::tabulate_simplex_fixed"
             : L.fkind == 1 ? "fxk::tabulate_simplex_stream"
                            : "fxk::tabulate_simplex_pair";
+    else if (L.stacked_id >= 0)
+        k = "fxk::tabulate_simplex_stacked";
     else if (L.coop_id >= 0) k = "fxk::tabulate_simplex_coop";
     else if (L.small_id >= 0) k = "fxk::tabulate_simplex_small";
     snprintf(name, (size_t)name_len, "%s", k);

@@ -40,8 +40,10 @@ template <int NC> struct StackedArgs {
 
 // per-wave LDS: the output image of a row tile (16 x 16 CT doubles + dump row + read slack); the expansion
 // values of a group ([4 KS slots][16 CT columns]) alias it while they are produced
+// (four column tiles: the values are produced in two passes of two tiles, which halves the slab)
+constexpr int stacked_passes(int CT) { return CT > 3 ? 2 : 1; }
 constexpr int stacked_image_doubles(int CT, int KS) {
-    return (4 * KS * 16 * CT > 16 * 16 * CT + 128) ? 4 * KS * 16 * CT : 16 * 16 * CT + 128;
+    return (4 * KS * 16 * CT / stacked_passes(CT) > 16 * 16 * CT + 128) ? 4 * KS * 16 * CT / stacked_passes(CT) : 16 * 16 * CT + 128;
 }
 
 // G requests of <= (16 CT / G) points per group.  RTC > 0: the stacked matrix has exactly RTC row tiles and
@@ -93,13 +95,16 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
         }
     }
 
-    // production: lane <-> column `lane` of the group (lanes < 16 CT)
-    int pg, ppt;
-    {
-        const int g = idiv_small(lane, 1.0f / (float)npts);
-        const bool valid = g < G;
-        pg = valid ? g : 0;
-        ppt = valid ? lane - g * npts : 0;
+    // production: lane <-> column `h PWP + lane` of the group in pass h (lanes < PWP)
+    constexpr int PH = stacked_passes(CT), PWP = 16 * CT / PH;
+    int pg[PH], ppt[PH];
+#pragma unroll
+    for (int h = 0; h < PH; ++h) {
+        const int j = h * PWP + lane;
+        const int g = idiv_small(j, 1.0f / (float)npts);
+        const bool valid = g < G && lane < PWP;
+        pg[h] = valid ? g : 0;
+        ppt[h] = valid ? j - g * npts : 0;
     }
 
 #if FX_DBG & 512
@@ -108,14 +113,17 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
     long long grp = wqueue.claim();
     wqueue.service();
     // points of the wave's next group, one group ahead (their latency would otherwise be paid per group)
-    auto load_points = [&](long long g_, double (&x)[SD]) {
-        long long req = (g_ < ngroups ? g_ : ngroups - 1) * G + pg;
-        req = req < a.nreq ? req : a.nreq - 1;
-        const double* pp = a.pts + ((size_t)req * npts + ppt) * SD;
+    auto load_points = [&](long long g_, double (&x)[PH][SD]) {
 #pragma unroll
-        for (int d = 0; d < SD; ++d) x[d] = pp[d];
+        for (int h = 0; h < PH; ++h) {
+            long long req = (g_ < ngroups ? g_ : ngroups - 1) * G + pg[h];
+            req = req < a.nreq ? req : a.nreq - 1;
+            const double* pp = a.pts + ((size_t)req * npts + ppt[h]) * SD;
+#pragma unroll
+            for (int d = 0; d < SD; ++d) x[h][d] = pp[d];
+        }
     };
-    double xnext[SD];
+    double xnext[PH][SD];
     load_points(grp, xnext);
     double areg[RTC > 0 ? RTC : 1][KS];
     if constexpr (RTC > 0) {
@@ -125,7 +133,9 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
             for (int ks = 0; ks < KS; ++ks) areg[t][ks] = a.afrag[((size_t)t * KS + ks) * 64 + lane];
     }
 #pragma unroll
-    for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
+    for (int h = 0; h < PH; ++h)
+#pragma unroll
+        for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[h][d]));
     while (grp < ngroups) {
         const long long gnext = wqueue.claim();
         wqueue.service();
@@ -135,61 +145,61 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
         // each lane (kk, col) picks the members 4 ks + kk of its columns: the MFMA B fragments, kept in registers.
         double bf[KS][CT];
         {
-            constexpr int PW = 16 * CT;
             double* phi = img;
-            double xcur[SD];
+            double xcur[PH][SD];
 #pragma unroll
-            for (int d = 0; d < SD; ++d) xcur[d] = xnext[d];
+            for (int h = 0; h < PH; ++h)
+#pragma unroll
+                for (int d = 0; d < SD; ++d) xcur[h][d] = xnext[h][d];
             load_points(gnext, xnext);
-            if (lane < PW) {
-                double X[SD];
-                {
-                    double x[SD];
 #pragma unroll
-                    for (int d = 0; d < SD; ++d) x[d] = xcur[d];
+            for (int h = 0; h < PH; ++h) {
+                if (lane < PWP) {
+                    double X[SD];
 #pragma unroll
                     for (int i = 0; i < SD; ++i) {
                         double t = a.b0[i];
 #pragma unroll
-                        for (int d = 0; d < SD; ++d) t += a.A0[i * SD + d] * x[d];
+                        for (int d = 0; d < SD; ++d) t += a.A0[i * SD + d] * xcur[h][d];
                         X[i] = t;
                     }
+                    double mem[NEXP];
+                    double ufa = 0.0, ufb = 0.0, ufc = 0.0;
+                    int fcodim = -1;
+                    auto produce = [&](int slot) -> double {
+                        if (slot == 0) {
+                            mem[0] = a.phi0;
+                            return mem[0];
+                        }
+                        if (slot >= NEXP) return 0.0;
+                        const int s = slot - 1;
+                        const CDouble* cb = kcoef;
+                        // opaque base, immediate offsets (see simplex_pair.hpp); tied to the step's input so that
+                        // the pointer copies are not all made (and spilled) ahead of the recurrence
+                        asm volatile("" : "+s"(cb) : "v"(mem[TBL.cur[s]]));
+                        const CDouble* cq = cb + 3 * s;
+                        const double cA = cq[0], cB = cq[1], cC = cq[2];
+                        if (TBL.codim[s] != fcodim) {
+                            fcodim = TBL.codim[s];
+                            point_factors<SD>(fcodim, X, ufa, ufb, ufc);
+                        }
+                        const double f = cA * ufa - cB * ufb;
+                        double v = mem[TBL.cur[s]] * f;
+                        if (TBL.prv[s] >= 0) v -= cC * ufc * mem[TBL.prv[s]];
+                        mem[TBL.dst[s]] = v;
+                        return v;
+                    };
+#pragma unroll
+                    for (int slot = 0; slot < 4 * KS; ++slot) phi[slot * PWP + lane] = produce(slot);
                 }
-                double mem[NEXP];
-                double ufa = 0.0, ufb = 0.0, ufc = 0.0;
-                int fcodim = -1;
-                auto produce = [&](int slot) -> double {
-                    if (slot == 0) {
-                        mem[0] = a.phi0;
-                        return mem[0];
-                    }
-                    if (slot >= NEXP) return 0.0;
-                    const int s = slot - 1;
-                    const CDouble* cb = kcoef;
-                    // opaque base, immediate offsets (see simplex_pair.hpp); tied to the step's input so that the
-                    // 83 pointer copies are not all made (and spilled) ahead of the recurrence
-                    asm volatile("" : "+s"(cb) : "v"(mem[TBL.cur[s]]));
-                    const CDouble* cq = cb + 3 * s;
-                    const double cA = cq[0], cB = cq[1], cC = cq[2];
-                    if (TBL.codim[s] != fcodim) {
-                        fcodim = TBL.codim[s];
-                        point_factors<SD>(fcodim, X, ufa, ufb, ufc);
-                    }
-                    const double f = cA * ufa - cB * ufb;
-                    double v = mem[TBL.cur[s]] * f;
-                    if (TBL.prv[s] >= 0) v -= cC * ufc * mem[TBL.prv[s]];
-                    mem[TBL.dst[s]] = v;
-                    return v;
-                };
+                wave_lds_fence();
 #pragma unroll
-                for (int slot = 0; slot < 4 * KS; ++slot) phi[slot * PW + lane] = produce(slot);
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int cc = 0; cc < CT / PH; ++cc)
+                        bf[ks][h * (CT / PH) + cc] = phi[(4 * ks + kk) * PWP + 16 * cc + (lane & 15)];
+                wave_lds_fence();
             }
-            wave_lds_fence();
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int c = 0; c < CT; ++c) bf[ks][c] = phi[(4 * ks + kk) * PW + 16 * c + (lane & 15)];
-            wave_lds_fence();
         }
 
         // ---------------- sweep the row tiles of A_stack ----------------
@@ -347,7 +357,9 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
         }
         // first use of the prefetched points in the same block as the last stores: exact vmcnt
 #pragma unroll
-        for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
+        for (int h = 0; h < PH; ++h)
+#pragma unroll
+            for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[h][d]));
         grp = gnext;
     }
     wqueue.finish();

@@ -178,7 +178,7 @@ def test_c2_full_baseline_batch(rt, golden):
     num = np.abs(out - ref).max(axis=(2, 3))
     den = np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))
     err = (num / den).max(axis=0)
-    assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
+    assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), err
     # size-independent property: the Lagrange basis is a partition of unity, its gradient sums to zero
     assert np.abs(out[:, 0].sum(axis=1) - 1.0).max() < 1e-12
     assert np.abs(out[:, 1:].sum(axis=2)).max() < 1e-10
@@ -351,7 +351,8 @@ def test_kernel_selection(rt, golden):
     assert p3.kernel_name(1, 1000, 23) == "fxk::tabulate_simplex_pair"
     assert p3.kernel_name(1, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_pair"
     assert p3.kernel_name(1, 1000, 40) == "fxk::tabulate_simplex_pair"       # one request per wave, 10 column tiles
-    assert p3.kernel_name(1, 1000, 50) == "fxk::tabulate_simplex_kernel"     # more points than the registered tilings
+    assert p3.kernel_name(1, 1000, 50) == "fxk::tabulate_simplex_stacked"    # 49..64 points: four column tiles
+    assert p3.kernel_name(1, 1000, 70) == "fxk::tabulate_simplex_kernel"     # more points than a wave has lanes
     assert p3.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_stacked"    # Hessians: 200 stacked rows
     assert p3.kernel_name(2, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_kernel"
     dg6 = rt.SimplexPolySet(3, 6, coeffs=g["c4_dg6tet_q6_coeffs"])
@@ -411,7 +412,7 @@ def test_p3_tet_paired_kernel_point_counts(rt, golden, npts, nreq, cells):
     num = np.abs(out - ref).max(axis=(2, 3))
     den = np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))
     err = (num / den).max(axis=0)
-    assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
+    assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), err
 
 
 @pytest.mark.parametrize("fam,deg", [("Lagrange", 4), ("RaviartThomas", 2), ("DiscontinuousLagrange", 4)])
@@ -440,11 +441,12 @@ def test_one_request_per_wave_instances(rt, fam, deg, npts, nreq, cells):
     num = np.abs(out - ref).max(axis=axes)
     den = np.maximum(1.0, np.abs(ref).max(axis=axes))
     err = (num / den).max(axis=0)
-    assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
+    assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), err
 
 
 @pytest.mark.parametrize("order", [1, 2])
-@pytest.mark.parametrize("npts,nreq", [(17, 5), (23, 1), (23, 2050), (24, 333), (25, 64), (32, 129), (33, 7), (40, 100), (48, 65)])
+@pytest.mark.parametrize("npts,nreq", [(13, 8), (16, 100), (17, 5), (23, 1), (23, 2050), (24, 333), (25, 64), (32, 129), (33, 7),
+                                       (40, 100), (48, 65), (49, 3), (64, 130)])
 def test_stacked_matrix_kernel(rt, golden, order, npts, nreq):
     """Degree-6 tetrahedron on the element's own cell: all derivative tables as rows of ONE stacked matrix
     [C; C D^alpha] (simplex_stacked.hpp), every (column tiles, requests per group) instance, odd batch sizes
@@ -461,7 +463,7 @@ def test_stacked_matrix_kernel(rt, golden, order, npts, nreq):
     ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[3], 6, co, order, pts).reshape(out.shape)
     axes = tuple(range(2, out.ndim))
     err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)
-    assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
+    assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), err
 
 
 def test_stacked_matrix_kernel_on_a_physical_element_cell(rt):
@@ -481,13 +483,14 @@ def test_stacked_matrix_kernel_on_a_physical_element_cell(rt):
                                   variant=el._expansion_variant).reshape(out.shape)
     axes = tuple(range(2, out.ndim))
     err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)
-    assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
+    assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), err
 
 
 @pytest.mark.parametrize("fam,deg,order,npts", [
     ("Lagrange", 3, 2, 23), ("Lagrange", 4, 2, 23), ("Lagrange", 5, 1, 23), ("Lagrange", 5, 2, 30), ("Lagrange", 6, 2, 23),
     ("DiscontinuousLagrange", 5, 1, 40), ("DiscontinuousLagrange", 4, 2, 19), ("Nedelec", 3, 1, 23), ("Nedelec", 4, 1, 23),
-    ("Nedelec", 4, 2, 17), ("RaviartThomas", 3, 1, 28), ("BrezziDouglasMarini", 3, 1, 23), ("NedelecSecondKind", 3, 2, 23)])
+    ("Nedelec", 4, 2, 17), ("RaviartThomas", 3, 1, 28), ("BrezziDouglasMarini", 3, 1, 23), ("NedelecSecondKind", 3, 2, 23),
+    ("Lagrange", 5, 0, 23), ("Lagrange", 4, 1, 30), ("Lagrange", 3, 1, 55), ("DiscontinuousLagrange", 6, 0, 14)])
 def test_stacked_matrix_kernel_families(fam, deg, order, npts):
     """The stacked-matrix kernel across expansion degrees 3-6, bubble (Lagrange: the C0 transform is folded
     into the coefficients, the derivative matrices are those of the raw hierarchy) and orthonormal variants,
@@ -506,7 +509,7 @@ def test_stacked_matrix_kernel_families(fam, deg, order, npts):
                                   variant=el._expansion_variant).reshape(out.shape)
     axes = tuple(range(2, out.ndim))
     err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)
-    assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
+    assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), err
 
 
 @pytest.mark.parametrize("npts,nreq", [(23, 4001), (17, 3), (28, 500), (40, 77)])
@@ -525,6 +528,27 @@ def test_stacked_matrix_kernel_small_shape_ab(rt, golden, monkeypatch, npts, nre
     ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[3], 3, co, 1, pts, scale=1.0, variant="bubble").reshape(out.shape)
     axes = tuple(range(2, out.ndim))
     err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)
-    assert err[0] <= TOL_VAL and err[1:].max() <= TOL_DER, err
+    assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), err
     monkeypatch.delenv("FIAT_AMD_STACKED_SMALL")
     assert ps.kernel_name(1, nreq, npts) == "fxk::tabulate_simplex_pair"
+
+
+@pytest.mark.parametrize("fam,deg,order,npts", [("Lagrange", 5, 1, 16), ("Lagrange", 5, 2, 23), ("Lagrange", 6, 1, 23),
+                                                ("DiscontinuousLagrange", 6, 2, 30), ("Nedelec", 5, 1, 23),
+                                                ("RaviartThomas", 6, 2, 52), ("Lagrange", 6, 2, 13)])
+def test_stacked_matrix_kernel_triangles(fam, deg, order, npts):
+    import fiat_amd
+    from oracle import c_oracle
+    el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(2), deg)
+    ps = el.device_polyset()
+    nreq = 301
+    assert ps.kernel_name(order, nreq, npts) == "fxk::tabulate_simplex_stacked"
+    rng = np.random.default_rng(23 * deg + npts + order)
+    pts = rand_points(rng, 2, (nreq, npts))
+    out = ps.tabulate_batch(order, pts).cpu().numpy()
+    n = el.get_nodal_basis().get_embedded_degree()
+    ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[2], n, el.get_coeffs(), order, pts, scale=el._expansion_scale,
+                                  variant=el._expansion_variant).reshape(out.shape)
+    axes = tuple(range(2, out.ndim))
+    err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)
+    assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), err

@@ -12,8 +12,13 @@ CASES = [("Lagrange", 2, 1, 3), ("Lagrange", 2, 2, 6), ("Lagrange", 2, 3, 12), (
 BIG = [("Lagrange", 3, 4, 23, 2), ("Lagrange", 3, 5, 23, 1), ("Lagrange", 3, 5, 23, 2), ("DiscontinuousLagrange", 3, 5, 30, 1),
        ("DiscontinuousLagrange", 3, 6, 23, 1), ("DiscontinuousLagrange", 3, 6, 40, 2), ("Lagrange", 3, 6, 23, 2),
        ("Nedelec", 3, 4, 23, 1), ("Nedelec", 3, 3, 23, 1), ("BrezziDouglasMarini", 3, 3, 23, 1)]
+MID = [("Lagrange", 2, 5, 16, 1), ("Lagrange", 2, 5, 23, 2), ("Lagrange", 2, 6, 23, 1), ("Lagrange", 2, 6, 23, 2),
+       ("DiscontinuousLagrange", 2, 6, 30, 2), ("Nedelec", 2, 5, 23, 1), ("Lagrange", 3, 4, 30, 1), ("Lagrange", 3, 5, 23, 0),
+       ("Lagrange", 3, 3, 23, 2), ("RaviartThomas", 3, 3, 23, 0), ("Lagrange", 3, 6, 23, 0)]
 if "--big" in sys.argv:
     CASES = BIG
+if "--mid" in sys.argv:
+    CASES = MID
 for case in CASES:
     fam, sd, deg, npts = case[:4]
     el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg)
