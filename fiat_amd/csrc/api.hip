@@ -711,6 +711,7 @@ const StackedShape kStackedShapes[] = {
     {3, 3, 3, 3, 0}, {3, 3, 4, 1, 0},
     {2, 6, 3, 3, 0}, {2, 6, 4, 1, 0},
     {2, 5, 3, 3, 0}, {2, 5, 4, 1, 0},
+    {3, 2, 3, 2, 0}, {3, 2, 2, 1, 0}, {3, 2, 3, 1, 0}, {3, 2, 3, 3, 0}, {3, 2, 4, 1, 0},  // degree-2 tetrahedron (N2, RT2, BDM2 ...)
 };
 constexpr int STACKED_NW = 4;  // one wave per SIMD
 
@@ -791,6 +792,11 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 30: return launch_stacked<2, 6, 4, 1>(L, s);
         case 31: return launch_stacked<2, 5, 3, 3>(L, s);
         case 32: return launch_stacked<2, 5, 4, 1>(L, s);
+        case 33: return launch_stacked<3, 2, 3, 2>(L, s);
+        case 34: return launch_stacked<3, 2, 2, 1>(L, s);
+        case 35: return launch_stacked<3, 2, 3, 1>(L, s);
+        case 36: return launch_stacked<3, 2, 3, 3>(L, s);
+        case 37: return launch_stacked<3, 2, 4, 1>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown stacked kernel %d", L.stacked_id);
 }
@@ -1177,73 +1183,6 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             break;
         }
     }
-    // ---- stacked-matrix kernel (requests on the element's own cell, large shapes)? ----
-    L.stacked_id = -1;
-    {
-        static const bool nostacked = getenv("FIAT_AMD_NO_STACKED") != nullptr;
-        // (fewer stacked rows: the production of the B fragments is no longer amortised over enough row tiles)
-        static const long long stacked_min_rows = getenv("FIAT_AMD_STACKED_MIN_ROWS") ? atoll(getenv("FIAT_AMD_STACKED_MIN_ROWS")) : 48;
-        const long long R = (long long)ntab * rows;
-        const int RT = (int)((R + 15) / 16);
-        const bool even = ((R * npts) % 2 == 0) && (((R - 16LL * (RT - 1)) * npts) % 2 == 0);
-        // (after the shape-specialised registry: its tuned paired instances keep their shapes)
-        if (!nostacked && L.fixed_id < 0 && !verts && mapping == FX_MAP_AFFINE && !e->raw_expansion && order <= 2 && even) {
-            for (size_t i = 0; i < sizeof(kStackedShapes) / sizeof(kStackedShapes[0]); ++i) {
-                const StackedShape& k = kStackedShapes[i];
-                if (k.sd != e->sd || k.n != e->n) continue;
-                // small shapes with register-resident fragments: A/B partner of the paired kernel only (measured
-                // equal on C2, 302 vs 303 us -- both sit on the store-path plateau -- and the paired kernel's
-                // recurrence derivatives are two digits more accurate), opt-in with FIAT_AMD_STACKED_SMALL=1
-                const char* small = getenv("FIAT_AMD_STACKED_SMALL");
-                if (k.rtc > 0 ? (RT != k.rtc || !(small && atoi(small))) : R < stacked_min_rows) continue;
-                const int cap = 16 * k.ct / k.g;              // points one request may have
-                const int lo = 16 * k.ct / (k.g + 1);         // below: one more request fits the tiles
-                if (npts > cap || npts <= lo) continue;
-                bool ok = false;
-                if (e->sd == 3 && e->n == 6) ok = table_matches<3, 6>(e->prog);
-                if (e->sd == 3 && e->n == 5) ok = table_matches<3, 5>(e->prog);
-                if (e->sd == 3 && e->n == 4) ok = table_matches<3, 4>(e->prog);
-                if (e->sd == 3 && e->n == 3) ok = table_matches<3, 3>(e->prog);
-                if (e->sd == 2 && e->n == 6) ok = table_matches<2, 6>(e->prog);
-                if (e->sd == 2 && e->n == 5) ok = table_matches<2, 5>(e->prog);
-                if (!ok) continue;
-                int rc = ensure_stacked(ctx, const_cast<fx_element*>(e), order);
-                if (rc != FX_OK) return rc;
-                if (e->stack_state[order] != 1) continue;
-                fxk::StackedArgs<0>& ka = L.khead;
-                memset(&ka, 0, sizeof ka);
-                L.fcoef.resize(e->prog.steps.size() * 3);
-                for (size_t q = 0; q < e->prog.steps.size(); ++q) {
-                    L.fcoef[3 * q + 0] = e->prog.steps[q].A;
-                    L.fcoef[3 * q + 1] = e->prog.steps[q].B;
-                    L.fcoef[3 * q + 2] = e->prog.steps[q].C;
-                }
-                ka.pts = pts;
-                ka.out = out;
-                ka.afrag = e->d_astack[order];
-                ka.phi0 = e->prog.phi0;
-                memcpy(ka.A0, e->A0, sizeof ka.A0);
-                memcpy(ka.b0, e->b0, sizeof ka.b0);
-                ka.nreq = nreq;
-                ka.npts = npts;
-                ka.R = (int)R;
-                ka.RT = RT;
-                ka.debug = a.debug;
-                L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * fxk::stacked_image_doubles(k.ct, (e->nexp + 3) / 4)) * 8;
-                if (L.klds_bytes > ctx->lds_per_cu) continue;
-                const long long groups = (nreq + k.g - 1) / k.g;
-                // one workgroup per CU = one wave per SIMD (measured: a second wave per SIMD at half the registers
-                // spills in the production phase and gains nothing, 1.45 -> 1.48 ms: the kernel is bound by the
-                // shared fp64 MFMA/VALU pipe, not by latencies)
-                L.kgrid = (int)std::max<long long>(1, std::min<long long>((groups + STACKED_NW - 1) / STACKED_NW, ctx->num_cu));
-                L.ncu = ctx->num_cu;
-                L.trash = ctx->d_trash;
-                L.queue = ctx->d_queue + (size_t)(ctx->launch_seq++ % FX_QUEUE_SLOTS) * 16;
-                L.stacked_id = (int)i;
-                break;
-            }
-        }
-    }
     // ---- low-order lane-local kernel? ----
     L.small_id = -1;
     {
@@ -1281,6 +1220,74 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 const long long nwg = (sa.nitems + SMALL_NW - 1) / SMALL_NW;
                 L.sgrid = (int)std::max<long long>(1, std::min<long long>(nwg, (long long)ctx->num_cu * wg_per_cu * 4));
                 L.small_id = (int)i;
+                break;
+            }
+        }
+    }
+    // ---- stacked-matrix kernel (requests on the element's own cell, large shapes)? ----
+    L.stacked_id = -1;
+    {
+        static const bool nostacked = getenv("FIAT_AMD_NO_STACKED") != nullptr;
+        // (fewer stacked rows: the production of the B fragments is no longer amortised over enough row tiles)
+        static const long long stacked_min_rows = getenv("FIAT_AMD_STACKED_MIN_ROWS") ? atoll(getenv("FIAT_AMD_STACKED_MIN_ROWS")) : 48;
+        const long long R = (long long)ntab * rows;
+        const int RT = (int)((R + 15) / 16);
+        const bool even = ((R * npts) % 2 == 0) && (((R - 16LL * (RT - 1)) * npts) % 2 == 0);
+        // (after the shape-specialised registries: the tuned paired instances and the lane-local kernel keep their shapes)
+        if (!nostacked && L.fixed_id < 0 && L.small_id < 0 && !verts && mapping == FX_MAP_AFFINE && !e->raw_expansion && order <= 2 && even) {
+            for (size_t i = 0; i < sizeof(kStackedShapes) / sizeof(kStackedShapes[0]); ++i) {
+                const StackedShape& k = kStackedShapes[i];
+                if (k.sd != e->sd || k.n != e->n) continue;
+                // small shapes with register-resident fragments: A/B partner of the paired kernel only (measured
+                // equal on C2, 302 vs 303 us -- both sit on the store-path plateau -- and the paired kernel's
+                // recurrence derivatives are two digits more accurate), opt-in with FIAT_AMD_STACKED_SMALL=1
+                const char* small = getenv("FIAT_AMD_STACKED_SMALL");
+                if (k.rtc > 0 ? (RT != k.rtc || !(small && atoi(small))) : R < stacked_min_rows) continue;
+                const int cap = 16 * k.ct / k.g;              // points one request may have
+                const int lo = 16 * k.ct / (k.g + 1);         // below: one more request fits the tiles
+                if (npts > cap || npts <= lo) continue;
+                bool ok = false;
+                if (e->sd == 3 && e->n == 6) ok = table_matches<3, 6>(e->prog);
+                if (e->sd == 3 && e->n == 5) ok = table_matches<3, 5>(e->prog);
+                if (e->sd == 3 && e->n == 4) ok = table_matches<3, 4>(e->prog);
+                if (e->sd == 3 && e->n == 3) ok = table_matches<3, 3>(e->prog);
+                if (e->sd == 2 && e->n == 6) ok = table_matches<2, 6>(e->prog);
+                if (e->sd == 2 && e->n == 5) ok = table_matches<2, 5>(e->prog);
+                if (e->sd == 3 && e->n == 2) ok = table_matches<3, 2>(e->prog);
+                if (!ok) continue;
+                int rc = ensure_stacked(ctx, const_cast<fx_element*>(e), order);
+                if (rc != FX_OK) return rc;
+                if (e->stack_state[order] != 1) continue;
+                fxk::StackedArgs<0>& ka = L.khead;
+                memset(&ka, 0, sizeof ka);
+                L.fcoef.resize(e->prog.steps.size() * 3);
+                for (size_t q = 0; q < e->prog.steps.size(); ++q) {
+                    L.fcoef[3 * q + 0] = e->prog.steps[q].A;
+                    L.fcoef[3 * q + 1] = e->prog.steps[q].B;
+                    L.fcoef[3 * q + 2] = e->prog.steps[q].C;
+                }
+                ka.pts = pts;
+                ka.out = out;
+                ka.afrag = e->d_astack[order];
+                ka.phi0 = e->prog.phi0;
+                memcpy(ka.A0, e->A0, sizeof ka.A0);
+                memcpy(ka.b0, e->b0, sizeof ka.b0);
+                ka.nreq = nreq;
+                ka.npts = npts;
+                ka.R = (int)R;
+                ka.RT = RT;
+                ka.debug = a.debug;
+                L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * fxk::stacked_image_doubles(k.ct, (e->nexp + 3) / 4)) * 8;
+                if (L.klds_bytes > ctx->lds_per_cu) continue;
+                const long long groups = (nreq + k.g - 1) / k.g;
+                // one workgroup per CU = one wave per SIMD (measured: a second wave per SIMD at half the registers
+                // spills in the production phase and gains nothing, 1.45 -> 1.48 ms: the kernel is bound by the
+                // shared fp64 MFMA/VALU pipe, not by latencies)
+                L.kgrid = (int)std::max<long long>(1, std::min<long long>((groups + STACKED_NW - 1) / STACKED_NW, ctx->num_cu));
+                L.ncu = ctx->num_cu;
+                L.trash = ctx->d_trash;
+                L.queue = ctx->d_queue + (size_t)(ctx->launch_seq++ % FX_QUEUE_SLOTS) * 16;
+                L.stacked_id = (int)i;
                 break;
             }
         }

@@ -56,7 +56,8 @@ def test_small_kernel_vs_c_oracle(rt, sd, n, order, nreq, npts, cells):
         e = rng.exponential(size=(nreq, npts, sd + 1))
         pts = np.einsum("rpv,rvd->rpd", e / e.sum(axis=-1, keepdims=True), verts)
     if 12 * 1024 >= 8 * (1 + sd * order) * ndof * npts or npts * 1 <= 64:
-        assert ps.kernel_name(order, nreq, npts, has_verts=cells) in ("fxk::tabulate_simplex_small", "fxk::tabulate_simplex_kernel")
+        assert ps.kernel_name(order, nreq, npts, has_verts=cells) in ("fxk::tabulate_simplex_small", "fxk::tabulate_simplex_kernel",
+                                                                      "fxk::tabulate_simplex_stacked")
     out = ps.tabulate_batch(order, pts, verts=verts).cpu().numpy()
     ref = c_oracle.tabulate_batch(ref_cell, n, co, order, pts, verts=verts)
     compare(out, ref, order)
