@@ -27,6 +27,10 @@ from .nedelec_second_kind import NedelecSecondKind  # noqa: F401
 from .hermite import CubicHermite  # noqa: F401
 from .morley import Morley  # noqa: F401
 from .crouzeix_raviart import CrouzeixRaviart  # noqa: F401
+from .restricted import RestrictedElement  # noqa: F401
+from .bubble import Bubble, FacetBubble  # noqa: F401
+from .brezzi_douglas_fortin_marini import BrezziDouglasFortinMarini  # noqa: F401
+from .discontinuous_raviart_thomas import DiscontinuousRaviartThomas  # noqa: F401
 from .tensor_product import FlattenedDimensions, TensorProductElement  # noqa: F401
 
 # the element registry of the reference (FIAT/__init__.py:72-131), in-scope subset
@@ -40,6 +44,11 @@ supported_elements = {
     "Hermite": CubicHermite,
     "Morley": Morley,
     "Crouzeix-Raviart": CrouzeixRaviart,
+    "Bubble": Bubble,
+    "FacetBubble": FacetBubble,
+    "Brezzi-Douglas-Fortin-Marini": BrezziDouglasFortinMarini,
+    "Discontinuous Raviart-Thomas": DiscontinuousRaviartThomas,
+    "RestrictedElement": RestrictedElement,
     "TensorProductElement": TensorProductElement,
     "FlattenedDimensions": FlattenedDimensions,
 }

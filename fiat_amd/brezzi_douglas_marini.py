@@ -1,8 +1,8 @@
 """Brezzi-Douglas-Marini H(div) element on triangles and tetrahedra
 (FIAT/brezzi_douglas_marini.py:15-112): the full space P_k^d; dofs = normal moments against
 P_k on every facet (:30-43) and, for k > 1, interior moments against the first-kind Nedelec
-functions of degree k - 1 (:56-71).  "integral" variants only (the point variant needs
-PointScaledNormalEvaluation, outside the in-scope functionals).  Tabulation runs on the same
+functions of degree k - 1 (:56-71); "point" variant: scaled-normal point evaluations on the
+facets (:45-54).  Tabulation runs on the same
 kernels as every other coeffs x Dubiner element."""
 import numpy
 
@@ -27,16 +27,21 @@ def _normal_moments(ref_el, degree, quad_degree, quad_scheme):
 
 class BDMDualSet(dual_set.DualSet):
     def __init__(self, ref_el, degree, variant, interpolant_deg, quad_scheme):
-        if variant != "integral":
-            raise NotImplementedError("BrezziDouglasMarini: only the 'integral' variants are supported by fiat_amd")
         sd = ref_el.get_spatial_dimension()
         top = ref_el.get_topology()
         entity_ids = {dim: {entity: [] for entity in top[dim]} for dim in top}
         nodes = []
-        for f, moments in _normal_moments(ref_el, degree, interpolant_deg + degree, quad_scheme):
+        if variant == "integral":
+            facet_nodes = _normal_moments(ref_el, degree, interpolant_deg + degree, quad_scheme)
+        else:  # "point": scaled-normal evaluations on the facet lattices
+            facet_nodes = [(f, [functional.PointScaledNormalEvaluation(ref_el, f, pt)
+                                for pt in ref_el.make_points(sd - 1, f, sd + degree)]) for f in sorted(top[sd - 1])]
+        for f, moments in facet_nodes:
             entity_ids[sd - 1][f] = list(range(len(nodes), len(nodes) + len(moments)))
             nodes += moments
         if degree > 1:
+            if interpolant_deg is None:
+                interpolant_deg = degree
             cell = ref_el.construct_subelement(sd)
             Q_ref = parse_quadrature_scheme(cell, interpolant_deg + degree - 1, quad_scheme)
             ned = nedelec.Nedelec(cell, degree - 1, variant).tabulate(0, Q_ref.get_points())[(0,) * sd]

@@ -48,6 +48,21 @@ class DualSet:
     def get_reference_element(self):
         return self.ref_el
 
+    def get_indices(self, restriction_domain, take_closure=True):
+        """Dofs supported on a restriction domain: "interior" (the cell's own dofs), or all dofs on entities
+        of dimension <= that of "vertex" / "edge" / "face" / "facet" / "ridge" (only that dimension when
+        ``take_closure`` is false); FIAT/dual_set.py:208-252."""
+        sd = self.ref_el.get_spatial_dimension()
+        if restriction_domain == "interior":
+            dims = [max(self.entity_ids)]
+        else:
+            try:
+                dim = {"vertex": 0, "edge": 1, "face": 2, "facet": sd - 1, "ridge": sd - 2}[restriction_domain]
+            except KeyError:
+                raise RuntimeError("Invalid restriction domain")
+            dims = range(0 if take_closure else dim, dim + 1)
+        return [dof for d in dims for entity in sorted(self.entity_ids[d]) for dof in self.entity_ids[d][entity]]
+
     def riesz_weights(self):
         """(points, W): sorted unique functional points and the dense weight tensor
         W[node, *target_shape, point] such that the value part of node(f) = sum W . f(points);

@@ -2,7 +2,7 @@
 
 Only the kinds the in-scope families need (FIAT/functional.py: Functional
 :22-153, PointEvaluation :156-170, ComponentPointEvaluation :173-190,
-point derivatives :193-271, IntegralMoment :286-315, IntegralMomentOf(Normal)Derivative
+point derivatives :193-271, point normal / tangent evaluations :499-614, IntegralMoment :286-315, IntegralMomentOf(Normal)Derivative
 :318-366, FrobeniusIntegralMoment :369-385).  A functional is data:
 ``pt_dict = {point: [(weight, component), ...]}`` and
 ``deriv_dict = {point: [(weight, alpha, component), ...]}``; the arithmetic of
@@ -178,3 +178,53 @@ class IntegralMomentOfNormalDerivative(IntegralMomentOfDerivative):
         sd = ref_el.get_spatial_dimension()
         Q = FacetQuadratureRule(ref_el, sd - 1, facet_no, Q_face, avg=True)
         super().__init__(ref_el, Q, f_at_qpts, ref_el.compute_normal(facet_no), nm="IntegralMomentOfNormalDerivative")
+
+
+class _PointVectorEvaluation(Functional):
+    """f -> v . f(pt) for a fixed vector v."""
+
+    def __init__(self, ref_el, v, pt, tag):
+        v = numpy.asarray(v, dtype=float)
+        self.v = v
+        super().__init__(ref_el, v.shape, {tuple(pt): [(v[i], (i,)) for i in range(len(v))]}, {}, tag)
+
+
+class PointNormalEvaluation(_PointVectorEvaluation):
+    """Normal component at a point of a codimension-1 facet."""
+
+    def __init__(self, ref_el, facet_no, pt):
+        super().__init__(ref_el, ref_el.compute_normal(facet_no), pt, "PointNormalEval")
+        self.n = self.v
+
+
+class PointScaledNormalEvaluation(_PointVectorEvaluation):
+    """Normal component at a point of a facet, the normal scaled by the facet's volume."""
+
+    def __init__(self, ref_el, facet_no, pt):
+        super().__init__(ref_el, ref_el.compute_scaled_normal(facet_no), pt, "PointScaledNormalEval")
+
+    def tostr(self):
+        return "(u.n)(%s)" % ",".join(map(str, list(self.pt_dict)[0]))
+
+
+class PointEdgeTangentEvaluation(_PointVectorEvaluation):
+    """Tangential component (un-normalised edge tangent) at a point of an edge."""
+
+    def __init__(self, ref_el, edge_no, pt):
+        super().__init__(ref_el, ref_el.compute_edge_tangent(edge_no), pt, "PointEdgeTangent")
+        self.t = self.v
+
+    def tostr(self):
+        return "(u.t)(%s)" % ",".join(map(str, list(self.pt_dict)[0]))
+
+
+class PointFaceTangentEvaluation(_PointVectorEvaluation):
+    """Component along tangent `tno` of a face at a point of that face."""
+
+    def __init__(self, ref_el, face_no, tno, pt):
+        super().__init__(ref_el, ref_el.compute_face_tangents(face_no)[tno], pt, "PointFaceTangent")
+        self.t = self.v
+        self.tno = tno
+
+    def tostr(self):
+        return "(u.t%d)(%s)" % (self.tno, ",".join(map(str, list(self.pt_dict)[0])))

@@ -66,10 +66,19 @@ class NedelecDual(dual_set.DualSet):
         top = ref_el.get_topology()
         nodes = []
         entity_ids = {dim: {entity: [] for entity in top[dim]} for dim in top}
-        if variant != "integral":
-            raise NotImplementedError("Nedelec: only the 'integral' variants are supported by fiat_amd")
+        if variant == "point":  # tangential point evaluations on edge (and face) lattices
+            for e in sorted(top[1]):
+                first = len(nodes)
+                nodes.extend(functional.PointEdgeTangentEvaluation(ref_el, e, pt) for pt in ref_el.make_points(1, e, degree + 1))
+                entity_ids[1][e] = list(range(first, len(nodes)))
+            if sd > 2 and degree > 1:
+                for f in sorted(top[2]):
+                    first = len(nodes)
+                    pts = ref_el.make_points(2, f, degree + 1)
+                    nodes.extend(functional.PointFaceTangentEvaluation(ref_el, f, k, pt) for k in range(2) for pt in pts)
+                    entity_ids[2][f] = list(range(first, len(nodes)))
         # tangential moments against an orthonormal basis on edges (and faces)
-        for dim in range(1, sd):
+        for dim in range(1, sd) if variant == "integral" else ():
             phi_deg = degree - dim
             if phi_deg < 0:
                 continue
@@ -87,6 +96,8 @@ class NedelecDual(dual_set.DualSet):
         # interior moments against P_{degree-sd}^sd
         phi_deg = degree - sd
         if phi_deg >= 0:
+            if interpolant_deg is None:
+                interpolant_deg = degree
             cell = ref_el.construct_subelement(sd)
             Q_ref = parse_quadrature_scheme(cell, interpolant_deg + phi_deg, quad_scheme)
             Phis = polynomial_set.ONPolynomialSet(cell, phi_deg).tabulate(Q_ref.get_points())[(0,) * sd]

@@ -2,8 +2,7 @@
 (FIAT/nedelec_second_kind.py:20-222): the full space P_k^d; dofs on every entity of dimension
 m = 1 .. d are Frobenius moments against the contravariantly mapped vector polynomials of degree
 k - m + 1 of that entity: all of P_k on edges, Raviart-Thomas RT_{k-m+1} on faces and in the cell
-(:107-158).  "integral" variants only (the point variant needs tangential point evaluations,
-outside the in-scope functionals).  Tabulation runs on the same kernels as every other
+(:107-158); "point" variant: tangential point evaluations on the edges instead of the edge moments.  Tabulation runs on the same kernels as every other
 coeffs x Dubiner element."""
 import numpy
 
@@ -23,14 +22,19 @@ def _entity_test_functions(entity_cell, dim, deg, variant, qpts):
 
 class NedelecSecondKindDual(dual_set.DualSet):
     def __init__(self, cell, degree, variant, interpolant_deg, quad_scheme):
-        if variant != "integral":
-            raise NotImplementedError("NedelecSecondKind: only the 'integral' variants are supported by fiat_amd")
         d = cell.get_spatial_dimension()
         assert d in (2, 3), "Second kind Nedelecs only implemented in 2/3D."
         top = cell.get_topology()
         ids = {dim: {entity: [] for entity in sorted(top[dim])} for dim in top}
         dofs = []
-        for dim in range(1, d + 1):
+        if interpolant_deg is None:
+            interpolant_deg = degree
+        if variant == "point":  # tangential evaluations at degree + 1 points of every edge (:96-110)
+            for edge in sorted(top[1]):
+                points = cell.make_points(1, edge, degree + 2)
+                ids[1][edge] = list(range(len(dofs), len(dofs) + len(points)))
+                dofs += [functional.PointEdgeTangentEvaluation(cell, edge, pt) for pt in points]
+        for dim in range(2 if variant == "point" else 1, d + 1):
             test_degree = degree - dim + 1
             if test_degree < 1:
                 continue

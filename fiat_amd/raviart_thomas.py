@@ -36,30 +36,40 @@ class RTDualSet(dual_set.DualSet):
         top = ref_el.get_topology()
         nodes = []
         entity_ids = {dim: {entity: [] for entity in top[dim]} for dim in top}
-        if variant != "integral":
-            raise NotImplementedError("RaviartThomas: only the 'integral' variants are supported by fiat_amd")
-        facet = ref_el.construct_subelement(sd - 1)
-        q = degree - 1
-        Q_ref = parse_quadrature_scheme(facet, interpolant_deg + q, quad_scheme)
-        Pq = polynomial_set.ONPolynomialSet(facet, q if sd > 1 else 0)
-        Pq_at_qpts = Pq.tabulate(Q_ref.get_points())[(0,) * (sd - 1)]
-        for f in sorted(top[sd - 1]):
-            first = len(nodes)
-            Q = FacetQuadratureRule(ref_el, sd - 1, f, Q_ref, avg=True)
-            n = ref_el.compute_scaled_normal(f)
-            phis = n[None, :, None] * Pq_at_qpts[:, None, :]
-            nodes.extend(functional.FrobeniusIntegralMoment(ref_el, Q, phi) for phi in phis)
-            entity_ids[sd - 1][f] = list(range(first, len(nodes)))
-        if q > 0:
-            cell = ref_el.construct_subelement(sd)
-            Q_ref = parse_quadrature_scheme(cell, interpolant_deg + q - 1, quad_scheme)
-            Pqm1_at_qpts = polynomial_set.ONPolynomialSet(cell, q - 1).tabulate(Q_ref.get_points())[(0,) * sd]
-            for entity in sorted(top[sd]):
-                Q = FacetQuadratureRule(ref_el, sd, entity, Q_ref)
+        if variant == "integral":
+            facet = ref_el.construct_subelement(sd - 1)
+            q = degree - 1
+            Q_ref = parse_quadrature_scheme(facet, interpolant_deg + q, quad_scheme)
+            Pq = polynomial_set.ONPolynomialSet(facet, q if sd > 1 else 0)
+            Pq_at_qpts = Pq.tabulate(Q_ref.get_points())[(0,) * (sd - 1)]
+            for f in sorted(top[sd - 1]):
                 first = len(nodes)
-                nodes.extend(functional.IntegralMoment(ref_el, Q, phi, (d,), (sd,))
-                             for d in range(sd) for phi in Pqm1_at_qpts)
-                entity_ids[sd][entity] = list(range(first, len(nodes)))
+                Q = FacetQuadratureRule(ref_el, sd - 1, f, Q_ref, avg=True)
+                n = ref_el.compute_scaled_normal(f)
+                phis = n[None, :, None] * Pq_at_qpts[:, None, :]
+                nodes.extend(functional.FrobeniusIntegralMoment(ref_el, Q, phi) for phi in phis)
+                entity_ids[sd - 1][f] = list(range(first, len(nodes)))
+            if q > 0:
+                cell = ref_el.construct_subelement(sd)
+                Q_ref = parse_quadrature_scheme(cell, interpolant_deg + q - 1, quad_scheme)
+                Pqm1_at_qpts = polynomial_set.ONPolynomialSet(cell, q - 1).tabulate(Q_ref.get_points())[(0,) * sd]
+                for entity in sorted(top[sd]):
+                    Q = FacetQuadratureRule(ref_el, sd, entity, Q_ref)
+                    first = len(nodes)
+                    nodes.extend(functional.IntegralMoment(ref_el, Q, phi, (d,), (sd,))
+                                 for d in range(sd) for phi in Pqm1_at_qpts)
+                    entity_ids[sd][entity] = list(range(first, len(nodes)))
+        else:  # "point": scaled-normal evaluations on facet lattices, component evaluations on the interior lattice
+            for f in sorted(top[sd - 1]):
+                first = len(nodes)
+                nodes.extend(functional.PointScaledNormalEvaluation(ref_el, f, pt)
+                             for pt in ref_el.make_points(sd - 1, f, sd + degree - 1))
+                entity_ids[sd - 1][f] = list(range(first, len(nodes)))
+            if degree > 1:
+                first = len(nodes)
+                pts = ref_el.make_points(sd, 0, sd + degree - 1)
+                nodes.extend(functional.ComponentPointEvaluation(ref_el, d, (sd,), pt) for d in range(sd) for pt in pts)
+                entity_ids[sd][0] = list(range(first, len(nodes)))
         super().__init__(nodes, ref_el, entity_ids)
 
 

@@ -13,7 +13,9 @@ import os
 
 import numpy as np
 
-from FIAT import BrezziDouglasMarini, CrouzeixRaviart, CubicHermite, Morley, NedelecSecondKind, ufc_simplex
+from FIAT import (BrezziDouglasFortinMarini, BrezziDouglasMarini, Bubble, CrouzeixRaviart, CubicHermite,
+                  DiscontinuousRaviartThomas, FacetBubble, Lagrange, Morley, Nedelec, NedelecSecondKind, RaviartThomas,
+                  RestrictedElement, ufc_simplex)
 from FIAT.polynomial_set import mis
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -22,7 +24,22 @@ CASES = [("bdm", BrezziDouglasMarini, 2, (1, 2, 3)), ("bdm", BrezziDouglasMarini
          # derivative functionals in the dual set (FIAT/dual_set.py:175-205)
          ("hermite", CubicHermite, 1, (3,)), ("hermite", CubicHermite, 2, (3,)), ("hermite", CubicHermite, 3, (3,)),
          ("morley", Morley, 2, (2,)), ("morley", Morley, 3, (2,)),
-         ("cr", CrouzeixRaviart, 2, (1, 3)), ("cr", CrouzeixRaviart, 3, (1,))]
+         ("cr", CrouzeixRaviart, 2, (1, 3)), ("cr", CrouzeixRaviart, 3, (1,)),
+         # point variants (normal / tangential point evaluations) and restricted elements
+         ("rtpt", lambda c, k: RaviartThomas(c, k, variant="point"), 2, (1, 2)),
+         ("rtpt", lambda c, k: RaviartThomas(c, k, variant="point"), 3, (1, 2)),
+         ("nedpt", lambda c, k: Nedelec(c, k, variant="point"), 2, (1, 2)),
+         ("nedpt", lambda c, k: Nedelec(c, k, variant="point"), 3, (1, 2)),
+         ("bdmpt", lambda c, k: BrezziDouglasMarini(c, k, variant="point"), 2, (1, 2)),
+         ("bdmpt", lambda c, k: BrezziDouglasMarini(c, k, variant="point"), 3, (1, 2)),
+         ("n2curlpt", lambda c, k: NedelecSecondKind(c, k, variant="point"), 2, (1, 2)),
+         ("n2curlpt", lambda c, k: NedelecSecondKind(c, k, variant="point"), 3, (1, 2)),
+         ("drt", DiscontinuousRaviartThomas, 2, (1, 2)), ("drt", DiscontinuousRaviartThomas, 3, (1, 2)),
+         ("bubble", Bubble, 2, (3, 4)), ("bubble", Bubble, 3, (4,)),
+         ("facetbubble", FacetBubble, 2, (2, 3)), ("facetbubble", FacetBubble, 3, (3,)),
+         ("bdfm", BrezziDouglasFortinMarini, 2, (2,)), ("bdfm", BrezziDouglasFortinMarini, 3, (2,)),
+         ("lagfacet", lambda c, k: RestrictedElement(Lagrange(c, k), restriction_domain="facet"), 2, (3,)),
+         ("lagedge", lambda c, k: RestrictedElement(Lagrange(c, k), restriction_domain="edge", take_closure=False), 3, (3,))]
 
 
 def main():

@@ -20,6 +20,28 @@ CASES = [("bdm", "BrezziDouglasMarini", 2, 1), ("bdm", "BrezziDouglasMarini", 2,
 VECTOR = ("bdm", "n2curl")
 
 
+def _pt(cls):
+    return lambda fa, c, k: getattr(fa, cls)(c, k, variant="point")
+
+
+# (golden name, constructor(fiat_amd, cell, degree), sd, degree): point variants and restricted elements
+MORE = [("rtpt", _pt("RaviartThomas"), 2, 1), ("rtpt", _pt("RaviartThomas"), 2, 2), ("rtpt", _pt("RaviartThomas"), 3, 1),
+        ("rtpt", _pt("RaviartThomas"), 3, 2), ("nedpt", _pt("Nedelec"), 2, 1), ("nedpt", _pt("Nedelec"), 2, 2),
+        ("nedpt", _pt("Nedelec"), 3, 1), ("nedpt", _pt("Nedelec"), 3, 2), ("bdmpt", _pt("BrezziDouglasMarini"), 2, 1),
+        ("bdmpt", _pt("BrezziDouglasMarini"), 2, 2), ("bdmpt", _pt("BrezziDouglasMarini"), 3, 1),
+        ("bdmpt", _pt("BrezziDouglasMarini"), 3, 2), ("n2curlpt", _pt("NedelecSecondKind"), 2, 1),
+        ("n2curlpt", _pt("NedelecSecondKind"), 2, 2), ("n2curlpt", _pt("NedelecSecondKind"), 3, 1),
+        ("n2curlpt", _pt("NedelecSecondKind"), 3, 2),
+        ("drt", lambda fa, c, k: fa.DiscontinuousRaviartThomas(c, k), 2, 1), ("drt", lambda fa, c, k: fa.DiscontinuousRaviartThomas(c, k), 2, 2),
+        ("drt", lambda fa, c, k: fa.DiscontinuousRaviartThomas(c, k), 3, 1), ("drt", lambda fa, c, k: fa.DiscontinuousRaviartThomas(c, k), 3, 2),
+        ("bubble", lambda fa, c, k: fa.Bubble(c, k), 2, 3), ("bubble", lambda fa, c, k: fa.Bubble(c, k), 2, 4),
+        ("bubble", lambda fa, c, k: fa.Bubble(c, k), 3, 4), ("facetbubble", lambda fa, c, k: fa.FacetBubble(c, k), 2, 2),
+        ("facetbubble", lambda fa, c, k: fa.FacetBubble(c, k), 2, 3), ("facetbubble", lambda fa, c, k: fa.FacetBubble(c, k), 3, 3),
+        ("bdfm", lambda fa, c, k: fa.BrezziDouglasFortinMarini(c, k), 2, 2), ("bdfm", lambda fa, c, k: fa.BrezziDouglasFortinMarini(c, k), 3, 2),
+        ("lagfacet", lambda fa, c, k: fa.RestrictedElement(fa.Lagrange(c, k), restriction_domain="facet"), 2, 3),
+        ("lagedge", lambda fa, c, k: fa.RestrictedElement(fa.Lagrange(c, k), restriction_domain="edge", take_closure=False), 3, 3)]
+
+
 def rel(x, ref):
     return np.abs(x - ref).max() / max(1.0, np.abs(ref).max())
 
@@ -59,9 +81,7 @@ def test_family_errors():
     with pytest.raises(Exception):
         fiat_amd.BrezziDouglasMarini(fiat_amd.ufc_simplex(2), 0)
     with pytest.raises(NotImplementedError):
-        fiat_amd.BrezziDouglasMarini(fiat_amd.ufc_simplex(2), 1, variant="point")
-    with pytest.raises(NotImplementedError):
-        fiat_amd.NedelecSecondKind(fiat_amd.ufc_simplex(3), 1, variant="point")
+        fiat_amd.BrezziDouglasFortinMarini(fiat_amd.ufc_simplex(2), 2, variant="point")
     assert fiat_amd.supported_elements["Brezzi-Douglas-Marini"] is fiat_amd.BrezziDouglasMarini
     assert fiat_amd.supported_elements["Nedelec 2nd kind H(curl)"] is fiat_amd.NedelecSecondKind
     with pytest.raises(ValueError):
@@ -112,3 +132,39 @@ def test_large_vandermonde_systems_nodality(cls, degree):
     nodes = np.array([list(ell.get_point_dict().keys())[0] for ell in el.dual_basis()])
     tab = el.tabulate(0, nodes)[(0, 0, 0)]
     assert np.abs(tab - np.eye(120)).max() < 1e-9
+
+
+@pytest.mark.parametrize("name,make,sd,k", MORE, ids=[f"{m[0]}{m[3]}_sd{m[2]}" for m in MORE])
+def test_point_variants_and_restricted_elements(golden, name, make, sd, k):
+    """Point variants of RT / Nedelec / BDM / N2curl (normal and tangential point evaluations,
+    FIAT/functional.py:499-614), discontinuous RT, bubbles, BDFM and RestrictedElement against the reference."""
+    import fiat_amd
+    g = golden("families")
+    key = f"{name}{k}_sd{sd}"
+    el = make(fiat_amd, fiat_amd.ufc_simplex(sd), k)
+    co = g[key + "_coeffs"]
+    assert el.get_coeffs().shape == co.shape
+    assert rel(el.get_coeffs(), co) <= 1e-11, rel(el.get_coeffs(), co)
+    assert el.mapping()[0] == str(g[key + "_mapping"])
+    want = json.loads(str(g[key + "_entity_dofs"]))
+    got = {str(d): {str(i): list(v) for i, v in ents.items()} for d, ents in el.entity_dofs().items()}
+    assert got == want
+    tab = el.tabulate(1, g[f"pts_sd{sd}"])
+    for t, a in enumerate([a for j in range(2) for a in fiat_amd.mis(sd, j)]):
+        assert rel(tab[a], g[key + "_tab"][t]) <= (1e-11 if t == 0 else 1e-10), (a, rel(tab[a], g[key + "_tab"][t]))
+
+
+def test_restricted_element_errors():
+    import fiat_amd
+    el = fiat_amd.Lagrange(fiat_amd.ufc_simplex(2), 2)
+    with pytest.raises(RuntimeError):
+        fiat_amd.RestrictedElement(el)
+    with pytest.raises(RuntimeError):
+        fiat_amd.RestrictedElement(el, indices="facet")
+    with pytest.raises(RuntimeError):
+        fiat_amd.RestrictedElement(el, restriction_domain="nonsense")
+    with pytest.raises(RuntimeError):
+        fiat_amd.Bubble(fiat_amd.ufc_simplex(2), 2)       # no interior dofs
+    assert el.get_dual_set().get_indices("vertex") == [0, 1, 2]
+    assert el.get_dual_set().get_indices("interior") == []
+    assert el.get_dual_set().get_indices("edge", take_closure=False) == [3, 4, 5]
