@@ -522,7 +522,7 @@ struct Launch {
     // stacked-matrix kernel (simplex_stacked.hpp)
     int stacked_id = -1;
     fxk::StackedArgs<0> khead;
-    int kgrid = 0, klds_bytes = 0;
+    int kgrid = 0, klds_bytes = 0, kmix_order = 0;
     // cooperative large-shape kernel
     int coop_id = -1;
     fxk::CoopArgs cargs;
@@ -720,6 +720,7 @@ int launch_stacked(const Launch& L, hipStream_t s) {
     constexpr int NC = fxk::FixedNC<SD, N>::value;
     fxk::StackedArgs<NC> ka;
     ka.pts = L.khead.pts;
+    ka.verts = L.khead.verts;
     ka.out = L.khead.out;
     ka.afrag = L.khead.afrag;
     ka.phi0 = L.khead.phi0;
@@ -754,6 +755,19 @@ int launch_stacked(const Launch& L, hipStream_t s) {
 #if defined(FX_DBG) && (FX_DBG & 512)
     if (getenv("FIAT_AMD_VERBOSE")) HIP_TRY(report_wave_lifetimes(L.trash, grid, STACKED_NW));
 #endif
+    if (L.khead.verts && L.kmix_order >= 1) {  // chain rule across the derivative tables, in place
+        fxk::TableMixArgs ma;
+        ma.out = L.khead.out;
+        ma.verts = L.khead.verts;
+        if (!invert_small(SD, L.khead.A0, ma.A0inv)) return fail(FX_EINVAL, "degenerate cell");
+        const int ntab = fx::binom(SD + L.kmix_order, SD);
+        ma.n = L.khead.R / ntab * L.khead.npts;
+        ma.order = L.kmix_order;
+        ma.slices = std::max(1, std::min(8, (ma.n + 2047) / 2048));
+        if (L.khead.nreq * ma.slices > 0x7fffffffLL) return fail(FX_EINVAL, "batch too large for the table-mixing pass");
+        hipLaunchKernelGGL((fxk::table_mix_kernel<SD>), dim3((unsigned)(L.khead.nreq * ma.slices)), dim3(256), 0, s, ma);
+        HIP_TRY(hipGetLastError());
+    }
     return FX_OK;
 }
 
@@ -1234,7 +1248,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
         const int RT = (int)((R + 15) / 16);
         const bool even = ((R * npts) % 2 == 0) && (((R - 16LL * (RT - 1)) * npts) % 2 == 0);
         // (after the shape-specialised registries: the tuned paired instances and the lane-local kernel keep their shapes)
-        if (!nostacked && L.fixed_id < 0 && L.small_id < 0 && !verts && mapping == FX_MAP_AFFINE && !e->raw_expansion && order <= 2 && even) {
+        // (per-request cells: the kernel maps the points through the request's cell and a second pass applies the
+        // chain rule across the derivative tables, table_mix_kernel; a Piola map is left to fx_pushforward_batch)
+        if (!nostacked && L.fixed_id < 0 && L.small_id < 0 && !L.fused_mapping && !e->raw_expansion && order <= 2 && even) {
             for (size_t i = 0; i < sizeof(kStackedShapes) / sizeof(kStackedShapes[0]); ++i) {
                 const StackedShape& k = kStackedShapes[i];
                 if (k.sd != e->sd || k.n != e->n) continue;
@@ -1242,7 +1258,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 // equal on C2, 302 vs 303 us -- both sit on the store-path plateau -- and the paired kernel's
                 // recurrence derivatives are two digits more accurate), opt-in with FIAT_AMD_STACKED_SMALL=1
                 const char* small = getenv("FIAT_AMD_STACKED_SMALL");
-                if (k.rtc > 0 ? (RT != k.rtc || !(small && atoi(small))) : R < stacked_min_rows) continue;
+                if (k.rtc > 0 ? (RT != k.rtc || verts || !(small && atoi(small))) : R < stacked_min_rows) continue;
                 const int cap = 16 * k.ct / k.g;              // points one request may have
                 const int lo = 16 * k.ct / (k.g + 1);         // below: one more request fits the tiles
                 if (npts > cap || npts <= lo) continue;
@@ -1267,6 +1283,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     L.fcoef[3 * q + 2] = e->prog.steps[q].C;
                 }
                 ka.pts = pts;
+                ka.verts = verts;
                 ka.out = out;
                 ka.afrag = e->d_astack[order];
                 ka.phi0 = e->prog.phi0;
@@ -1287,6 +1304,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 L.ncu = ctx->num_cu;
                 L.trash = ctx->d_trash;
                 L.queue = ctx->d_queue + (size_t)(ctx->launch_seq++ % FX_QUEUE_SLOTS) * 16;
+                L.kmix_order = order;
                 L.stacked_id = (int)i;
                 break;
             }

@@ -25,6 +25,9 @@ namespace fxk {
 
 template <int NC> struct StackedArgs {
     const double* pts;    // [nreq][npts][SD]
+    const double* verts;  // [nreq][SD+1][SD] per-request cells, or nullptr: the element's own cell (A0, b0).  With
+                          // cells the tables are still derivatives w.r.t. the ELEMENT's cell coordinates; the chain
+                          // rule across tables is applied by table_mix_kernel afterwards (api.hip)
     double* out;          // [nreq][R][npts]
     const double* afrag;  // [RT + 1][KS][64]: 16x16x4 A fragments of A_stack, K in production order; last tile zero
     double coef[NC > 0 ? NC : 1];  // [nsteps][3] = A, B, C
@@ -156,12 +159,26 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
             for (int h = 0; h < PH; ++h) {
                 if (lane < PWP) {
                     double X[SD];
+                    if (a.verts) {  // (wave-uniform branch) physical point -> default simplex through the request's cell
+                        long long req = grp * G + pg[h];
+                        req = req < a.nreq ? req : a.nreq - 1;
+                        double J[SD][SD], bb[SD];
+                        cell_map<SD>(a.verts + (size_t)req * (SD + 1) * SD, J, bb);
 #pragma unroll
-                    for (int i = 0; i < SD; ++i) {
-                        double t = a.b0[i];
+                        for (int i = 0; i < SD; ++i) {
+                            double t = bb[i];
 #pragma unroll
-                        for (int d = 0; d < SD; ++d) t += a.A0[i * SD + d] * xcur[h][d];
-                        X[i] = t;
+                            for (int d = 0; d < SD; ++d) t += J[i][d] * xcur[h][d];
+                            X[i] = t;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < SD; ++i) {
+                            double t = a.b0[i];
+#pragma unroll
+                            for (int d = 0; d < SD; ++d) t += a.A0[i * SD + d] * xcur[h][d];
+                            X[i] = t;
+                        }
                     }
                     double mem[NEXP];
                     double ufa = 0.0, ufb = 0.0, ufc = 0.0;

@@ -7,6 +7,7 @@
 // Both are single HBM passes over the tables.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "simplex_kernel.hpp"  // cell_map
 
 namespace fxk {
 
@@ -76,6 +77,91 @@ __global__ __launch_bounds__(256) void point_major_kernel(const PointMajorArgs a
     for (int j = ty; j < 32; j += 8) {
         const int p = p0 + j, r = r0 + tx;
         if (r < a.rows && p < a.npts) out[(size_t)p * a.rows + r] = tile[tx][j];
+    }
+}
+
+// Chain rule across the derivative tables of a request, in place: the tables were computed with respect
+// to the coordinates X of the element's own cell, the request lives on the affine image x of that cell;
+//   d/dx_d = sum_c K[c][d] d/dX_c,   d2/dx_d dx_e = sum_{c,c'} K[c][d] K[c'][e] d2/dX_c dX_c',   K = A0^-1 A_req
+// (A_req x + b_req and A0 X + b0 are the two maps to the default simplex).  One workgroup per request and
+// slice of positions; every thread owns (row, point) positions and all ntab values at them.
+struct TableMixArgs {
+    double* out;          // [nreq][ntab][n]   n = rows * npts
+    const double* verts;  // [nreq][SD+1][SD]
+    double A0inv[9];
+    int n;
+    int order;            // 1 or 2
+    int slices;           // workgroups per request
+};
+
+template <int SD>
+__global__ __launch_bounds__(256) void table_mix_kernel(const TableMixArgs a) {
+    constexpr int NH = SD * (SD + 1) / 2;
+    __shared__ double sK[SD * SD];
+    const size_t req = blockIdx.x / a.slices;
+    const int slice = blockIdx.x % a.slices;
+    if (threadIdx.x == 0) {
+        double A[SD][SD], b[SD];
+        cell_map<SD>(a.verts + req * (SD + 1) * SD, A, b);
+        for (int c = 0; c < SD; ++c)
+            for (int d = 0; d < SD; ++d) {
+                double t = 0.0;
+                for (int k = 0; k < SD; ++k) t += a.A0inv[c * SD + k] * A[k][d];
+                sK[c * SD + d] = t;
+            }
+    }
+    __syncthreads();
+    double K[SD][SD];
+#pragma unroll
+    for (int c = 0; c < SD; ++c)
+#pragma unroll
+        for (int d = 0; d < SD; ++d) K[c][d] = sK[c * SD + d];
+    const int ntab = a.order >= 2 ? 1 + SD + NH : 1 + SD;
+    double* base = a.out + req * (size_t)ntab * a.n;
+    for (int i = slice * 256 + threadIdx.x; i < a.n; i += a.slices * 256) {
+        double g[SD], og[SD];
+#pragma unroll
+        for (int c = 0; c < SD; ++c) g[c] = base[(size_t)(1 + c) * a.n + i];
+#pragma unroll
+        for (int d = 0; d < SD; ++d) {
+            double t = 0.0;
+#pragma unroll
+            for (int c = 0; c < SD; ++c) t += K[c][d] * g[c];
+            og[d] = t;
+        }
+#pragma unroll
+        for (int d = 0; d < SD; ++d) base[(size_t)(1 + d) * a.n + i] = og[d];
+        if (a.order >= 2) {
+            // Hessian tables in mis() order: (c, c'), c <= c' -> index c (2 SD - c - 1) / 2 + c'
+            double H[SD][SD];
+#pragma unroll
+            for (int c = 0; c < SD; ++c)
+#pragma unroll
+                for (int e = c; e < SD; ++e) {
+                    const double v = base[(size_t)(1 + SD + c * (2 * SD - c - 1) / 2 + e) * a.n + i];
+                    H[c][e] = v;
+                    H[e][c] = v;
+                }
+            double T[SD][SD];  // T[c][e] = sum_c' H[c][c'] K[c'][e]
+#pragma unroll
+            for (int c = 0; c < SD; ++c)
+#pragma unroll
+                for (int e = 0; e < SD; ++e) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < SD; ++k) t += H[c][k] * K[k][e];
+                    T[c][e] = t;
+                }
+#pragma unroll
+            for (int d = 0; d < SD; ++d)
+#pragma unroll
+                for (int e = d; e < SD; ++e) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int c = 0; c < SD; ++c) t += K[c][d] * T[c][e];
+                    base[(size_t)(1 + SD + d * (2 * SD - d - 1) / 2 + e) * a.n + i] = t;
+                }
+        }
     }
 }
 

@@ -354,10 +354,10 @@ def test_kernel_selection(rt, golden):
     assert p3.kernel_name(1, 1000, 50) == "fxk::tabulate_simplex_stacked"    # 49..64 points: four column tiles
     assert p3.kernel_name(1, 1000, 70) == "fxk::tabulate_simplex_kernel"     # more points than a wave has lanes
     assert p3.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_stacked"    # Hessians: 200 stacked rows
-    assert p3.kernel_name(2, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_kernel"
+    assert p3.kernel_name(2, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_stacked"   # + table-mixing pass
     dg6 = rt.SimplexPolySet(3, 6, coeffs=g["c4_dg6tet_q6_coeffs"])
     assert dg6.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_stacked"          # requests on the element's cell
-    assert dg6.kernel_name(2, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_coop"  # per-request cells
+    assert dg6.kernel_name(2, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_stacked"  # per-request cells: + table-mixing pass
     assert dg6.kernel_name(2, 1000, 122) == "fxk::tabulate_simplex_kernel"
 
 
@@ -548,6 +548,35 @@ def test_stacked_matrix_kernel_triangles(fam, deg, order, npts):
     out = ps.tabulate_batch(order, pts).cpu().numpy()
     n = el.get_nodal_basis().get_embedded_degree()
     ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[2], n, el.get_coeffs(), order, pts, scale=el._expansion_scale,
+                                  variant=el._expansion_variant).reshape(out.shape)
+    axes = tuple(range(2, out.ndim))
+    err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)
+    assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), err
+
+
+@pytest.mark.parametrize("fam,sd,deg,order,npts", [("DiscontinuousLagrange", 3, 6, 2, 23), ("DiscontinuousLagrange", 3, 6, 1, 40),
+                                                   ("Lagrange", 3, 4, 2, 23), ("Lagrange", 3, 5, 1, 30), ("Nedelec", 3, 3, 1, 23),
+                                                   ("Lagrange", 2, 6, 2, 16), ("RaviartThomas", 2, 5, 1, 23),
+                                                   ("Lagrange", 3, 5, 0, 23)])
+def test_stacked_matrix_kernel_with_per_request_cells(fam, sd, deg, order, npts):
+    """Per-request cells on the stacked-matrix kernel: points mapped through the request's cell in the kernel,
+    chain rule across the derivative tables by the in-place mixing pass (table_mix_kernel), against the C
+    oracle's recurrence on the physical cells; one negatively oriented cell."""
+    import fiat_amd
+    from oracle import c_oracle
+    el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg)
+    ps = el.device_polyset()
+    nreq = 131
+    assert ps.kernel_name(order, nreq, npts, has_verts=True) == "fxk::tabulate_simplex_stacked"
+    rng = np.random.default_rng(31 * deg + npts + order + sd)
+    A = np.eye(sd) + 0.1 * rng.standard_normal((nreq, sd, sd))
+    A[7, :, 0] *= -1.0
+    verts = np.einsum("vd,red->rve", fo.UFC_SIMPLEX[sd], A) + rng.standard_normal((nreq, 1, sd))
+    e = rng.exponential(size=(nreq, npts, sd + 1))
+    pts = np.einsum("rpv,rvd->rpd", e / e.sum(axis=-1, keepdims=True), verts)
+    out = ps.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    n = el.get_nodal_basis().get_embedded_degree()
+    ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[sd], n, el.get_coeffs(), order, pts, verts=verts, scale=el._expansion_scale,
                                   variant=el._expansion_variant).reshape(out.shape)
     axes = tuple(range(2, out.ndim))
     err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)

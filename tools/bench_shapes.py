@@ -28,8 +28,16 @@ for case in CASES:
     per_req = 8 * (npts * sd + int(np.prod(shape1[1:])))
     nreq = int(min(4_000_000, 1.2e9 // per_req))
     pts = torch.as_tensor(bench.synth_points(sd, nreq, npts, 1)).cuda()
+    verts = None
+    if "--verts" in sys.argv:  # per-request cells: affine images of the reference cell, points mapped along
+        rng = np.random.default_rng(3)
+        A = torch.as_tensor(np.eye(sd) + 0.1 * rng.standard_normal((nreq, sd, sd))).cuda()
+        b = torch.as_tensor(rng.standard_normal((nreq, 1, sd))).cuda()
+        ref = torch.as_tensor(np.array(fiat_amd.ufc_simplex(sd).get_vertices(), dtype=float)).cuda()
+        verts = (torch.einsum("vd,red->rve", ref, A) + b).contiguous()
+        pts = (torch.einsum("rpd,red->rpe", pts, A) + b).contiguous()
     out = torch.empty(ps.out_shape(order, nreq, npts), dtype=torch.float64, device="cuda")
-    t = statistics.median(ps.time_tabulate_batch(order, pts, None, out, 10) for _ in range(3))
+    t = statistics.median(ps.time_tabulate_batch(order, pts, verts, out, 10) for _ in range(3))
     print(f"{fam:22s} sd{sd} P{deg} npts {npts:3d}: {nreq:8d} requests, {t*1e3:8.1f} us, {nreq/t/1e3:8.1f} M req/s, "
-          f"{per_req*nreq/t/1e6:6.0f} GB/s ({per_req*nreq/t/1e6/80:.0f} %)  {ps.kernel_name(order, nreq, npts)}")
+          f"{per_req*nreq/t/1e6:6.0f} GB/s ({per_req*nreq/t/1e6/80:.0f} %)  {ps.kernel_name(order, nreq, npts, has_verts=verts is not None)}")
     del pts, out
