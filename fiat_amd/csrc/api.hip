@@ -682,6 +682,8 @@ int launch_fixed(const Launch& L, hipStream_t s) {
 struct StackedShape {
     int sd, n, ct, g;
     int rtc;  // > 0: instance for exactly rtc row tiles with register-resident A fragments (small shapes); 0: any
+              // < 0: point-chunked instance (a unit = 16 ct points of one request): any number of points >= 13, odd
+              //      table sizes too -- taken when no whole-request instance applies
 };
 const StackedShape kStackedShapes[] = {
     {3, 3, 3, 2, 5},  // Lagrange P3 tetrahedron, values + gradient (80 stacked rows): the benchmark shape C2, 17..24 points
@@ -712,10 +714,11 @@ const StackedShape kStackedShapes[] = {
     {2, 6, 3, 3, 0}, {2, 6, 4, 1, 0},
     {2, 5, 3, 3, 0}, {2, 5, 4, 1, 0},
     {3, 2, 3, 2, 0}, {3, 2, 2, 1, 0}, {3, 2, 3, 1, 0}, {3, 2, 3, 3, 0}, {3, 2, 4, 1, 0},  // degree-2 tetrahedron (N2, RT2, BDM2 ...)
+    {3, 6, 3, 1, -1}, {3, 5, 3, 1, -1}, {3, 4, 3, 1, -1}, {3, 3, 3, 1, -1}, {3, 2, 3, 1, -1}, {2, 6, 3, 1, -1}, {2, 5, 3, 1, -1},  // point-chunked
 };
 constexpr int STACKED_NW = 4;  // one wave per SIMD
 
-template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1>
+template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false>
 int launch_stacked(const Launch& L, hipStream_t s) {
     constexpr int NC = fxk::FixedNC<SD, N>::value;
     fxk::StackedArgs<NC> ka;
@@ -733,7 +736,7 @@ int launch_stacked(const Launch& L, hipStream_t s) {
     ka.debug = L.khead.debug;
     if ((int)L.fcoef.size() != NC) return fail(FX_EINVAL, "internal: coefficient table size mismatch");
     memcpy(ka.coef, L.fcoef.data(), NC * sizeof(double));
-    auto kern = fxk::tabulate_simplex_stacked<SD, N, CT, G, RTC, WPS>;
+    auto kern = fxk::tabulate_simplex_stacked<SD, N, CT, G, RTC, WPS, CHUNK>;
     // as many workgroups per CU as registers and LDS allow (low degrees need few registers: their short
     // row sweeps rely on other waves to cover the production phase); asked once per kernel
     static thread_local int occ = 0;
@@ -747,7 +750,7 @@ int launch_stacked(const Launch& L, hipStream_t s) {
         occ = std::min(occ, std::max(1, cap));
         if (getenv("FIAT_AMD_VERBOSE")) fprintf(stderr, "[fiat_amd] stacked kernel <%d,%d,%d,%d>: %d workgroups per CU, lds %d B\n", SD, N, CT, G, occ, L.klds_bytes);
     }
-    const long long groups = (L.khead.nreq + G - 1) / G;
+    const long long groups = CHUNK ? L.khead.nreq * ((L.khead.npts + 16 * CT - 1) / (16 * CT)) : (L.khead.nreq + G - 1) / G;
     const int grid = (int)std::max<long long>(1, std::min<long long>((groups + STACKED_NW - 1) / STACKED_NW, (long long)L.ncu * occ));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * STACKED_NW), L.klds_bytes, s, ka, L.trash,
                        reinterpret_cast<unsigned int*>(L.queue));
@@ -811,6 +814,13 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 35: return launch_stacked<3, 2, 3, 1>(L, s);
         case 36: return launch_stacked<3, 2, 3, 3>(L, s);
         case 37: return launch_stacked<3, 2, 4, 1>(L, s);
+        case 38: return launch_stacked<3, 6, 3, 1, 0, 1, true>(L, s);
+        case 39: return launch_stacked<3, 5, 3, 1, 0, 1, true>(L, s);
+        case 40: return launch_stacked<3, 4, 3, 1, 0, 1, true>(L, s);
+        case 41: return launch_stacked<3, 3, 3, 1, 0, 1, true>(L, s);
+        case 42: return launch_stacked<3, 2, 3, 1, 0, 1, true>(L, s);
+        case 43: return launch_stacked<2, 6, 3, 1, 0, 1, true>(L, s);
+        case 44: return launch_stacked<2, 5, 3, 1, 0, 1, true>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown stacked kernel %d", L.stacked_id);
 }
@@ -1250,7 +1260,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
         // (after the shape-specialised registries: the tuned paired instances and the lane-local kernel keep their shapes)
         // (per-request cells: the kernel maps the points through the request's cell and a second pass applies the
         // chain rule across the derivative tables, table_mix_kernel; a Piola map is left to fx_pushforward_batch)
-        if (!nostacked && L.fixed_id < 0 && L.small_id < 0 && !L.fused_mapping && !e->raw_expansion && order <= 2 && even) {
+        if (!nostacked && L.fixed_id < 0 && L.small_id < 0 && !L.fused_mapping && !e->raw_expansion && order <= 2) {
             for (size_t i = 0; i < sizeof(kStackedShapes) / sizeof(kStackedShapes[0]); ++i) {
                 const StackedShape& k = kStackedShapes[i];
                 if (k.sd != e->sd || k.n != e->n) continue;
@@ -1259,9 +1269,14 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 // recurrence derivatives are two digits more accurate), opt-in with FIAT_AMD_STACKED_SMALL=1
                 const char* small = getenv("FIAT_AMD_STACKED_SMALL");
                 if (k.rtc > 0 ? (RT != k.rtc || verts || !(small && atoi(small))) : R < stacked_min_rows) continue;
-                const int cap = 16 * k.ct / k.g;              // points one request may have
-                const int lo = 16 * k.ct / (k.g + 1);         // below: one more request fits the tiles
-                if (npts > cap || npts <= lo) continue;
+                if (k.rtc < 0) {  // point-chunked: whatever the whole-request instances above did not take
+                    if (npts < 13 || nreq * (long long)((npts + 16 * k.ct - 1) / (16 * k.ct)) > 0x7fffffffLL) continue;
+                } else {
+                    if (!even) continue;  // (16-byte stores of whole request chunks)
+                    const int cap = 16 * k.ct / k.g;              // points one request may have
+                    const int lo = 16 * k.ct / (k.g + 1);         // below: one more request fits the tiles
+                    if (npts > cap || npts <= lo) continue;
+                }
                 bool ok = false;
                 if (e->sd == 3 && e->n == 6) ok = table_matches<3, 6>(e->prog);
                 if (e->sd == 3 && e->n == 5) ok = table_matches<3, 5>(e->prog);
@@ -1296,7 +1311,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 ka.debug = a.debug;
                 L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * fxk::stacked_image_doubles(k.ct, (e->nexp + 3) / 4)) * 8;
                 if (L.klds_bytes > ctx->lds_per_cu) continue;
-                const long long groups = (nreq + k.g - 1) / k.g;
+                const long long groups = k.rtc < 0 ? nreq * ((npts + 16 * k.ct - 1) / (16 * k.ct)) : (nreq + k.g - 1) / k.g;
                 // one workgroup per CU = one wave per SIMD (measured: a second wave per SIMD at half the registers
                 // spills in the production phase and gains nothing, 1.45 -> 1.48 ms: the kernel is bound by the
                 // shared fp64 MFMA/VALU pipe, not by latencies)

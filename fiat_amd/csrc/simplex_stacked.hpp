@@ -54,7 +54,9 @@ constexpr int stacked_image_doubles(int CT, int KS) {
 // sweep, which is fully unrolled); RTC == 0: any number of row tiles, fragments streamed from L2.
 // WPS: waves per SIMD the register allocation aims for (short sweeps need other waves to cover the
 // production phase of a group).
-template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1>
+// CHUNK: a unit is one request's next 16 CT points (any number of points per request, odd table sizes too):
+// the image of a row tile is [row][points of the chunk] and leaves row by row as 8-byte stores.
+template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false>
 __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const StackedArgs<FixedNC<SD, N>::value> a,
                                                                    double* __restrict__ trash,
                                                                    unsigned int* __restrict__ gqueue) {
@@ -63,6 +65,8 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
     constexpr int KS = (NEXP + 3) / 4;
     constexpr int CPR = 16 * CT / G;                // column budget of one request
     constexpr int NST = (16 * CPR / 2 + 63) / 64;   // 16-byte stores per lane and request chunk
+    constexpr int PCH = 16 * CT;                    // points per chunk (CHUNK)
+    static_assert(!CHUNK || (G == 1 && RTC == 0), "point-chunked units: one request per group, streamed fragments");
     constexpr int IMG = stacked_image_doubles(CT, KS);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63;
@@ -78,7 +82,8 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
 
     const int npts = a.npts;
     const int chunk = 16 * npts;  // doubles one request contributes to a row tile
-    const long long ngroups = (a.nreq + G - 1) / G;
+    const int nchunk = CHUNK ? (npts + PCH - 1) / PCH : 1;
+    const long long ngroups = CHUNK ? a.nreq * nchunk : (a.nreq + G - 1) / G;
     WorkQueue wqueue;
     wqueue.init(lds, gqueue, ngroups);
     __syncthreads();
@@ -119,9 +124,19 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
     auto load_points = [&](long long g_, double (&x)[PH][SD]) {
 #pragma unroll
         for (int h = 0; h < PH; ++h) {
-            long long req = (g_ < ngroups ? g_ : ngroups - 1) * G + pg[h];
-            req = req < a.nreq ? req : a.nreq - 1;
-            const double* pp = a.pts + ((size_t)req * npts + ppt[h]) * SD;
+            const long long gg = g_ < ngroups ? g_ : ngroups - 1;
+            long long req;
+            int pt;
+            if constexpr (CHUNK) {
+                req = gg / nchunk;
+                const int p0 = (int)(gg - req * nchunk) * PCH;
+                pt = min(p0 + h * PWP + lane, npts - 1);  // (lanes past the chunk recompute a valid point)
+            } else {
+                req = gg * G + pg[h];
+                req = req < a.nreq ? req : a.nreq - 1;
+                pt = ppt[h];
+            }
+            const double* pp = a.pts + ((size_t)req * npts + pt) * SD;
 #pragma unroll
             for (int d = 0; d < SD; ++d) x[h][d] = pp[d];
         }
@@ -160,7 +175,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                 if (lane < PWP) {
                     double X[SD];
                     if (a.verts) {  // (wave-uniform branch) physical point -> default simplex through the request's cell
-                        long long req = grp * G + pg[h];
+                        long long req = CHUNK ? grp / nchunk : grp * G + pg[h];
                         req = req < a.nreq ? req : a.nreq - 1;
                         double J[SD][SD], bb[SD];
                         cell_map<SD>(a.verts + (size_t)req * (SD + 1) * SD, J, bb);
@@ -233,14 +248,23 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
         }
         long long oreq[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) oreq[g] = grp * G + g;
+        for (int g = 0; g < G; ++g) oreq[g] = CHUNK ? grp / nchunk : grp * G + g;
+        const int p0 = CHUNK ? (int)(grp - oreq[0] * nchunk) * PCH : 0;  // first point of the chunk
+        const int pc = CHUNK ? min(PCH, npts - p0) : npts;             // points of the chunk = row stride of the image
         const int RTn = RTC > 0 ? RTC : a.RT;
         // opaque per-group copies of the lane-derived offsets: otherwise every (tile, store) address of the
         // unrolled sweep is precomputed outside the group loop and spilled (see simplex_pair.hpp)
         int elane = lane, ekk = kk, enpts = npts;
         int eoff[CT];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) eoff[c] = ioff[c];
+        for (int c = 0; c < CT; ++c) {
+            if constexpr (CHUNK) {
+                const int j = 16 * c + (lane & 15);
+                eoff[c] = j < pc ? kk * pc + j : -1;
+            } else {
+                eoff[c] = ioff[c];
+            }
+        }
         if constexpr (RTC > 0) {
             asm volatile("" : "+v"(elane), "+v"(ekk), "+s"(enpts));
 #pragma unroll
@@ -253,23 +277,38 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
         // (`nrows`: 16 for every tile but possibly the last one -- the pipelined stages only ever flush full
         // tiles, which makes all their LDS and output offsets loop invariants)
         // D tile: element jj of lane (kk, col) is row 4 jj + kk -> image [request][row][point]
+        const int estr = CHUNK ? pc : enpts;  // row stride of the image
         auto image_put = [&](const v4d (&acc)[CT], int w, int nrows) {  // w-th of the 4 CT image stores
             const int c = w >> 2, jj = w & 3;
             const bool ok = eoff[c] >= 0 && 4 * jj + ekk < nrows;
-            img[ok ? eoff[c] + 4 * jj * enpts : DUMP + elane] = acc[c][jj];
+            img[ok ? eoff[c] + 4 * jj * estr : DUMP + elane] = acc[c][jj];
         };
-        v2d fbuf[G * NST];
-        auto image_get = [&](int r, int nrows) {  // r-th of the G NST 16-byte image reads
-            const int g = r / NST, it = r % NST;
-            const int nch = (nrows * enpts) >> 1;  // 16-byte pieces of a request's chunk (host: even)
-            fbuf[r] = reinterpret_cast<const v2d*>(img + g * echunk)[min(it * 64 + elane, nch - 1)];
+        constexpr int NRD = CHUNK ? (16 * PCH + 63) / 64 : G * NST;  // image reads = output stores per row tile
+        v2d fbuf[CHUNK ? 1 : NRD];
+        double fbuf1[CHUNK ? NRD : 1];
+        const float rpc = 1.0f / (float)pc;
+        auto image_get = [&](int r, int nrows) {  // r-th image read
+            if constexpr (CHUNK) {
+                fbuf1[r] = img[min(r * 64 + elane, nrows * pc - 1)];
+            } else {
+                const int g = r / NST, it = r % NST;
+                const int nch = (nrows * enpts) >> 1;  // 16-byte pieces of a request's chunk (host: even)
+                fbuf[r] = reinterpret_cast<const v2d*>(img + g * echunk)[min(it * 64 + elane, nch - 1)];
+            }
         };
         auto image_out = [&](int r, int rt, int nrows) {  // r-th output store of row tile rt
-            const int g = r / NST, it = r % NST;
-            const int nch = (nrows * enpts) >> 1;
-            v2d* g2 = oreq[g] < a.nreq ? reinterpret_cast<v2d*>(a.out + ((size_t)oreq[g] * a.R + (size_t)16 * rt) * enpts)
-                                       : reinterpret_cast<v2d*>(trash);
-            stream_store(&g2[min(it * 64 + elane, nch - 1)], fbuf[r]);
+            if constexpr (CHUNK) {
+                const int i = min(r * 64 + elane, nrows * pc - 1);
+                const int row = idiv_small(i, rpc);
+                double* dst = a.out + ((size_t)oreq[0] * a.R + (size_t)16 * rt + row) * enpts + p0 + (i - row * pc);
+                stream_store(dst, fbuf1[r]);
+            } else {
+                const int g = r / NST, it = r % NST;
+                const int nch = (nrows * enpts) >> 1;
+                v2d* g2 = oreq[g] < a.nreq ? reinterpret_cast<v2d*>(a.out + ((size_t)oreq[g] * a.R + (size_t)16 * rt) * enpts)
+                                           : reinterpret_cast<v2d*>(trash);
+                stream_store(&g2[min(it * 64 + elane, nch - 1)], fbuf[r]);
+            }
         };
         auto mfma_steps = [&](v4d (&acc)[CT], const double (&af)[KS], int k0, int k1) {
 #pragma unroll
@@ -283,7 +322,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
         // a burst of 17 loads or 18 LDS operations between two MFMAs leaves the matrix pipe idle): every K-step
         // CT MFMAs + its share of the fragment loads (first two thirds), image stores (first third), image
         // reads (second third) or output stores (last third); the scheduler may not move anything across a K-step.
-        constexpr int NWR = 4 * CT, NRD = G * NST, T3 = KS / 3;
+        constexpr int NWR = 4 * CT, T3 = KS / 3;
         constexpr int LPK = (KS + 2 * T3 - 1) / (2 * T3);
         constexpr int WPK = (NWR + T3 - 1) / T3, RPK = (NRD + T3 - 1) / T3, SPK = (NRD + (KS - 2 * T3) - 1) / (KS - 2 * T3);
         auto stage = [&](v4d (&cur)[CT], const v4d (&prev)[CT], int rt, const double (&af)[KS], double (&an)[KS]) {

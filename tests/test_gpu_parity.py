@@ -352,13 +352,14 @@ def test_kernel_selection(rt, golden):
     assert p3.kernel_name(1, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_pair"
     assert p3.kernel_name(1, 1000, 40) == "fxk::tabulate_simplex_pair"       # one request per wave, 10 column tiles
     assert p3.kernel_name(1, 1000, 50) == "fxk::tabulate_simplex_stacked"    # 49..64 points: four column tiles
-    assert p3.kernel_name(1, 1000, 70) == "fxk::tabulate_simplex_kernel"     # more points than a wave has lanes
+    assert p3.kernel_name(1, 1000, 70) == "fxk::tabulate_simplex_stacked"    # point-chunked units
+    assert p3.kernel_name(1, 1000, 7) == "fxk::tabulate_simplex_kernel"      # fewer points than any registered tiling
     assert p3.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_stacked"    # Hessians: 200 stacked rows
     assert p3.kernel_name(2, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_stacked"   # + table-mixing pass
     dg6 = rt.SimplexPolySet(3, 6, coeffs=g["c4_dg6tet_q6_coeffs"])
     assert dg6.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_stacked"          # requests on the element's cell
     assert dg6.kernel_name(2, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_stacked"  # per-request cells: + table-mixing pass
-    assert dg6.kernel_name(2, 1000, 122) == "fxk::tabulate_simplex_kernel"
+    assert dg6.kernel_name(2, 1000, 122) == "fxk::tabulate_simplex_stacked"         # point-chunked units (C4 stress variant)
 
 
 def test_concurrent_streams(rt, golden):
@@ -574,6 +575,37 @@ def test_stacked_matrix_kernel_with_per_request_cells(fam, sd, deg, order, npts)
     verts = np.einsum("vd,red->rve", fo.UFC_SIMPLEX[sd], A) + rng.standard_normal((nreq, 1, sd))
     e = rng.exponential(size=(nreq, npts, sd + 1))
     pts = np.einsum("rpv,rvd->rpd", e / e.sum(axis=-1, keepdims=True), verts)
+    out = ps.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    n = el.get_nodal_basis().get_embedded_degree()
+    ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[sd], n, el.get_coeffs(), order, pts, verts=verts, scale=el._expansion_scale,
+                                  variant=el._expansion_variant).reshape(out.shape)
+    axes = tuple(range(2, out.ndim))
+    err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)
+    assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), err
+
+
+@pytest.mark.parametrize("fam,sd,deg,order,npts,cells", [
+    ("DiscontinuousLagrange", 3, 6, 2, 122, False), ("DiscontinuousLagrange", 3, 6, 1, 65, True), ("Lagrange", 3, 3, 1, 70, False),
+    ("Lagrange", 3, 5, 1, 97, False), ("Lagrange", 2, 6, 2, 73, True), ("DiscontinuousLagrange", 2, 5, 1, 15, False),
+    ("Nedelec", 3, 3, 1, 49, False), ("Lagrange", 3, 4, 2, 200, False), ("RaviartThomas", 3, 3, 1, 23, True)])
+def test_stacked_matrix_kernel_point_chunks(fam, sd, deg, order, npts, cells):
+    """Point-chunked units of the stacked-matrix kernel (16 CT points of one request per unit, 8-byte row stores): more
+    than 64 points per request (the C4 stress variant: 122 points), a last chunk of any size, and odd table sizes
+    that the 16-byte whole-request instances cannot take; against the C oracle."""
+    import fiat_amd
+    from oracle import c_oracle
+    el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg)
+    ps = el.device_polyset()
+    nreq = 57
+    assert ps.kernel_name(order, nreq, npts, has_verts=cells) == "fxk::tabulate_simplex_stacked"
+    rng = np.random.default_rng(7 * deg + npts + order + sd)
+    pts = rand_points(rng, sd, (nreq, npts))
+    verts = None
+    if cells:
+        A = np.eye(sd) + 0.1 * rng.standard_normal((nreq, sd, sd))
+        b = rng.standard_normal((nreq, 1, sd))
+        verts = np.einsum("vd,red->rve", fo.UFC_SIMPLEX[sd], A) + b
+        pts = np.einsum("rpd,red->rpe", pts, A) + b
     out = ps.tabulate_batch(order, pts, verts=verts).cpu().numpy()
     n = el.get_nodal_basis().get_embedded_degree()
     ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[sd], n, el.get_coeffs(), order, pts, verts=verts, scale=el._expansion_scale,

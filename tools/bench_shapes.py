@@ -15,6 +15,10 @@ BIG = [("Lagrange", 3, 4, 23, 2), ("Lagrange", 3, 5, 23, 1), ("Lagrange", 3, 5, 
 MID = [("Lagrange", 2, 5, 16, 1), ("Lagrange", 2, 5, 23, 2), ("Lagrange", 2, 6, 23, 1), ("Lagrange", 2, 6, 23, 2),
        ("DiscontinuousLagrange", 2, 6, 30, 2), ("Nedelec", 2, 5, 23, 1), ("Lagrange", 3, 4, 30, 1), ("Lagrange", 3, 5, 23, 0),
        ("Lagrange", 3, 3, 23, 2), ("RaviartThomas", 3, 3, 23, 0), ("Lagrange", 3, 6, 23, 0)]
+MANY = [("DiscontinuousLagrange", 3, 6, 122, 2), ("Lagrange", 3, 5, 97, 1), ("Lagrange", 3, 4, 122, 2), ("Lagrange", 3, 3, 70, 1),
+        ("Lagrange", 2, 6, 73, 2), ("Nedelec", 3, 3, 100, 1)]
+if "--many-points" in sys.argv:
+    CASES = MANY
 if "--big" in sys.argv:
     CASES = BIG
 if "--mid" in sys.argv:
