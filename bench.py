@@ -38,6 +38,7 @@ WORKLOADS = {
     "n2tet": ("Nedelec", 3, 2, 1, 23, 25_000),
     "rt2tet": ("RaviartThomas", 3, 2, 1, 23, 25_000),
     "dg6tet": ("DiscontinuousLagrange", 3, 6, 2, 23, 20_000),
+    "dg6tet122": ("DiscontinuousLagrange", 3, 6, 2, 122, 8_000),  # C4 stress variant: 122 points (823 kB per request)
     # low-order shapes served by the generic kernel (not BASELINE configs; for tools/kernel_ab.py)
     "p1tet": ("Lagrange", 3, 1, 1, 4, 2_000_000),
     "p2tet": ("Lagrange", 3, 2, 1, 11, 300_000),
