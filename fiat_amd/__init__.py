@@ -15,7 +15,7 @@ from .reference_element import (DefaultLine, DefaultTetrahedron, DefaultTriangle
                                 UFCInterval, UFCTetrahedron, UFCTriangle, default_simplex,
                                 make_affine_mapping, make_lattice, physical_simplex, ufc_simplex)
 from .quadrature import create_quadrature, make_quadrature  # noqa: F401
-from .polynomial_set import ONPolynomialSet, PolynomialSet, mis  # noqa: F401
+from .polynomial_set import ONPolynomialSet, ONSymTensorPolynomialSet, PolynomialSet, mis  # noqa: F401
 from .expansions import ExpansionSet  # noqa: F401
 from .finite_element import CiarletElement, FiniteElement  # noqa: F401
 from .lagrange import Lagrange  # noqa: F401
@@ -31,6 +31,8 @@ from .restricted import RestrictedElement  # noqa: F401
 from .bubble import Bubble, FacetBubble  # noqa: F401
 from .brezzi_douglas_fortin_marini import BrezziDouglasFortinMarini  # noqa: F401
 from .discontinuous_raviart_thomas import DiscontinuousRaviartThomas  # noqa: F401
+from .regge import Regge  # noqa: F401
+from .hellan_herrmann_johnson import HellanHerrmannJohnson  # noqa: F401
 from .tensor_product import FlattenedDimensions, TensorProductElement  # noqa: F401
 
 # the element registry of the reference (FIAT/__init__.py:72-131), in-scope subset
@@ -49,6 +51,8 @@ supported_elements = {
     "Brezzi-Douglas-Fortin-Marini": BrezziDouglasFortinMarini,
     "Discontinuous Raviart-Thomas": DiscontinuousRaviartThomas,
     "RestrictedElement": RestrictedElement,
+    "Regge": Regge,
+    "Hellan-Herrmann-Johnson": HellanHerrmannJohnson,
     "TensorProductElement": TensorProductElement,
     "FlattenedDimensions": FlattenedDimensions,
 }

@@ -228,3 +228,21 @@ class PointFaceTangentEvaluation(_PointVectorEvaluation):
 
     def tostr(self):
         return "(u.t%d)(%s)" % (self.tno, ",".join(map(str, list(self.pt_dict)[0])))
+
+
+class PointwiseInnerProductEvaluation(Functional):
+    """u -> v^T u(pt) w for symmetric-matrix-valued u: the Frobenius product with w v^T
+    (FIAT/functional.py:639-656)."""
+
+    def __init__(self, ref_el, v, w, pt):
+        wvT = numpy.outer(w, v)
+        pt_dict = {tuple(pt): [(wvT[idx], idx) for idx in numpy.ndindex(wvT.shape)]}
+        super().__init__(ref_el, wvT.shape, pt_dict, {}, "PointwiseInnerProductEval")
+
+
+class TensorBidirectionalIntegralMoment(FrobeniusIntegralMoment):
+    """u -> sum_q w_q f(x_q) v^T u(x_q) w (FIAT/functional.py:659-672)."""
+
+    def __init__(self, ref_el, v, w, Q, f_at_qpts):
+        F = numpy.multiply(numpy.outer(v, w)[..., None], f_at_qpts)
+        super().__init__(ref_el, Q, F, "TensorBidirectionalMomentInnerProductEvaluation")

@@ -95,6 +95,24 @@ class ONPolynomialSet(PolynomialSet):
         super().__init__(ref_el, degree, degree, es, coeffs)
 
 
+class ONSymTensorPolynomialSet(PolynomialSet):
+    """Symmetric-matrix-valued polynomials (FIAT/polynomial_set.py:220-249): for every component pair i <= j one
+    copy of the expansion set with the value e_i e_j^T + e_j e_i^T (the diagonal ones: e_i e_i^T)."""
+
+    def __init__(self, ref_el, degree, size=None, **kwargs):
+        es = expansions.ExpansionSet(ref_el, **kwargs)
+        if size is None:
+            size = ref_el.get_spatial_dimension()
+        nexp = es.get_num_members(degree)
+        pairs = [(i, j) for i in range(size) for j in range(i, size)]
+        coeffs = numpy.zeros((len(pairs) * nexp, size, size, nexp))
+        members = numpy.arange(nexp)
+        for block, (i, j) in enumerate(pairs):
+            coeffs[block * nexp + members, i, j, members] = 1.0
+            coeffs[block * nexp + members, j, i, members] = 1.0
+        super().__init__(ref_el, degree, degree, es, coeffs)
+
+
 def spanning_basis(A, nullspace=False, rtol=1e-10):
     """Orthonormal basis of the row space (or its complement) of A via SVD."""
     Aflat = A.reshape(A.shape[0], -1)

@@ -147,6 +147,13 @@ class Simplex(Cell):
         vs = numpy.array(self.get_vertices_of_subcomplex(self.topology[dim][i]))
         return vs[1:] - vs[:1]
 
+    def compute_face_edge_tangents(self, dim, entity_id):
+        """All edge tangents of a sub-entity of dimension >= 1: vertex differences v_dest - v_source over the
+        vertex pairs source < dest (FIAT/reference_element.py:511-524)."""
+        vs = numpy.asarray(self.get_vertices_of_subcomplex(self.topology[dim][entity_id]))
+        pairs = [(a, b) for a in range(dim) for b in range(a + 1, dim + 1)]
+        return numpy.array([vs[b] - vs[a] for a, b in pairs])
+
     def compute_edge_tangent(self, edge_i):
         return self.compute_tangents(1, edge_i)[0]
 

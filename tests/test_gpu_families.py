@@ -38,6 +38,14 @@ MORE = [("rtpt", _pt("RaviartThomas"), 2, 1), ("rtpt", _pt("RaviartThomas"), 2, 
         ("bubble", lambda fa, c, k: fa.Bubble(c, k), 3, 4), ("facetbubble", lambda fa, c, k: fa.FacetBubble(c, k), 2, 2),
         ("facetbubble", lambda fa, c, k: fa.FacetBubble(c, k), 2, 3), ("facetbubble", lambda fa, c, k: fa.FacetBubble(c, k), 3, 3),
         ("bdfm", lambda fa, c, k: fa.BrezziDouglasFortinMarini(c, k), 2, 2), ("bdfm", lambda fa, c, k: fa.BrezziDouglasFortinMarini(c, k), 3, 2),
+        ("regge", lambda fa, c, k: fa.Regge(c, k), 2, 0), ("regge", lambda fa, c, k: fa.Regge(c, k), 2, 1),
+        ("regge", lambda fa, c, k: fa.Regge(c, k), 2, 2), ("regge", lambda fa, c, k: fa.Regge(c, k), 3, 0),
+        ("regge", lambda fa, c, k: fa.Regge(c, k), 3, 1), ("reggept", lambda fa, c, k: fa.Regge(c, k, variant="point"), 2, 1),
+        ("reggept", lambda fa, c, k: fa.Regge(c, k, variant="point"), 3, 1),
+        ("hhj", lambda fa, c, k: fa.HellanHerrmannJohnson(c, k), 2, 0), ("hhj", lambda fa, c, k: fa.HellanHerrmannJohnson(c, k), 2, 1),
+        ("hhj", lambda fa, c, k: fa.HellanHerrmannJohnson(c, k), 2, 2), ("hhj", lambda fa, c, k: fa.HellanHerrmannJohnson(c, k), 3, 0),
+        ("hhj", lambda fa, c, k: fa.HellanHerrmannJohnson(c, k), 3, 1),
+        ("hhjpt", lambda fa, c, k: fa.HellanHerrmannJohnson(c, k, variant="point"), 3, 1),
         ("lagfacet", lambda fa, c, k: fa.RestrictedElement(fa.Lagrange(c, k), restriction_domain="facet"), 2, 3),
         ("lagedge", lambda fa, c, k: fa.RestrictedElement(fa.Lagrange(c, k), restriction_domain="edge", take_closure=False), 3, 3)]
 
@@ -137,7 +145,8 @@ def test_large_vandermonde_systems_nodality(cls, degree):
 @pytest.mark.parametrize("name,make,sd,k", MORE, ids=[f"{m[0]}{m[3]}_sd{m[2]}" for m in MORE])
 def test_point_variants_and_restricted_elements(golden, name, make, sd, k):
     """Point variants of RT / Nedelec / BDM / N2curl (normal and tangential point evaluations,
-    FIAT/functional.py:499-614), discontinuous RT, bubbles, BDFM and RestrictedElement against the reference."""
+    FIAT/functional.py:499-614), discontinuous RT, bubbles, BDFM, RestrictedElement and the symmetric-matrix-valued
+    Regge / Hellan-Herrmann-Johnson elements against the reference."""
     import fiat_amd
     g = golden("families")
     key = f"{name}{k}_sd{sd}"
