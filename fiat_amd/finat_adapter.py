@@ -136,6 +136,64 @@ class FiatElement:
                 result[alpha] = Table(fiat_table.reshape(index_shape + value_shape + ps.extents), POINTWISE)
         return result
 
+    @property
+    def dual_basis(self):
+        """(Q, PointSet): the dual basis as a weight tensor over the unique evaluation points,
+        ``dof_i(f) = sum_{k, cmp} Q[i, k, *cmp] f(x_k)[cmp]`` (finat/fiat_elements.py:162-258 without GEM:
+        Q is the dense array that would become the GEM literal; ``Q_is_identity`` tells when FInAT would
+        express it symbolically as a Kronecker delta).  Point order as in the reference: sorted points of
+        each functional in order of first appearance, duplicates (atol 1e-12) merged."""
+        if getattr(self, "_dual_cache", None) is None:
+            nodes = self._element.dual_basis()[:self.space_dimension()]
+            seen, allpts = {}, []
+            for dual in nodes:
+                if len(dual.deriv_dict) != 0:
+                    raise NotImplementedError("FIAT dual bases with derivative nodes represented via a ``Functional.deriv_dict`` "
+                                              "property do not currently have a FInAT dual basis")
+                pts = tuple(sorted(dual.get_point_dict().keys()))
+                if pts not in seen:
+                    seen[pts] = (len(allpts), len(allpts) + len(pts))
+                    allpts.extend(pts)
+            unique, index = [], []
+            for p in allpts:
+                for j in reversed(range(len(unique))):
+                    if numpy.allclose(unique[j], p, atol=1e-12):
+                        index.append(j)
+                        break
+                else:
+                    index.append(len(unique))
+                    unique.append(p)
+            entries = {}
+            for i, dual in enumerate(nodes):
+                point_dict = dual.get_point_dict()
+                pts = tuple(sorted(point_dict.keys()))
+                k0, k1 = seen[pts]
+                for p, k in zip(pts, index[k0:k1]):
+                    for weight, cmp in point_dict[p]:
+                        entries[(i, k, *cmp)] = weight
+            shape = tuple(m + 1 for m in map(max, zip(*entries)))
+            Q = numpy.zeros(shape)
+            for idx, value in entries.items():
+                Q[idx] = value
+            self.Q_is_identity = all(len(key) == 2 and len(set(key)) == 1 and numpy.isclose(w, 1) for key, w in entries.items())
+            self._dual_cache = (Q, PointSet(numpy.asarray(unique)))
+        return self._dual_cache
+
+    def dual_evaluation_batch(self, values, stream=None):
+        """Degrees of freedom of a batch of functions given by their values at the dual basis' points:
+        ``values`` (ncell, npts, *value_shape) -> device tensor (ncell, ndof), ``dofs = Q : values`` on the
+        device (fx_riesz_assemble); interpolation into the element's space when ``values`` are function
+        values at ``dual_basis[1].points``."""
+        import torch
+        Q, ps = self.dual_basis
+        ctx = runtime.Context.get()
+        values = runtime._as_device(values, ctx)
+        ncell = values.shape[0]
+        if tuple(values.shape[1:]) != tuple(Q.shape[1:]):
+            raise ValueError(f"values must have shape (ncell, {', '.join(map(str, Q.shape[1:]))})")
+        Qd = torch.as_tensor(Q.reshape(Q.shape[0], -1)).to(ctx.device)
+        return runtime.riesz_assemble(values.reshape(ncell, -1), Qd, ctx)
+
     def basis_evaluation_batch(self, order, points, verts=None, pushforward=False, check=True, stream=None):
         """Batched ``basis_evaluation``: ``points`` (nreq, npts, sd) [+ per-request cells ``verts``]
         -> {alpha: Table} whose arrays are views of ONE device tensor (nreq, ntab, ndof, *value_shape, npts)

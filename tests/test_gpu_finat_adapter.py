@@ -169,3 +169,39 @@ def test_tensor_product_factor_tables(fa):
             arrs.append(a)
         prod = np.einsum("ai,bj,ck->abcijk", *arrs).reshape(24, -1)
         np.testing.assert_allclose(prod, full[Delta], rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("family,sd,degree", [("Lagrange", 2, 2), ("Lagrange", 3, 3), ("DiscontinuousLagrange", 3, 2),
+                                              ("RaviartThomas", 2, 2), ("Nedelec", 3, 2), ("BrezziDouglasMarini", 3, 1),
+                                              ("Regge", 2, 1)])
+def test_dual_basis_weights(fa, family, sd, degree):
+    """finat/fiat_elements.py:162-258: Q and the unique points.  Independent check: the dofs of the basis
+    functions are the identity, sum_{k, cmp} Q[i, k, cmp] phi_j(x_k)[cmp] = delta_ij, and interpolating a
+    member of the space on the device returns its coefficients."""
+    fiat_amd, ad = fa
+    el = getattr(fiat_amd, family)(fiat_amd.ufc_simplex(sd), degree)
+    fe = ad.FiatElement(el)
+    Q, ps = fe.dual_basis
+    ndof = el.space_dimension()
+    assert Q.shape[0] == ndof and Q.shape[1] == len(ps.points) and Q.shape[2:] == tuple(el.value_shape())
+    assert len({tuple(np.round(p, 12)) for p in ps.points}) == len(ps.points)   # unique
+    phi = el.tabulate(0, ps.points)[(0,) * sd]                                    # (ndof, *shape, npts)
+    phi_k = np.moveaxis(phi, -1, 1)                                               # (ndof, npts, *shape)
+    dofs = np.tensordot(Q.reshape(ndof, -1), phi_k.reshape(ndof, -1), axes=(1, 1))
+    np.testing.assert_allclose(dofs, np.eye(ndof), rtol=0, atol=1e-11)
+    assert fe.Q_is_identity == (family in ("Lagrange", "DiscontinuousLagrange"))
+    # interpolation of random members of the space, a batch of "cells", on the device
+    rng = np.random.default_rng(0)
+    coef = rng.standard_normal((5, ndof))
+    values = np.tensordot(coef, phi_k, axes=(1, 0))                               # (5, npts, *shape)
+    got = fe.dual_evaluation_batch(values).cpu().numpy()
+    np.testing.assert_allclose(got, coef, rtol=0, atol=1e-10)
+    with pytest.raises(ValueError):
+        fe.dual_evaluation_batch(values[:, :-1])
+
+
+def test_dual_basis_rejects_derivative_nodes(fa):
+    fiat_amd, ad = fa
+    fe = ad.FiatElement(fiat_amd.CubicHermite(fiat_amd.ufc_simplex(2)))
+    with pytest.raises(NotImplementedError):
+        fe.dual_basis
