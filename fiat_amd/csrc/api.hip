@@ -1035,7 +1035,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             for (size_t i = 0; i < sizeof(kCoopShapes) / sizeof(kCoopShapes[0]); ++i) {
                 const CoopShape& c = kCoopShapes[i];
                 if (c.sd != e->sd || c.order != order || c.mt16 != mt16 || c.m4 != m4 || nt_need > 4 * c.tpw) continue;
-                const bool piola = c.can_piola && mapping != FX_MAP_AFFINE && verts && e->vdim == e->sd;
+                const bool piola = c.can_piola && (mapping == FX_MAP_COVARIANT_PIOLA || mapping == FX_MAP_CONTRAVARIANT_PIOLA) && verts && e->vdim == e->sd;
                 if (c.piola_only && !piola) continue;
                 const int table = rows * npts;
                 // tables per output round: as many as LDS holds next to the A fragments and the chain
@@ -1102,7 +1102,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             // (half-image shapes keep the tables of each half in their own tiles: one spare tile is fine)
             const bool nt_ok = f.nt == nt_need || (!f.fullimg && f.nt == nt_need + 1);
             if (f.sd != e->sd || f.n != e->n || f.order != order || f.rows != rows || !nt_ok) continue;
-            const bool want_piola = mapping != FX_MAP_AFFINE;
+            const bool want_piola = mapping == FX_MAP_COVARIANT_PIOLA || mapping == FX_MAP_CONTRAVARIANT_PIOLA;
             const bool fuse_here = want_piola && f.can_piola && verts && e->vdim == e->sd;
             if (L.fused_mapping && !fuse_here) continue;  // the cooperative kernel fuses the map, this one cannot
             bool ok = false;
@@ -1438,10 +1438,14 @@ int fx_tabulate_batch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq,
 
 int fx_tabulate_batch_mapped(fx_ctx* ctx, const fx_element* e, int mapping, int order, int64_t nreq, int npts,
                              const double* pts, const double* verts, double* out, void* stream) {
-    if (mapping < FX_MAP_AFFINE || mapping > FX_MAP_CONTRAVARIANT_PIOLA) return fail(FX_EINVAL, "unknown mapping %d", mapping);
+    if (mapping < FX_MAP_AFFINE || mapping > FX_MAP_DOUBLE_CONTRAVARIANT_PIOLA) return fail(FX_EINVAL, "unknown mapping %d", mapping);
     if (mapping == FX_MAP_AFFINE) return fx_tabulate_batch(ctx, e, order, nreq, npts, pts, verts, out, stream);
     if (!e) return fail(FX_EINVAL, "null context/element");
-    if (e->vdim != e->sd || e->sd < 2)
+    if (mapping >= FX_MAP_DOUBLE_COVARIANT_PIOLA) {
+        if (e->vdim != e->sd * e->sd || e->sd < 2)
+            return fail(FX_EINVAL, "double Piola maps need matrix-valued functions with value shape (%d, %d), got %d components",
+                        e->sd, e->sd, e->vdim);
+    } else if (e->vdim != e->sd || e->sd < 2)
         return fail(FX_EINVAL, "Piola maps need vector-valued functions with value shape (%d,), got %d components", e->sd, e->vdim);
     if (!verts && nreq > 0 && npts > 0) return fail(FX_EINVAL, "a Piola push-forward needs the physical cells (verts)");
     Launch L;
@@ -1455,12 +1459,16 @@ int fx_tabulate_batch_mapped(fx_ctx* ctx, const fx_element* e, int mapping, int 
 int fx_pushforward_batch(fx_ctx* ctx, const fx_element* e, int mapping, int order, int64_t nreq, int npts,
                          const double* verts, double* out, void* stream) {
     if (!ctx || !e) return fail(FX_EINVAL, "null context/element");
-    if (mapping < FX_MAP_AFFINE || mapping > FX_MAP_CONTRAVARIANT_PIOLA) return fail(FX_EINVAL, "unknown mapping %d", mapping);
+    if (mapping < FX_MAP_AFFINE || mapping > FX_MAP_DOUBLE_CONTRAVARIANT_PIOLA) return fail(FX_EINVAL, "unknown mapping %d", mapping);
     if (order < 0) return fail(FX_EINVAL, "negative derivative order");
     if (order > 2) return fail(FX_ENOTIMPL, "derivative order %d > 2 is not implemented on the device", order);
     if (nreq < 0 || npts < 0) return fail(FX_EINVAL, "negative batch size");
     if (mapping == FX_MAP_AFFINE || nreq == 0 || npts == 0) return FX_OK;  // derivatives are w.r.t. physical x already
-    if (e->vdim != e->sd || e->sd < 2)
+    if (mapping >= FX_MAP_DOUBLE_COVARIANT_PIOLA) {
+        if (e->vdim != e->sd * e->sd || e->sd < 2)
+            return fail(FX_EINVAL, "double Piola maps need matrix-valued functions with value shape (%d, %d), got %d components",
+                        e->sd, e->sd, e->vdim);
+    } else if (e->vdim != e->sd || e->sd < 2)
         return fail(FX_EINVAL, "Piola maps need vector-valued functions with value shape (%d,), got %d components", e->sd, e->vdim);
     if (!verts || !out) return fail(FX_EINVAL, "null device pointer");
     fxk::PiolaArgs pa;

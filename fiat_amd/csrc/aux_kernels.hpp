@@ -416,7 +416,7 @@ struct PiolaArgs {
     const double* verts;  // [nreq][SD+1][SD]
     double* out;          // [nreq][ntab][ndof][SD][npts]
     double G[9];
-    int ntab, ndof, npts, kind;  // kind 1 covariant, 2 contravariant
+    int ntab, ndof, npts, kind;  // kind 1 covariant, 2 contravariant; 3 / 4: the double maps of matrix-valued functions
 };
 
 template <int SD> __global__ __launch_bounds__(256) void piola_apply_kernel(const PiolaArgs a) {
@@ -456,7 +456,7 @@ template <int SD> __global__ __launch_bounds__(256) void piola_apply_kernel(cons
             inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
         }
         for (int r = 0; r < SD; ++r)
-            for (int c = 0; c < SD; ++c) M[r * SD + c] = a.kind == 1 ? inv[c][r] : J[r][c] / det;
+            for (int c = 0; c < SD; ++c) M[r * SD + c] = (a.kind == 1 || a.kind == 3) ? inv[c][r] : J[r][c] / det;
     }
     __syncthreads();
     double m[SD][SD];
@@ -465,6 +465,39 @@ template <int SD> __global__ __launch_bounds__(256) void piola_apply_kernel(cons
 #pragma unroll
         for (int c = 0; c < SD; ++c) m[r][c] = M[r * SD + c];
     const int groups = a.ntab * a.ndof;  // (table, dof) pairs: SD rows of npts each
+    if (a.kind >= 3) {
+        // matrix-valued functions (value shape (SD, SD), row-major: SD*SD rows per dof): M Phi M^T with the same M
+        // -- double covariant J^-T Phi J^-1, double contravariant J Phi J^T / det^2 (Regge, Hellan-Herrmann-Johnson)
+        double* o2 = a.out + req * (size_t)groups * SD * SD * a.npts;
+        for (int e = threadIdx.x; e < groups * a.npts; e += blockDim.x) {
+            const int g = e / a.npts, p = e - g * a.npts;
+            double* q = o2 + (size_t)g * SD * SD * a.npts + p;
+            double X[SD][SD], T[SD][SD];
+#pragma unroll
+            for (int i = 0; i < SD; ++i)
+#pragma unroll
+                for (int j = 0; j < SD; ++j) X[i][j] = q[(i * SD + j) * a.npts];
+#pragma unroll
+            for (int i = 0; i < SD; ++i)
+#pragma unroll
+                for (int j = 0; j < SD; ++j) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < SD; ++k) t += m[i][k] * X[k][j];
+                    T[i][j] = t;
+                }
+#pragma unroll
+            for (int i = 0; i < SD; ++i)
+#pragma unroll
+                for (int j = 0; j < SD; ++j) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < SD; ++k) t += T[i][k] * m[j][k];
+                    q[(i * SD + j) * a.npts] = t;
+                }
+        }
+        return;
+    }
     double* o = a.out + req * (size_t)groups * SD * a.npts;
     for (int e = threadIdx.x; e < groups * a.npts; e += blockDim.x) {
         const int g = e / a.npts, p = e - g * a.npts;

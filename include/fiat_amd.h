@@ -167,6 +167,11 @@ int fx_plan_coop(int sd, int n, int variant, double scale, int cap, int* KS, int
 #define FX_MAP_AFFINE 0
 #define FX_MAP_COVARIANT_PIOLA 1
 #define FX_MAP_CONTRAVARIANT_PIOLA 2
+/* matrix-valued elements, value shape (sd, sd) (fx_pushforward_batch / fx_tabulate_batch_mapped only):
+ *   FX_MAP_DOUBLE_COVARIANT_PIOLA      phi = J^{-T} Phi J^{-1}        (Regge)
+ *   FX_MAP_DOUBLE_CONTRAVARIANT_PIOLA  phi = J Phi J^T / (det J)^2    (Hellan-Herrmann-Johnson) */
+#define FX_MAP_DOUBLE_COVARIANT_PIOLA 3
+#define FX_MAP_DOUBLE_CONTRAVARIANT_PIOLA 4
 int fx_pushforward_batch(fx_ctx* ctx, const fx_element* elem, int mapping, int order,
                          int64_t nreq, int npts, const double* verts, double* out, void* stream);
 /* fx_tabulate_batch followed by the push-forward `mapping`, in ONE kernel where the shape's kernel

@@ -63,6 +63,29 @@ def main():
             out[key + "_entity_dofs"] = np.array(json.dumps({str(d): {str(i): v for i, v in ents.items()}
                                                              for d, ents in el.entity_dofs().items()}))
             out[key + "_mapping"] = np.array(el.mapping()[0])
+    # matrix-valued elements built DIRECTLY on physical cells (double Piola push-forward check)
+    from FIAT import reference_element
+    for sd in (2, 3):
+        base = ufc_simplex(sd)
+        ref = np.array(base.get_vertices(), dtype=float)
+        ncell = 3
+        A = np.eye(sd) + 0.3 * rng.standard_normal((ncell, sd, sd))
+        for i in range(ncell):
+            if np.linalg.det(A[i]) < 0:
+                A[i, :, 0] *= -1
+        A[ncell - 1, :, 0] *= -1                    # one negatively oriented cell
+        verts = np.einsum("vd,red->rve", ref, A) + rng.standard_normal((ncell, 1, sd))
+        e = rng.exponential(size=(ncell, 5, sd + 1))
+        pts = np.einsum("rpv,rvd->rpd", e / e.sum(axis=-1, keepdims=True), verts)
+        out[f"phys_verts_sd{sd}"] = verts
+        out[f"phys_pts_sd{sd}"] = pts
+        for name, cls in (("regge", Regge), ("hhj", HellanHerrmannJohnson)):
+            tabs = []
+            for i in range(ncell):
+                cell = reference_element.UFCSimplex(base.get_shape(), tuple(map(tuple, verts[i])), base.get_topology())
+                tab = cls(cell, 1).tabulate(1, pts[i])
+                tabs.append(np.stack([np.asarray(tab[a]) for j in range(2) for a in mis(sd, j)]))
+            out[f"{name}1_phys_sd{sd}_tab"] = np.stack(tabs)
     np.savez_compressed(os.path.join(HERE, "families.npz"), **out)
     print("wrote families.npz:", {k: v.shape for k, v in out.items()})
 

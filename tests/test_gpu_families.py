@@ -177,3 +177,27 @@ def test_restricted_element_errors():
     assert el.get_dual_set().get_indices("vertex") == [0, 1, 2]
     assert el.get_dual_set().get_indices("interior") == []
     assert el.get_dual_set().get_indices("edge", take_closure=False) == [3, 4, 5]
+
+
+@pytest.mark.parametrize("name,cls", [("regge", "Regge"), ("hhj", "HellanHerrmannJohnson")])
+@pytest.mark.parametrize("sd", [2, 3])
+def test_double_piola_pushforward(golden, name, cls, sd):
+    """Matrix-valued elements pushed forward to physical cells (double covariant J^-T Phi J^-1 for Regge, double
+    contravariant J Phi J^T / det^2 for HHJ; fx_pushforward_batch kinds 3 / 4) equal the reference's elements
+    built directly on those cells (one of them negatively oriented)."""
+    import fiat_amd
+    g = golden("families")
+    verts, pts = g[f"phys_verts_sd{sd}"], g[f"phys_pts_sd{sd}"]
+    el = getattr(fiat_amd, cls)(fiat_amd.ufc_simplex(sd), 1)
+    assert el.mapping()[0] == ("double covariant piola" if name == "regge" else "double contravariant piola")
+    out = el.tabulate_batch(1, pts, verts=verts, pushforward=True).cpu().numpy()
+    want = g[f"{name}1_phys_sd{sd}_tab"]
+    assert out.shape == want.shape
+    for t in range(want.shape[1]):
+        assert rel(out[:, t], want[:, t]) <= (1e-11 if t == 0 else 1e-10), (t, rel(out[:, t], want[:, t]))
+    # errors: a vector-valued element cannot take a double map and vice versa
+    rt = fiat_amd.RaviartThomas(fiat_amd.ufc_simplex(sd), 1).device_polyset()
+    with pytest.raises(ValueError):
+        rt.tabulate_batch(0, pts, verts=verts, mapping="double covariant piola")
+    with pytest.raises(ValueError):
+        el.device_polyset().tabulate_batch(0, pts, verts=verts, mapping="covariant piola")
