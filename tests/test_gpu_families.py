@@ -102,12 +102,13 @@ def test_family_errors():
         fiat_amd.Morley(fiat_amd.ufc_simplex(1))
 
 
-def test_pushforward_of_the_new_families(golden):
+@pytest.mark.parametrize("npts", [9, 23])
+def test_pushforward_of_the_new_families(golden, npts):
     """BDM / N2curl with their Piola maps on physical cells: fused or second-pass result == formula on
     the reference tables (the maps themselves are pinned in test_gpu_pushforward.py)."""
     import fiat_amd
     rng = np.random.default_rng(3)
-    sd, nreq, npts = 3, 40, 9
+    sd, nreq = 3, 40   # (23 points: stacked-matrix kernel + table-mixing pass + Piola pass)
     ref = np.array(fiat_amd.ufc_simplex(sd).get_vertices(), dtype=float)
     A = np.eye(sd) + 0.15 * rng.standard_normal((nreq, sd, sd))
     verts = np.einsum("vd,red->rve", ref, A) + rng.standard_normal((nreq, 1, sd))
@@ -115,8 +116,8 @@ def test_pushforward_of_the_new_families(golden):
     bary = e / e.sum(axis=-1, keepdims=True)
     pts = np.einsum("rpv,rvd->rpd", bary, verts)
     ref_pts = np.einsum("rpv,vd->rpd", bary, ref)
-    for cls in (fiat_amd.BrezziDouglasMarini, fiat_amd.NedelecSecondKind):
-        el = cls(fiat_amd.ufc_simplex(sd), 2)
+    for cls, deg in ((fiat_amd.BrezziDouglasMarini, 2), (fiat_amd.NedelecSecondKind, 2), (fiat_amd.Nedelec, 3)):
+        el = cls(fiat_amd.ufc_simplex(sd), deg)
         got = el.tabulate_batch(1, pts, verts=verts, pushforward=True).cpu().numpy()
         raw = el.tabulate_batch(1, ref_pts).cpu().numpy()  # reference cell: (nreq, 4, ndof, sd, npts)
         for i in (0, 17, 39):
