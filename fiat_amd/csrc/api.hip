@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -168,6 +169,7 @@ struct fx_element {
     // [C; C D^alpha ...] per derivative order (built at first use, ensure_stacked)
     std::vector<double> hC;
     double* d_astack[3] = {nullptr, nullptr, nullptr};
+    double* d_astack_dm = nullptr;   // order 1, dof-major tiles (tables of 16 dofs consecutive, each table padded): MIXT instances
     int stack_state[3] = {0, 0, 0};  // 0 not built, 1 built, -1 failed
     bool raw_expansion = false;      // internal helper element (identity coefficients): never takes the stacked path
 };
@@ -323,6 +325,8 @@ static int upload_coeffs(fx_element* e, int ndof, int vdim, const double* coeffs
         e->d_astack[o] = nullptr;
         e->stack_state[o] = 0;
     }
+    if (e->d_astack_dm) (void)hipFree(e->d_astack_dm);
+    e->d_astack_dm = nullptr;
     if (e->d_cmat) {
         HIP_TRY(hipFree(e->d_cmat));
         e->d_cmat = nullptr;
@@ -475,6 +479,7 @@ int fx_element_destroy(fx_element* e) {
     if (e->d_afrag_coop) (void)hipFree(e->d_afrag_coop);
     for (int o = 0; o < 3; ++o)
         if (e->d_astack[o]) (void)hipFree(e->d_astack[o]);
+    if (e->d_astack_dm) (void)hipFree(e->d_astack_dm);
     delete e;
     return FX_OK;
 }
@@ -682,13 +687,17 @@ int launch_fixed(const Launch& L, hipStream_t s) {
 struct StackedShape {
     int sd, n, ct, g;
     int rtc;  // > 0: instance for exactly rtc row tiles with register-resident A fragments (small shapes); 0: any
-              // < 0: point-chunked instance (a unit = 16 ct points of one request): any number of points >= 13, odd
+              // -2: per-request cells, order 1 on tetrahedra: dof-major tiles, chain rule across the tables in registers
+              // -1: point-chunked instance (a unit = 16 ct points of one request): any number of points >= 13, odd
               //      table sizes too -- taken when no whole-request instance applies
 };
 const StackedShape kStackedShapes[] = {
     {3, 3, 3, 2, 5},  // Lagrange P3 tetrahedron, values + gradient (80 stacked rows): the benchmark shape C2, 17..24 points
     {3, 3, 2, 1, 5},  // ... 25..32 points
     {3, 3, 3, 1, 5},  // ... 33..48 points
+    // (rtc -2 instances -- chain rule across the tables in registers, simplex_stacked.hpp MIXT -- are NOT registered:
+    //  the two-requests-per-group instance faulted under a 28 730-request load on the GPU (cause not yet found);
+    //  per-request cells go through the whole-request instances + table_mix_kernel)
     {3, 6, 3, 2, 0},  // degree-6 tetrahedron (DG P6 with Hessians: C4), 17..24 points
     {3, 6, 2, 1, 0},  // ... 25..32 points
     {3, 6, 3, 1, 0},  // ... 33..48 points
@@ -707,7 +716,8 @@ const StackedShape kStackedShapes[] = {
     {2, 5, 3, 2, 0},
     {2, 5, 2, 1, 0},
     {2, 5, 3, 1, 0},
-    {3, 6, 3, 3, 0}, {3, 6, 4, 1, 0},  // 13..16 and 49..64 points
+    {3, 6, 3, 3, 0},                   // 13..16 points ((3, 6, 4, 1) would spill 62 registers: 49..64 points are point-chunked)
+    // 13..16 and 49..64 points
     {3, 5, 3, 3, 0}, {3, 5, 4, 1, 0},
     {3, 4, 3, 3, 0}, {3, 4, 4, 1, 0},
     {3, 3, 3, 3, 0}, {3, 3, 4, 1, 0},
@@ -718,7 +728,7 @@ const StackedShape kStackedShapes[] = {
 };
 constexpr int STACKED_NW = 4;  // one wave per SIMD
 
-template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false>
+template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0>
 int launch_stacked(const Launch& L, hipStream_t s) {
     constexpr int NC = fxk::FixedNC<SD, N>::value;
     fxk::StackedArgs<NC> ka;
@@ -729,6 +739,7 @@ int launch_stacked(const Launch& L, hipStream_t s) {
     ka.phi0 = L.khead.phi0;
     memcpy(ka.A0, L.khead.A0, sizeof ka.A0);
     memcpy(ka.b0, L.khead.b0, sizeof ka.b0);
+    memcpy(ka.A0inv, L.khead.A0inv, sizeof ka.A0inv);
     ka.nreq = L.khead.nreq;
     ka.npts = L.khead.npts;
     ka.R = L.khead.R;
@@ -736,7 +747,7 @@ int launch_stacked(const Launch& L, hipStream_t s) {
     ka.debug = L.khead.debug;
     if ((int)L.fcoef.size() != NC) return fail(FX_EINVAL, "internal: coefficient table size mismatch");
     memcpy(ka.coef, L.fcoef.data(), NC * sizeof(double));
-    auto kern = fxk::tabulate_simplex_stacked<SD, N, CT, G, RTC, WPS, CHUNK>;
+    auto kern = fxk::tabulate_simplex_stacked<SD, N, CT, G, RTC, WPS, CHUNK, MIXT>;
     // as many workgroups per CU as registers and LDS allow (low degrees need few registers: their short
     // row sweeps rely on other waves to cover the production phase); asked once per kernel
     static thread_local int occ = 0;
@@ -758,7 +769,7 @@ int launch_stacked(const Launch& L, hipStream_t s) {
 #if defined(FX_DBG) && (FX_DBG & 512)
     if (getenv("FIAT_AMD_VERBOSE")) HIP_TRY(report_wave_lifetimes(L.trash, grid, STACKED_NW));
 #endif
-    if (L.khead.verts && L.kmix_order >= 1) {  // chain rule across the derivative tables, in place
+    if (L.khead.verts && L.kmix_order >= 1 && MIXT == 0) {  // chain rule across the derivative tables, in place
         fxk::TableMixArgs ma;
         ma.out = L.khead.out;
         ma.verts = L.khead.verts;
@@ -798,29 +809,28 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 19: return launch_stacked<2, 5, 2, 1>(L, s);
         case 20: return launch_stacked<2, 5, 3, 1>(L, s);
         case 21: return launch_stacked<3, 6, 3, 3>(L, s);
-        case 22: return launch_stacked<3, 6, 4, 1>(L, s);
-        case 23: return launch_stacked<3, 5, 3, 3>(L, s);
-        case 24: return launch_stacked<3, 5, 4, 1>(L, s);
-        case 25: return launch_stacked<3, 4, 3, 3>(L, s);
-        case 26: return launch_stacked<3, 4, 4, 1>(L, s);
-        case 27: return launch_stacked<3, 3, 3, 3>(L, s);
-        case 28: return launch_stacked<3, 3, 4, 1>(L, s);
-        case 29: return launch_stacked<2, 6, 3, 3>(L, s);
-        case 30: return launch_stacked<2, 6, 4, 1>(L, s);
-        case 31: return launch_stacked<2, 5, 3, 3>(L, s);
-        case 32: return launch_stacked<2, 5, 4, 1>(L, s);
-        case 33: return launch_stacked<3, 2, 3, 2>(L, s);
-        case 34: return launch_stacked<3, 2, 2, 1>(L, s);
-        case 35: return launch_stacked<3, 2, 3, 1>(L, s);
-        case 36: return launch_stacked<3, 2, 3, 3>(L, s);
-        case 37: return launch_stacked<3, 2, 4, 1>(L, s);
-        case 38: return launch_stacked<3, 6, 3, 1, 0, 1, true>(L, s);
-        case 39: return launch_stacked<3, 5, 3, 1, 0, 1, true>(L, s);
-        case 40: return launch_stacked<3, 4, 3, 1, 0, 1, true>(L, s);
-        case 41: return launch_stacked<3, 3, 3, 1, 0, 1, true>(L, s);
-        case 42: return launch_stacked<3, 2, 3, 1, 0, 1, true>(L, s);
-        case 43: return launch_stacked<2, 6, 3, 1, 0, 1, true>(L, s);
-        case 44: return launch_stacked<2, 5, 3, 1, 0, 1, true>(L, s);
+        case 22: return launch_stacked<3, 5, 3, 3>(L, s);
+        case 23: return launch_stacked<3, 5, 4, 1>(L, s);
+        case 24: return launch_stacked<3, 4, 3, 3>(L, s);
+        case 25: return launch_stacked<3, 4, 4, 1>(L, s);
+        case 26: return launch_stacked<3, 3, 3, 3>(L, s);
+        case 27: return launch_stacked<3, 3, 4, 1>(L, s);
+        case 28: return launch_stacked<2, 6, 3, 3>(L, s);
+        case 29: return launch_stacked<2, 6, 4, 1>(L, s);
+        case 30: return launch_stacked<2, 5, 3, 3>(L, s);
+        case 31: return launch_stacked<2, 5, 4, 1>(L, s);
+        case 32: return launch_stacked<3, 2, 3, 2>(L, s);
+        case 33: return launch_stacked<3, 2, 2, 1>(L, s);
+        case 34: return launch_stacked<3, 2, 3, 1>(L, s);
+        case 35: return launch_stacked<3, 2, 3, 3>(L, s);
+        case 36: return launch_stacked<3, 2, 4, 1>(L, s);
+        case 37: return launch_stacked<3, 6, 3, 1, 0, 1, true>(L, s);
+        case 38: return launch_stacked<3, 5, 3, 1, 0, 1, true>(L, s);
+        case 39: return launch_stacked<3, 4, 3, 1, 0, 1, true>(L, s);
+        case 40: return launch_stacked<3, 3, 3, 1, 0, 1, true>(L, s);
+        case 41: return launch_stacked<3, 2, 3, 1, 0, 1, true>(L, s);
+        case 42: return launch_stacked<2, 6, 3, 1, 0, 1, true>(L, s);
+        case 43: return launch_stacked<2, 5, 3, 1, 0, 1, true>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown stacked kernel %d", L.stacked_id);
 }
@@ -1269,7 +1279,13 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 // recurrence derivatives are two digits more accurate), opt-in with FIAT_AMD_STACKED_SMALL=1
                 const char* small = getenv("FIAT_AMD_STACKED_SMALL");
                 if (k.rtc > 0 ? (RT != k.rtc || verts || !(small && atoi(small))) : R < stacked_min_rows) continue;
-                if (k.rtc < 0) {  // point-chunked: whatever the whole-request instances above did not take
+                if (k.rtc == -2) {  // per-request cells, order 1: tables mixed in registers (dof-major tiles)
+                    static const bool nomix = getenv("FIAT_AMD_NO_STACKED_MIX") != nullptr;
+                    if (nomix || !verts || order != 1 || ((long long)rows * npts) % 2 || ((long long)(rows - 16 * ((rows + 15) / 16 - 1)) * npts) % 2)
+                        continue;
+                    const int cap = 16 * k.ct / k.g, lo = 16 * k.ct / (k.g + 1);
+                    if (npts > cap || npts <= lo) continue;
+                } else if (k.rtc < 0) {  // point-chunked: whatever the whole-request instances above did not take
                     if (npts < 13 || nreq * (long long)((npts + 16 * k.ct - 1) / (16 * k.ct)) > 0x7fffffffLL) continue;
                 } else {
                     if (!even) continue;  // (16-byte stores of whole request chunks)
@@ -1300,7 +1316,8 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 ka.pts = pts;
                 ka.verts = verts;
                 ka.out = out;
-                ka.afrag = e->d_astack[order];
+                ka.afrag = k.rtc == -2 ? e->d_astack_dm : e->d_astack[order];
+                if (k.rtc == -2 && !invert_small(e->sd, e->A0, ka.A0inv)) continue;
                 ka.phi0 = e->prog.phi0;
                 memcpy(ka.A0, e->A0, sizeof ka.A0);
                 memcpy(ka.b0, e->b0, sizeof ka.b0);
@@ -1309,9 +1326,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 ka.R = (int)R;
                 ka.RT = RT;
                 ka.debug = a.debug;
-                L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * fxk::stacked_image_doubles(k.ct, (e->nexp + 3) / 4)) * 8;
+                L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * fxk::stacked_image_doubles(k.ct, (e->nexp + 3) / 4, k.rtc == -2 ? e->sd + 1 : 1)) * 8;
                 if (L.klds_bytes > ctx->lds_per_cu) continue;
-                const long long groups = k.rtc < 0 ? nreq * ((npts + 16 * k.ct - 1) / (16 * k.ct)) : (nreq + k.g - 1) / k.g;
+                const long long groups = k.rtc == -1 ? nreq * ((npts + 16 * k.ct - 1) / (16 * k.ct)) : (nreq + k.g - 1) / k.g;
                 // one workgroup per CU = one wave per SIMD (measured: a second wave per SIMD at half the registers
                 // spills in the production phase and gains nothing, 1.45 -> 1.48 ms: the kernel is bound by the
                 // shared fp64 MFMA/VALU pipe, not by latencies)
@@ -1937,6 +1954,9 @@ bool solve_dense(int n, std::vector<double> M, int nrhs, std::vector<double>& B)
 // with the mass matrix M = sum w phi phi^T and R_alpha = sum w (d^alpha phi) phi^T.
 int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
     if (order < 0 || order > 2) return FX_OK;
+    // built lazily from plan_launch, which may run on several host threads for the same element
+    static std::mutex build_mutex;
+    std::lock_guard<std::mutex> lock(build_mutex);
     if (e->stack_state[order] != 0) return FX_OK;
     e->stack_state[order] = -1;
     const int sd = e->sd, nexp = e->nexp;
@@ -2045,6 +2065,21 @@ int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
             }
     HIP_TRY(hipMalloc(&e->d_astack[order], F.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(e->d_astack[order], F.data(), F.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (order == 1) {  // dof-major tiles for the instances that mix the tables in registers (per-request cells)
+        const int RTd = (rows + 15) / 16;
+        std::vector<double> Fd((size_t)(RTd * ntab + 1) * KS * 64, 0.0);
+        for (int i = 0; i < RTd; ++i)
+            for (int t = 0; t < ntab; ++t)
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int r = 16 * i + (lane & 15);
+                        const int mem = member[4 * ks + (lane >> 4)];
+                        if (r < rows && mem >= 0)
+                            Fd[(((size_t)i * ntab + t) * KS + ks) * 64 + lane] = S[((size_t)t * rows + r) * nexp + mem];
+                    }
+        HIP_TRY(hipMalloc(&e->d_astack_dm, Fd.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(e->d_astack_dm, Fd.data(), Fd.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     e->stack_state[order] = 1;
     return FX_OK;
 }

@@ -20,6 +20,7 @@
 #include "simplex_stream.hpp"
 #include "store.hpp"
 #include "work_queue.hpp"
+#include <type_traits>
 
 namespace fxk {
 
@@ -34,6 +35,7 @@ template <int NC> struct StackedArgs {
     double phi0;
     double A0[9];
     double b0[3];
+    double A0inv[9];  // (MIXT instances: K = A0^-1 A_req of the chain rule)
     long long nreq;
     int npts;
     int R;   // stacked rows = ntab * rows
@@ -45,8 +47,9 @@ template <int NC> struct StackedArgs {
 // values of a group ([4 KS slots][16 CT columns]) alias it while they are produced
 // (four column tiles: the values are produced in two passes of two tiles, which halves the slab)
 constexpr int stacked_passes(int CT) { return CT > 3 ? 2 : 1; }
-constexpr int stacked_image_doubles(int CT, int KS) {
-    return (4 * KS * 16 * CT / stacked_passes(CT) > 16 * 16 * CT + 128) ? 4 * KS * 16 * CT / stacked_passes(CT) : 16 * 16 * CT + 128;
+constexpr int stacked_image_doubles(int CT, int KS, int slots = 1) {
+    return (4 * KS * 16 * CT / stacked_passes(CT) > slots * 16 * 16 * CT + 128) ? 4 * KS * 16 * CT / stacked_passes(CT)
+                                                                                : slots * 16 * 16 * CT + 128;
 }
 
 // G requests of <= (16 CT / G) points per group.  RTC > 0: the stacked matrix has exactly RTC row tiles and
@@ -56,7 +59,10 @@ constexpr int stacked_image_doubles(int CT, int KS) {
 // production phase of a group).
 // CHUNK: a unit is one request's next 16 CT points (any number of points per request, odd table sizes too):
 // the image of a row tile is [row][points of the chunk] and leaves row by row as 8-byte stores.
-template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false>
+// MIXT > 0 (= 1 + SD, per-request cells, order 1): the row tiles come dof-major -- the MIXT tables of 16 dofs one
+// after the other (each table padded to whole tiles) -- so that a wave holds values and all first derivatives of
+// those dofs at once and applies the chain rule d/dx_d = sum_c K[c][d] d/dX_c in registers before the flush.
+template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0>
 __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const StackedArgs<FixedNC<SD, N>::value> a,
                                                                    double* __restrict__ trash,
                                                                    unsigned int* __restrict__ gqueue) {
@@ -67,12 +73,14 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
     constexpr int NST = (16 * CPR / 2 + 63) / 64;   // 16-byte stores per lane and request chunk
     constexpr int PCH = 16 * CT;                    // points per chunk (CHUNK)
     static_assert(!CHUNK || (G == 1 && RTC == 0), "point-chunked units: one request per group, streamed fragments");
-    constexpr int IMG = stacked_image_doubles(CT, KS);
+    constexpr int SLOTS = MIXT > 0 ? MIXT : 1;  // row-tile images per wave
+    constexpr int IMG = stacked_image_doubles(CT, KS, SLOTS);
+    static_assert(MIXT == 0 || (MIXT == 1 + SD && MIXT % 2 == 0 && !CHUNK && RTC == 0), "table mixing: tetrahedra, order 1");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double* img = lds + WQ_CTL_DOUBLES + (size_t)wave * IMG;
-    constexpr int DUMP = 16 * 16 * CT;
+    constexpr int DUMP = SLOTS * 16 * 16 * CT;
 
     typedef const __attribute__((address_space(4))) double CDouble;
     typedef StackedArgs<FixedNC<SD, N>::value> ArgsT;
@@ -278,34 +286,34 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
         // tiles, which makes all their LDS and output offsets loop invariants)
         // D tile: element jj of lane (kk, col) is row 4 jj + kk -> image [request][row][point]
         const int estr = CHUNK ? pc : enpts;  // row stride of the image
-        auto image_put = [&](const v4d (&acc)[CT], int w, int nrows) {  // w-th of the 4 CT image stores
+        auto image_put = [&](const v4d (&acc)[CT], int w, int nrows, int soff = 0) {  // w-th of the 4 CT image stores
             const int c = w >> 2, jj = w & 3;
             const bool ok = eoff[c] >= 0 && 4 * jj + ekk < nrows;
-            img[ok ? eoff[c] + 4 * jj * estr : DUMP + elane] = acc[c][jj];
+            img[ok ? soff + eoff[c] + 4 * jj * estr : DUMP + elane] = acc[c][jj];
         };
         constexpr int NRD = CHUNK ? (16 * PCH + 63) / 64 : G * NST;  // image reads = output stores per row tile
         v2d fbuf[CHUNK ? 1 : NRD];
         double fbuf1[CHUNK ? NRD : 1];
         const float rpc = 1.0f / (float)pc;
-        auto image_get = [&](int r, int nrows) {  // r-th image read
+        auto image_get = [&](int r, int nrows, int soff = 0) {  // r-th image read
             if constexpr (CHUNK) {
                 fbuf1[r] = img[min(r * 64 + elane, nrows * pc - 1)];
             } else {
                 const int g = r / NST, it = r % NST;
                 const int nch = (nrows * enpts) >> 1;  // 16-byte pieces of a request's chunk (host: even)
-                fbuf[r] = reinterpret_cast<const v2d*>(img + g * echunk)[min(it * 64 + elane, nch - 1)];
+                fbuf[r] = reinterpret_cast<const v2d*>(img + soff + g * echunk)[min(it * 64 + elane, nch - 1)];
             }
         };
-        auto image_out = [&](int r, int rt, int nrows) {  // r-th output store of row tile rt
+        auto image_out = [&](int r, int rowbase, int nrows) {  // r-th output store of the row tile starting at row `rowbase`
             if constexpr (CHUNK) {
                 const int i = min(r * 64 + elane, nrows * pc - 1);
                 const int row = idiv_small(i, rpc);
-                double* dst = a.out + ((size_t)oreq[0] * a.R + (size_t)16 * rt + row) * enpts + p0 + (i - row * pc);
+                double* dst = a.out + ((size_t)oreq[0] * a.R + (size_t)rowbase + row) * enpts + p0 + (i - row * pc);
                 stream_store(dst, fbuf1[r]);
             } else {
                 const int g = r / NST, it = r % NST;
                 const int nch = (nrows * enpts) >> 1;
-                v2d* g2 = oreq[g] < a.nreq ? reinterpret_cast<v2d*>(a.out + ((size_t)oreq[g] * a.R + (size_t)16 * rt) * enpts)
+                v2d* g2 = oreq[g] < a.nreq ? reinterpret_cast<v2d*>(a.out + ((size_t)oreq[g] * a.R + (size_t)rowbase) * enpts)
                                            : reinterpret_cast<v2d*>(trash);
                 stream_store(&g2[min(it * 64 + elane, nch - 1)], fbuf[r]);
             }
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                     for (int r = (ks - T3) * RPK; r < (ks - T3 + 1) * RPK && r < NRD; ++r) image_get(r, 16);
                 } else {
 #pragma unroll
-                    for (int r = (ks - 2 * T3) * SPK; r < (ks - 2 * T3 + 1) * SPK && r < NRD; ++r) image_out(r, rt - 1, 16);
+                    for (int r = (ks - 2 * T3) * SPK; r < (ks - 2 * T3 + 1) * SPK && r < NRD; ++r) image_out(r, 16 * (rt - 1), 16);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -365,10 +373,125 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
 #pragma unroll
             for (int r = 0; r < NRD; ++r) image_get(r, last_rows);
 #pragma unroll
-            for (int r = 0; r < NRD; ++r) image_out(r, RTn - 1, last_rows);
+            for (int r = 0; r < NRD; ++r) image_out(r, 16 * (RTn - 1), last_rows);
             wave_lds_fence();
         };
-        if constexpr (RTC > 0) {
+        if constexpr (MIXT > 0) {
+            // ---- dof-major tiles with the chain rule across the tables applied in registers ----
+            const int rows = a.R / MIXT;                      // rows per table
+            const int RTd = (rows + 15) / 16;                 // dof tiles; tile (i, t) = table t, rows [16 i, 16 i + 16)
+            const int rows_last = rows - 16 * (RTd - 1);
+            constexpr int SLOT = 16 * 16 * CT;
+            // K = A0^-1 A_req of every request of the group, wave uniform (scalar registers); a lane picks the one of
+            // its column's request when it mixes (per-lane copies for all column tiles would cost 54 registers)
+            double Ks[G][SD][SD];
+            int gcol[CT];
+            {
+                const float rinv = 1.0f / (float)npts;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const int g = idiv_small(16 * c + (lane & 15), rinv);
+                    gcol[c] = g < G ? g : 0;
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    long long req = grp * G + g;
+                    req = req < a.nreq ? req : a.nreq - 1;
+                    double J[SD][SD], bb[SD];
+                    cell_map<SD>(a.verts + (size_t)req * (SD + 1) * SD, J, bb);
+#pragma unroll
+                    for (int i = 0; i < SD; ++i)
+#pragma unroll
+                        for (int d = 0; d < SD; ++d) {
+                            double t = 0.0;
+#pragma unroll
+                            for (int k = 0; k < SD; ++k) t += a.A0inv[i * SD + k] * J[k][d];
+                            Ks[g][i][d] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(t)),
+                                                           __builtin_amdgcn_readfirstlane(__double2loint(t)));
+                        }
+                }
+            }
+            v4d acc[MIXT][CT];
+            // one tile: MFMAs into `cur`, fragments of the next tile into `an`, and (FLUSH) slot `slot` of the previous
+            // dof tile out -- the same K-step schedule as `stage`
+            auto mix_stage = [&](v4d (&cur)[CT], int q, int slot, int prev_rowbase, const double (&af)[KS], double (&an)[KS], auto flush) {
+                const double* anp = ap + (size_t)(q + 1) * KS * 64;  // (the buffer ends with a zero tile)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) cur[c] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    mfma_steps(cur, af, ks, ks + 1);
+                    if (ks < 2 * T3) {
+#pragma unroll
+                        for (int l = ks * LPK; l < (ks + 1) * LPK && l < KS; ++l) an[l] = anp[l * 64];
+                    }
+                    if constexpr (decltype(flush)::value) {
+                        if (ks >= T3 && ks < 2 * T3) {
+#pragma unroll
+                            for (int r = (ks - T3) * RPK; r < (ks - T3 + 1) * RPK && r < NRD; ++r) image_get(r, 16, slot * SLOT);
+                        } else if (ks >= 2 * T3) {
+#pragma unroll
+                            for (int r = (ks - 2 * T3) * SPK; r < (ks - 2 * T3 + 1) * SPK && r < NRD; ++r) image_out(r, prev_rowbase, 16);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(an[ks]));
+            };
+            auto dof_tile = [&](int i, auto flush) {
+#pragma unroll
+                for (int t = 0; t < MIXT; ++t) {
+                    if (t & 1) mix_stage(acc[t], i * MIXT + t, t, t * rows + 16 * (i - 1), fa1, fa0, flush);
+                    else mix_stage(acc[t], i * MIXT + t, t, t * rows + 16 * (i - 1), fa0, fa1, flush);
+                }
+                wave_lds_fence();  // (the previous dof tile's images have been read)
+                // chain rule: lane (kk, col) holds element jj = row 4 jj + kk of every table at its column
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    double Kl[SD][SD];
+#pragma unroll
+                    for (int e = 0; e < SD; ++e)
+#pragma unroll
+                        for (int d = 0; d < SD; ++d) {
+                            double v = Ks[0][e][d];
+#pragma unroll
+                            for (int g = 1; g < G; ++g) v = gcol[c] == g ? Ks[g][e][d] : v;
+                            Kl[e][d] = v;
+                        }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        double gX[SD];
+#pragma unroll
+                        for (int e = 0; e < SD; ++e) gX[e] = acc[1 + e][c][jj];
+#pragma unroll
+                        for (int d = 0; d < SD; ++d) {
+                            double t = 0.0;
+#pragma unroll
+                            for (int e = 0; e < SD; ++e) t += Kl[e][d] * gX[e];
+                            acc[1 + d][c][jj] = t;
+                        }
+                    }
+                }
+                const int nrows = i == RTd - 1 ? rows_last : 16;
+#pragma unroll
+                for (int t = 0; t < MIXT; ++t)
+#pragma unroll
+                    for (int w = 0; w < NWR; ++w) image_put(acc[t], w, nrows, t * SLOT);
+                wave_lds_fence();
+            };
+            dof_tile(0, std::false_type{});
+            for (int i = 1; i < RTd; ++i) dof_tile(i, std::true_type{});
+            // the last dof tile's images
+#pragma unroll
+            for (int t = 0; t < MIXT; ++t) {
+#pragma unroll
+                for (int r = 0; r < NRD; ++r) image_get(r, rows_last, t * SLOT);
+#pragma unroll
+                for (int r = 0; r < NRD; ++r) image_out(r, t * rows + 16 * (RTd - 1), rows_last);
+            }
+            wave_lds_fence();
+        } else if constexpr (RTC > 0) {
             // register-resident fragments, fully unrolled; one accumulator set and no pipelining inside the wave:
             // these shapes run several waves per SIMD, which overlap each other's flushes
             v4d acc[CT];
@@ -384,7 +507,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
 #pragma unroll
                 for (int r = 0; r < NRD; ++r) image_get(r, nrows);
 #pragma unroll
-                for (int r = 0; r < NRD; ++r) image_out(r, t, nrows);
+                for (int r = 0; r < NRD; ++r) image_out(r, 16 * t, nrows);
                 wave_lds_fence();
             }
         } else {
