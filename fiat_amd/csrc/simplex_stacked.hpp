@@ -61,7 +61,8 @@ constexpr int stacked_image_doubles(int CT, int KS, int slots = 1) {
 // the image of a row tile is [row][points of the chunk] and leaves row by row as 8-byte stores.
 // MIXT > 0 (= 1 + SD, per-request cells, order 1): the row tiles come dof-major -- the MIXT tables of 16 dofs one
 // after the other (each table padded to whole tiles) -- so that a wave holds values and all first derivatives of
-// those dofs at once and applies the chain rule d/dx_d = sum_c K[c][d] d/dX_c in registers before the flush.
+// those dofs at once; their images go to LDS together and the flush applies the chain rule
+// d/dx_d = sum_c K[c][d] d/dX_c while it copies them out.
 template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0>
 __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const StackedArgs<FixedNC<SD, N>::value> a,
                                                                    double* __restrict__ trash,
@@ -382,17 +383,12 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
             const int RTd = (rows + 15) / 16;                 // dof tiles; tile (i, t) = table t, rows [16 i, 16 i + 16)
             const int rows_last = rows - 16 * (RTd - 1);
             constexpr int SLOT = 16 * 16 * CT;
-            // K = A0^-1 A_req of every request of the group, wave uniform (scalar registers); a lane picks the one of
-            // its column's request when it mixes (per-lane copies for all column tiles would cost 54 registers)
+            // K = A0^-1 A_req of every request of the group, wave uniform (scalar registers).  The tables go to the
+            // LDS images UNMIXED; the flush of derivative table d reads the SD reference-derivative images at its
+            // position and combines them with K[.][d] of the request it is copying -- a scalar operand, because the
+            // copy runs request by request (mixing the accumulators in registers instead costs ~90 more VGPRs)
             double Ks[G][SD][SD];
-            int gcol[CT];
             {
-                const float rinv = 1.0f / (float)npts;
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    const int g = idiv_small(16 * c + (lane & 15), rinv);
-                    gcol[c] = g < G ? g : 0;
-                }
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     long long req = grp * G + g;
@@ -411,11 +407,31 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                         }
                 }
             }
+            // r-th 16-byte piece of table `slot` of the image set: the values as they are, derivative d = slot - 1 as
+            // sum_c K[c][d] (reference derivative c)
+            auto mixed_get = [&](int r, int nrows, int slot) {
+                if (slot == 0) {
+                    image_get(r, nrows, 0);
+                } else {
+                    const int g = r / NST, it = r % NST, d = slot - 1;
+                    const int nch = (nrows * enpts) >> 1;
+                    const int idx = min(it * 64 + elane, nch - 1);
+                    v2d m = v2d{0.0, 0.0};
+#pragma unroll
+                    for (int c = 0; c < SD; ++c) {
+                        const v2d x = reinterpret_cast<const v2d*>(img + (1 + c) * SLOT + g * echunk)[idx];
+                        m += Ks[g][c][d] * x;
+                    }
+                    fbuf[r] = m;
+                }
+            };
             v4d acc[MIXT][CT];
             // one tile: MFMAs into `cur`, fragments of the next tile into `an`, and (FLUSH) slot `slot` of the previous
             // dof tile out -- the same K-step schedule as `stage`
             auto mix_stage = [&](v4d (&cur)[CT], int q, int slot, int prev_rowbase, const double (&af)[KS], double (&an)[KS], auto flush) {
-                const double* anp = ap + (size_t)(q + 1) * KS * 64;  // (the buffer ends with a zero tile)
+                // (uniform tile base + 32-bit lane offset: scalar-base addressing; per-lane 64-bit pointers for the four
+                // stages of a dof tile get strength-reduced into ~50 registers of induction variables and spill)
+                const double* anp = a.afrag + (size_t)(q + 1) * KS * 64;  // (the buffer ends with a zero tile)
 #pragma unroll
                 for (int c = 0; c < CT; ++c) cur[c] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -423,12 +439,12 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                     mfma_steps(cur, af, ks, ks + 1);
                     if (ks < 2 * T3) {
 #pragma unroll
-                        for (int l = ks * LPK; l < (ks + 1) * LPK && l < KS; ++l) an[l] = anp[l * 64];
+                        for (int l = ks * LPK; l < (ks + 1) * LPK && l < KS; ++l) an[l] = anp[l * 64 + elane];
                     }
                     if constexpr (decltype(flush)::value) {
                         if (ks >= T3 && ks < 2 * T3) {
 #pragma unroll
-                            for (int r = (ks - T3) * RPK; r < (ks - T3 + 1) * RPK && r < NRD; ++r) image_get(r, 16, slot * SLOT);
+                            for (int r = (ks - T3) * RPK; r < (ks - T3 + 1) * RPK && r < NRD; ++r) mixed_get(r, 16, slot);
                         } else if (ks >= 2 * T3) {
 #pragma unroll
                             for (int r = (ks - 2 * T3) * SPK; r < (ks - 2 * T3 + 1) * SPK && r < NRD; ++r) image_out(r, prev_rowbase, 16);
@@ -446,33 +462,6 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                     else mix_stage(acc[t], i * MIXT + t, t, t * rows + 16 * (i - 1), fa0, fa1, flush);
                 }
                 wave_lds_fence();  // (the previous dof tile's images have been read)
-                // chain rule: lane (kk, col) holds element jj = row 4 jj + kk of every table at its column
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    double Kl[SD][SD];
-#pragma unroll
-                    for (int e = 0; e < SD; ++e)
-#pragma unroll
-                        for (int d = 0; d < SD; ++d) {
-                            double v = Ks[0][e][d];
-#pragma unroll
-                            for (int g = 1; g < G; ++g) v = gcol[c] == g ? Ks[g][e][d] : v;
-                            Kl[e][d] = v;
-                        }
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        double gX[SD];
-#pragma unroll
-                        for (int e = 0; e < SD; ++e) gX[e] = acc[1 + e][c][jj];
-#pragma unroll
-                        for (int d = 0; d < SD; ++d) {
-                            double t = 0.0;
-#pragma unroll
-                            for (int e = 0; e < SD; ++e) t += Kl[e][d] * gX[e];
-                            acc[1 + d][c][jj] = t;
-                        }
-                    }
-                }
                 const int nrows = i == RTd - 1 ? rows_last : 16;
 #pragma unroll
                 for (int t = 0; t < MIXT; ++t)
@@ -486,7 +475,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
 #pragma unroll
             for (int t = 0; t < MIXT; ++t) {
 #pragma unroll
-                for (int r = 0; r < NRD; ++r) image_get(r, rows_last, t * SLOT);
+                for (int r = 0; r < NRD; ++r) mixed_get(r, rows_last, t);
 #pragma unroll
                 for (int r = 0; r < NRD; ++r) image_out(r, t * rows + 16 * (RTd - 1), rows_last);
             }
