@@ -695,9 +695,11 @@ const StackedShape kStackedShapes[] = {
     {3, 3, 3, 2, 5},  // Lagrange P3 tetrahedron, values + gradient (80 stacked rows): the benchmark shape C2, 17..24 points
     {3, 3, 2, 1, 5},  // ... 25..32 points
     {3, 3, 3, 1, 5},  // ... 33..48 points
-    // (rtc -2 instances -- chain rule across the tables in registers, simplex_stacked.hpp MIXT -- are NOT registered:
-    //  the two-requests-per-group instance faulted under a 28 730-request load on the GPU (cause not yet found);
-    //  per-request cells go through the whole-request instances + table_mix_kernel)
+    // rtc -2: per-request cells, order 1, chain rule applied inside the kernel (simplex_stacked.hpp MIXT;
+    // FIAT_AMD_STACKED_MIX=0 switches them off: whole-request instances + table_mix_kernel).  Degree 6 with three
+    // column tiles is not registered: 150+ spilled registers make it slower than the two-pass route.
+    {3, 6, 2, 1, -2}, {3, 5, 3, 2, -2}, {3, 5, 2, 1, -2}, {3, 5, 3, 1, -2},
+    {3, 4, 3, 2, -2}, {3, 4, 2, 1, -2}, {3, 4, 3, 1, -2}, {3, 3, 3, 2, -2}, {3, 3, 2, 1, -2}, {3, 3, 3, 1, -2},
     {3, 6, 3, 2, 0},  // degree-6 tetrahedron (DG P6 with Hessians: C4), 17..24 points
     {3, 6, 2, 1, 0},  // ... 25..32 points
     {3, 6, 3, 1, 0},  // ... 33..48 points
@@ -745,6 +747,10 @@ int launch_stacked(const Launch& L, hipStream_t s) {
     ka.R = L.khead.R;
     ka.RT = L.khead.RT;
     ka.debug = L.khead.debug;
+    ka.lim_pts = L.khead.lim_pts;
+    ka.lim_verts = L.khead.lim_verts;
+    ka.lim_out = L.khead.lim_out;
+    ka.lim_afrag = L.khead.lim_afrag;
     if ((int)L.fcoef.size() != NC) return fail(FX_EINVAL, "internal: coefficient table size mismatch");
     memcpy(ka.coef, L.fcoef.data(), NC * sizeof(double));
     auto kern = fxk::tabulate_simplex_stacked<SD, N, CT, G, RTC, WPS, CHUNK, MIXT>;
@@ -769,6 +775,23 @@ int launch_stacked(const Launch& L, hipStream_t s) {
 #if defined(FX_DBG) && (FX_DBG & 512)
     if (getenv("FIAT_AMD_VERBOSE")) HIP_TRY(report_wave_lifetimes(L.trash, grid, STACKED_NW));
 #endif
+#if defined(FX_DBG) && (FX_DBG & 1024)
+    {   // range-check build: report accesses that left their buffers (redirected to the scratch area by the kernel)
+        double rep[20];
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(rep, L.trash + 4096, sizeof rep, hipMemcpyDeviceToHost));
+        static const char* site[] = {"", "pts", "verts", "afrag", "out"};
+        for (int k = 1; k <= 4; ++k) {
+            unsigned long long cnt;
+            memcpy(&cnt, &rep[4 * k], sizeof cnt);
+            if (cnt)
+                fprintf(stderr, "[fiat_amd] RANGE CHECK <%d,%d,%d,%d,mixt %d>: %llu accesses outside `%s`: first index %.0f, limit %.0f, group %.0f\n",
+                        SD, N, CT, G, MIXT, cnt, site[k], rep[4 * k + 1], rep[4 * k + 2], rep[4 * k + 3]);
+        }
+        HIP_TRY(hipMemset(L.trash + 4096, 0, sizeof rep));
+        if (getenv("FIAT_AMD_VERBOSE")) fprintf(stderr, "[fiat_amd] range check done <%d,%d,%d,%d,mixt %d>\n", SD, N, CT, G, MIXT);
+    }
+#endif
     if (L.khead.verts && L.kmix_order >= 1 && MIXT == 0) {  // chain rule across the derivative tables, in place
         fxk::TableMixArgs ma;
         ma.out = L.khead.out;
@@ -790,47 +813,57 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 0: return launch_stacked<3, 3, 3, 2, 5, 3>(L, s);
         case 1: return launch_stacked<3, 3, 2, 1, 5, 3>(L, s);
         case 2: return launch_stacked<3, 3, 3, 1, 5, 3>(L, s);
-        case 3: return launch_stacked<3, 6, 3, 2>(L, s);
-        case 4: return launch_stacked<3, 6, 2, 1>(L, s);
-        case 5: return launch_stacked<3, 6, 3, 1>(L, s);
-        case 6: return launch_stacked<3, 5, 3, 2>(L, s);
-        case 7: return launch_stacked<3, 5, 2, 1>(L, s);
-        case 8: return launch_stacked<3, 5, 3, 1>(L, s);
-        case 9: return launch_stacked<3, 4, 3, 2>(L, s);
-        case 10: return launch_stacked<3, 4, 2, 1>(L, s);
-        case 11: return launch_stacked<3, 4, 3, 1>(L, s);
-        case 12: return launch_stacked<3, 3, 3, 2>(L, s);
-        case 13: return launch_stacked<3, 3, 2, 1>(L, s);
-        case 14: return launch_stacked<3, 3, 3, 1>(L, s);
-        case 15: return launch_stacked<2, 6, 3, 2>(L, s);
-        case 16: return launch_stacked<2, 6, 2, 1>(L, s);
-        case 17: return launch_stacked<2, 6, 3, 1>(L, s);
-        case 18: return launch_stacked<2, 5, 3, 2>(L, s);
-        case 19: return launch_stacked<2, 5, 2, 1>(L, s);
-        case 20: return launch_stacked<2, 5, 3, 1>(L, s);
-        case 21: return launch_stacked<3, 6, 3, 3>(L, s);
-        case 22: return launch_stacked<3, 5, 3, 3>(L, s);
-        case 23: return launch_stacked<3, 5, 4, 1>(L, s);
-        case 24: return launch_stacked<3, 4, 3, 3>(L, s);
-        case 25: return launch_stacked<3, 4, 4, 1>(L, s);
-        case 26: return launch_stacked<3, 3, 3, 3>(L, s);
-        case 27: return launch_stacked<3, 3, 4, 1>(L, s);
-        case 28: return launch_stacked<2, 6, 3, 3>(L, s);
-        case 29: return launch_stacked<2, 6, 4, 1>(L, s);
-        case 30: return launch_stacked<2, 5, 3, 3>(L, s);
-        case 31: return launch_stacked<2, 5, 4, 1>(L, s);
-        case 32: return launch_stacked<3, 2, 3, 2>(L, s);
-        case 33: return launch_stacked<3, 2, 2, 1>(L, s);
-        case 34: return launch_stacked<3, 2, 3, 1>(L, s);
-        case 35: return launch_stacked<3, 2, 3, 3>(L, s);
-        case 36: return launch_stacked<3, 2, 4, 1>(L, s);
-        case 37: return launch_stacked<3, 6, 3, 1, 0, 1, true>(L, s);
-        case 38: return launch_stacked<3, 5, 3, 1, 0, 1, true>(L, s);
-        case 39: return launch_stacked<3, 4, 3, 1, 0, 1, true>(L, s);
-        case 40: return launch_stacked<3, 3, 3, 1, 0, 1, true>(L, s);
-        case 41: return launch_stacked<3, 2, 3, 1, 0, 1, true>(L, s);
-        case 42: return launch_stacked<2, 6, 3, 1, 0, 1, true>(L, s);
-        case 43: return launch_stacked<2, 5, 3, 1, 0, 1, true>(L, s);
+        case 3: return launch_stacked<3, 6, 2, 1, 0, 1, false, 4>(L, s);
+        case 4: return launch_stacked<3, 5, 3, 2, 0, 1, false, 4>(L, s);
+        case 5: return launch_stacked<3, 5, 2, 1, 0, 1, false, 4>(L, s);
+        case 6: return launch_stacked<3, 5, 3, 1, 0, 1, false, 4>(L, s);
+        case 7: return launch_stacked<3, 4, 3, 2, 0, 1, false, 4>(L, s);
+        case 8: return launch_stacked<3, 4, 2, 1, 0, 1, false, 4>(L, s);
+        case 9: return launch_stacked<3, 4, 3, 1, 0, 1, false, 4>(L, s);
+        case 10: return launch_stacked<3, 3, 3, 2, 0, 1, false, 4>(L, s);
+        case 11: return launch_stacked<3, 3, 2, 1, 0, 1, false, 4>(L, s);
+        case 12: return launch_stacked<3, 3, 3, 1, 0, 1, false, 4>(L, s);
+        case 13: return launch_stacked<3, 6, 3, 2>(L, s);
+        case 14: return launch_stacked<3, 6, 2, 1>(L, s);
+        case 15: return launch_stacked<3, 6, 3, 1>(L, s);
+        case 16: return launch_stacked<3, 5, 3, 2>(L, s);
+        case 17: return launch_stacked<3, 5, 2, 1>(L, s);
+        case 18: return launch_stacked<3, 5, 3, 1>(L, s);
+        case 19: return launch_stacked<3, 4, 3, 2>(L, s);
+        case 20: return launch_stacked<3, 4, 2, 1>(L, s);
+        case 21: return launch_stacked<3, 4, 3, 1>(L, s);
+        case 22: return launch_stacked<3, 3, 3, 2>(L, s);
+        case 23: return launch_stacked<3, 3, 2, 1>(L, s);
+        case 24: return launch_stacked<3, 3, 3, 1>(L, s);
+        case 25: return launch_stacked<2, 6, 3, 2>(L, s);
+        case 26: return launch_stacked<2, 6, 2, 1>(L, s);
+        case 27: return launch_stacked<2, 6, 3, 1>(L, s);
+        case 28: return launch_stacked<2, 5, 3, 2>(L, s);
+        case 29: return launch_stacked<2, 5, 2, 1>(L, s);
+        case 30: return launch_stacked<2, 5, 3, 1>(L, s);
+        case 31: return launch_stacked<3, 6, 3, 3>(L, s);
+        case 32: return launch_stacked<3, 5, 3, 3>(L, s);
+        case 33: return launch_stacked<3, 5, 4, 1>(L, s);
+        case 34: return launch_stacked<3, 4, 3, 3>(L, s);
+        case 35: return launch_stacked<3, 4, 4, 1>(L, s);
+        case 36: return launch_stacked<3, 3, 3, 3>(L, s);
+        case 37: return launch_stacked<3, 3, 4, 1>(L, s);
+        case 38: return launch_stacked<2, 6, 3, 3>(L, s);
+        case 39: return launch_stacked<2, 6, 4, 1>(L, s);
+        case 40: return launch_stacked<2, 5, 3, 3>(L, s);
+        case 41: return launch_stacked<2, 5, 4, 1>(L, s);
+        case 42: return launch_stacked<3, 2, 3, 2>(L, s);
+        case 43: return launch_stacked<3, 2, 2, 1>(L, s);
+        case 44: return launch_stacked<3, 2, 3, 1>(L, s);
+        case 45: return launch_stacked<3, 2, 3, 3>(L, s);
+        case 46: return launch_stacked<3, 2, 4, 1>(L, s);
+        case 47: return launch_stacked<3, 6, 3, 1, 0, 1, true>(L, s);
+        case 48: return launch_stacked<3, 5, 3, 1, 0, 1, true>(L, s);
+        case 49: return launch_stacked<3, 4, 3, 1, 0, 1, true>(L, s);
+        case 50: return launch_stacked<3, 3, 3, 1, 0, 1, true>(L, s);
+        case 51: return launch_stacked<3, 2, 3, 1, 0, 1, true>(L, s);
+        case 52: return launch_stacked<2, 6, 3, 1, 0, 1, true>(L, s);
+        case 53: return launch_stacked<2, 5, 3, 1, 0, 1, true>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown stacked kernel %d", L.stacked_id);
 }
@@ -1280,7 +1313,8 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 const char* small = getenv("FIAT_AMD_STACKED_SMALL");
                 if (k.rtc > 0 ? (RT != k.rtc || verts || !(small && atoi(small))) : R < stacked_min_rows) continue;
                 if (k.rtc == -2) {  // per-request cells, order 1: tables mixed in registers (dof-major tiles)
-                    static const bool nomix = getenv("FIAT_AMD_NO_STACKED_MIX") != nullptr;
+                    const char* mixenv = getenv("FIAT_AMD_STACKED_MIX");
+                    const bool nomix = mixenv && !atoi(mixenv);
                     if (nomix || !verts || order != 1 || ((long long)rows * npts) % 2 || ((long long)(rows - 16 * ((rows + 15) / 16 - 1)) * npts) % 2)
                         continue;
                     const int cap = 16 * k.ct / k.g, lo = 16 * k.ct / (k.g + 1);
@@ -1326,6 +1360,10 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 ka.R = (int)R;
                 ka.RT = RT;
                 ka.debug = a.debug;
+                ka.lim_pts = (long long)nreq * npts * e->sd;
+                ka.lim_verts = verts ? (long long)nreq * (e->sd + 1) * e->sd : 0;
+                ka.lim_out = (long long)nreq * R * npts;
+                ka.lim_afrag = (k.rtc == -2 ? ((long long)((rows + 15) / 16) * ntab + 1) : (long long)(RT + 1)) * ((e->nexp + 3) / 4) * 64;
                 L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * fxk::stacked_image_doubles(k.ct, (e->nexp + 3) / 4, k.rtc == -2 ? e->sd + 1 : 1)) * 8;
                 if (L.klds_bytes > ctx->lds_per_cu) continue;
                 const long long groups = k.rtc == -1 ? nreq * ((npts + 16 * k.ct - 1) / (16 * k.ct)) : (nreq + k.g - 1) / k.g;

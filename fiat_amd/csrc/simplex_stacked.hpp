@@ -41,7 +41,27 @@ template <int NC> struct StackedArgs {
     int R;   // stacked rows = ntab * rows
     int RT;  // row tiles = ceil(R / 16)
     int debug;
+    // FX_DBG & 1024 builds: sizes (in doubles) of the buffers behind pts / verts / out / afrag; every global access
+    // of the kernel is range-checked against them, redirected to the scratch area when outside and reported there
+    long long lim_pts, lim_verts, lim_out, lim_afrag;
 };
+
+#if FX_DBG & 1024
+// site: 1 pts, 2 verts, 3 afrag, 4 out; trash[4096 + 4 site ..] = {count, first offending index, limit, group}
+__device__ __forceinline__ long long dbg_check(long long idx, long long lim, int site, long long grp, double* trash) {
+    if (idx >= 0 && idx < lim) return idx;
+    double* t = trash + 4096 + 4 * site;
+    if (atomicAdd(reinterpret_cast<unsigned long long*>(t), 1ULL) == 0ULL) {
+        t[1] = (double)idx;
+        t[2] = (double)lim;
+        t[3] = (double)grp;
+    }
+    return 0;
+}
+#define FX_CHK(idx, lim, site) dbg_check((long long)(idx), (lim), (site), (long long)grp_dbg, trash)
+#else
+#define FX_CHK(idx, lim, site) (idx)
+#endif
 
 // per-wave LDS: the output image of a row tile (16 x 16 CT doubles + dump row + read slack); the expansion
 // values of a group ([4 KS slots][16 CT columns]) alias it while they are produced
@@ -128,6 +148,8 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
     const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     long long grp = wqueue.claim();
+    long long grp_dbg = grp;
+    (void)grp_dbg;
     wqueue.service();
     // points of the wave's next group, one group ahead (their latency would otherwise be paid per group)
     auto load_points = [&](long long g_, double (&x)[PH][SD]) {
@@ -145,7 +167,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                 req = req < a.nreq ? req : a.nreq - 1;
                 pt = ppt[h];
             }
-            const double* pp = a.pts + ((size_t)req * npts + pt) * SD;
+            const double* pp = a.pts + FX_CHK(((size_t)req * npts + pt) * SD, a.lim_pts - SD + 1, 1);
 #pragma unroll
             for (int d = 0; d < SD; ++d) x[h][d] = pp[d];
         }
@@ -166,6 +188,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
     while (grp < ngroups) {
         const long long gnext = wqueue.claim();
         wqueue.service();
+        grp_dbg = grp;
         // ---------------- expansion values -> B fragments ----------------
         // lane <-> column (request of the group, point): the order-0 recurrence once per column, every member to
         // a [slot][column] slab in LDS (it aliases the output image, which is idle until the sweep starts), then
@@ -187,7 +210,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                         long long req = CHUNK ? grp / nchunk : grp * G + pg[h];
                         req = req < a.nreq ? req : a.nreq - 1;
                         double J[SD][SD], bb[SD];
-                        cell_map<SD>(a.verts + (size_t)req * (SD + 1) * SD, J, bb);
+                        cell_map<SD>(a.verts + FX_CHK((size_t)req * (SD + 1) * SD, a.lim_verts - (SD + 1) * SD + 1, 2), J, bb);
 #pragma unroll
                         for (int i = 0; i < SD; ++i) {
                             double t = bb[i];
@@ -251,7 +274,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
         double fa0[KS], fa1[KS];  // A fragments of the even / odd row tiles (loaded one tile ahead)
         if constexpr (RTC == 0) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) fa0[ks] = ap[ks * 64];
+            for (int ks = 0; ks < KS; ++ks) fa0[ks] = a.afrag[FX_CHK(ks * 64 + lane, a.lim_afrag, 3)];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa0[ks]));
         }
@@ -314,9 +337,16 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
             } else {
                 const int g = r / NST, it = r % NST;
                 const int nch = (nrows * enpts) >> 1;
+#if FX_DBG & 1024
+                const long long o0 = ((long long)oreq[g] * a.R + (long long)rowbase) * enpts + 2 * min(it * 64 + elane, nch - 1);
+                v2d* g2 = oreq[g] < a.nreq ? reinterpret_cast<v2d*>(a.out + FX_CHK(o0, a.lim_out - 1, 4)) : reinterpret_cast<v2d*>(trash);
+                if (oreq[g] < a.nreq && (o0 < 0 || o0 >= a.lim_out - 1)) g2 = reinterpret_cast<v2d*>(trash);
+                stream_store(g2, fbuf[r]);
+#else
                 v2d* g2 = oreq[g] < a.nreq ? reinterpret_cast<v2d*>(a.out + ((size_t)oreq[g] * a.R + (size_t)rowbase) * enpts)
                                            : reinterpret_cast<v2d*>(trash);
                 stream_store(&g2[min(it * 64 + elane, nch - 1)], fbuf[r]);
+#endif
             }
         };
         auto mfma_steps = [&](v4d (&acc)[CT], const double (&af)[KS], int k0, int k1) {
@@ -394,7 +424,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                     long long req = grp * G + g;
                     req = req < a.nreq ? req : a.nreq - 1;
                     double J[SD][SD], bb[SD];
-                    cell_map<SD>(a.verts + (size_t)req * (SD + 1) * SD, J, bb);
+                    cell_map<SD>(a.verts + FX_CHK((size_t)req * (SD + 1) * SD, a.lim_verts - (SD + 1) * SD + 1, 2), J, bb);
 #pragma unroll
                     for (int i = 0; i < SD; ++i)
 #pragma unroll
@@ -439,7 +469,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                     mfma_steps(cur, af, ks, ks + 1);
                     if (ks < 2 * T3) {
 #pragma unroll
-                        for (int l = ks * LPK; l < (ks + 1) * LPK && l < KS; ++l) an[l] = anp[l * 64 + elane];
+                        for (int l = ks * LPK; l < (ks + 1) * LPK && l < KS; ++l) an[l] = a.afrag[FX_CHK((size_t)(q + 1) * KS * 64 + l * 64 + elane, a.lim_afrag, 3)];
                     }
                     if constexpr (decltype(flush)::value) {
                         if (ks >= T3 && ks < 2 * T3) {

@@ -558,16 +558,21 @@ def test_stacked_matrix_kernel_triangles(fam, deg, order, npts):
 @pytest.mark.parametrize("fam,sd,deg,order,npts", [("DiscontinuousLagrange", 3, 6, 2, 23), ("DiscontinuousLagrange", 3, 6, 1, 40),
                                                    ("Lagrange", 3, 4, 2, 23), ("Lagrange", 3, 5, 1, 30), ("Nedelec", 3, 3, 1, 23),
                                                    ("Lagrange", 2, 6, 2, 16), ("RaviartThomas", 2, 5, 1, 23),
-                                                   ("Lagrange", 3, 5, 0, 23)])
-def test_stacked_matrix_kernel_with_per_request_cells(fam, sd, deg, order, npts):
+                                                   ("Lagrange", 3, 5, 0, 23), ("Nedelec", 3, 4, 1, 24),
+                                                   ("BrezziDouglasMarini", 3, 3, 1, 23), ("DiscontinuousLagrange", 3, 4, 1, 44),
+                                                   ("DiscontinuousLagrange", 3, 6, 1, 30)])
+@pytest.mark.parametrize("mix", ["1", "0"])
+def test_stacked_matrix_kernel_with_per_request_cells(monkeypatch, mix, fam, sd, deg, order, npts):
     """Per-request cells on the stacked-matrix kernel: points mapped through the request's cell in the kernel,
     chain rule across the derivative tables by the in-place mixing pass (table_mix_kernel), against the C
     oracle's recurrence on the physical cells; one negatively oriented cell."""
     import fiat_amd
     from oracle import c_oracle
+    # order 1 on tetrahedra: chain rule inside the kernel (MIXT instances) or, FIAT_AMD_STACKED_MIX=0, the mixing pass
+    monkeypatch.setenv("FIAT_AMD_STACKED_MIX", mix)
     el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg)
     ps = el.device_polyset()
-    nreq = 131
+    nreq = 131 if mix == "0" else 4133   # (several groups per wave for the in-kernel variant)
     assert ps.kernel_name(order, nreq, npts, has_verts=True) == "fxk::tabulate_simplex_stacked"
     rng = np.random.default_rng(31 * deg + npts + order + sd)
     A = np.eye(sd) + 0.1 * rng.standard_normal((nreq, sd, sd))
