@@ -332,7 +332,10 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
             if constexpr (CHUNK) {
                 const int i = min(r * 64 + elane, nrows * pc - 1);
                 const int row = idiv_small(i, rpc);
-                double* dst = a.out + ((size_t)oreq[0] * a.R + (size_t)rowbase + row) * enpts + p0 + (i - row * pc);
+                double* dst = a.out + FX_CHK(((size_t)oreq[0] * a.R + (size_t)rowbase + row) * enpts + p0 + (i - row * pc), a.lim_out, 4);
+#if FX_DBG & 1024
+                if (dst == a.out && !(oreq[0] == 0 && rowbase + row == 0 && p0 + (i - row * pc) == 0)) dst = trash;
+#endif
                 stream_store(dst, fbuf1[r]);
             } else {
                 const int g = r / NST, it = r % NST;
@@ -375,7 +378,8 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                 // output store, so the wait for them is an exact vmcnt(#stores), not a wait for the stores
                 if (RTC == 0 && ks < 2 * T3) {
 #pragma unroll
-                    for (int q = ks * LPK; q < (ks + 1) * LPK && q < KS; ++q) an[q] = anp[q * 64];
+                    for (int q = ks * LPK; q < (ks + 1) * LPK && q < KS; ++q)
+                        an[q] = anp[FX_CHK(q * 64 + (anp - a.afrag), a.lim_afrag, 3) - (anp - a.afrag)];
                 }
                 if (ks < T3) {
 #pragma unroll
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
             {   // tile 0: nothing to flush yet
                 const double* anp = ap + (size_t)KS * 64;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) fa1[ks] = anp[ks * 64];
+                for (int ks = 0; ks < KS; ++ks) fa1[ks] = anp[FX_CHK(ks * 64 + (anp - a.afrag), a.lim_afrag, 3) - (anp - a.afrag)];
 #pragma unroll
                 for (int c = 0; c < CT; ++c) accA[c] = v4d{0.0, 0.0, 0.0, 0.0};
                 mfma_steps(accA, fa0, 0, KS);
