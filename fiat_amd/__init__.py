@@ -32,6 +32,7 @@ from .bubble import Bubble, FacetBubble  # noqa: F401
 from .brezzi_douglas_fortin_marini import BrezziDouglasFortinMarini  # noqa: F401
 from .discontinuous_raviart_thomas import DiscontinuousRaviartThomas  # noqa: F401
 from .regge import Regge  # noqa: F401
+from .argyris import Argyris  # noqa: F401
 from .hellan_herrmann_johnson import HellanHerrmannJohnson  # noqa: F401
 from .tensor_product import FlattenedDimensions, TensorProductElement  # noqa: F401
 
@@ -52,6 +53,7 @@ supported_elements = {
     "Discontinuous Raviart-Thomas": DiscontinuousRaviartThomas,
     "RestrictedElement": RestrictedElement,
     "Regge": Regge,
+    "Argyris": Argyris,
     "Hellan-Herrmann-Johnson": HellanHerrmannJohnson,
     "TensorProductElement": TensorProductElement,
     "FlattenedDimensions": FlattenedDimensions,

@@ -13,7 +13,7 @@ import os
 
 import numpy as np
 
-from FIAT import (HellanHerrmannJohnson, Regge, BrezziDouglasFortinMarini, BrezziDouglasMarini, Bubble, CrouzeixRaviart, CubicHermite,
+from FIAT import (Argyris, HellanHerrmannJohnson, Regge, BrezziDouglasFortinMarini, BrezziDouglasMarini, Bubble, CrouzeixRaviart, CubicHermite,
                   DiscontinuousRaviartThomas, FacetBubble, Lagrange, Morley, Nedelec, NedelecSecondKind, RaviartThomas,
                   RestrictedElement, ufc_simplex)
 from FIAT.polynomial_set import mis
@@ -43,6 +43,7 @@ CASES = [("bdm", BrezziDouglasMarini, 2, (1, 2, 3)), ("bdm", BrezziDouglasMarini
          ("reggept", lambda c, k: Regge(c, k, variant="point"), 2, (1,)), ("reggept", lambda c, k: Regge(c, k, variant="point"), 3, (1,)),
          ("hhj", HellanHerrmannJohnson, 2, (0, 1, 2)), ("hhj", HellanHerrmannJohnson, 3, (0, 1)),
          ("hhjpt", lambda c, k: HellanHerrmannJohnson(c, k, variant="point"), 3, (1,)),
+         ("argyris", Argyris, 2, (5, 6)), ("argyrispt", lambda c, k: Argyris(c, k, variant="point"), 2, (5, 6)),
          ("lagfacet", lambda c, k: RestrictedElement(Lagrange(c, k), restriction_domain="facet"), 2, (3,)),
          ("lagedge", lambda c, k: RestrictedElement(Lagrange(c, k), restriction_domain="edge", take_closure=False), 3, (3,))]
 

@@ -46,6 +46,9 @@ MORE = [("rtpt", _pt("RaviartThomas"), 2, 1), ("rtpt", _pt("RaviartThomas"), 2, 
         ("hhj", lambda fa, c, k: fa.HellanHerrmannJohnson(c, k), 2, 2), ("hhj", lambda fa, c, k: fa.HellanHerrmannJohnson(c, k), 3, 0),
         ("hhj", lambda fa, c, k: fa.HellanHerrmannJohnson(c, k), 3, 1),
         ("hhjpt", lambda fa, c, k: fa.HellanHerrmannJohnson(c, k, variant="point"), 3, 1),
+        ("argyris", lambda fa, c, k: fa.Argyris(c, k), 2, 5), ("argyris", lambda fa, c, k: fa.Argyris(c, k), 2, 6),
+        ("argyrispt", lambda fa, c, k: fa.Argyris(c, k, variant="point"), 2, 5),
+        ("argyrispt", lambda fa, c, k: fa.Argyris(c, k, variant="point"), 2, 6),
         ("lagfacet", lambda fa, c, k: fa.RestrictedElement(fa.Lagrange(c, k), restriction_domain="facet"), 2, 3),
         ("lagedge", lambda fa, c, k: fa.RestrictedElement(fa.Lagrange(c, k), restriction_domain="edge", take_closure=False), 3, 3)]
 
