@@ -28,6 +28,7 @@ from .hermite import CubicHermite  # noqa: F401
 from .morley import Morley  # noqa: F401
 from .crouzeix_raviart import CrouzeixRaviart  # noqa: F401
 from .restricted import RestrictedElement  # noqa: F401
+from .nodal_enriched import NodalEnrichedElement  # noqa: F401
 from .bubble import Bubble, FacetBubble  # noqa: F401
 from .brezzi_douglas_fortin_marini import BrezziDouglasFortinMarini  # noqa: F401
 from .discontinuous_raviart_thomas import DiscontinuousRaviartThomas  # noqa: F401
@@ -52,6 +53,7 @@ supported_elements = {
     "Brezzi-Douglas-Fortin-Marini": BrezziDouglasFortinMarini,
     "Discontinuous Raviart-Thomas": DiscontinuousRaviartThomas,
     "RestrictedElement": RestrictedElement,
+    "NodalEnrichedElement": NodalEnrichedElement,
     "Regge": Regge,
     "Argyris": Argyris,
     "Hellan-Herrmann-Johnson": HellanHerrmannJohnson,

@@ -7,8 +7,11 @@ from .restricted import RestrictedElement
 
 
 def BrezziDouglasFortinMarini(ref_el, degree, variant=None, quad_scheme=None):
-    if variant == "point":
-        raise NotImplementedError("the point variant of BDFM needs NodalEnrichedElement, out of scope for fiat_amd")
+    if variant == "point":  # interior dofs of BDM_k + facet dofs of BDM_{k-1} (:12-15)
+        from .nodal_enriched import NodalEnrichedElement
+        interior = RestrictedElement(BrezziDouglasMarini(ref_el, degree, variant=variant), restriction_domain="interior")
+        facets = RestrictedElement(BrezziDouglasMarini(ref_el, degree - 1, variant=variant), restriction_domain="facet")
+        return NodalEnrichedElement(interior, facets)
     bdm = BrezziDouglasMarini(ref_el, degree, variant=variant, quad_scheme=quad_scheme)
     entity_ids = bdm.get_dual_set().get_entity_ids()
     sd = ref_el.get_spatial_dimension()

@@ -35,6 +35,22 @@ def polynomial_dimension(ref_el, n, continuity=None):
     return math.comb(n + sd, sd)
 
 
+def polynomial_entity_ids(ref_el, n, continuity=None):
+    """{dim: {entity: members}} of the hierarchical numbering of a degree-n expansion set
+    (FIAT/expansions.py:717-741): C0 sets own comb(n - 1, dim) members per entity of dimension dim,
+    discontinuous sets keep everything in the cell."""
+    top = ref_el.get_topology()
+    sd = ref_el.get_spatial_dimension()
+    entity_ids, cur = {}, 0
+    for dim in sorted(top):
+        dofs = math.comb(n - 1, dim) if continuity == "C0" else (math.comb(n + dim, dim) if dim == sd else 0)
+        entity_ids[dim] = {}
+        for entity in sorted(top[dim]):
+            entity_ids[dim][entity] = list(range(cur, cur + dofs))
+            cur += dofs
+    return entity_ids
+
+
 class ExpansionSet:
     def __init__(self, ref_el, scale=None, variant=None):
         if variant not in (None, "bubble", "dual"):

@@ -15,7 +15,7 @@ import numpy as np
 
 from FIAT import (Argyris, HellanHerrmannJohnson, Regge, BrezziDouglasFortinMarini, BrezziDouglasMarini, Bubble, CrouzeixRaviart, CubicHermite,
                   DiscontinuousRaviartThomas, FacetBubble, Lagrange, Morley, Nedelec, NedelecSecondKind, RaviartThomas,
-                  RestrictedElement, ufc_simplex)
+                  NodalEnrichedElement, RestrictedElement, ufc_simplex)
 from FIAT.polynomial_set import mis
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -44,6 +44,10 @@ CASES = [("bdm", BrezziDouglasMarini, 2, (1, 2, 3)), ("bdm", BrezziDouglasMarini
          ("hhj", HellanHerrmannJohnson, 2, (0, 1, 2)), ("hhj", HellanHerrmannJohnson, 3, (0, 1)),
          ("hhjpt", lambda c, k: HellanHerrmannJohnson(c, k, variant="point"), 3, (1,)),
          ("argyris", Argyris, 2, (5, 6)), ("argyrispt", lambda c, k: Argyris(c, k, variant="point"), 2, (5, 6)),
+         ("mini", lambda c, k: NodalEnrichedElement(Lagrange(c, 1), Bubble(c, k)), 2, (3,)),
+         ("mini", lambda c, k: NodalEnrichedElement(Lagrange(c, 1), Bubble(c, k)), 3, (4,)),
+         ("p2facetbubble", lambda c, k: NodalEnrichedElement(Lagrange(c, 2), FacetBubble(c, k)), 3, (3,)),
+         ("bdfmpt", lambda c, k: BrezziDouglasFortinMarini(c, k, variant="point"), 2, (2,)),
          ("lagfacet", lambda c, k: RestrictedElement(Lagrange(c, k), restriction_domain="facet"), 2, (3,)),
          ("lagedge", lambda c, k: RestrictedElement(Lagrange(c, k), restriction_domain="edge", take_closure=False), 3, (3,))]
 
@@ -61,7 +65,7 @@ def main():
             out[key + "_coeffs"] = np.asarray(el.get_coeffs())
             tab = el.tabulate(1, out[f"pts_sd{sd}"])
             out[key + "_tab"] = np.stack([np.asarray(tab[a]) for j in range(2) for a in mis(sd, j)])
-            out[key + "_entity_dofs"] = np.array(json.dumps({str(d): {str(i): v for i, v in ents.items()}
+            out[key + "_entity_dofs"] = np.array(json.dumps({str(d): {str(i): [int(x) for x in v] for i, v in ents.items()}
                                                              for d, ents in el.entity_dofs().items()}))
             out[key + "_mapping"] = np.array(el.mapping()[0])
     # matrix-valued elements built DIRECTLY on physical cells (double Piola push-forward check)

@@ -49,6 +49,10 @@ MORE = [("rtpt", _pt("RaviartThomas"), 2, 1), ("rtpt", _pt("RaviartThomas"), 2, 
         ("argyris", lambda fa, c, k: fa.Argyris(c, k), 2, 5), ("argyris", lambda fa, c, k: fa.Argyris(c, k), 2, 6),
         ("argyrispt", lambda fa, c, k: fa.Argyris(c, k, variant="point"), 2, 5),
         ("argyrispt", lambda fa, c, k: fa.Argyris(c, k, variant="point"), 2, 6),
+        ("mini", lambda fa, c, k: fa.NodalEnrichedElement(fa.Lagrange(c, 1), fa.Bubble(c, k)), 2, 3),
+        ("mini", lambda fa, c, k: fa.NodalEnrichedElement(fa.Lagrange(c, 1), fa.Bubble(c, k)), 3, 4),
+        ("p2facetbubble", lambda fa, c, k: fa.NodalEnrichedElement(fa.Lagrange(c, 2), fa.FacetBubble(c, k)), 3, 3),
+        ("bdfmpt", lambda fa, c, k: fa.BrezziDouglasFortinMarini(c, k, variant="point"), 2, 2),
         ("lagfacet", lambda fa, c, k: fa.RestrictedElement(fa.Lagrange(c, k), restriction_domain="facet"), 2, 3),
         ("lagedge", lambda fa, c, k: fa.RestrictedElement(fa.Lagrange(c, k), restriction_domain="edge", take_closure=False), 3, 3)]
 
@@ -91,8 +95,6 @@ def test_family_errors():
     import fiat_amd
     with pytest.raises(Exception):
         fiat_amd.BrezziDouglasMarini(fiat_amd.ufc_simplex(2), 0)
-    with pytest.raises(NotImplementedError):
-        fiat_amd.BrezziDouglasFortinMarini(fiat_amd.ufc_simplex(2), 2, variant="point")
     assert fiat_amd.supported_elements["Brezzi-Douglas-Marini"] is fiat_amd.BrezziDouglasMarini
     assert fiat_amd.supported_elements["Nedelec 2nd kind H(curl)"] is fiat_amd.NedelecSecondKind
     with pytest.raises(ValueError):
