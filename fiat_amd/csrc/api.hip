@@ -695,10 +695,11 @@ const StackedShape kStackedShapes[] = {
     {3, 3, 3, 2, 5},  // Lagrange P3 tetrahedron, values + gradient (80 stacked rows): the benchmark shape C2, 17..24 points
     {3, 3, 2, 1, 5},  // ... 25..32 points
     {3, 3, 3, 1, 5},  // ... 33..48 points
-    // rtc -2: per-request cells, order 1, chain rule applied inside the kernel (simplex_stacked.hpp MIXT;
+    // rtc -2: per-request cells, order 1 (tetrahedra and triangles), chain rule applied inside the kernel (simplex_stacked.hpp MIXT;
     // FIAT_AMD_STACKED_MIX=0 switches them off: whole-request instances + table_mix_kernel).  Degree 6 with three
     // column tiles is not registered: 150+ spilled registers make it slower than the two-pass route.
     {3, 6, 2, 1, -2}, {3, 5, 3, 2, -2}, {3, 5, 2, 1, -2}, {3, 5, 3, 1, -2},
+    {2, 6, 3, 2, -2}, {2, 6, 2, 1, -2}, {2, 6, 3, 1, -2}, {2, 5, 3, 2, -2}, {2, 5, 2, 1, -2}, {2, 5, 3, 1, -2},
     {3, 4, 3, 2, -2}, {3, 4, 2, 1, -2}, {3, 4, 3, 1, -2}, {3, 3, 3, 2, -2}, {3, 3, 2, 1, -2}, {3, 3, 3, 1, -2},
     {3, 6, 3, 2, 0},  // degree-6 tetrahedron (DG P6 with Hessians: C4), 17..24 points
     {3, 6, 2, 1, 0},  // ... 25..32 points
@@ -817,53 +818,59 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 4: return launch_stacked<3, 5, 3, 2, 0, 1, false, 4>(L, s);
         case 5: return launch_stacked<3, 5, 2, 1, 0, 1, false, 4>(L, s);
         case 6: return launch_stacked<3, 5, 3, 1, 0, 1, false, 4>(L, s);
-        case 7: return launch_stacked<3, 4, 3, 2, 0, 1, false, 4>(L, s);
-        case 8: return launch_stacked<3, 4, 2, 1, 0, 1, false, 4>(L, s);
-        case 9: return launch_stacked<3, 4, 3, 1, 0, 1, false, 4>(L, s);
-        case 10: return launch_stacked<3, 3, 3, 2, 0, 1, false, 4>(L, s);
-        case 11: return launch_stacked<3, 3, 2, 1, 0, 1, false, 4>(L, s);
-        case 12: return launch_stacked<3, 3, 3, 1, 0, 1, false, 4>(L, s);
-        case 13: return launch_stacked<3, 6, 3, 2>(L, s);
-        case 14: return launch_stacked<3, 6, 2, 1>(L, s);
-        case 15: return launch_stacked<3, 6, 3, 1>(L, s);
-        case 16: return launch_stacked<3, 5, 3, 2>(L, s);
-        case 17: return launch_stacked<3, 5, 2, 1>(L, s);
-        case 18: return launch_stacked<3, 5, 3, 1>(L, s);
-        case 19: return launch_stacked<3, 4, 3, 2>(L, s);
-        case 20: return launch_stacked<3, 4, 2, 1>(L, s);
-        case 21: return launch_stacked<3, 4, 3, 1>(L, s);
-        case 22: return launch_stacked<3, 3, 3, 2>(L, s);
-        case 23: return launch_stacked<3, 3, 2, 1>(L, s);
-        case 24: return launch_stacked<3, 3, 3, 1>(L, s);
-        case 25: return launch_stacked<2, 6, 3, 2>(L, s);
-        case 26: return launch_stacked<2, 6, 2, 1>(L, s);
-        case 27: return launch_stacked<2, 6, 3, 1>(L, s);
-        case 28: return launch_stacked<2, 5, 3, 2>(L, s);
-        case 29: return launch_stacked<2, 5, 2, 1>(L, s);
-        case 30: return launch_stacked<2, 5, 3, 1>(L, s);
-        case 31: return launch_stacked<3, 6, 3, 3>(L, s);
-        case 32: return launch_stacked<3, 5, 3, 3>(L, s);
-        case 33: return launch_stacked<3, 5, 4, 1>(L, s);
-        case 34: return launch_stacked<3, 4, 3, 3>(L, s);
-        case 35: return launch_stacked<3, 4, 4, 1>(L, s);
-        case 36: return launch_stacked<3, 3, 3, 3>(L, s);
-        case 37: return launch_stacked<3, 3, 4, 1>(L, s);
-        case 38: return launch_stacked<2, 6, 3, 3>(L, s);
-        case 39: return launch_stacked<2, 6, 4, 1>(L, s);
-        case 40: return launch_stacked<2, 5, 3, 3>(L, s);
-        case 41: return launch_stacked<2, 5, 4, 1>(L, s);
-        case 42: return launch_stacked<3, 2, 3, 2>(L, s);
-        case 43: return launch_stacked<3, 2, 2, 1>(L, s);
-        case 44: return launch_stacked<3, 2, 3, 1>(L, s);
-        case 45: return launch_stacked<3, 2, 3, 3>(L, s);
-        case 46: return launch_stacked<3, 2, 4, 1>(L, s);
-        case 47: return launch_stacked<3, 6, 3, 1, 0, 1, true>(L, s);
-        case 48: return launch_stacked<3, 5, 3, 1, 0, 1, true>(L, s);
-        case 49: return launch_stacked<3, 4, 3, 1, 0, 1, true>(L, s);
-        case 50: return launch_stacked<3, 3, 3, 1, 0, 1, true>(L, s);
-        case 51: return launch_stacked<3, 2, 3, 1, 0, 1, true>(L, s);
-        case 52: return launch_stacked<2, 6, 3, 1, 0, 1, true>(L, s);
-        case 53: return launch_stacked<2, 5, 3, 1, 0, 1, true>(L, s);
+        case 7: return launch_stacked<2, 6, 3, 2, 0, 1, false, 3>(L, s);
+        case 8: return launch_stacked<2, 6, 2, 1, 0, 1, false, 3>(L, s);
+        case 9: return launch_stacked<2, 6, 3, 1, 0, 1, false, 3>(L, s);
+        case 10: return launch_stacked<2, 5, 3, 2, 0, 1, false, 3>(L, s);
+        case 11: return launch_stacked<2, 5, 2, 1, 0, 1, false, 3>(L, s);
+        case 12: return launch_stacked<2, 5, 3, 1, 0, 1, false, 3>(L, s);
+        case 13: return launch_stacked<3, 4, 3, 2, 0, 1, false, 4>(L, s);
+        case 14: return launch_stacked<3, 4, 2, 1, 0, 1, false, 4>(L, s);
+        case 15: return launch_stacked<3, 4, 3, 1, 0, 1, false, 4>(L, s);
+        case 16: return launch_stacked<3, 3, 3, 2, 0, 1, false, 4>(L, s);
+        case 17: return launch_stacked<3, 3, 2, 1, 0, 1, false, 4>(L, s);
+        case 18: return launch_stacked<3, 3, 3, 1, 0, 1, false, 4>(L, s);
+        case 19: return launch_stacked<3, 6, 3, 2>(L, s);
+        case 20: return launch_stacked<3, 6, 2, 1>(L, s);
+        case 21: return launch_stacked<3, 6, 3, 1>(L, s);
+        case 22: return launch_stacked<3, 5, 3, 2>(L, s);
+        case 23: return launch_stacked<3, 5, 2, 1>(L, s);
+        case 24: return launch_stacked<3, 5, 3, 1>(L, s);
+        case 25: return launch_stacked<3, 4, 3, 2>(L, s);
+        case 26: return launch_stacked<3, 4, 2, 1>(L, s);
+        case 27: return launch_stacked<3, 4, 3, 1>(L, s);
+        case 28: return launch_stacked<3, 3, 3, 2>(L, s);
+        case 29: return launch_stacked<3, 3, 2, 1>(L, s);
+        case 30: return launch_stacked<3, 3, 3, 1>(L, s);
+        case 31: return launch_stacked<2, 6, 3, 2>(L, s);
+        case 32: return launch_stacked<2, 6, 2, 1>(L, s);
+        case 33: return launch_stacked<2, 6, 3, 1>(L, s);
+        case 34: return launch_stacked<2, 5, 3, 2>(L, s);
+        case 35: return launch_stacked<2, 5, 2, 1>(L, s);
+        case 36: return launch_stacked<2, 5, 3, 1>(L, s);
+        case 37: return launch_stacked<3, 6, 3, 3>(L, s);
+        case 38: return launch_stacked<3, 5, 3, 3>(L, s);
+        case 39: return launch_stacked<3, 5, 4, 1>(L, s);
+        case 40: return launch_stacked<3, 4, 3, 3>(L, s);
+        case 41: return launch_stacked<3, 4, 4, 1>(L, s);
+        case 42: return launch_stacked<3, 3, 3, 3>(L, s);
+        case 43: return launch_stacked<3, 3, 4, 1>(L, s);
+        case 44: return launch_stacked<2, 6, 3, 3>(L, s);
+        case 45: return launch_stacked<2, 6, 4, 1>(L, s);
+        case 46: return launch_stacked<2, 5, 3, 3>(L, s);
+        case 47: return launch_stacked<2, 5, 4, 1>(L, s);
+        case 48: return launch_stacked<3, 2, 3, 2>(L, s);
+        case 49: return launch_stacked<3, 2, 2, 1>(L, s);
+        case 50: return launch_stacked<3, 2, 3, 1>(L, s);
+        case 51: return launch_stacked<3, 2, 3, 3>(L, s);
+        case 52: return launch_stacked<3, 2, 4, 1>(L, s);
+        case 53: return launch_stacked<3, 6, 3, 1, 0, 1, true>(L, s);
+        case 54: return launch_stacked<3, 5, 3, 1, 0, 1, true>(L, s);
+        case 55: return launch_stacked<3, 4, 3, 1, 0, 1, true>(L, s);
+        case 56: return launch_stacked<3, 3, 3, 1, 0, 1, true>(L, s);
+        case 57: return launch_stacked<3, 2, 3, 1, 0, 1, true>(L, s);
+        case 58: return launch_stacked<2, 6, 3, 1, 0, 1, true>(L, s);
+        case 59: return launch_stacked<2, 5, 3, 1, 0, 1, true>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown stacked kernel %d", L.stacked_id);
 }

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
     static_assert(!CHUNK || (G == 1 && RTC == 0), "point-chunked units: one request per group, streamed fragments");
     constexpr int SLOTS = MIXT > 0 ? MIXT : 1;  // row-tile images per wave
     constexpr int IMG = stacked_image_doubles(CT, KS, SLOTS);
-    static_assert(MIXT == 0 || (MIXT == 1 + SD && MIXT % 2 == 0 && !CHUNK && RTC == 0), "table mixing: tetrahedra, order 1");
+    static_assert(MIXT == 0 || (MIXT == 1 + SD && !CHUNK && RTC == 0), "table mixing: order 1, whole-request groups");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -489,10 +489,12 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(an[ks]));
             };
-            auto dof_tile = [&](int i, auto flush) {
+            // (`odd`: parity of the dof tile's first row tile -- the fragment buffers alternate per row tile, and with an
+            // odd number of tables per dof tile (triangles) every other dof tile starts on the second buffer)
+            auto dof_tile = [&](int i, auto flush, auto odd) {
 #pragma unroll
                 for (int t = 0; t < MIXT; ++t) {
-                    if (t & 1) mix_stage(acc[t], i * MIXT + t, t, t * rows + 16 * (i - 1), fa1, fa0, flush);
+                    if ((t + (decltype(odd)::value ? 1 : 0)) & 1) mix_stage(acc[t], i * MIXT + t, t, t * rows + 16 * (i - 1), fa1, fa0, flush);
                     else mix_stage(acc[t], i * MIXT + t, t, t * rows + 16 * (i - 1), fa0, fa1, flush);
                 }
                 wave_lds_fence();  // (the previous dof tile's images have been read)
@@ -503,8 +505,17 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                     for (int w = 0; w < NWR; ++w) image_put(acc[t], w, nrows, t * SLOT);
                 wave_lds_fence();
             };
-            dof_tile(0, std::false_type{});
-            for (int i = 1; i < RTd; ++i) dof_tile(i, std::true_type{});
+            dof_tile(0, std::false_type{}, std::false_type{});
+            if constexpr (MIXT % 2 == 0) {
+                for (int i = 1; i < RTd; ++i) dof_tile(i, std::true_type{}, std::false_type{});
+            } else {
+                int i = 1;
+                for (; i + 1 < RTd; i += 2) {
+                    dof_tile(i, std::true_type{}, std::true_type{});
+                    dof_tile(i + 1, std::true_type{}, std::false_type{});
+                }
+                if (i < RTd) dof_tile(i, std::true_type{}, std::true_type{});
+            }
             // the last dof tile's images
 #pragma unroll
             for (int t = 0; t < MIXT; ++t) {

@@ -560,7 +560,9 @@ def test_stacked_matrix_kernel_triangles(fam, deg, order, npts):
                                                    ("Lagrange", 2, 6, 2, 16), ("RaviartThomas", 2, 5, 1, 23),
                                                    ("Lagrange", 3, 5, 0, 23), ("Nedelec", 3, 4, 1, 24),
                                                    ("BrezziDouglasMarini", 3, 3, 1, 23), ("DiscontinuousLagrange", 3, 4, 1, 44),
-                                                   ("DiscontinuousLagrange", 3, 6, 1, 30)])
+                                                   ("DiscontinuousLagrange", 3, 6, 1, 30), ("Lagrange", 2, 6, 1, 23),
+                                                   ("DiscontinuousLagrange", 2, 5, 1, 30), ("Lagrange", 2, 5, 1, 44),
+                                                   ("Nedelec", 2, 6, 1, 22)])
 @pytest.mark.parametrize("mix", ["1", "0"])
 def test_stacked_matrix_kernel_with_per_request_cells(monkeypatch, mix, fam, sd, deg, order, npts):
     """Per-request cells on the stacked-matrix kernel: points mapped through the request's cell in the kernel,
@@ -568,7 +570,7 @@ def test_stacked_matrix_kernel_with_per_request_cells(monkeypatch, mix, fam, sd,
     oracle's recurrence on the physical cells; one negatively oriented cell."""
     import fiat_amd
     from oracle import c_oracle
-    # order 1 on tetrahedra: chain rule inside the kernel (MIXT instances) or, FIAT_AMD_STACKED_MIX=0, the mixing pass
+    # order 1: chain rule inside the kernel (MIXT instances) or, FIAT_AMD_STACKED_MIX=0, the mixing pass
     monkeypatch.setenv("FIAT_AMD_STACKED_MIX", mix)
     el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg)
     ps = el.device_polyset()
