@@ -17,6 +17,8 @@ from .reference_element import (DefaultLine, DefaultTetrahedron, DefaultTriangle
 from .quadrature import create_quadrature, make_quadrature  # noqa: F401
 from .polynomial_set import ONPolynomialSet, ONSymTensorPolynomialSet, PolynomialSet, mis  # noqa: F401
 from .expansions import ExpansionSet  # noqa: F401
+from .macro import (AlfeldSplit, IsoSplit, PowellSabin12Split, PowellSabinSplit,  # noqa: F401
+                    WorseyFarinSplit)
 from .finite_element import CiarletElement, FiniteElement  # noqa: F401
 from .lagrange import Lagrange  # noqa: F401
 from .discontinuous_lagrange import P0, DiscontinuousLagrange  # noqa: F401

@@ -76,6 +76,12 @@ _SIGS = {
     "fx_classify_tables": (c_int, [c_void_p, c_int64, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "fx_tables_point_major": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "fx_plan_kernel": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_char_p, c_int]),
+    "fx_macro_element_create": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_int, c_void_p, c_int,
+                                        c_void_p, c_void_p, c_int, c_int, c_void_p, POINTER(c_void_p)]),
+    "fx_macro_element_destroy": (c_int, [c_void_p]),
+    "fx_macro_element_set_coeffs": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "fx_macro_tabulate_batch": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
     "fx_time_tabulate_batch": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, POINTER(c_float)]),
 }

@@ -1,15 +1,17 @@
 """Variant-string parsing for the in-scope families (FIAT/check_format_variant.py
-:30-136).  Macro-element splittings and the spectral point families depend on
-components that are out of scope (macro.py, recursivenodes) and raise
-NotImplementedError."""
+:30-136), including the macro-element splittings ("alfeld", "iso", "iso(k)", "powell-sabin",
+"worsey-farin", "powell-sabin(12)").  The spectral point families depend on the absent
+third-party recursivenodes package and raise NotImplementedError where points are made."""
 import re
 
+from . import macro
 from .quadrature import create_quadrature
 
 _CG_POINTS = {"spectral": "gll", "chebyshev": "lgc", "equispaced": "equispaced", "gll": "gll"}
 _DG_POINTS = {"spectral": "gl", "chebyshev": "gc", "equispaced": "equispaced",
               "equispaced_interior": "equispaced_interior", "gll": "gll", "gl": "gl"}
-_SPLITS = ("iso", "alfeld", "worsey-farin", "powell-sabin", "powell-sabin(12)")
+_SPLITS = {"iso": macro.IsoSplit, "alfeld": macro.AlfeldSplit, "worsey-farin": macro.WorseyFarinSplit,
+           "powell-sabin": macro.PowellSabinSplit, "powell-sabin(12)": macro.PowellSabin12Split}
 
 
 def parse_lagrange_variant(variant, discontinuous=False, integral=False):
@@ -25,22 +27,35 @@ def parse_lagrange_variant(variant, discontinuous=False, integral=False):
     else:
         table = _DG_POINTS if discontinuous else _CG_POINTS
         point_variant = table["spectral"]
+    splitting, iso_degree = None, None
     for raw in options:
         opt = raw.lower()
-        if opt in _SPLITS or opt.startswith("iso"):
-            raise NotImplementedError("macro-element splittings are out of scope for fiat_amd")
-        if opt.startswith("integral"):
+        if opt in _SPLITS:
+            splitting = _SPLITS[opt]
+        elif opt.startswith("iso"):
+            match = re.match(r"^iso\((\d+)\)$", opt)
+            if not match:
+                raise ValueError("Illegal variant option")
+            iso_degree = int(match.group(1))
+        elif opt.startswith("integral"):
             point_variant = opt
         elif opt in table:
             point_variant = table[opt]
         else:
             raise ValueError("Illegal variant option")
-    return None, point_variant
+    if discontinuous and (splitting is not None or iso_degree is not None) and point_variant in _CG_POINTS.values():
+        raise ValueError("Illegal variant. DG macroelements with DOFs on subcell boundaries are not unisolvent.")
+    if iso_degree is not None:
+        lattice = point_variant or "gll"
+        splitting = lambda T: macro.IsoSplit(T, iso_degree, lattice)   # noqa: E731
+    return splitting, point_variant
 
 
 def check_format_variant(variant, degree):
     """-> (splitting, 'point' | 'integral', interpolant_degree)."""
     splitting, variant = parse_lagrange_variant(variant, integral=True)
+    if splitting is not None:
+        raise NotImplementedError("macro-element splittings are implemented for Lagrange / DiscontinuousLagrange only")
     if variant is None:
         variant = "integral"
     interpolant_degree = None

@@ -2129,3 +2129,268 @@ int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
     return FX_OK;
 }
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// Macro elements: the element's cell is a simplicial complex (FIAT/expansions.py:449-490).
+// One MACRO instance of the generic kernel; the members of sub-cell c are the K rows
+// [c*nexp, (c+1)*nexp) of the contraction, A = [C[:, map[0]] T s_0 | C[:, map[1]] T s_1 | ...].
+// ---------------------------------------------------------------------------------------------
+struct fx_macro_element {
+    fx_ctx* ctx = nullptr;
+    int sd = 0, n = 0, variant = 0, nexp = 0, ncell = 0, nmacro = 0, ndof = 0, vdim = 1;
+    double A0[9] = {0}, b0[3] = {0};
+    fx::Program prog;
+    std::vector<double> T;       // C0 transform of one sub-cell (bubble) or empty
+    std::vector<int> map;        // [ncell][nexp]
+    std::vector<double> cscale;  // [ncell]
+    int KS = 0, MT = 0;
+    fxk::Step* d_steps = nullptr;
+    double* d_cells = nullptr;
+    double* d_afrag = nullptr;
+};
+
+namespace {
+
+// rescaled barycentric coordinates of the simplex whose map to (-1,1)^sd is (Ac, bc), as functions of the
+// parent's (-1,1)^sd coordinates xi (x = A0inv (xi - b0)): rows L[i*3+d], offsets l[i]
+void barycentric_rows(int sd, const double* Ac, const double* bc, const double* A0inv, const double* b0, double* L,
+                      double* l) {
+    double g[4][3] = {{0}}, g0[4] = {0};
+    g0[0] = 1.0;
+    for (int i = 1; i <= sd; ++i) {  // lambda_i = (X_{i-1} + 1) / 2, lambda_0 = 1 - sum
+        for (int d = 0; d < sd; ++d) g[i][d] = 0.5 * Ac[(i - 1) * sd + d];
+        g0[i] = 0.5 * (bc[i - 1] + 1.0);
+        for (int d = 0; d < sd; ++d) g[0][d] -= g[i][d];
+        g0[0] -= g0[i];
+    }
+    for (int i = 0; i <= sd; ++i) {
+        double nrm = 0.0;
+        for (int d = 0; d < sd; ++d) nrm += g[i][d] * g[i][d];
+        const double h = 1.0 / std::sqrt(nrm);  // height over the facet (reference_element.py:638-642)
+        double shift = 0.0;
+        for (int d = 0; d < sd; ++d) {
+            double t = 0.0;
+            for (int e = 0; e < sd; ++e) t += g[i][e] * A0inv[e * sd + d];
+            L[i * 3 + d] = h * t;
+            shift += t * b0[d];
+        }
+        l[i] = h * (g0[i] - shift);
+    }
+}
+
+int macro_upload_coeffs(fx_macro_element* e, int ndof, int vdim, const double* coeffs) {
+    const int rows = ndof * vdim, nexp = e->nexp, K = e->ncell * nexp;
+    if (!coeffs && rows != e->nmacro) return fail(FX_EINVAL, "identity coefficients need ndof*vdim == nmacro");
+    std::vector<double> S((size_t)rows * K, 0.0);
+    for (int i = 0; i < rows; ++i)
+        for (int c = 0; c < e->ncell; ++c)
+            for (int j = 0; j < nexp; ++j) {
+                const int m = e->map[(size_t)c * nexp + j];
+                const double cij = (coeffs ? coeffs[(size_t)i * e->nmacro + m] : (i == m ? 1.0 : 0.0)) * e->cscale[c];
+                if (cij == 0.0) continue;
+                double* dst = &S[(size_t)i * K + (size_t)c * nexp];
+                if (e->T.empty()) {
+                    dst[j] += cij;
+                } else {  // member j of the C0 set = sum_k T[j][k] raw_k
+                    const double* trow = &e->T[(size_t)j * nexp];
+                    for (int k = 0; k < nexp; ++k) dst[k] += cij * trow[k];
+                }
+            }
+    std::vector<double> F = fx::pack_a_fragments(S, rows, K);
+    if (e->d_afrag) {
+        (void)hipFree(e->d_afrag);
+        e->d_afrag = nullptr;
+    }
+    HIP_TRY(hipMalloc(&e->d_afrag, F.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(e->d_afrag, F.data(), F.size() * sizeof(double), hipMemcpyHostToDevice));
+    e->ndof = ndof;
+    e->vdim = vdim;
+    e->MT = (rows + 15) / 16;
+    e->KS = (K + 3) / 4;
+    return FX_OK;
+}
+
+template <int SD, int ORDER>
+int launch_macro_one(const fxk::TabArgs& a, int grid, int lds_bytes, hipStream_t s) {
+    auto kern = fxk::tabulate_simplex_kernel<SD, ORDER, 1, 0, 0, true>;
+    if (lds_bytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds_bytes, s, a);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+template <int SD>
+int launch_macro_sd(int order, const fxk::TabArgs& a, int grid, int lds_bytes, hipStream_t s) {
+    switch (order) {
+        case 0: return launch_macro_one<SD, 0>(a, grid, lds_bytes, s);
+        case 1: return launch_macro_one<SD, 1>(a, grid, lds_bytes, s);
+        case 2: return launch_macro_one<SD, 2>(a, grid, lds_bytes, s);
+    }
+    return fail(FX_ENOTIMPL, "derivative order %d > 2 is not implemented on the device", order);
+}
+
+}  // namespace
+
+extern "C" {
+
+int fx_macro_element_destroy(fx_macro_element* e) {
+    if (!e) return FX_OK;
+    if (e->d_steps) (void)hipFree(e->d_steps);
+    if (e->d_cells) (void)hipFree(e->d_cells);
+    if (e->d_afrag) (void)hipFree(e->d_afrag);
+    delete e;
+    return FX_OK;
+}
+
+int fx_macro_element_create(fx_ctx* ctx, int sd, int n, int variant, double scale, const double* parent_verts, int ncell,
+                            const double* cell_verts, int nmacro, const int* cell_node_map, const double* cell_scale,
+                            int ndof, int vdim, const double* coeffs, fx_macro_element** out) {
+    if (!ctx || !out || !cell_verts || !cell_node_map) return fail(FX_EINVAL, "fx_macro_element_create: null argument");
+    if (sd < 1 || sd > 3) return fail(FX_EINVAL, "Invalid number of spatial dimensions");
+    if (n < 0) return fail(FX_EINVAL, "negative degree");
+    if (variant < 0 || variant > 2) return fail(FX_EINVAL, "Invalid variant %d", variant);
+    if (variant == FX_VARIANT_BUBBLE && n < 1) return fail(FX_EINVAL, "bubble variant needs degree >= 1");
+    if (ncell < 1 || ncell > 32) return fail(FX_EINVAL, "a macro cell needs 1..32 sub-cells, got %d", ncell);
+    if (ndof < 1 || vdim < 1 || nmacro < 1) return fail(FX_EINVAL, "bad ndof/vdim/nmacro");
+    if (!(scale > 0.0)) return fail(FX_EINVAL, "a macro expansion set needs an explicit positive scale");
+    HIP_TRY(hipSetDevice(ctx->device));
+    fx_macro_element* e = new fx_macro_element;
+    e->ctx = ctx;
+    e->sd = sd;
+    e->n = n;
+    e->variant = variant;
+    e->nexp = fx::binom(n + sd, sd);
+    e->ncell = ncell;
+    e->nmacro = nmacro;
+    e->map.assign(cell_node_map, cell_node_map + (size_t)ncell * e->nexp);
+    for (int m : e->map)
+        if (m < 0 || m >= nmacro) {
+            delete e;
+            return fail(FX_EINVAL, "cell_node_map entry %d outside [0, %d)", m, nmacro);
+        }
+    e->cscale.assign(ncell, 1.0);
+    if (cell_scale) e->cscale.assign(cell_scale, cell_scale + ncell);
+    if (!host_cell_map(sd, parent_verts ? parent_verts : UFC[sd - 1], e->A0, e->b0)) {
+        delete e;
+        return fail(FX_EINVAL, "degenerate cell");
+    }
+    double A0inv[9];
+    invert_small(sd, e->A0, A0inv);
+    std::vector<double> cells(16 + (size_t)ncell * 28, 0.0);
+    barycentric_rows(sd, e->A0, e->b0, A0inv, e->b0, &cells[0], &cells[12]);
+    for (int c = 0; c < ncell; ++c) {
+        double Ac[9], bc[3];
+        if (!host_cell_map(sd, cell_verts + (size_t)c * (sd + 1) * sd, Ac, bc)) {
+            delete e;
+            return fail(FX_EINVAL, "degenerate sub-cell %d", c);
+        }
+        double* cd = &cells[16 + (size_t)c * 28];
+        for (int i = 0; i < sd; ++i) {  // X_c = Ac A0inv (xi - b0) + bc
+            double shift = 0.0;
+            for (int d = 0; d < sd; ++d) {
+                double t = 0.0;
+                for (int k = 0; k < sd; ++k) t += Ac[i * sd + k] * A0inv[k * sd + d];
+                cd[i * 3 + d] = t;
+                shift += t * e->b0[d];
+            }
+            cd[9 + i] = bc[i] - shift;
+        }
+        barycentric_rows(sd, Ac, bc, A0inv, e->b0, cd + 12, cd + 24);
+    }
+    e->prog = fx::build_program(sd, n, variant, scale);
+    if (variant == FX_VARIANT_BUBBLE) e->T = fx::c0_transform(sd, n);
+    size_t sbytes = std::max<size_t>(1, e->prog.steps.size()) * sizeof(fxk::Step);
+    hipError_t he = hipMalloc(&e->d_steps, sbytes);
+    if (he == hipSuccess && !e->prog.steps.empty())
+        he = hipMemcpy(e->d_steps, e->prog.steps.data(), e->prog.steps.size() * sizeof(fxk::Step), hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMalloc(&e->d_cells, cells.size() * sizeof(double));
+    if (he == hipSuccess) he = hipMemcpy(e->d_cells, cells.data(), cells.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (he != hipSuccess) {
+        fx_macro_element_destroy(e);
+        return fail(FX_EHIP, "fx_macro_element_create: %s", hipGetErrorString(he));
+    }
+    int rc = macro_upload_coeffs(e, ndof, vdim, coeffs);
+    if (rc != FX_OK) {
+        fx_macro_element_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return FX_OK;
+}
+
+int fx_macro_element_set_coeffs(fx_macro_element* e, int ndof, int vdim, const double* coeffs) {
+    if (!e || ndof < 1 || vdim < 1) return fail(FX_EINVAL, "fx_macro_element_set_coeffs: bad argument");
+    HIP_TRY(hipSetDevice(e->ctx->device));
+    return macro_upload_coeffs(e, ndof, vdim, coeffs);
+}
+
+int fx_macro_tabulate_batch(fx_ctx* ctx, const fx_macro_element* e, int order, int64_t nreq, int npts, const double* pts,
+                            const double* verts, double* out, void* stream) {
+    if (!ctx || !e) return fail(FX_EINVAL, "null context/element");
+    if (order < 0) return fail(FX_EINVAL, "negative derivative order");
+    if (order > 2) return fail(FX_ENOTIMPL, "derivative order %d > 2 is not implemented on the device", order);
+    if (nreq < 0 || npts < 0) return fail(FX_EINVAL, "negative batch size");
+    if (nreq == 0 || npts == 0) return FX_OK;
+    if (!pts || !out) return fail(FX_EINVAL, "null device pointer");
+    const int ntab = fx::binom(e->sd + order, e->sd);
+    const int rows = e->ndof * e->vdim;
+    fxk::TabArgs a;
+    memset(&a, 0, sizeof a);
+    a.pts = pts;
+    a.verts = verts;
+    a.out = out;
+    a.afrag = e->d_afrag;
+    a.steps = e->d_steps;
+    a.phi0 = e->prog.phi0;
+    memcpy(a.A0, e->A0, sizeof a.A0);
+    memcpy(a.b0, e->b0, sizeof a.b0);
+    a.nreq = nreq;
+    a.npts = npts;
+    a.rows = rows;
+    a.nexp = e->nexp;
+    a.nsteps = (int)e->prog.steps.size();
+    a.KS = e->KS;
+    a.MT = e->MT;
+    a.ntab = ntab;
+    a.cells = e->d_cells;
+    a.ncell = e->ncell;
+    a.unique = (e->variant == FX_VARIANT_BUBBLE && order == 0) ? 1 : 0;
+    // work-item shape under a per-wave LDS budget (as for the generic kernel, with the K rows of all sub-cells)
+    const long long budget = 40 * 1024, hard = 64 * 1024;
+    auto phi_bytes = [&](long long cols) { return ((cols + 15) / 16) * (long long)e->KS * 64 * 8; };
+    const long long reqbytes = (long long)ntab * rows * npts * 8;
+    int P = 1, pc = npts, nchunk = 1;
+    long long stage = 0;
+    if (npts <= 64 && phi_bytes((long long)ntab * npts) + reqbytes <= budget) {
+        const int pmax = 64 / npts;
+        for (int p = 2; p <= pmax; ++p)
+            if (phi_bytes((long long)p * ntab * npts) + p * reqbytes <= budget) P = p;
+        stage = P * reqbytes;
+    } else {
+        pc = std::min(npts, 64);
+        while (pc > 1 && phi_bytes((long long)ntab * pc) > budget) --pc;
+        if (phi_bytes((long long)ntab * pc) > hard)
+            return fail(FX_ENOTIMPL, "macro expansion set too large for the LDS tile (ncell=%d, nexp=%d, ntab=%d)", e->ncell,
+                        e->nexp, ntab);
+        nchunk = (npts + pc - 1) / pc;
+    }
+    a.P = P;
+    a.pc = pc;
+    a.nchunk = nchunk;
+    a.nitems = nchunk > 1 ? nreq * nchunk : (nreq + P - 1) / P;
+    a.phi_doubles = (int)(phi_bytes((long long)P * ntab * pc) / 8);
+    a.stage_doubles = stage ? (int)((stage / 8 + 1) & ~1LL) : 0;
+    const int lds_bytes = (a.phi_doubles + a.stage_doubles) * 8;
+    const int per_cu = std::max(1, std::min(16, ctx->lds_per_cu / std::max(1, lds_bytes)));
+    const int grid = (int)std::max<long long>(1, std::min<long long>(a.nitems, (long long)ctx->num_cu * per_cu * 4));
+    HIP_TRY(hipSetDevice(ctx->device));
+    switch (e->sd) {
+        case 1: return launch_macro_sd<1>(order, a, grid, lds_bytes, (hipStream_t)stream);
+        case 2: return launch_macro_sd<2>(order, a, grid, lds_bytes, (hipStream_t)stream);
+        case 3: return launch_macro_sd<3>(order, a, grid, lds_bytes, (hipStream_t)stream);
+    }
+    return fail(FX_EINVAL, "Invalid number of spatial dimensions");
+}
+
+}  // extern "C"

@@ -48,6 +48,14 @@ struct TabArgs {
     int phi_doubles;    // per-wave LDS doubles for the Phi fragments
     int stage_doubles;  // per-wave LDS doubles for the output image (0: direct stores)
     int debug;          // measurement builds only: 1 skip recurrence, 2 skip MFMA, 4 skip HBM stores
+    // MACRO instances (cells of a simplicial complex, FIAT/expansions.py:449-490): the members of
+    // sub-cell c occupy the K rows [c*nexp, (c+1)*nexp) of the Phi tile (cell-node map, C0 transform
+    // and per-cell scale are folded into the A fragments on the host).
+    // cells: [parent: L(4x3) l(4)] then per sub-cell [M(3x3) m(3) L(4x3) l(4)], all in the (-1,1)^SD
+    // coordinates of the parent: X_c = M xi + m, rescaled barycentric coordinates lambda = L xi + l
+    const double* cells;
+    int ncell;
+    int unique;         // bin every point to its first cell only (C0 sets at order 0, expansions.py:452)
 };
 
 template <int SD> struct Dims {
@@ -222,7 +230,9 @@ template <int SD, int ORDER> struct NTab {
 };
 
 // KS_T/MT_T > 0: compile-time fragment counts, A fragments live in registers.
-template <int SD, int ORDER, int NW, int KS_T, int MT_T>
+// MACRO: the element's cell is a complex; every point is binned to its sub-cell(s) and the recurrence
+// runs on the sub-cell's own collapsed coordinates.
+template <int SD, int ORDER, int NW, int KS_T, int MT_T, bool MACRO = false>
 __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs a) {
     constexpr int NTAB = NTab<SD, ORDER>::value;
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -275,6 +285,10 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
         const int rl = idiv_small(lane_c, 1.0f / (float)pcur);
         const int pl = lane_c - rl * pcur;
         const long long req = r0 + rl;
+        if constexpr (MACRO) {  // rows of the cells a point is not in must read as zero
+            for (int i = lane; i < a.phi_doubles; i += 64) phi[i] = 0.0;
+            wave_lds_fence();
+        }
 
         // ---------------- phase 1: points -> reference coordinates ----------------
         double X[SD];
@@ -304,6 +318,35 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
             }
         }
 
+        // ---------------- MACRO: bin the point (expansions.py:771-811) ----------------
+        // l1 distance = sum of the negative parts of the rescaled barycentric coordinates
+        // (reference_element.py:778-780); a point belongs to every sub-cell within 1e-12 of its
+        // distance to the parent simplex
+        unsigned cellmask = 0;
+        double seed = a.phi0;
+        if constexpr (MACRO) {
+            auto dist = [&](const double* Lp) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i <= SD; ++i) {
+                    double lam = Lp[12 + i];
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) lam += Lp[i * 3 + d] * X[d];
+                    s += fabs(lam) - lam;
+                }
+                return 0.5 * fabs(s);
+            };
+            const double tol = dist(a.cells) + 1e-12;
+            for (int c = 0; c < a.ncell; ++c)
+                if (dist(a.cells + 16 + c * 28 + 12) < tol) cellmask |= 1u << c;
+            if (a.unique) cellmask &= ~cellmask + 1u;
+            if (!active) cellmask = 0;
+            const int mult = __popc(cellmask);
+            if (mult > 1) seed = a.phi0 / (double)mult;  // non-unique binning: average (expansions.py:469-477)
+        }
+        int kb = 0;          // first K row of the current sub-cell
+        bool wr = active;    // this lane writes expansion values in the current pass
+
         // LDS slot of (member k, column c): ((c>>4)*KS + (k>>2))*64 + (k&3)*16 + (c&15)
         int colbase[NTAB];
 #pragma unroll
@@ -312,7 +355,8 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
             colbase[t] = (c >> 4) * KS * 64 + (c & 15);
         }
         auto put = [&](int k, const Jet<SD, ORDER>& j) {
-            if (!active) return;
+            if (!wr) return;
+            if constexpr (MACRO) k += kb;
             const int kofs = (k >> 2) * 64 + (k & 3) * 16;
             phi[colbase[0] + kofs] = j.v;
             if constexpr (ORDER >= 1) {
@@ -325,6 +369,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
             }
         };
         auto get = [&](int k, Jet<SD, ORDER>& j) {
+            if constexpr (MACRO) k += kb;
             const int kofs = (k >> 2) * 64 + (k & 3) * 16;
             j.v = phi[colbase[0] + kofs];
             if constexpr (ORDER >= 1) {
@@ -338,11 +383,11 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
         };
 
         // ---------------- phase 1: recurrence ----------------
-        {
+        auto recurrence = [&](const double* X, const double (*J)[SD]) {
             Jet<SD, ORDER> cur, prv, nw;
             jet_zero(cur);
             jet_zero(prv);
-            cur.v = a.phi0;
+            cur.v = seed;
             put(0, cur);
             Factors<SD, ORDER> F;
             int fcodim = -1;
@@ -367,6 +412,36 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
                 prv = cur;
                 cur = nw;
                 last_dst = st.dst;
+            }
+        };
+        if constexpr (!MACRO) {
+            recurrence(X, J);
+        } else {
+            // one pass per sub-cell a lane's point lies in (one pass unless points sit on interfaces)
+            while (__any(cellmask != 0)) {
+                wr = cellmask != 0;
+                const int c = wr ? __ffs((int)cellmask) - 1 : 0;
+                cellmask &= cellmask - 1u;
+                kb = c * a.nexp;
+                const double* cd = a.cells + 16 + c * 28;
+                double Xc[SD];
+                double Jc[SD][SD];
+#pragma unroll
+                for (int i = 0; i < SD; ++i) {
+                    double t = cd[9 + i];
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) t += cd[i * 3 + d] * X[d];
+                    Xc[i] = t;
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) {
+                        double u = 0.0;
+#pragma unroll
+                        for (int e = 0; e < SD; ++e) u += cd[i * 3 + e] * J[e][d];
+                        Jc[i][d] = u;
+                    }
+                }
+                recurrence(Xc, Jc);
+                wave_lds_fence();
             }
         }
         wave_lds_fence();

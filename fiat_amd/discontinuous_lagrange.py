@@ -29,9 +29,12 @@ class DiscontinuousLagrangeDualSet(dual_set.DualSet):
         top = ref_el.get_topology()
         sd = ref_el.get_dimension()
         entity_ids = {dim: {entity: [] for entity in top[dim]} for dim in top}
-        pts = make_lattice(ref_el.get_vertices_of_subcomplex(top[sd][0]), degree, variant=point_variant)
-        nodes = [functional.PointEvaluation(ref_el, x) for x in pts]
-        entity_ids[sd][0] = list(range(len(nodes)))
+        nodes = []
+        for cell in sorted(top[sd]):    # every cell of a complex owns its own lattice
+            first = len(nodes)
+            pts = make_lattice(ref_el.get_vertices_of_subcomplex(top[sd][cell]), degree, variant=point_variant)
+            nodes.extend(functional.PointEvaluation(ref_el, x) for x in pts)
+            entity_ids[sd][cell] = list(range(first, len(nodes)))
         super().__init__(nodes, ref_el, entity_ids)
 
 
@@ -54,12 +57,17 @@ class P0(finite_element.CiarletElement):
 class DiscontinuousLagrange(finite_element.CiarletElement):
     def __new__(cls, ref_el, degree, variant="equispaced"):
         if degree == 0:
-            parse_lagrange_variant(variant, discontinuous=True)
-            return P0(ref_el)
+            splitting, _ = parse_lagrange_variant(variant, discontinuous=True)
+            if splitting is None and not ref_el.is_macrocell():
+                return P0(ref_el)
         return super().__new__(cls)
 
     def __init__(self, ref_el, degree, variant="equispaced"):
-        _, point_variant = parse_lagrange_variant(variant, discontinuous=True)
+        splitting, point_variant = parse_lagrange_variant(variant, discontinuous=True)
+        if splitting is not None:
+            ref_el = splitting(ref_el)
+        if ref_el.is_macrocell() and ref_el.get_shape() == LINE:
+            raise NotImplementedError("macro Lagrange elements on intervals")
         if point_variant in ("equispaced", "gll", "lgc"):
             dual = BrokenLagrangeDualSet(ref_el, degree, point_variant=point_variant)
         else:

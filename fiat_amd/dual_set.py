@@ -10,8 +10,44 @@ import torch
 from . import runtime
 
 
+def merge_entities(nodes, ref_el, entity_ids, entity_permutations):
+    """Dual set on a split cell -> dual set on the parent simplex (FIAT/dual_set.py:305-335): the dofs of
+    all children of a parent entity are collected on that entity; point evaluations are re-ordered
+    lexicographically by their barycentric coordinates on the parent (:291-302), other functionals keep
+    their order."""
+    parent = ref_el.get_parent()
+    if parent is None:
+        return nodes, ref_el, entity_ids, entity_permutations
+    from . import functional
+    from .macro import xy_to_bary
+    children = ref_el.get_parent_to_children()
+    parent_ids = {}
+    if all(isinstance(node, functional.PointEvaluation) for node in nodes):
+        merged = []
+        for dim in sorted(children):
+            parent_ids[dim] = {}
+            for entity in sorted(children[dim]):
+                first = len(merged)
+                for cdim, centity in children[dim][entity]:
+                    merged.extend(nodes[i] for i in entity_ids[cdim][centity])
+                count = len(merged) - first
+                if count > 1:
+                    pts = [next(iter(node.pt_dict)) for node in merged[first:]]
+                    order = numpy.lexsort(xy_to_bary(parent.get_vertices(), pts).T)
+                    parent_ids[dim][entity] = [first + int(j) for j in order]
+                else:
+                    parent_ids[dim][entity] = list(range(first, first + count))
+    else:
+        merged = nodes
+        for dim in sorted(children):
+            parent_ids[dim] = {entity: [i for cdim, centity in children[dim][entity] for i in entity_ids[cdim][centity]]
+                               for entity in sorted(children[dim])}
+    return merged, parent, parent_ids, None
+
+
 class DualSet:
     def __init__(self, nodes, ref_el, entity_ids, entity_permutations=None):
+        nodes, ref_el, entity_ids, entity_permutations = merge_entities(nodes, ref_el, entity_ids, entity_permutations)
         self.nodes = nodes
         self.ref_el = ref_el
         self.entity_ids = entity_ids

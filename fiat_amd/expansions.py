@@ -5,6 +5,11 @@ Same constructor and methods as FIAT/expansions.py ExpansionSet (:342-635):
 ``ExpansionSet(ref_el, scale=None, variant=None)``, ``_tabulate(n, pts, order)``
 -> {alpha: (nexp, npts)}, ``tabulate(n, pts)``, ``get_num_members``,
 ``get_scale``.  Every evaluation runs on the GPU; there is no CPU path.
+
+On a macro cell (``ref_el.is_macrocell()``, macro.py) the set is the piecewise expansion set of
+FIAT/expansions.py:449-490: members numbered by ``polynomial_entity_ids`` over the complex,
+``get_cell_node_map`` (:744-768) maps the members of each sub-cell into them; binning, per-cell
+recurrence and scatter run in the MACRO instance of the generic kernel (``fx_macro_tabulate_batch``).
 """
 import math
 
@@ -29,10 +34,30 @@ def polynomial_dimension(ref_el, n, continuity=None):
             raise ValueError("Only degree zero polynomials supported on point elements.")
         return 1
     sd = ref_el.get_spatial_dimension()
+    top = ref_el.get_topology()
     if continuity == "C0":
-        top = ref_el.get_topology()
         return sum(math.comb(n - 1, dim) * len(top[dim]) for dim in top)
-    return math.comb(n + sd, sd)
+    return math.comb(n + sd, sd) * len(top[sd])
+
+
+def polynomial_cell_node_map(ref_el, n, continuity=None):
+    """(ncell, nexp) members of the complex carried by each cell, in the member order of a single
+    cell (FIAT/expansions.py:744-768)."""
+    top = ref_el.get_topology()
+    sd = ref_el.get_spatial_dimension()
+    entity_ids = polynomial_entity_ids(ref_el, n, continuity)
+    ref_ids = polynomial_entity_ids(ref_el.construct_subelement(sd), n, continuity)
+    width = sum(len(ref_ids[dim][e]) for dim in ref_ids for e in ref_ids[dim])
+    cmap = numpy.zeros((len(top[sd]), width), dtype=int)
+    if len(top[sd]) == 1:
+        conn = {0: {dim: sorted(top[dim]) for dim in top}}
+    else:
+        conn = ref_el.get_cell_connectivity()
+    for cell in sorted(top[sd]):
+        for dim in top:
+            for ref_entity, entity in enumerate(conn[cell][dim]):
+                cmap[cell, ref_ids[dim][ref_entity]] = entity_ids[dim][entity]
+    return cmap
 
 
 def polynomial_entity_ids(ref_el, n, continuity=None):
@@ -61,27 +86,52 @@ class ExpansionSet:
             raise ValueError("Invalid reference element type.")
         self.ref_el = ref_el
         self.variant = variant
+        self.num_cells = len(ref_el.get_topology()[sd])
         if scale is None:
             scale = math.sqrt(1.0 / reference_element.default_simplex(sd).volume())
         elif isinstance(scale, str):
-            vol = ref_el.volume()
-            key = scale.lower()
-            if key == "orthonormal":
-                scale = math.sqrt(1.0 / vol)
-            elif key == "l2 piola":
-                scale = 1.0 / vol
-            else:
+            if scale.lower() not in ("orthonormal", "l2 piola"):
                 raise ValueError(f"Invalid scale {scale}")
+            if self.num_cells == 1:
+                scale = self._named_scale(scale, ref_el.volume())
         self.scale = scale
         self.continuity = "C0" if variant == "bubble" else None
         self.recurrence_order = math.inf
         self._dev = {}
+        self._cell_node_map_cache = {}
+
+    @staticmethod
+    def _named_scale(name, vol):
+        return math.sqrt(1.0 / vol) if name.lower() == "orthonormal" else 1.0 / vol
 
     def get_scale(self, n, cell=0):
+        """FIAT/expansions.py:386-399."""
         sd = self.ref_el.get_spatial_dimension()
-        if n == 0 and sd > 1:
+        if isinstance(self.scale, str):
+            return self._named_scale(self.scale, self.ref_el.volume_of_subcomplex(sd, cell))
+        if n == 0 and sd > 1 and self.num_cells == 1:
             return 1
         return self.scale
+
+    def get_cell_node_map(self, n):
+        if n not in self._cell_node_map_cache:
+            self._cell_node_map_cache[n] = polynomial_cell_node_map(self.ref_el, n, self.continuity)
+        return self._cell_node_map_cache[n]
+
+    def device_polyset(self, n, coeffs=None, value_shape=()):
+        """Device polynomial set over this expansion set: fx_element on a single cell, fx_macro_element
+        on a complex."""
+        sd = self.ref_el.get_spatial_dimension()
+        if self.num_cells == 1:
+            return runtime.SimplexPolySet(sd, n, variant=self.variant, scale=self.get_scale(n),
+                                          verts=numpy.asarray(self.ref_el.get_vertices()), coeffs=coeffs,
+                                          value_shape=value_shape)
+        top = self.ref_el.get_topology()
+        cells = numpy.array([self.ref_el.get_vertices_of_subcomplex(top[sd][c]) for c in sorted(top[sd])])
+        scales = numpy.array([float(self.get_scale(n, c)) for c in sorted(top[sd])])
+        return runtime.MacroPolySet(sd, n, self.variant, scales[0], numpy.asarray(self.ref_el.get_parent().get_vertices()),
+                                    cells, self.get_cell_node_map(n), self.get_num_members(n),
+                                    cell_scale=scales / scales[0], coeffs=coeffs, value_shape=value_shape)
 
     def get_num_members(self, n):
         return polynomial_dimension(self.ref_el, n, self.continuity)
@@ -89,9 +139,7 @@ class ExpansionSet:
     def _device_set(self, n):
         """Identity-coefficient polynomial set on the device (cached per degree)."""
         if n not in self._dev:
-            sd = self.ref_el.get_spatial_dimension()
-            self._dev[n] = runtime.SimplexPolySet(sd, n, variant=self.variant, scale=self.get_scale(n),
-                                                  verts=numpy.asarray(self.ref_el.get_vertices()))
+            self._dev[n] = self.device_polyset(n)
         return self._dev[n]
 
     def _tabulate(self, n, pts, order=0):

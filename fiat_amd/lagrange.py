@@ -26,6 +26,10 @@ class LagrangeDualSet(dual_set.DualSet):
 class Lagrange(finite_element.CiarletElement):
     def __init__(self, ref_el, degree, variant="equispaced", sort_entities=False):
         splitting, point_variant = parse_lagrange_variant(variant)
+        if splitting is not None:       # macro element: the nodes and the C0 expansion set live on the split cell
+            ref_el = splitting(ref_el)
+        if ref_el.is_macrocell() and ref_el.get_shape() == LINE:
+            raise NotImplementedError("macro Lagrange elements on intervals")
         dual = LagrangeDualSet(ref_el, degree, point_variant=point_variant, sort_entities=sort_entities)
         if ref_el.get_shape() == LINE:
             poly_set = LagrangePolynomialSet(ref_el, get_lagrange_points(dual))

@@ -26,12 +26,8 @@ class PolynomialSet:
     def device_polyset(self):
         """The device-resident form used by the batched API (created once)."""
         if self._dev is None:
-            es = self.expansion_set
-            sd = self.ref_el.get_spatial_dimension()
-            self._dev = runtime.SimplexPolySet(
-                sd, self.embedded_degree, variant=es.variant, scale=es.get_scale(self.embedded_degree),
-                verts=numpy.asarray(self.ref_el.get_vertices()), coeffs=self.coeffs,
-                value_shape=self.get_shape())
+            self._dev = self.expansion_set.device_polyset(self.embedded_degree, coeffs=self.coeffs,
+                                                          value_shape=self.get_shape())
         return self._dev
 
     def tabulate(self, pts, jet_order=0):

@@ -48,17 +48,46 @@ def multiindex_equal(d, isum, imin=0):
     yield (imin,) * (d - 1) + (imax,)
 
 
+def _interior_family(n):
+    """1-D nodes of the "equispaced_interior" family: midpoints of n + 1 equal sub-intervals."""
+    return (numpy.arange(n + 1) + 0.5) / (n + 1)
+
+
+def _recursive_barycentric(alpha, family):
+    """Barycentric coordinates of lattice index ``alpha`` by the recursive rule the reference takes from
+    ``recursivenodes`` (Isaac, "Recursive, parameter-free, explicitly defined interpolation nodes for
+    simplices", 2020, eq. 3.1): on a segment the 1-D nodes; otherwise the weighted mean over the facets
+    of the rule one dimension lower, facet i (drop alpha_i) weighted with the 1-D node x_n[n - alpha_i]."""
+    n = sum(alpha)
+    x = family(n)
+    if len(alpha) == 2:
+        return numpy.array([x[alpha[0]], x[alpha[1]]])
+    acc = numpy.zeros(len(alpha))
+    total = 0.0
+    for i, ai in enumerate(alpha):
+        w = x[n - ai]
+        sub = _recursive_barycentric(alpha[:i] + alpha[i + 1:], family)
+        acc[:i] += w * sub[:i]
+        acc[i + 1:] += w * sub[i:]
+        total += w
+    return acc / total
+
+
 def make_lattice(verts, n, interior=0, variant=None):
     """Lattice of points on the simplex spanned by ``verts``; ``interior`` layers
-    next to the boundary are dropped.  Only the equispaced family is available:
-    the spectral families need the third-party ``recursivenodes`` package."""
-    if variant not in (None, "equispaced"):
-        raise NotImplementedError(f"point variant {variant!r}: only 'equispaced' is supported by fiat_amd")
+    next to the boundary are dropped.  Families: "equispaced" (alpha / n) and
+    "equispaced_interior" (recursive rule over midpoint nodes); the spectral families
+    need the third-party ``recursivenodes`` package."""
+    if variant not in (None, "equispaced", "equispaced_interior"):
+        raise NotImplementedError(f"point variant {variant!r}: only the equispaced families are supported by fiat_amd")
     X = numpy.asarray(verts, dtype=float)
     D = len(verts)
     pts = []
     for alpha in multiindex_equal(D, n, interior):
-        bary = numpy.asarray(alpha, dtype=float) / n if n > 0 else numpy.full(D, 1.0 / D)
+        if variant == "equispaced_interior":
+            bary = _recursive_barycentric(tuple(alpha), _interior_family) if D > 1 else numpy.ones(1)
+        else:
+            bary = numpy.asarray(alpha, dtype=float) / n if n > 0 else numpy.full(D, 1.0 / D)
         pts.append(tuple(numpy.dot(bary, X)))
     return pts
 

@@ -198,6 +198,87 @@ class SimplexPolySet:
         return ms.value
 
 
+class MacroPolySet:
+    """Device-resident polynomial set over the expansion set of a macro cell (fx_macro_element):
+    coeffs (ndof, *value_shape, nmacro) over the members of the complex; the kernel bins every point to
+    its sub-cell(s), runs the sub-cell's recurrence and contracts (FIAT/expansions.py:449-490)."""
+
+    def __init__(self, sd, n, variant, scale, parent_verts, cell_verts, cell_node_map, nmacro, cell_scale=None,
+                 coeffs=None, value_shape=(), ctx=None):
+        self.ctx = ctx or Context.get()
+        self.sd, self.n, self.variant = sd, n, variant
+        self.nexp = math.comb(n + sd, sd)
+        self.nmacro = int(nmacro)
+        self.value_shape = tuple(value_shape)
+        self.vdim = int(np.prod(self.value_shape, dtype=int)) if self.value_shape else 1
+        parent = np.ascontiguousarray(parent_verts, dtype=np.float64).reshape(sd + 1, sd)
+        cells = np.ascontiguousarray(cell_verts, dtype=np.float64)
+        ncell = cells.shape[0]
+        if cells.shape != (ncell, sd + 1, sd):
+            raise ValueError("cell_verts must have shape (ncell, sd+1, sd)")
+        cmap = np.ascontiguousarray(cell_node_map, dtype=np.int32)
+        if cmap.shape != (ncell, self.nexp):
+            raise ValueError(f"cell_node_map must have shape ({ncell}, {self.nexp}), got {cmap.shape}")
+        cs = None if cell_scale is None else np.ascontiguousarray(cell_scale, dtype=np.float64).reshape(ncell)
+        if coeffs is not None:
+            coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+            self.ndof = coeffs.shape[0]
+            assert coeffs.size == self.ndof * self.vdim * self.nmacro
+        else:
+            self.ndof = self.nmacro
+        self.ncell = ncell
+        h = c_void_p()
+        check(lib.fx_macro_element_create(self.ctx.handle, sd, n, VARIANTS[variant], float(scale), host_ptr(parent), ncell,
+                                          host_ptr(cells), self.nmacro, host_ptr(cmap),
+                                          None if cs is None else host_ptr(cs), self.ndof, self.vdim,
+                                          None if coeffs is None else host_ptr(coeffs), ctypes.byref(h)))
+        self.handle = h
+
+    def set_coeffs(self, coeffs):
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.float64)
+        ndof = coeffs.shape[0]
+        assert coeffs.size == ndof * self.vdim * self.nmacro
+        check(lib.fx_macro_element_set_coeffs(self.handle, ndof, self.vdim, host_ptr(coeffs)))
+        self.ndof = ndof
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                lib.fx_macro_element_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def out_shape(self, order, nreq, npts):
+        return (nreq, num_tables(self.sd, order), self.ndof) + self.value_shape + (npts,)
+
+    def tabulate_batch(self, order, pts, verts=None, out=None, stream=None, mapping=None):
+        """pts (nreq, npts, sd) -> (nreq, ntab, ndof, *value_shape, npts) on the GPU; ``verts``: per-request
+        parent cells (points are binned after pulling them back to the element's parent cell)."""
+        if mapping not in (None, "affine"):
+            raise NotImplementedError("Piola push-forwards of macro elements")
+        ctx = self.ctx
+        pts = _as_device(pts, ctx)
+        if pts.dim() != 3 or pts.shape[2] != self.sd:
+            raise ValueError(f"points must have shape (nreq, npts, {self.sd}), got {tuple(pts.shape)}")
+        nreq, npts = pts.shape[0], pts.shape[1]
+        if verts is not None:
+            verts = _as_device(verts, ctx)
+            if tuple(verts.shape) != (nreq, self.sd + 1, self.sd):
+                raise ValueError("verts must have shape (nreq, sd+1, sd)")
+        shape = self.out_shape(order, nreq, npts)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float64, device=ctx.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.float64 or not out.is_contiguous():
+            raise ValueError("out has the wrong shape/dtype/layout")
+        check(lib.fx_macro_tabulate_batch(ctx.handle, self.handle, int(order), nreq, npts, _dev_ptr(pts),
+                                          None if verts is None else _dev_ptr(verts), _dev_ptr(out), _stream_ptr(stream)))
+        return out
+
+    def kernel_name(self, order, nreq, npts, has_verts=False):
+        return "fxk::tabulate_simplex_kernel<MACRO>"
+
+
 def collapsed_quadrature(sd, m, verts=None, ctx=None, stream=None):
     """Collapsed Gauss-Jacobi rule with ``m`` points per direction on the simplex ``verts``
     ((sd+1, sd) array, default: the UFC simplex), produced on the device:

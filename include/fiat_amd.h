@@ -224,6 +224,35 @@ int fx_tables_point_major(fx_ctx* ctx, int64_t ntables, int rows, int npts, cons
 int fx_plan_kernel(fx_ctx* ctx, const fx_element* elem, int order, int64_t nreq, int npts, int has_verts, char* name,
                    int name_len);
 
+/* ---- macro elements: tabulation on a split cell (simplicial complex) ------------------
+ * ExpansionSet._tabulate on a macro cell (FIAT/expansions.py:449-490): every point is binned to the
+ * sub-cell(s) it lies in (compute_cell_point_map :771-811, l1 distance in rescaled barycentric
+ * coordinates, reference_element.py:616-644,778-780, tolerance 1e-12), the expansion set of that
+ * sub-cell is evaluated there (:411-447), divided by the multiplicity of the point where the binning
+ * is not unique (:469-477), and scattered into the members cell_node_map[cell] (:479-490,
+ * polynomial_cell_node_map :744-768); PolynomialSet.tabulate contracts with coeffs
+ * (polynomial_set.py:68-72).  Binning is unique (first cell) for C0 sets ("bubble") at order 0 (:452).
+ *   parent_verts  host [sd+1][sd]          the split simplex (NULL: UFC simplex)
+ *   cell_verts    host [ncell][sd+1][sd]   vertices of the sub-cells, in the parent's coordinates
+ *   cell_node_map host [ncell][nexp]       member of the complex for every member of a sub-cell,
+ *                                          nexp = C(n+sd, sd); values in [0, nmacro)
+ *   cell_scale    host [ncell] or NULL     per-cell factor on the expansion values (string scales
+ *                                          "orthonormal" / "L2 piola" of get_scale :386-399)
+ *   coeffs        host [ndof][vdim][nmacro] or NULL = identity (ndof*vdim == nmacro)
+ * ncell <= 32.  fx_macro_tabulate_batch: same argument meaning and output layout as
+ * fx_tabulate_batch; with per-request cells (verts) the points are pulled back to the element's
+ * parent cell for the binning and derivatives are with respect to the caller's coordinates. */
+typedef struct fx_macro_element fx_macro_element;
+int fx_macro_element_create(fx_ctx* ctx, int sd, int n, int variant, double scale,
+                            const double* parent_verts, int ncell, const double* cell_verts,
+                            int nmacro, const int* cell_node_map, const double* cell_scale,
+                            int ndof, int vdim, const double* coeffs, fx_macro_element** elem);
+int fx_macro_element_destroy(fx_macro_element* elem);
+int fx_macro_element_set_coeffs(fx_macro_element* elem, int ndof, int vdim, const double* coeffs);
+int fx_macro_tabulate_batch(fx_ctx* ctx, const fx_macro_element* elem, int order,
+                            int64_t nreq, int npts, const double* pts,
+                            const double* verts, double* out, void* stream);
+
 /* ---- measurement helpers ---------------------------------------------------------
  * Time `reps` launches of fx_tabulate_batch with HIP events on `stream`;
  * returns average milliseconds per launch in *ms. */

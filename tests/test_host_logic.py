@@ -152,8 +152,10 @@ def test_variant_parsing():
         cfv.check_format_variant("integral(-1)", 2)
     with pytest.raises(ValueError):
         cfv.parse_lagrange_variant("bogus")
-    with pytest.raises(NotImplementedError):
-        cfv.parse_lagrange_variant("equispaced,alfeld")
+    from fiat_amd import macro
+    assert cfv.parse_lagrange_variant("equispaced,alfeld") == (macro.AlfeldSplit, "equispaced")
+    with pytest.raises(NotImplementedError):      # moment-based families on split cells
+        cfv.check_format_variant("integral,alfeld", 2)
 
 
 def test_lagrange_node_placement_matches_oracle():
