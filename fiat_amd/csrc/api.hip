@@ -22,6 +22,7 @@
 #include "shared_points.hpp"
 #include "quadrature.hpp"
 #include "simplex_small.hpp"
+#include "macro_small.hpp"
 #include "table_kernels.hpp"
 #include "simplex_stacked.hpp"
 
@@ -2147,6 +2148,7 @@ struct fx_macro_element {
     fxk::Step* d_steps = nullptr;
     double* d_cells = nullptr;
     double* d_afrag = nullptr;
+    double* d_cmat = nullptr;  // [ncell][rows][nexp] blocks of the lane-local kernel (macro_small.hpp)
 };
 
 namespace {
@@ -2203,6 +2205,16 @@ int macro_upload_coeffs(fx_macro_element* e, int ndof, int vdim, const double* c
     }
     HIP_TRY(hipMalloc(&e->d_afrag, F.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(e->d_afrag, F.data(), F.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> CM((size_t)e->ncell * rows * nexp);
+    for (int c = 0; c < e->ncell; ++c)
+        for (int i = 0; i < rows; ++i)
+            for (int k = 0; k < nexp; ++k) CM[((size_t)c * rows + i) * nexp + k] = S[(size_t)i * K + (size_t)c * nexp + k];
+    if (e->d_cmat) {
+        (void)hipFree(e->d_cmat);
+        e->d_cmat = nullptr;
+    }
+    HIP_TRY(hipMalloc(&e->d_cmat, CM.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(e->d_cmat, CM.data(), CM.size() * sizeof(double), hipMemcpyHostToDevice));
     e->ndof = ndof;
     e->vdim = vdim;
     e->MT = (rows + 15) / 16;
@@ -2230,6 +2242,57 @@ int launch_macro_sd(int order, const fxk::TabArgs& a, int grid, int lds_bytes, h
     return fail(FX_ENOTIMPL, "derivative order %d > 2 is not implemented on the device", order);
 }
 
+// ---- lane-local kernel for low-order macro elements (macro_small.hpp): (sd, n, highest order) ----
+struct MacroSmallShape {
+    int sd, n, max_order;
+};
+const MacroSmallShape kMacroSmallShapes[] = {{2, 1, 2}, {2, 2, 2}, {2, 3, 2}, {3, 1, 2}, {3, 2, 2}, {3, 3, 1}};
+constexpr int MACRO_SMALL_NW = 4;
+
+template <int SD, int N, int ORDER>
+int launch_macro_small_one(const fxk::MacroSmallArgs& a, int grid, int lds_bytes, hipStream_t s) {
+    auto kern = fxk::tabulate_macro_small<SD, N, ORDER, MACRO_SMALL_NW>;
+    if (lds_bytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * MACRO_SMALL_NW), lds_bytes, s, a);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+template <int SD, int N, int MAXORDER>
+int launch_macro_small(int order, const fxk::MacroSmallArgs& a, int grid, int lds_bytes, hipStream_t s) {
+    if (order == 0) return launch_macro_small_one<SD, N, 0>(a, grid, lds_bytes, s);
+    if (order == 1) return launch_macro_small_one<SD, N, 1>(a, grid, lds_bytes, s);
+    if constexpr (MAXORDER >= 2) {
+        if (order == 2) return launch_macro_small_one<SD, N, 2>(a, grid, lds_bytes, s);
+    }
+    return fail(FX_EINVAL, "internal: order %d not instantiated for the lane-local macro kernel", order);
+}
+
+int run_macro_small(int id, int order, const fxk::MacroSmallArgs& a, int grid, int lds_bytes, hipStream_t s) {
+    switch (id) {
+        case 0: return launch_macro_small<2, 1, 2>(order, a, grid, lds_bytes, s);
+        case 1: return launch_macro_small<2, 2, 2>(order, a, grid, lds_bytes, s);
+        case 2: return launch_macro_small<2, 3, 2>(order, a, grid, lds_bytes, s);
+        case 3: return launch_macro_small<3, 1, 2>(order, a, grid, lds_bytes, s);
+        case 4: return launch_macro_small<3, 2, 2>(order, a, grid, lds_bytes, s);
+        case 5: return launch_macro_small<3, 3, 1>(order, a, grid, lds_bytes, s);
+    }
+    return fail(FX_EINVAL, "internal: unknown lane-local macro kernel %d", id);
+}
+
+bool macro_small_table_matches(int id, const fx::Program& P) {
+    switch (id) {
+        case 0: return table_matches<2, 1>(P);
+        case 1: return table_matches<2, 2>(P);
+        case 2: return table_matches<2, 3>(P);
+        case 3: return table_matches<3, 1>(P);
+        case 4: return table_matches<3, 2>(P);
+        case 5: return table_matches<3, 3>(P);
+    }
+    return false;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2239,6 +2302,7 @@ int fx_macro_element_destroy(fx_macro_element* e) {
     if (e->d_steps) (void)hipFree(e->d_steps);
     if (e->d_cells) (void)hipFree(e->d_cells);
     if (e->d_afrag) (void)hipFree(e->d_afrag);
+    if (e->d_cmat) (void)hipFree(e->d_cmat);
     delete e;
     return FX_OK;
 }
@@ -2335,6 +2399,50 @@ int fx_macro_tabulate_batch(fx_ctx* ctx, const fx_macro_element* e, int order, i
     if (!pts || !out) return fail(FX_EINVAL, "null device pointer");
     const int ntab = fx::binom(e->sd + order, e->sd);
     const int rows = e->ndof * e->vdim;
+    HIP_TRY(hipSetDevice(ctx->device));
+    {   // lane-local kernel for the registered low-order shapes
+        static const bool nosmall = getenv("FIAT_AMD_NO_MACRO_SMALL") != nullptr;
+        const long long reqbytes8 = (long long)ntab * rows * npts * 8;
+        const long long cmat_doubles = ((long long)e->ncell * rows * e->nexp + 1) & ~1LL;
+        for (size_t i = 0; !nosmall && i < sizeof(kMacroSmallShapes) / sizeof(kMacroSmallShapes[0]); ++i) {
+            const MacroSmallShape& m = kMacroSmallShapes[i];
+            if (m.sd != e->sd || m.n != e->n || order > m.max_order || npts > 64) continue;
+            if (!macro_small_table_matches((int)i, e->prog)) continue;
+            int P = std::max(1, 64 / npts);
+            while (P > 1 && P * reqbytes8 > 16 * 1024) --P;
+            const long long stage_doubles = ((long long)P * ntab * rows * npts + 1) & ~1LL;
+            const long long lds_bytes = (cmat_doubles + stage_doubles * MACRO_SMALL_NW) * 8;
+            if (lds_bytes > ctx->lds_per_cu - 1024 || lds_bytes > 150 * 1024) continue;
+            fxk::MacroSmallArgs sa;
+            memset(&sa, 0, sizeof sa);
+            sa.pts = pts;
+            sa.verts = verts;
+            sa.out = out;
+            sa.cmat = e->d_cmat;
+            sa.cells = e->d_cells;
+            for (size_t k = 0; k < e->prog.steps.size(); ++k) {
+                sa.coef[3 * k + 0] = e->prog.steps[k].A;
+                sa.coef[3 * k + 1] = e->prog.steps[k].B;
+                sa.coef[3 * k + 2] = e->prog.steps[k].C;
+            }
+            sa.phi0 = e->prog.phi0;
+            memcpy(sa.A0, e->A0, sizeof sa.A0);
+            memcpy(sa.b0, e->b0, sizeof sa.b0);
+            sa.nreq = nreq;
+            sa.nitems = (nreq + P - 1) / P;
+            sa.npts = npts;
+            sa.rows = rows;
+            sa.ncell = e->ncell;
+            sa.unique = (e->variant == FX_VARIANT_BUBBLE && order == 0) ? 1 : 0;
+            sa.P = P;
+            sa.stage_doubles = (int)stage_doubles;
+            sa.cmat_doubles = (int)cmat_doubles;
+            const int wg_per_cu = std::max(1, std::min(8, ctx->lds_per_cu / (int)lds_bytes));
+            const long long nwg = (sa.nitems + MACRO_SMALL_NW - 1) / MACRO_SMALL_NW;
+            const int grid = (int)std::max<long long>(1, std::min<long long>(nwg, (long long)ctx->num_cu * wg_per_cu * 2));
+            return run_macro_small((int)i, order, sa, grid, (int)lds_bytes, (hipStream_t)stream);
+        }
+    }
     fxk::TabArgs a;
     memset(&a, 0, sizeof a);
     a.pts = pts;

@@ -1,0 +1,217 @@
+// Macro elements of low order (gfx950): lane-local tabulation on a split cell.
+//
+// On a simplicial complex every point has its own coefficient matrix -- the columns of the members of
+// the sub-cell it lies in (FIAT/expansions.py:449-490) -- so the columns of an MFMA tile do not share
+// an A operand; stacking the sub-cells along K (the MACRO instance of the generic kernel) multiplies the
+// matrix work by the number of sub-cells.  Here lane <-> (request, point) as in simplex_small.hpp:
+// the lane bins its point (expansions.py:771-811), runs the unrolled recurrence on the sub-cell's
+// collapsed coordinates with every member in registers, and contracts with ITS sub-cell's coefficient
+// block, read from an LDS copy of all blocks (per-lane addresses; lanes in the same sub-cell read the
+// same words).  Points on interfaces take one more pass per further sub-cell and accumulate with weight
+// 1/multiplicity (:469-477).  Results leave through a per-wave LDS image of the item's whole requests.
+#pragma once
+#include "simplex_fixed.hpp"
+#include "store.hpp"
+
+namespace fxk {
+
+constexpr int MACRO_SMALL_MAXSTEPS = 19;  // (sd, n) = (3, 3): 20 members
+
+struct MacroSmallArgs {
+    const double* pts;    // [nreq][npts][SD]
+    const double* verts;  // [nreq][SD+1][SD] or nullptr
+    double* out;          // [nreq][ntab][rows][npts]
+    const double* cmat;   // [ncell][rows][nexp]: C[:, map[c]] T s_c (cell-node map, C0 transform, scale folded in)
+    const double* cells;  // [parent: L(4x3) l(4)] then per sub-cell [M(3x3) m(3) L(4x3) l(4)] (simplex_kernel.hpp)
+    double coef[3 * MACRO_SMALL_MAXSTEPS];
+    double phi0;
+    double A0[9];
+    double b0[3];
+    long long nreq, nitems;
+    int npts, rows, ncell, unique;
+    int P;              // whole requests per wave item (P * npts <= 64)
+    int stage_doubles;  // per-wave LDS doubles (>= P * ntab * rows * npts, even)
+    int cmat_doubles;   // ncell * rows * nexp, rounded up to even
+};
+
+template <int SD, int N, int ORDER, int NW>
+__global__ __launch_bounds__(64 * NW) void tabulate_macro_small(const MacroSmallArgs a) {
+    constexpr int NTAB = NTab<SD, ORDER>::value;
+    constexpr StepTable<SD, N> TBL{};
+    constexpr int NEXP = StepTable<SD, N>::NEXP;
+    static_assert(NEXP - 1 <= MACRO_SMALL_MAXSTEPS, "step table too long for MacroSmallArgs");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double* cm = lds;
+    double* stage = lds + a.cmat_doubles + (size_t)wave * a.stage_doubles;
+    for (int i = threadIdx.x; i < a.ncell * a.rows * NEXP; i += 64 * NW) cm[i] = a.cmat[i];
+    __syncthreads();
+    const int npts = a.npts, rows = a.rows;
+    const int table = rows * npts;
+    const long long reqsize = (long long)NTAB * table;
+    const float rinv = 1.0f / (float)npts;
+    const int rl = idiv_small(lane, rinv);
+    const int pl = lane - rl * npts;
+    typedef const __attribute__((address_space(4))) double CDouble;
+    const __attribute__((address_space(4))) char* kargs =
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    CDouble* kcoef = (CDouble*)(kargs + __builtin_offsetof(MacroSmallArgs, coef));
+
+    for (long long item = (long long)blockIdx.x * NW + wave; item < a.nitems; item += (long long)gridDim.x * NW) {
+        const long long r0 = item * a.P;
+        const long long left = a.nreq - r0;
+        const int Pcur = left < a.P ? (int)left : a.P;
+        const bool active = rl < Pcur;
+        const long long req = r0 + (active ? rl : 0);
+
+        // ---------------- points -> (-1,1)^SD coordinates of the parent simplex ----------------
+        double X[SD];
+        double J[SD][SD];
+        {
+            double x[SD];
+            const double* pp = a.pts + ((size_t)req * npts + (active ? pl : 0)) * SD;
+#pragma unroll
+            for (int d = 0; d < SD; ++d) x[d] = pp[d];
+            double bb[SD];
+            if (a.verts != nullptr) {
+                cell_map<SD>(a.verts + (size_t)req * (SD + 1) * SD, J, bb);
+            } else {
+#pragma unroll
+                for (int i = 0; i < SD; ++i) {
+                    bb[i] = a.b0[i];
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) J[i][d] = a.A0[i * SD + d];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < SD; ++i) {
+                double t = bb[i];
+#pragma unroll
+                for (int d = 0; d < SD; ++d) t += J[i][d] * x[d];
+                X[i] = t;
+            }
+        }
+
+        // ---------------- bin the point: l1 distance in rescaled barycentric coordinates ----------------
+        unsigned cellmask = 0;
+        {
+            auto dist = [&](const double* Lp) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i <= SD; ++i) {
+                    double lam = Lp[12 + i];
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) lam += Lp[i * 3 + d] * X[d];
+                    s += fabs(lam) - lam;
+                }
+                return 0.5 * fabs(s);
+            };
+            const double tol = dist(a.cells) + 1e-12;
+            for (int c = 0; c < a.ncell; ++c)
+                if (dist(a.cells + 16 + c * 28 + 12) < tol) cellmask |= 1u << c;
+            if (a.unique) cellmask &= ~cellmask + 1u;
+            if (!active) cellmask = 0;
+        }
+        const int mult = __popc(cellmask);
+        const double seed = mult > 1 ? a.phi0 / (double)mult : a.phi0;
+        double* sp = stage + (size_t)(active ? rl : 0) * reqsize + (active ? pl : 0);
+        if (__any(active && cellmask == 0)) {  // a point in no sub-cell: zero column (as in the reference)
+            if (active && cellmask == 0)
+                for (int i = 0; i < NTAB * rows; ++i) sp[(size_t)i * npts] = 0.0;
+        }
+
+        bool fresh = true;  // this lane's column of the image has not been written yet
+        while (__any(cellmask != 0)) {
+            const bool wr = cellmask != 0;
+            const int c = wr ? __ffs((int)cellmask) - 1 : 0;
+            cellmask &= cellmask - 1u;
+            const double* cd = a.cells + 16 + c * 28;
+            double Xc[SD];
+            double Jc[SD][SD];
+#pragma unroll
+            for (int i = 0; i < SD; ++i) {
+                double t = cd[9 + i];
+#pragma unroll
+                for (int d = 0; d < SD; ++d) t += cd[i * 3 + d] * X[d];
+                Xc[i] = t;
+#pragma unroll
+                for (int d = 0; d < SD; ++d) {
+                    double u = 0.0;
+#pragma unroll
+                    for (int e = 0; e < SD; ++e) u += cd[i * 3 + e] * J[e][d];
+                    Jc[i][d] = u;
+                }
+            }
+
+            // ---- recurrence on the sub-cell, every member in registers ----
+            Jet<SD, ORDER> mem[NEXP];
+            Jet<SD, ORDER> zero;
+            jet_zero(zero);
+            jet_zero(mem[0]);
+            mem[0].v = seed;
+            {
+                Factors<SD, ORDER> F;
+                int fcodim = -1;
+#pragma unroll
+                for (int s = 0; s < NEXP - 1; ++s) {
+                    if (TBL.codim[s] != fcodim) {
+                        fcodim = TBL.codim[s];
+                        make_factors<SD, ORDER>(F, fcodim, Xc, Jc);
+                    }
+                    apply_step<SD, ORDER>(mem[TBL.dst[s]], mem[TBL.cur[s]], TBL.prv[s] < 0 ? zero : mem[TBL.prv[s]], F,
+                                          kcoef[3 * s], kcoef[3 * s + 1], kcoef[3 * s + 2]);
+                }
+            }
+
+            // ---- lane-local contraction with the sub-cell's coefficient block -> LDS image ----
+            const double* cblock = cm + (size_t)c * rows * NEXP;
+            for (int row = 0; row < rows; ++row) {
+                const double* crow = cblock + row * NEXP;
+                double acc[NTAB];
+#pragma unroll
+                for (int t = 0; t < NTAB; ++t) acc[t] = 0.0;
+#pragma unroll
+                for (int k = 0; k < NEXP; ++k) {
+                    const double cf = crow[k];
+                    acc[0] += cf * mem[k].v;
+                    if constexpr (ORDER >= 1) {
+#pragma unroll
+                        for (int d = 0; d < SD; ++d) acc[1 + d] += cf * mem[k].g[d];
+                    }
+                    if constexpr (ORDER >= 2) {
+#pragma unroll
+                        for (int h = 0; h < SD * (SD + 1) / 2; ++h) acc[1 + SD + h] += cf * mem[k].h[h];
+                    }
+                }
+                if (wr) {
+                    if (fresh) {
+#pragma unroll
+                        for (int t = 0; t < NTAB; ++t) sp[(size_t)t * table + row * npts] = acc[t];
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < NTAB; ++t) sp[(size_t)t * table + row * npts] += acc[t];
+                    }
+                }
+            }
+            if (wr) fresh = false;
+        }
+        wave_lds_fence();
+
+        // ---------------- image -> HBM: P whole requests, contiguous ----------------
+        {
+            const long long total = (long long)Pcur * reqsize;
+            double* gout = a.out + (size_t)r0 * reqsize;
+            if ((reqsize & 1) == 0) {
+                const v2d* s2 = reinterpret_cast<const v2d*>(stage);
+                v2d* g2 = reinterpret_cast<v2d*>(gout);
+                for (long long i = lane; i < (total >> 1); i += 64) stream_store(&g2[i], s2[i]);
+            } else {
+                for (long long i = lane; i < total; i += 64) gout[i] = stage[i];
+            }
+        }
+        wave_lds_fence();  // the next item overwrites the image
+    }
+}
+
+}  // namespace fxk

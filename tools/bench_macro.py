@@ -1,0 +1,76 @@
+"""Throughput of macro-element tabulation (fx_macro_tabulate_batch) on one GPU: HIP-event time per launch,
+algorithmic bytes 8*(npts*sd + ntab*ndof*npts) per request against the 8 TB/s HBM peak, and a parity spot
+check against the oracle.  usage: python tools/bench_macro.py [--reps 50] [--only name]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CASES = {
+    # name: (family, sd, degree, variant, order, npts, batch)
+    "p2isop1_tet": ("Lagrange", 3, 1, "equispaced,iso", 1, 23, 200_000),
+    "p2isop1_tri": ("Lagrange", 2, 1, "equispaced,iso", 1, 12, 600_000),
+    "cg2_alfeld_tri": ("Lagrange", 2, 2, "equispaced,alfeld", 1, 12, 400_000),
+    "cg3_alfeld_tet": ("Lagrange", 3, 3, "equispaced,alfeld", 1, 23, 50_000),
+    "cg2_iso_tet": ("Lagrange", 3, 2, "equispaced,iso", 1, 23, 50_000),
+    "cg2_iso_tet_hess": ("Lagrange", 3, 2, "equispaced,iso", 2, 23, 20_000),
+    "dg1_alfeld_tet": ("DiscontinuousLagrange", 3, 1, "equispaced_interior,alfeld", 1, 23, 100_000),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    import fiat_amd
+    from oracle import fiat_oracle as fo
+    for name, (fam, sd, deg, variant, order, npts, batch) in CASES.items():
+        if args.only and name != args.only:
+            continue
+        el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg, variant)
+        ps = el.device_polyset()
+        rng = np.random.default_rng(7)
+        e = rng.exponential(size=(batch, npts, sd + 1))
+        pts_h = (e / e.sum(-1, keepdims=True))[..., 1:].copy()
+        pts = torch.as_tensor(pts_h).cuda()
+        out = torch.empty(ps.out_shape(order, batch, npts), dtype=torch.float64, device="cuda")
+        for _ in range(5):
+            ps.tabulate_batch(order, pts, out=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            ps.tabulate_batch(order, pts, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.reps
+        ntab = out.shape[1]
+        bytes_per_req = 8 * (npts * sd + ntab * ps.ndof * npts)
+        gbs = bytes_per_req * batch / (ms * 1e-3) / 1e9
+        # parity sample
+        S = el.get_reference_complex()
+        es = el.get_nodal_basis().get_expansion_set()
+        top = S.get_topology()
+        V = np.array(S.get_vertices())
+        cells = [V[list(top[sd][c])] for c in sorted(top[sd])]
+        got = out[:16].cpu().numpy()
+        worst = 0.0
+        for r in range(16):
+            ref = fo.macro_element_tabulate(np.array(S.get_parent().get_vertices()), cells, es.get_cell_node_map(deg), deg,
+                                            el.get_coeffs(), order, pts_h[r], es.scale, es.variant)
+            for t, a in enumerate(fo.jet_indices(sd, order)):
+                worst = max(worst, np.max(np.abs(got[r, t] - ref[a])) / max(1.0, np.max(np.abs(ref[a]))))
+        print(json.dumps({"case": name, "ncell": len(cells), "ndof": ps.ndof, "order": order, "npts": npts, "batch": batch,
+                          "ms": round(ms, 4), "tab_per_s": batch / (ms * 1e-3), "GBps": round(gbs, 1),
+                          "frac_hbm": round(gbs / 8000.0, 4), "max_rel_err": worst}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
