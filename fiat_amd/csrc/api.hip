@@ -2402,15 +2402,25 @@ int fx_macro_tabulate_batch(fx_ctx* ctx, const fx_macro_element* e, int order, i
     HIP_TRY(hipSetDevice(ctx->device));
     {   // lane-local kernel for the registered low-order shapes
         static const bool nosmall = getenv("FIAT_AMD_NO_MACRO_SMALL") != nullptr;
-        const long long reqbytes8 = (long long)ntab * rows * npts * 8;
         const long long cmat_doubles = ((long long)e->ncell * rows * e->nexp + 1) & ~1LL;
         for (size_t i = 0; !nosmall && i < sizeof(kMacroSmallShapes) / sizeof(kMacroSmallShapes[0]); ++i) {
             const MacroSmallShape& m = kMacroSmallShapes[i];
             if (m.sd != e->sd || m.n != e->n || order > m.max_order || npts > 64) continue;
             if (!macro_small_table_matches((int)i, e->prog)) continue;
-            int P = std::max(1, 64 / npts);
-            while (P > 1 && P * reqbytes8 > 16 * 1024) --P;
-            const long long stage_doubles = ((long long)P * ntab * rows * npts + 1) & ~1LL;
+            const int P = std::max(1, 64 / npts);
+            // rows per image round: <= 16 KB per wave, an even number of doubles per run where possible
+            const long long row_bytes = (long long)P * ntab * npts * 8;
+            int RC = (int)std::max<long long>(1, std::min<long long>(rows, 16 * 1024 / row_bytes));
+            if (RC < rows) {  // rounds of equal size
+                const int rounds = (rows + RC - 1) / RC;
+                RC = (rows + rounds - 1) / rounds;
+                if (((RC * npts) & 1) && (long long)(RC + 1) * row_bytes <= 16 * 1024) ++RC;
+                if (RC > 1 && ((RC * npts) & 1)) --RC;
+            }
+            const int table = rows * npts;
+            const int vec2 = ((table & 1) == 0 && (RC >= rows || ((RC * npts) & 1) == 0)) ? 1 : 0;
+            const int Ls = (RC * npts + 1) & ~1;
+            const long long stage_doubles = (long long)P * ntab * Ls;
             const long long lds_bytes = (cmat_doubles + stage_doubles * MACRO_SMALL_NW) * 8;
             if (lds_bytes > ctx->lds_per_cu - 1024 || lds_bytes > 150 * 1024) continue;
             fxk::MacroSmallArgs sa;
@@ -2435,6 +2445,9 @@ int fx_macro_tabulate_batch(fx_ctx* ctx, const fx_macro_element* e, int order, i
             sa.ncell = e->ncell;
             sa.unique = (e->variant == FX_VARIANT_BUBBLE && order == 0) ? 1 : 0;
             sa.P = P;
+            sa.RC = RC;
+            sa.Ls = Ls;
+            sa.vec2 = vec2;
             sa.stage_doubles = (int)stage_doubles;
             sa.cmat_doubles = (int)cmat_doubles;
             const int wg_per_cu = std::max(1, std::min(8, ctx->lds_per_cu / (int)lds_bytes));

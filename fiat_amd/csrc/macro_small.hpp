@@ -8,7 +8,9 @@
 // collapsed coordinates with every member in registers, and contracts with ITS sub-cell's coefficient
 // block, read from an LDS copy of all blocks (per-lane addresses; lanes in the same sub-cell read the
 // same words).  Points on interfaces take one more pass per further sub-cell and accumulate with weight
-// 1/multiplicity (:469-477).  Results leave through a per-wave LDS image of the item's whole requests.
+// 1/multiplicity (:469-477): the first pass covers every column and leaves through a per-wave LDS image,
+// RC rows of all tables of the item's requests at a time (runs of RC*npts contiguous doubles per request
+// and table), the rare further passes add their share to the stored tables directly.
 #pragma once
 #include "simplex_fixed.hpp"
 #include "store.hpp"
@@ -30,7 +32,10 @@ struct MacroSmallArgs {
     long long nreq, nitems;
     int npts, rows, ncell, unique;
     int P;              // whole requests per wave item (P * npts <= 64)
-    int stage_doubles;  // per-wave LDS doubles (>= P * ntab * rows * npts, even)
+    int RC;             // rows per image round
+    int Ls;             // image stride of one (request, table) run: >= RC * npts, even
+    int vec2;           // every run starts and ends on a 16-byte boundary: 16-byte stores
+    int stage_doubles;  // per-wave LDS doubles (>= P * ntab * Ls, even)
     int cmat_doubles;   // ncell * rows * nexp, rounded up to even
 };
 
@@ -115,13 +120,12 @@ __global__ __launch_bounds__(64 * NW) void tabulate_macro_small(const MacroSmall
         }
         const int mult = __popc(cellmask);
         const double seed = mult > 1 ? a.phi0 / (double)mult : a.phi0;
-        double* sp = stage + (size_t)(active ? rl : 0) * reqsize + (active ? pl : 0);
-        if (__any(active && cellmask == 0)) {  // a point in no sub-cell: zero column (as in the reference)
-            if (active && cellmask == 0)
-                for (int i = 0; i < NTAB * rows; ++i) sp[(size_t)i * npts] = 0.0;
-        }
+        double* gout = a.out + (size_t)r0 * reqsize;
+        const int RC = a.RC, Ls = a.Ls;
+        const int runs = Pcur * NTAB;
+        const int rla = active ? rl : 0, pla = active ? pl : 0;
 
-        bool fresh = true;  // this lane's column of the image has not been written yet
+        bool first = true;  // wave-uniform: the pass that covers every column
         while (__any(cellmask != 0)) {
             const bool wr = cellmask != 0;
             const int c = wr ? __ffs((int)cellmask) - 1 : 0;
@@ -164,11 +168,10 @@ __global__ __launch_bounds__(64 * NW) void tabulate_macro_small(const MacroSmall
                 }
             }
 
-            // ---- lane-local contraction with the sub-cell's coefficient block -> LDS image ----
+            // ---- lane-local contraction with the sub-cell's coefficient block ----
             const double* cblock = cm + (size_t)c * rows * NEXP;
-            for (int row = 0; row < rows; ++row) {
+            auto contract = [&](int row, double* acc) {
                 const double* crow = cblock + row * NEXP;
-                double acc[NTAB];
 #pragma unroll
                 for (int t = 0; t < NTAB; ++t) acc[t] = 0.0;
 #pragma unroll
@@ -184,33 +187,71 @@ __global__ __launch_bounds__(64 * NW) void tabulate_macro_small(const MacroSmall
                         for (int h = 0; h < SD * (SD + 1) / 2; ++h) acc[1 + SD + h] += cf * mem[k].h[h];
                     }
                 }
-                if (wr) {
-                    if (fresh) {
+            };
+            if (first) {
+                double* sp = stage + (size_t)rla * NTAB * Ls + pla;
+                for (int row0 = 0; row0 < rows; row0 += RC) {
+                    const int rc = min(RC, rows - row0);
+                    for (int r = 0; r < rc; ++r) {
+                        double acc[NTAB];
+                        contract(row0 + r, acc);
+                        if (active) {  // a point in no sub-cell keeps a zero column (as in the reference)
 #pragma unroll
-                        for (int t = 0; t < NTAB; ++t) sp[(size_t)t * table + row * npts] = acc[t];
+                            for (int t = 0; t < NTAB; ++t) sp[t * Ls + r * npts] = wr ? acc[t] : 0.0;
+                        }
+                    }
+                    wave_lds_fence();
+                    // image -> HBM: one run of rc*npts doubles per (request, table)
+                    const int L = rc * npts;
+                    double* gchunk = gout + (size_t)row0 * npts;
+                    if (a.vec2 && rc == rows && Ls == table) {
+                        // one round holds the item's whole requests: the image is contiguous in HBM
+                        const int total = (Pcur * NTAB * table) >> 1;
+                        const v2d* s2 = reinterpret_cast<const v2d*>(stage);
+                        v2d* g2 = reinterpret_cast<v2d*>(gout);
+                        for (int j = lane; j < total; j += 64) stream_store(&g2[j], s2[j]);
+                    } else if (a.vec2) {
+                        const int hp = L >> 1;
+                        const int total = runs * hp;
+                        const float rinv_hp = 1.0f / (float)hp;
+                        for (int j = lane; j < total; j += 64) {
+                            const int run = idiv_small(j, rinv_hp);
+                            const int q = j - run * hp;
+                            const int p = run / NTAB, t = run - p * NTAB;
+                            const v2d v = *reinterpret_cast<const v2d*>(stage + (size_t)run * Ls + 2 * q);
+                            stream_store(reinterpret_cast<v2d*>(gchunk + (size_t)p * reqsize + (size_t)t * table + 2 * q), v);
+                        }
                     } else {
+                        const int total = runs * L;
+                        const float rinv_L = 1.0f / (float)L;
+                        for (int j = lane; j < total; j += 64) {
+                            const int run = idiv_small(j, rinv_L);
+                            const int q = j - run * L;
+                            const int p = run / NTAB, t = run - p * NTAB;
+                            gchunk[(size_t)p * reqsize + (size_t)t * table + q] = stage[(size_t)run * Ls + q];
+                        }
+                    }
+                    wave_lds_fence();  // the next round overwrites the image
+                }
+                first = false;
+                if (__any(cellmask != 0)) __threadfence();  // the further passes read what this one stored
+            } else {
+                // points on interfaces: add this sub-cell's share (weight 1/multiplicity is in the seed)
+                double* gp = gout + (size_t)rla * reqsize + pla;
+                for (int row = 0; row < rows; ++row) {
+                    double acc[NTAB];
+                    contract(row, acc);
+                    if (wr) {
 #pragma unroll
-                        for (int t = 0; t < NTAB; ++t) sp[(size_t)t * table + row * npts] += acc[t];
+                        for (int t = 0; t < NTAB; ++t) gp[(size_t)t * table + (size_t)row * npts] += acc[t];
                     }
                 }
             }
-            if (wr) fresh = false;
         }
-        wave_lds_fence();
-
-        // ---------------- image -> HBM: P whole requests, contiguous ----------------
-        {
-            const long long total = (long long)Pcur * reqsize;
-            double* gout = a.out + (size_t)r0 * reqsize;
-            if ((reqsize & 1) == 0) {
-                const v2d* s2 = reinterpret_cast<const v2d*>(stage);
-                v2d* g2 = reinterpret_cast<v2d*>(gout);
-                for (long long i = lane; i < (total >> 1); i += 64) stream_store(&g2[i], s2[i]);
-            } else {
-                for (long long i = lane; i < total; i += 64) gout[i] = stage[i];
-            }
+        if (first && active) {  // no point of this item lies in any sub-cell: zero tables
+            double* gp = gout + (size_t)rl * reqsize + pl;
+            for (int i = 0; i < NTAB * rows; ++i) gp[(size_t)i * npts] = 0.0;
         }
-        wave_lds_fence();  // the next item overwrites the image
     }
 }
 
