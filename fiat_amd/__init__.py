@@ -36,6 +36,7 @@ from .brezzi_douglas_fortin_marini import BrezziDouglasFortinMarini  # noqa: F40
 from .discontinuous_raviart_thomas import DiscontinuousRaviartThomas  # noqa: F401
 from .regge import Regge  # noqa: F401
 from .argyris import Argyris  # noqa: F401
+from .hct import HsiehCloughTocher  # noqa: F401
 from .hellan_herrmann_johnson import HellanHerrmannJohnson  # noqa: F401
 from .tensor_product import FlattenedDimensions, TensorProductElement  # noqa: F401
 
@@ -58,6 +59,7 @@ supported_elements = {
     "NodalEnrichedElement": NodalEnrichedElement,
     "Regge": Regge,
     "Argyris": Argyris,
+    "Hsieh-Clough-Tocher": HsiehCloughTocher,
     "Hellan-Herrmann-Johnson": HellanHerrmannJohnson,
     "TensorProductElement": TensorProductElement,
     "FlattenedDimensions": FlattenedDimensions,

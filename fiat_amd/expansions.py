@@ -76,6 +76,35 @@ def polynomial_entity_ids(ref_el, n, continuity=None):
     return entity_ids
 
 
+def compute_cell_point_map(ref_el, pts, unique=True, tol=1e-12):
+    """{cell: indices of the points in that cell} on a complex (FIAT/expansions.py:771-811), host version for
+    the handful of points used while C^k spaces are constructed (tabulate_jumps); batched tabulation bins on
+    the device (macro_small.hpp, simplex_kernel.hpp)."""
+    sd = ref_el.get_spatial_dimension()
+    top = ref_el.get_topology()
+    pts = numpy.asarray(pts, dtype=float).reshape(-1, sd)
+    if len(top[sd]) == 1:
+        return {0: list(range(len(pts)))}
+
+    def distance(verts):
+        A, b = reference_element.make_affine_mapping(verts, numpy.eye(sd + 1))
+        h = 1.0 / numpy.linalg.norm(A, axis=1)
+        bary = pts @ (A * h[:, None]).T + b * h
+        return 0.5 * numpy.abs(numpy.sum(numpy.abs(bary) - bary, axis=-1))
+
+    limit = distance(ref_el.get_parent().get_vertices()) + tol
+    taken = numpy.zeros(len(pts), dtype=bool)
+    result = {}
+    for cell in sorted(top[sd]):
+        near = distance(ref_el.get_vertices_of_subcomplex(top[sd][cell])) < limit
+        if unique:
+            near &= ~taken
+            taken |= near
+        if near.any():
+            result[cell] = [int(i) for i in numpy.where(near)[0]]
+    return result
+
+
 class ExpansionSet:
     def __init__(self, ref_el, scale=None, variant=None):
         if variant not in (None, "bubble", "dual"):
@@ -141,6 +170,108 @@ class ExpansionSet:
         if n not in self._dev:
             self._dev[n] = self.device_polyset(n)
         return self._dev[n]
+
+    def _tabulate_on_cell(self, n, pts, order=0, cell=0):
+        """{alpha: (nexp, npts)} of the polynomials of ONE sub-cell, wherever the points lie
+        (FIAT/expansions.py:411-447) -- the single-cell kernels on the sub-cell's vertices."""
+        key = ("cell", n, cell)
+        if key not in self._dev:
+            sd = self.ref_el.get_spatial_dimension()
+            top = self.ref_el.get_topology()
+            self._dev[key] = runtime.SimplexPolySet(
+                sd, n, variant=self.variant, scale=float(self.get_scale(n, cell)),
+                verts=numpy.asarray(self.ref_el.get_vertices_of_subcomplex(top[sd][cell])))
+        sd = self.ref_el.get_spatial_dimension()
+        P = numpy.asarray(pts, dtype=float).reshape(1, -1, sd)
+        dev_order = min(order, 2)
+        out = self._dev[key].tabulate_batch(dev_order, P).cpu().numpy()[0]
+        keys = [a for k in range(dev_order + 1) for a in mis(sd, k)]
+        result = {a: out[t] for t, a in enumerate(keys)}
+        if order > 2:
+            # derivative orders beyond the kernels (super-smoothness constraints of C^k spaces, construction only):
+            # D^(beta + e_d) phi = dmat_d . D^beta phi with the differentiation matrices of the sub-cell
+            dmats = self.get_dmats(n, cell=cell)
+            for r in range(3, order + 1):
+                for alpha in mis(sd, r):
+                    d = next(i for i, a in enumerate(alpha) if a > 0)
+                    beta = tuple(a - (i == d) for i, a in enumerate(alpha))
+                    result[alpha] = dmats[d] @ result[beta]
+        return result
+
+    def get_dmats(self, degree, cell=0):
+        """dmats[d][j, i]: d/dx_d phi_j = sum_i dmats[d][j, i] phi_i on one sub-cell (FIAT/expansions.py:576-600,
+        transposed), from a device tabulation of values and gradients at a unisolvent interior lattice."""
+        key = ("dmats", degree, cell)
+        if key not in self._dev:
+            sd = self.ref_el.get_spatial_dimension()
+            top = self.ref_el.get_topology()
+            verts = self.ref_el.get_vertices_of_subcomplex(top[sd][cell])
+            lattice = reference_element.make_lattice(verts, degree, variant="equispaced_interior") if degree > 0 \
+                else [tuple(numpy.mean(numpy.asarray(verts), axis=0))]
+            tab = self._tabulate_on_cell(degree, numpy.array(lattice), 1, cell=cell)
+            V = tab[(0,) * sd]
+            self._dev[key] = [numpy.linalg.solve(V.T, tab[alpha].T).T for alpha in mis(sd, 1)]
+        return self._dev[key]
+
+    def _cells_of_facet(self, facet):
+        sd = self.ref_el.get_spatial_dimension()
+        top = self.ref_el.get_topology()
+        fv = set(top[sd - 1][facet])
+        return [c for c in sorted(top[sd]) if fv <= set(top[sd][c])]
+
+    def tabulate_normal_jumps(self, n, ref_pts, facet, order=0):
+        """(order+1, num_members, npts): jumps of the normal derivatives of order 0..order across an interior
+        facet, at points given on the reference facet (FIAT/expansions.py:492-530).  Host glue around
+        per-sub-cell device tabulations (construction of C^k spaces only)."""
+        sd = self.ref_el.get_spatial_dimension()
+        pts = numpy.asarray(self.ref_el.get_entity_transform(sd - 1, facet)(numpy.asarray(ref_pts, dtype=float)))
+        cmap = self.get_cell_node_map(n)
+        results = numpy.zeros((order + 1, self.get_num_members(n), len(pts)))
+        reference_normal = self.ref_el.compute_normal(facet)
+        for cell in self._cells_of_facet(facet):
+            normal = self.ref_el.compute_normal(facet, cell=cell)
+            side = numpy.dot(normal, reference_normal)
+            phi = self._tabulate_on_cell(n, pts, order, cell=cell)
+            v0 = phi[(0,) * sd]
+            for r in range(order + 1):
+                vr = numpy.zeros((sd,) * r + v0.shape)
+                for index in numpy.ndindex(vr.shape[:r]):
+                    vr[index] = phi[tuple(map(index.count, range(sd)))]
+                for _ in range(r):
+                    vr = numpy.tensordot(normal, vr, axes=(0, 0))
+                if r % 2 == 0 and side < 0:
+                    results[r][cmap[cell]] -= vr
+                else:
+                    results[r][cmap[cell]] += vr
+        return results
+
+    def tabulate_jumps(self, n, points, order=0):
+        """{r: (num_members, len(mis(sd, r)) * njumps)}: jumps of all derivatives of order r across the interior
+        facets that contain the given points (FIAT/expansions.py:532-574)."""
+        sd = self.ref_el.get_spatial_dimension()
+        points = numpy.asarray(points, dtype=float).reshape(-1, sd)
+        cmap = self.get_cell_node_map(n)
+        inside = compute_cell_point_map(self.ref_el, points, unique=False)
+        facet_points = {}
+        for facet in self.ref_el.get_interior_facets(sd - 1):
+            cells = self._cells_of_facet(facet)
+            if all(c in inside for c in cells):
+                facet_points[facet] = sorted(set.intersection(*(set(inside[c]) for c in cells)))
+        njumps = sum(len(v) for v in facet_points.values())
+        derivs = {cell: self._tabulate_on_cell(n, points, order, cell=cell) for cell in inside}
+        jumps = {}
+        for r in range(order + 1):
+            alphas = mis(sd, r)
+            jumps[r] = numpy.zeros((self.get_num_members(n), len(alphas) * njumps))
+            cur = 0
+            for facet, ipts in facet_points.items():
+                c0, c1 = self._cells_of_facet(facet)
+                for alpha in alphas:
+                    cols = range(cur, cur + len(ipts))
+                    jumps[r][numpy.ix_(cmap[c1], cols)] += derivs[c1][alpha][:, ipts]
+                    jumps[r][numpy.ix_(cmap[c0], cols)] -= derivs[c0][alpha][:, ipts]
+                    cur += len(ipts)
+        return jumps
 
     def _tabulate(self, n, pts, order=0):
         """{alpha: table[i, j] = D^alpha phi_i(pts[j])}; a single point drops the last axis."""

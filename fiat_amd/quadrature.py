@@ -151,6 +151,10 @@ def create_quadrature(ref_el, degree, scheme="default", entity=None):
         dimension, entity_id = entity
         Q_ref = create_quadrature(ref_el.construct_subelement(dimension), degree, scheme=scheme)
         return FacetQuadratureRule(ref_el, dimension, entity_id, Q_ref)
+    if ref_el.is_macrocell():     # composite rule that respects the splitting (FIAT/quadrature_schemes.py:71-75)
+        from .macro import MacroQuadratureRule
+        sub = ref_el.construct_subelement(ref_el.get_spatial_dimension())
+        return MacroQuadratureRule(ref_el, create_quadrature(sub, degree, scheme=scheme))
     if isinstance(ref_el, reference_element.TensorProductCell):
         try:
             degree = tuple(degree)
