@@ -2450,6 +2450,7 @@ int fx_macro_tabulate_batch(fx_ctx* ctx, const fx_macro_element* e, int order, i
             sa.vec2 = vec2;
             sa.stage_doubles = (int)stage_doubles;
             sa.cmat_doubles = (int)cmat_doubles;
+            if (const char* dbg = getenv("FIAT_AMD_DEBUG")) sa.debug = atoi(dbg);  // ablation switches (measurement only)
             const int wg_per_cu = std::max(1, std::min(8, ctx->lds_per_cu / (int)lds_bytes));
             const long long nwg = (sa.nitems + MACRO_SMALL_NW - 1) / MACRO_SMALL_NW;
             const int grid = (int)std::max<long long>(1, std::min<long long>(nwg, (long long)ctx->num_cu * wg_per_cu * 2));

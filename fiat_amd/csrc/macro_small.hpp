@@ -37,6 +37,7 @@ struct MacroSmallArgs {
     int vec2;           // every run starts and ends on a 16-byte boundary: 16-byte stores
     int stage_doubles;  // per-wave LDS doubles (>= P * ntab * Ls, even)
     int cmat_doubles;   // ncell * rows * nexp, rounded up to even
+    int debug;          // measurement only (FIAT_AMD_DEBUG): 1 bin every point to sub-cell 0, 2 skip the contraction, 4 skip HBM stores
 };
 
 template <int SD, int N, int ORDER, int NW>
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_macro_small(const MacroSmall
     const __attribute__((address_space(4))) char* kargs =
         (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
     CDouble* kcoef = (CDouble*)(kargs + __builtin_offsetof(MacroSmallArgs, coef));
+    CDouble* kcells = (CDouble*)(unsigned long long)a.cells;  // never written while the kernel runs
 
     for (long long item = (long long)blockIdx.x * NW + wave; item < a.nitems; item += (long long)gridDim.x * NW) {
         const long long r0 = item * a.P;
@@ -101,21 +103,25 @@ __global__ __launch_bounds__(64 * NW) void tabulate_macro_small(const MacroSmall
         // ---------------- bin the point: l1 distance in rescaled barycentric coordinates ----------------
         unsigned cellmask = 0;
         {
-            auto dist = [&](const double* Lp) {
+            // sum of the negative parts = 0.5 * |sum(|lambda| - lambda)| bit for bit; the tables are read through
+            // the constant address space: uniform addresses become scalar loads
+            auto dist = [&](CDouble* Lp) {
                 double s = 0.0;
 #pragma unroll
                 for (int i = 0; i <= SD; ++i) {
                     double lam = Lp[12 + i];
 #pragma unroll
                     for (int d = 0; d < SD; ++d) lam += Lp[i * 3 + d] * X[d];
-                    s += fabs(lam) - lam;
+                    s += fmax(-lam, 0.0);
                 }
-                return 0.5 * fabs(s);
+                return s;
             };
-            const double tol = dist(a.cells) + 1e-12;
-            for (int c = 0; c < a.ncell; ++c)
-                if (dist(a.cells + 16 + c * 28 + 12) < tol) cellmask |= 1u << c;
+            const double tol = dist(kcells) + 1e-12;
+            const int ncell_scan = (a.debug & 1) ? 0 : a.ncell;
+            for (int c = 0; c < ncell_scan; ++c)
+                if (dist(kcells + 16 + c * 28 + 12) < tol) cellmask |= 1u << c;
             if (a.unique) cellmask &= ~cellmask + 1u;
+            if (a.debug & 1) cellmask = 1u;
             if (!active) cellmask = 0;
         }
         const int mult = __popc(cellmask);
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_macro_small(const MacroSmall
             const bool wr = cellmask != 0;
             const int c = wr ? __ffs((int)cellmask) - 1 : 0;
             cellmask &= cellmask - 1u;
-            const double* cd = a.cells + 16 + c * 28;
+            CDouble* cd = kcells + 16 + c * 28;
             double Xc[SD];
             double Jc[SD][SD];
 #pragma unroll
@@ -192,7 +198,8 @@ __global__ __launch_bounds__(64 * NW) void tabulate_macro_small(const MacroSmall
                 double* sp = stage + (size_t)rla * NTAB * Ls + pla;
                 for (int row0 = 0; row0 < rows; row0 += RC) {
                     const int rc = min(RC, rows - row0);
-                    for (int r = 0; r < rc; ++r) {
+                    const int rc_run = (a.debug & 2) ? 0 : rc;
+                    for (int r = 0; r < rc_run; ++r) {
                         double acc[NTAB];
                         contract(row0 + r, acc);
                         if (active) {  // a point in no sub-cell keeps a zero column (as in the reference)
@@ -204,21 +211,26 @@ __global__ __launch_bounds__(64 * NW) void tabulate_macro_small(const MacroSmall
                     // image -> HBM: one run of rc*npts doubles per (request, table)
                     const int L = rc * npts;
                     double* gchunk = gout + (size_t)row0 * npts;
-                    if (a.vec2 && rc == rows && Ls == table) {
+                    if (a.debug & 4) {
+                    } else if (a.vec2 && rc == rows && Ls == table) {
                         // one round holds the item's whole requests: the image is contiguous in HBM
                         const int total = (Pcur * NTAB * table) >> 1;
                         const v2d* s2 = reinterpret_cast<const v2d*>(stage);
                         v2d* g2 = reinterpret_cast<v2d*>(gout);
+#pragma unroll 4
                         for (int j = lane; j < total; j += 64) stream_store(&g2[j], s2[j]);
                     } else if (a.vec2) {
                         const int hp = L >> 1;
                         const int total = runs * hp;
                         const float rinv_hp = 1.0f / (float)hp;
+#pragma unroll 4
                         for (int j = lane; j < total; j += 64) {
                             const int run = idiv_small(j, rinv_hp);
                             const int q = j - run * hp;
                             const int p = run / NTAB, t = run - p * NTAB;
                             const v2d v = *reinterpret_cast<const v2d*>(stage + (size_t)run * Ls + 2 * q);
+                            // (plain stores, hoping for L2 to merge the edge lines of neighbouring rounds, measured
+                            // equal or slower: 352 us stores-only either way for P3 on Alfeld tetrahedra)
                             stream_store(reinterpret_cast<v2d*>(gchunk + (size_t)p * reqsize + (size_t)t * table + 2 * q), v);
                         }
                     } else {

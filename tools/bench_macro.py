@@ -28,6 +28,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--debug", type=int, default=0, help="ablation bits of the lane-local kernel (FIAT_AMD_DEBUG), set "
+                    "after the element has been constructed: 1 no binning, 2 no contraction, 4 no HBM stores")
     args = ap.parse_args()
     import fiat_amd
     from oracle import fiat_oracle as fo
@@ -36,6 +38,8 @@ def main():
             continue
         el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg, variant)
         ps = el.device_polyset()
+        if args.debug:
+            os.environ["FIAT_AMD_DEBUG"] = str(args.debug)
         rng = np.random.default_rng(7)
         e = rng.exponential(size=(batch, npts, sd + 1))
         pts_h = (e / e.sum(-1, keepdims=True))[..., 1:].copy()
@@ -67,6 +71,7 @@ def main():
                                             el.get_coeffs(), order, pts_h[r], es.scale, es.variant)
             for t, a in enumerate(fo.jet_indices(sd, order)):
                 worst = max(worst, np.max(np.abs(got[r, t] - ref[a])) / max(1.0, np.max(np.abs(ref[a]))))
+        os.environ.pop("FIAT_AMD_DEBUG", None)
         print(json.dumps({"case": name, "ncell": len(cells), "ndof": ps.ndof, "order": order, "npts": npts, "batch": batch,
                           "ms": round(ms, 4), "tab_per_s": batch / (ms * 1e-3), "GBps": round(gbs, 1),
                           "frac_hbm": round(gbs / 8000.0, 4), "max_rel_err": worst}), flush=True)
