@@ -37,6 +37,8 @@ from .discontinuous_raviart_thomas import DiscontinuousRaviartThomas  # noqa: F4
 from .regge import Regge  # noqa: F401
 from .argyris import Argyris  # noqa: F401
 from .hct import HsiehCloughTocher  # noqa: F401
+from .gauss_lobatto_legendre import GaussLobattoLegendre  # noqa: F401
+from .gauss_legendre import GaussLegendre  # noqa: F401
 from .hellan_herrmann_johnson import HellanHerrmannJohnson  # noqa: F401
 from .tensor_product import FlattenedDimensions, TensorProductElement  # noqa: F401
 
@@ -60,6 +62,8 @@ supported_elements = {
     "Regge": Regge,
     "Argyris": Argyris,
     "Hsieh-Clough-Tocher": HsiehCloughTocher,
+    "Gauss-Lobatto-Legendre": GaussLobattoLegendre,
+    "Gauss-Legendre": GaussLegendre,
     "Hellan-Herrmann-Johnson": HellanHerrmannJohnson,
     "TensorProductElement": TensorProductElement,
     "FlattenedDimensions": FlattenedDimensions,

@@ -53,6 +53,40 @@ def _interior_family(n):
     return (numpy.arange(n + 1) + 0.5) / (n + 1)
 
 
+def _equispaced_family(n):
+    return numpy.array([0.5]) if n == 0 else numpy.linspace(0.0, 1.0, n + 1)
+
+
+def _gll_family(n):
+    """Gauss-Lobatto-Legendre nodes on [0, 1]: the end points and the roots of P_n' (= Jacobi(1,1) of degree n-1)."""
+    if n == 0:
+        return numpy.array([0.5])
+    if n == 1:
+        return numpy.array([0.0, 1.0])
+    from scipy.special import roots_jacobi
+    return numpy.concatenate([[0.0], 0.5 * (roots_jacobi(n - 1, 1, 1)[0] + 1.0), [1.0]])
+
+
+def _gl_family(n):
+    """Gauss-Legendre nodes on [0, 1]."""
+    from scipy.special import roots_jacobi
+    return 0.5 * (roots_jacobi(n + 1, 0, 0)[0] + 1.0)
+
+
+def _lgc_family(n):
+    """Chebyshev-Gauss-Lobatto nodes on [0, 1]."""
+    return numpy.array([0.5]) if n == 0 else 0.5 * (1.0 - numpy.cos(numpy.pi * numpy.arange(n + 1) / n))
+
+
+def _gc_family(n):
+    """Chebyshev-Gauss nodes on [0, 1]."""
+    return 0.5 * (1.0 - numpy.cos(numpy.pi * (2.0 * numpy.arange(n + 1) + 1.0) / (2.0 * n + 2.0)))
+
+
+_NODE_FAMILIES = {"equispaced": _equispaced_family, "equispaced_interior": _interior_family, "gll": _gll_family,
+                  "gl": _gl_family, "lgc": _lgc_family, "gc": _gc_family}
+
+
 def _recursive_barycentric(alpha, family):
     """Barycentric coordinates of lattice index ``alpha`` by the recursive rule the reference takes from
     ``recursivenodes`` (Isaac, "Recursive, parameter-free, explicitly defined interpolation nodes for
@@ -74,20 +108,25 @@ def _recursive_barycentric(alpha, family):
 
 
 def make_lattice(verts, n, interior=0, variant=None):
-    """Lattice of points on the simplex spanned by ``verts``; ``interior`` layers
-    next to the boundary are dropped.  Families: "equispaced" (alpha / n) and
-    "equispaced_interior" (recursive rule over midpoint nodes); the spectral families
-    need the third-party ``recursivenodes`` package."""
-    if variant not in (None, "equispaced", "equispaced_interior"):
-        raise NotImplementedError(f"point variant {variant!r}: only the equispaced families are supported by fiat_amd")
+    """Lattice of points on the simplex spanned by ``verts``; ``interior`` layers next to the boundary are dropped
+    (FIAT/reference_element.py:79-98).  Families: "equispaced" (alpha / n), "equispaced_interior", and the spectral
+    ones -- "gll", "gl", "lgc", "gc" -- whose 1-D nodes are carried to simplices by the recursive rule that the
+    reference takes from the third-party ``recursivenodes`` package (restated from the paper, see
+    ``_recursive_barycentric``)."""
+    variant = variant or "equispaced"
+    if variant not in _NODE_FAMILIES:
+        raise ValueError(f"unknown point variant {variant!r}")
     X = numpy.asarray(verts, dtype=float)
     D = len(verts)
+    family = _NODE_FAMILIES[variant]
     pts = []
     for alpha in multiindex_equal(D, n, interior):
-        if variant == "equispaced_interior":
-            bary = _recursive_barycentric(tuple(alpha), _interior_family) if D > 1 else numpy.ones(1)
-        else:
+        if variant == "equispaced":
             bary = numpy.asarray(alpha, dtype=float) / n if n > 0 else numpy.full(D, 1.0 / D)
+        elif D == 1:
+            bary = numpy.ones(1)
+        else:
+            bary = _recursive_barycentric(tuple(alpha), family)
         pts.append(tuple(numpy.dot(bary, X)))
     return pts
 

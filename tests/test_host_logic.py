@@ -59,8 +59,8 @@ def test_lattices_match_reference(golden, sd):
         assert np.max(np.abs(got - g[f"lattice_sd{sd}_n{n}"])) < 1e-15
         got = np.array(re_.make_lattice(cell.get_vertices(), n, 1)).reshape(-1, sd)
         assert np.max(np.abs(got - g[f"lattice_sd{sd}_n{n}_int1"]).reshape(-1), initial=0.0) < 1e-15
-    with pytest.raises(NotImplementedError):
-        re_.make_lattice(cell.get_vertices(), 3, variant="gll")
+    with pytest.raises(ValueError):
+        re_.make_lattice(cell.get_vertices(), 3, variant="no-such-family")
 
 
 def test_topology_and_entities():
