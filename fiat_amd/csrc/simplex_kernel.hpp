@@ -240,6 +240,11 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
     const int wave = threadIdx.x >> 6;
     const int KS = KS_T > 0 ? KS_T : a.KS;
     const int MT = MT_T > 0 ? MT_T : a.MT;
+    typedef const __attribute__((address_space(4))) Step CStep;
+    typedef const __attribute__((address_space(4))) double CDbl;
+    CStep* ksteps = (CStep*)(unsigned long long)a.steps;
+    CDbl* kcells = (CDbl*)(unsigned long long)a.cells;
+    (void)kcells;
 
     // ---- LDS carve-up: per wave [Phi fragments | output image]
     double* phi = lds + (size_t)wave * (a.phi_doubles + a.stage_doubles);
@@ -325,20 +330,20 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
         unsigned cellmask = 0;
         double seed = a.phi0;
         if constexpr (MACRO) {
-            auto dist = [&](const double* Lp) {
+            auto dist = [&](CDbl* Lp) {   // = 0.5 |sum(|lambda| - lambda)| bit for bit
                 double s = 0.0;
 #pragma unroll
                 for (int i = 0; i <= SD; ++i) {
                     double lam = Lp[12 + i];
 #pragma unroll
                     for (int d = 0; d < SD; ++d) lam += Lp[i * 3 + d] * X[d];
-                    s += fabs(lam) - lam;
+                    s += fmax(-lam, 0.0);
                 }
-                return 0.5 * fabs(s);
+                return s;
             };
-            const double tol = dist(a.cells) + 1e-12;
+            const double tol = dist(kcells) + 1e-12;
             for (int c = 0; c < a.ncell; ++c)
-                if (dist(a.cells + 16 + c * 28 + 12) < tol) cellmask |= 1u << c;
+                if (dist(kcells + 16 + c * 28 + 12) < tol) cellmask |= 1u << c;
             if (a.unique) cellmask &= ~cellmask + 1u;
             if (!active) cellmask = 0;
             const int mult = __popc(cellmask);
@@ -394,7 +399,17 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
             int last_dst = 0;
             const int nsteps = (a.debug & 1) ? 0 : a.nsteps;
             for (int s = 0; s < nsteps; ++s) {
-                const Step st = a.steps[s];
+                // the step table is never written while the kernel runs: read through the constant address space,
+                // so that the (uniform) loads are scalar -- next to the output stores the compiler cannot prove a
+                // plain global load invariant and falls back to vector loads
+                Step st;
+                st.dst = ksteps[s].dst;
+                st.cur = ksteps[s].cur;
+                st.prv = ksteps[s].prv;
+                st.codim = ksteps[s].codim;
+                st.A = ksteps[s].A;
+                st.B = ksteps[s].B;
+                st.C = ksteps[s].C;
                 if (st.codim != fcodim) {
                     fcodim = st.codim;
                     make_factors<SD, ORDER>(F, fcodim, X, J);
@@ -423,7 +438,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
                 const int c = wr ? __ffs((int)cellmask) - 1 : 0;
                 cellmask &= cellmask - 1u;
                 kb = c * a.nexp;
-                const double* cd = a.cells + 16 + c * 28;
+                CDbl* cd = kcells + 16 + c * 28;
                 double Xc[SD];
                 double Jc[SD][SD];
 #pragma unroll

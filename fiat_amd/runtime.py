@@ -275,8 +275,14 @@ class MacroPolySet:
                                           None if verts is None else _dev_ptr(verts), _dev_ptr(out), _stream_ptr(stream)))
         return out
 
+    _SMALL = {(2, 1): 2, (2, 2): 2, (2, 3): 2, (3, 1): 2, (3, 2): 2, (3, 3): 1}   # (sd, n): highest order (api.hip)
+
     def kernel_name(self, order, nreq, npts, has_verts=False):
-        return "fxk::tabulate_simplex_kernel<MACRO>"
+        """Kernel a request shape maps to (mirrors the selection in fx_macro_tabulate_batch)."""
+        import os
+        small = (order <= self._SMALL.get((self.sd, self.n), -1) and npts <= 64
+                 and "FIAT_AMD_NO_MACRO_SMALL" not in os.environ)
+        return "fxk::tabulate_macro_small" if small else "fxk::tabulate_simplex_kernel<MACRO>"
 
 
 def collapsed_quadrature(sd, m, verts=None, ctx=None, stream=None):

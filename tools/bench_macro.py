@@ -28,6 +28,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--only", default=None)
+    ap.add_argument("--cpu-baseline", type=float, default=0.0, metavar="SECONDS",
+                    help="also time the NumPy oracle (oracle/fiat_oracle.py macro_element_tabulate, one core) on a sample "
+                         "of the same requests for about SECONDS per case")
     ap.add_argument("--debug", type=int, default=0, help="ablation bits of the lane-local kernel (FIAT_AMD_DEBUG), set "
                     "after the element has been constructed: 1 no binning, 2 no contraction, 4 no HBM stores")
     args = ap.parse_args()
@@ -72,6 +75,27 @@ def main():
             for t, a in enumerate(fo.jet_indices(sd, order)):
                 worst = max(worst, np.max(np.abs(got[r, t] - ref[a])) / max(1.0, np.max(np.abs(ref[a]))))
         os.environ.pop("FIAT_AMD_DEBUG", None)
+        cpu = None
+        if args.cpu_baseline > 0:
+            import time
+            parent = np.array(S.get_parent().get_vertices())
+            cmap, coeffs = es.get_cell_node_map(deg), el.get_coeffs()
+            t0, done = time.perf_counter(), 0
+            while time.perf_counter() - t0 < args.cpu_baseline:
+                fo.macro_element_tabulate(parent, cells, cmap, deg, coeffs, order, pts_h[done % batch], es.scale, es.variant)
+                done += 1
+            dt = time.perf_counter() - t0
+            cpu = {"value": done / dt, "unit": "tabulations/s", "cores": 1, "kind": "port",
+                   "sample": f"{done} requests of the same workload, NumPy restatement of FIAT's macro tabulation "
+                             f"(oracle/fiat_oracle.py) on 1 host thread, {dt:.1f} s"}
+        print(json.dumps({"metric": f"element tabulations/sec ({name})", "value": batch / (ms * 1e-3), "unit": "tabulations/s",
+                          "n_gpus": 1, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": f"{fam} degree {deg} variant {variant}, order {order}, {npts} points/request, "
+                                                 f"batch {batch}"},
+                          "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                                       "traffic": None, "kernel": ps.kernel_name(order, batch, npts), "kernel_ms": ms,
+                                       "algorithmic_bytes_per_request": bytes_per_req, "requests_per_launch": batch},
+                          "cpu_baseline": cpu, "max_rel_err_vs_oracle": worst}), flush=True) if args.cpu_baseline > 0 else None
         print(json.dumps({"case": name, "ncell": len(cells), "ndof": ps.ndof, "order": order, "npts": npts, "batch": batch,
                           "ms": round(ms, 4), "tab_per_s": batch / (ms * 1e-3), "GBps": round(gbs, 1),
                           "frac_hbm": round(gbs / 8000.0, 4), "max_rel_err": worst}), flush=True)
