@@ -20,8 +20,8 @@ from .expansions import ExpansionSet  # noqa: F401
 from .macro import (AlfeldSplit, IsoSplit, PowellSabin12Split, PowellSabinSplit,  # noqa: F401
                     WorseyFarinSplit)
 from .finite_element import CiarletElement, FiniteElement  # noqa: F401
-from .lagrange import Lagrange  # noqa: F401
-from .discontinuous_lagrange import P0, DiscontinuousLagrange  # noqa: F401
+from .lagrange import GaussLobattoLegendre, Lagrange  # noqa: F401
+from .discontinuous_lagrange import P0, DiscontinuousLagrange, GaussLegendre  # noqa: F401
 from .nedelec import Nedelec  # noqa: F401
 from .raviart_thomas import RaviartThomas  # noqa: F401
 from .brezzi_douglas_marini import BrezziDouglasMarini  # noqa: F401
@@ -36,9 +36,7 @@ from .brezzi_douglas_fortin_marini import BrezziDouglasFortinMarini  # noqa: F40
 from .discontinuous_raviart_thomas import DiscontinuousRaviartThomas  # noqa: F401
 from .regge import Regge  # noqa: F401
 from .argyris import Argyris  # noqa: F401
-from .hct import HsiehCloughTocher  # noqa: F401
-from .gauss_lobatto_legendre import GaussLobattoLegendre  # noqa: F401
-from .gauss_legendre import GaussLegendre  # noqa: F401
+from .clough_tocher import HsiehCloughTocher  # noqa: F401
 from .hellan_herrmann_johnson import HellanHerrmannJohnson  # noqa: F401
 from .tensor_product import FlattenedDimensions, TensorProductElement  # noqa: F401
 

@@ -77,3 +77,10 @@ class DiscontinuousLagrange(finite_element.CiarletElement):
         else:
             poly_set = polynomial_set.ONPolynomialSet(ref_el, degree)
         super().__init__(poly_set, dual, degree, formdegree=ref_el.get_spatial_dimension())
+
+
+class GaussLegendre(DiscontinuousLagrange):
+    """Discontinuous element with nodes at the (recursive) Gauss-Legendre points (FIAT/gauss_legendre.py)."""
+
+    def __init__(self, ref_el, degree):
+        DiscontinuousLagrange.__init__(self, ref_el, degree, variant="gl")

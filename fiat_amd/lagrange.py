@@ -36,3 +36,11 @@ class Lagrange(finite_element.CiarletElement):
         else:
             poly_set = polynomial_set.ONPolynomialSet(ref_el, degree, variant="bubble", scale=1)
         super().__init__(poly_set, dual, degree, formdegree=0)
+
+
+class GaussLobattoLegendre(Lagrange):
+    """Nodes at the (recursive) Gauss-Lobatto-Legendre points, entities sorted by their vertices
+    (FIAT/gauss_lobatto_legendre.py)."""
+
+    def __init__(self, ref_el, degree):
+        Lagrange.__init__(self, ref_el, degree, variant="gll", sort_entities=True)
