@@ -6,7 +6,8 @@
         python -B tests/golden/make_golden_macro.py
 
 Writes tests/golden/macro.npz (plain numbers: vertices, topologies, cell-node maps,
-seeded points and the reference's tables/coefficients).  Covered reference code:
+seeded points and the reference's tables/coefficients) and tests/golden/hct.npz (C1 spaces as
+projectors, Hsieh-Clough-Tocher tables, composite quadrature rules).  Covered reference code:
 FIAT/macro.py:83-379 (splits), FIAT/expansions.py:449-490 (macro scatter), :744-811
 (cell-node map, point binning), FIAT/lagrange.py:75-88 and
 FIAT/discontinuous_lagrange.py:225-241 with a splitting in the variant.
@@ -129,10 +130,6 @@ def main():
     print("macro.npz:", len(out), "arrays")
 
 
-if __name__ == "__main__":
-    main()
-
-
 def hct_main():
     """C1 macro element (FIAT/hct.py, FIAT/macro.py:435-521) -> tests/golden/hct.npz."""
     from FIAT.hct import HsiehCloughTocher
@@ -166,5 +163,6 @@ def hct_main():
     print("hct.npz:", len(out), "arrays")
 
 
-if __name__ == "__main__" and os.environ.get("GOLDEN_HCT", "1") == "1":
+if __name__ == "__main__":
+    main()
     hct_main()

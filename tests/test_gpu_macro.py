@@ -190,3 +190,23 @@ def test_macro_errors():
     with pytest.raises(ValueError):                           # map entry outside the members
         runtime.MacroPolySet(2, 1, None, 1.0, np.array([[0, 0], [1, 0], [0, 1.0]]),
                              np.array([[[0, 0], [1, 0], [0, 1.0]]]), np.array([[0, 1, 7]]), 3)
+
+
+def test_macro_facet_entity_and_single_point():
+    """tabulate(order, points, entity=...) on a macro element: points given on a parent facet are mapped by the
+    parent's entity transform (FIAT/finite_element.py:181-197) and binned on the split; a single point (sd,)
+    drops the point axis (test_fiat.py:659-668)."""
+    import fiat_amd as fa
+    e = ELEMENTS["cg2_alfeld_tri"](fa)
+    T = e.get_reference_element()
+    s = np.linspace(0.05, 0.95, 7)[:, None]
+    for edge in range(3):
+        on_edge = T.get_entity_transform(1, edge)(s)
+        a = e.tabulate(1, s, entity=(1, edge))
+        b = e.tabulate(1, on_edge)
+        for alpha in a:
+            assert np.array_equal(a[alpha], b[alpha])
+    one = e.tabulate(1, np.array([0.2, 0.3]))
+    many = e.tabulate(1, np.array([[0.2, 0.3]]))
+    for alpha in one:
+        assert one[alpha].shape == (10,) and np.array_equal(one[alpha], many[alpha][:, 0])
