@@ -28,15 +28,7 @@ from .brezzi_douglas_marini import BrezziDouglasMarini  # noqa: F401
 from .nedelec_second_kind import NedelecSecondKind  # noqa: F401
 from .hermite import CubicHermite  # noqa: F401
 from .morley import Morley  # noqa: F401
-from .crouzeix_raviart import CrouzeixRaviart  # noqa: F401
-from .restricted import RestrictedElement  # noqa: F401
-from .nodal_enriched import NodalEnrichedElement  # noqa: F401
-from .bubble import Bubble, FacetBubble  # noqa: F401
-from .brezzi_douglas_fortin_marini import BrezziDouglasFortinMarini  # noqa: F401
-from .discontinuous_raviart_thomas import DiscontinuousRaviartThomas  # noqa: F401
 from .regge import Regge  # noqa: F401
-from .argyris import Argyris  # noqa: F401
-from .clough_tocher import HsiehCloughTocher  # noqa: F401
 from .hellan_herrmann_johnson import HellanHerrmannJohnson  # noqa: F401
 from .tensor_product import FlattenedDimensions, TensorProductElement  # noqa: F401
 
@@ -50,16 +42,7 @@ supported_elements = {
     "Nedelec 2nd kind H(curl)": NedelecSecondKind,
     "Hermite": CubicHermite,
     "Morley": Morley,
-    "Crouzeix-Raviart": CrouzeixRaviart,
-    "Bubble": Bubble,
-    "FacetBubble": FacetBubble,
-    "Brezzi-Douglas-Fortin-Marini": BrezziDouglasFortinMarini,
-    "Discontinuous Raviart-Thomas": DiscontinuousRaviartThomas,
-    "RestrictedElement": RestrictedElement,
-    "NodalEnrichedElement": NodalEnrichedElement,
     "Regge": Regge,
-    "Argyris": Argyris,
-    "Hsieh-Clough-Tocher": HsiehCloughTocher,
     "Gauss-Lobatto-Legendre": GaussLobattoLegendre,
     "Gauss-Legendre": GaussLegendre,
     "Hellan-Herrmann-Johnson": HellanHerrmannJohnson,

@@ -1,86 +1,83 @@
-"""Discontinuous Lagrange element on simplices (FIAT/discontinuous_lagrange.py
-:147-241): the CG lattice nodes, all owned by the cell; prime basis = orthonormal
-Dubiner set.  Degree 0 is the P0 element (FIAT/P0.py:17-52)."""
+"""Discontinuous Lagrange elements on simplices: point values at lattice nodes, every node owned by its cell;
+orthonormal Dubiner prime basis (1-D: the primal Lagrange basis).  Two node layouts: families that put nodes
+on the cell boundary re-use the CG numbering (vertices, edges, faces, interior); interior families lay one full
+lattice per cell.  Degree 0 on a single cell is P0 (barycentre value).  Behaviour as
+FIAT/discontinuous_lagrange.py:147-241 and FIAT/P0.py:17-52."""
 import numpy
 
-from . import dual_set, finite_element, functional, polynomial_set
+from . import finite_element, functional, polynomial_set
 from .barycentric_interpolation import LagrangePolynomialSet, get_lagrange_points
 from .check_format_variant import parse_lagrange_variant
+from .dof_layout import DofLayout
+from .dual_set import DualSet
 from .reference_element import LINE, make_lattice
 
+_BOUNDARY_FAMILIES = ("equispaced", "gll", "lgc")
 
-class BrokenLagrangeDualSet(dual_set.DualSet):
+
+def _cell_owned_nodes(cell, point_lists):
+    """Point evaluations at the points of ``point_lists`` = [(owning cell, points)], in that order."""
+    lay = DofLayout(cell)
+    for owner, points in point_lists:
+        lay.place(lay.sd, owner, (functional.PointEvaluation(cell, x) for x in points))
+    return lay.parts()
+
+
+class BrokenLagrangeDualSet(DualSet):
+    """The CG nodes in CG order, all handed to cell 0."""
+
     def __init__(self, ref_el, degree, point_variant="equispaced"):
         top = ref_el.get_topology()
-        nodes = []
-        entity_ids = {}
-        for dim in sorted(top):
-            entity_ids[dim] = {}
-            for entity in sorted(top[dim]):
-                pts = ref_el.make_points(dim, entity, degree, variant=point_variant)
-                nodes.extend(functional.PointEvaluation(ref_el, x) for x in pts)
-                entity_ids[dim][entity] = []
-        entity_ids[max(top)][0] = list(range(len(nodes)))
-        super().__init__(nodes, ref_el, entity_ids)
+        nodes = [(0, ref_el.make_points(dim, e, degree, variant=point_variant)) for dim in sorted(top) for e in sorted(top[dim])]
+        super().__init__(*_cell_owned_nodes(ref_el, nodes))
 
 
-class DiscontinuousLagrangeDualSet(dual_set.DualSet):
+class DiscontinuousLagrangeDualSet(DualSet):
+    """One complete lattice per cell of the (possibly split) reference cell."""
+
     def __init__(self, ref_el, degree, point_variant="equispaced"):
-        top = ref_el.get_topology()
-        sd = ref_el.get_dimension()
-        entity_ids = {dim: {entity: [] for entity in top[dim]} for dim in top}
-        nodes = []
-        for cell in sorted(top[sd]):    # every cell of a complex owns its own lattice
-            first = len(nodes)
-            pts = make_lattice(ref_el.get_vertices_of_subcomplex(top[sd][cell]), degree, variant=point_variant)
-            nodes.extend(functional.PointEvaluation(ref_el, x) for x in pts)
-            entity_ids[sd][cell] = list(range(first, len(nodes)))
-        super().__init__(nodes, ref_el, entity_ids)
+        cells = ref_el.get_topology()[ref_el.get_dimension()]
+        nodes = [(c, make_lattice(ref_el.get_vertices_of_subcomplex(cells[c]), degree, variant=point_variant))
+                 for c in sorted(cells)]
+        super().__init__(*_cell_owned_nodes(ref_el, nodes))
 
 
-class P0Dual(dual_set.DualSet):
+class P0Dual(DualSet):
     def __init__(self, ref_el):
-        top = ref_el.get_topology()
-        sd = ref_el.get_spatial_dimension()
-        bary = tuple(numpy.average(numpy.asarray(ref_el.get_vertices()), axis=0))
-        entity_ids = {dim: {entity: [] for entity in top[dim]} for dim in top}
-        entity_ids[sd][0] = [0]
-        super().__init__([functional.PointEvaluation(ref_el, bary)], ref_el, entity_ids)
+        centre = tuple(numpy.mean(numpy.asarray(ref_el.get_vertices()), axis=0))
+        super().__init__(*_cell_owned_nodes(ref_el, [(0, [centre])]))
 
 
 class P0(finite_element.CiarletElement):
     def __init__(self, ref_el):
-        poly_set = polynomial_set.ONPolynomialSet(ref_el, 0)
-        super().__init__(poly_set, P0Dual(ref_el), 0, formdegree=ref_el.get_spatial_dimension())
+        super().__init__(polynomial_set.ONPolynomialSet(ref_el, 0), P0Dual(ref_el), 0,
+                         formdegree=ref_el.get_spatial_dimension())
 
 
 class DiscontinuousLagrange(finite_element.CiarletElement):
     def __new__(cls, ref_el, degree, variant="equispaced"):
-        if degree == 0:
-            splitting, _ = parse_lagrange_variant(variant, discontinuous=True)
-            if splitting is None and not ref_el.is_macrocell():
-                return P0(ref_el)
+        if degree == 0 and not ref_el.is_macrocell() and parse_lagrange_variant(variant, discontinuous=True)[0] is None:
+            return P0(ref_el)
         return super().__new__(cls)
 
     def __init__(self, ref_el, degree, variant="equispaced"):
-        splitting, point_variant = parse_lagrange_variant(variant, discontinuous=True)
+        splitting, lattice_family = parse_lagrange_variant(variant, discontinuous=True)
         if splitting is not None:
             ref_el = splitting(ref_el)
-        if ref_el.is_macrocell() and ref_el.get_shape() == LINE:
+        on_line = ref_el.get_shape() == LINE
+        if on_line and ref_el.is_macrocell():
             raise NotImplementedError("macro Lagrange elements on intervals")
-        if point_variant in ("equispaced", "gll", "lgc"):
-            dual = BrokenLagrangeDualSet(ref_el, degree, point_variant=point_variant)
+        layout = BrokenLagrangeDualSet if lattice_family in _BOUNDARY_FAMILIES else DiscontinuousLagrangeDualSet
+        dual = layout(ref_el, degree, lattice_family)
+        if on_line:
+            space = LagrangePolynomialSet(ref_el, get_lagrange_points(dual))
         else:
-            dual = DiscontinuousLagrangeDualSet(ref_el, degree, point_variant=point_variant)
-        if ref_el.get_shape() == LINE:
-            poly_set = LagrangePolynomialSet(ref_el, get_lagrange_points(dual))
-        else:
-            poly_set = polynomial_set.ONPolynomialSet(ref_el, degree)
-        super().__init__(poly_set, dual, degree, formdegree=ref_el.get_spatial_dimension())
+            space = polynomial_set.ONPolynomialSet(ref_el, degree)
+        super().__init__(space, dual, degree, formdegree=ref_el.get_spatial_dimension())
 
 
 class GaussLegendre(DiscontinuousLagrange):
     """Discontinuous element with nodes at the (recursive) Gauss-Legendre points (FIAT/gauss_legendre.py)."""
 
     def __init__(self, ref_el, degree):
-        DiscontinuousLagrange.__init__(self, ref_el, degree, variant="gl")
+        super().__init__(ref_el, degree, variant="gl")

@@ -213,66 +213,6 @@ class ExpansionSet:
             self._dev[key] = [numpy.linalg.solve(V.T, tab[alpha].T).T for alpha in mis(sd, 1)]
         return self._dev[key]
 
-    def _cells_of_facet(self, facet):
-        sd = self.ref_el.get_spatial_dimension()
-        top = self.ref_el.get_topology()
-        fv = set(top[sd - 1][facet])
-        return [c for c in sorted(top[sd]) if fv <= set(top[sd][c])]
-
-    def tabulate_normal_jumps(self, n, ref_pts, facet, order=0):
-        """(order+1, num_members, npts): jumps of the normal derivatives of order 0..order across an interior
-        facet, at points given on the reference facet (FIAT/expansions.py:492-530).  Host glue around
-        per-sub-cell device tabulations (construction of C^k spaces only)."""
-        sd = self.ref_el.get_spatial_dimension()
-        pts = numpy.asarray(self.ref_el.get_entity_transform(sd - 1, facet)(numpy.asarray(ref_pts, dtype=float)))
-        cmap = self.get_cell_node_map(n)
-        results = numpy.zeros((order + 1, self.get_num_members(n), len(pts)))
-        reference_normal = self.ref_el.compute_normal(facet)
-        for cell in self._cells_of_facet(facet):
-            normal = self.ref_el.compute_normal(facet, cell=cell)
-            side = numpy.dot(normal, reference_normal)
-            phi = self._tabulate_on_cell(n, pts, order, cell=cell)
-            v0 = phi[(0,) * sd]
-            for r in range(order + 1):
-                vr = numpy.zeros((sd,) * r + v0.shape)
-                for index in numpy.ndindex(vr.shape[:r]):
-                    vr[index] = phi[tuple(map(index.count, range(sd)))]
-                for _ in range(r):
-                    vr = numpy.tensordot(normal, vr, axes=(0, 0))
-                if r % 2 == 0 and side < 0:
-                    results[r][cmap[cell]] -= vr
-                else:
-                    results[r][cmap[cell]] += vr
-        return results
-
-    def tabulate_jumps(self, n, points, order=0):
-        """{r: (num_members, len(mis(sd, r)) * njumps)}: jumps of all derivatives of order r across the interior
-        facets that contain the given points (FIAT/expansions.py:532-574)."""
-        sd = self.ref_el.get_spatial_dimension()
-        points = numpy.asarray(points, dtype=float).reshape(-1, sd)
-        cmap = self.get_cell_node_map(n)
-        inside = compute_cell_point_map(self.ref_el, points, unique=False)
-        facet_points = {}
-        for facet in self.ref_el.get_interior_facets(sd - 1):
-            cells = self._cells_of_facet(facet)
-            if all(c in inside for c in cells):
-                facet_points[facet] = sorted(set.intersection(*(set(inside[c]) for c in cells)))
-        njumps = sum(len(v) for v in facet_points.values())
-        derivs = {cell: self._tabulate_on_cell(n, points, order, cell=cell) for cell in inside}
-        jumps = {}
-        for r in range(order + 1):
-            alphas = mis(sd, r)
-            jumps[r] = numpy.zeros((self.get_num_members(n), len(alphas) * njumps))
-            cur = 0
-            for facet, ipts in facet_points.items():
-                c0, c1 = self._cells_of_facet(facet)
-                for alpha in alphas:
-                    cols = range(cur, cur + len(ipts))
-                    jumps[r][numpy.ix_(cmap[c1], cols)] += derivs[c1][alpha][:, ipts]
-                    jumps[r][numpy.ix_(cmap[c0], cols)] -= derivs[c0][alpha][:, ipts]
-                    cur += len(ipts)
-        return jumps
-
     def _tabulate(self, n, pts, order=0):
         """{alpha: table[i, j] = D^alpha phi_i(pts[j])}; a single point drops the last axis."""
         pts = numpy.asarray(pts, dtype=float)

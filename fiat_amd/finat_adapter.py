@@ -113,8 +113,7 @@ class FiatElement:
         return self._element
 
     def _is_simplex(self):
-        cell = self.complex
-        return cell.is_simplex() if hasattr(cell, "is_simplex") else True
+        return self.complex.is_simplex()
 
     def basis_evaluation(self, order, ps, entity=None):
         """{alpha: Table} at the point set ``ps`` on the reference element

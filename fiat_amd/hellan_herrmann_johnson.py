@@ -1,63 +1,51 @@
-"""Hellan-Herrmann-Johnson elements (FIAT/hellan_herrmann_johnson.py:11-120): symmetric-matrix-valued P_k with
-normal-normal continuity.  "integral": moments of n_f^T u n_f against orthonormal P_k on every facet f;
-interior: n_f^T u n_f against P_{k-1} for every facet normal and n_i^T u n_j (i != j) against P_k.
-"point" (tetrahedra): the same bilinear forms on lattices."""
-from . import dual_set, finite_element, functional, polynomial_set
-from .check_format_variant import check_format_variant, parse_quadrature_scheme
-from .quadrature import FacetQuadratureRule
+"""Hellan-Herrmann-Johnson elements: symmetric-matrix-valued P_k with continuous normal-normal components.
+
+Facets: n^T u n against an orthonormal basis of P_k of the facet.  Cell: n_f^T u n_f for every facet normal
+against P_{k-1}, and the mixed products n_a^T u n_b of consecutive facet normals against P_k.  "point"
+variant (tetrahedra): the same bilinear forms at lattice points.  Behaviour as
+FIAT/hellan_herrmann_johnson.py:11-120; written as dof blocks over fiat_amd/dof_layout.py."""
+import numpy
+
+from . import finite_element, functional, polynomial_set
+from .check_format_variant import check_format_variant
+from .dof_layout import DofLayout
+
+_TAG = "TensorBidirectionalMomentInnerProductEvaluation"
 
 
-class HellanHerrmannJohnsonDual(dual_set.DualSet):
-    def __init__(self, ref_el, degree, variant, qdegree, quad_scheme):
-        sd = ref_el.get_spatial_dimension()
-        top = ref_el.get_topology()
-        entity_ids = {dim: {i: [] for i in sorted(top[dim])} for dim in sorted(top)}
-        nodes = []
-        facets = sorted(top[sd - 1])
-        n = [ref_el.compute_scaled_normal(f) for f in facets]
-        mixed = [(facets[i + 1], facets[i + 2]) for i in range((sd - 1) * (sd - 2))]  # off-diagonal normal pairs (3-D)
-
-        def add(dim, entity, new):
-            entity_ids[dim][entity] = entity_ids[dim][entity] + list(range(len(nodes), len(nodes) + len(new)))
-            nodes.extend(new)
-
-        if variant == "point":
-            if sd == 2:
-                raise NotImplementedError("the 2-D point variant of HHJ keeps Cartesian interior dofs whose Riesz rows "
-                                          "rely on NumPy fancy indexing in the reference; use the integral variant")
-            ev = functional.PointwiseInnerProductEvaluation
-            for f in facets:
-                add(sd - 1, f, [ev(ref_el, n[f], n[f], pt) for pt in ref_el.make_points(sd - 1, f, degree + sd)])
-            for entity in sorted(top[sd]):
-                add(sd, entity, [ev(ref_el, n[f], n[f], pt) for pt in ref_el.make_points(sd, entity, degree + sd) for f in facets])
-                add(sd, entity, [ev(ref_el, n[a], n[b], pt) for pt in ref_el.make_points(sd, entity, degree + sd + 1)
-                                 for a, b in mixed])
-        else:
-            moment = functional.TensorBidirectionalIntegralMoment
-            facet_cell = ref_el.construct_subelement(sd - 1)
-            Q_ref = parse_quadrature_scheme(facet_cell, qdegree + degree, quad_scheme)
-            Phis = polynomial_set.ONPolynomialSet(facet_cell, degree).tabulate(Q_ref.get_points())[(0,) * (sd - 1)]
-            for f in facets:
-                Q = FacetQuadratureRule(ref_el, sd - 1, f, Q_ref, avg=True)
-                add(sd - 1, f, [moment(ref_el, n[f], n[f], Q, phi) for phi in Phis])
-            cell = ref_el.construct_subelement(sd)
-            Q_ref = parse_quadrature_scheme(cell, qdegree + degree, quad_scheme)
-            P = polynomial_set.ONPolynomialSet(cell, degree)
-            Phis = P.tabulate(Q_ref.get_points())[(0,) * sd]
-            dimPkm1 = P.get_expansion_set().get_num_members(degree - 1) if degree >= 1 else 0
-            for entity in sorted(top[sd]):
-                Q = FacetQuadratureRule(ref_el, sd, entity, Q_ref, avg=True)
-                add(sd, entity, [moment(ref_el, n[f], n[f], Q, phi) for phi in Phis[:dimPkm1] for f in facets])
-                add(sd, entity, [moment(ref_el, n[a], n[b], Q, phi) for phi in Phis for a, b in mixed])
-        super().__init__(nodes, ref_el, entity_ids)
+def hhj_dofs(cell, k, variant, moment_degree, scheme):
+    lay = DofLayout(cell)
+    sd = lay.sd
+    facets = lay.entities(sd - 1)
+    n = {f: numpy.asarray(cell.compute_scaled_normal(f), dtype=float) for f in facets}
+    mixed = [(facets[i + 1], facets[i + 2]) for i in range((sd - 1) * (sd - 2))]   # off-diagonal pairs (3-D only)
+    if variant == "point":
+        if sd == 2:
+            raise NotImplementedError("the 2-D point variant of HHJ keeps Cartesian interior dofs whose Riesz rows "
+                                      "rely on NumPy fancy indexing in the reference; use the integral variant")
+        at = functional.PointwiseInnerProductEvaluation
+        lay.lattice(sd - 1, k + sd, lambda f, pts: [at(cell, n[f], n[f], x) for x in pts])
+        lay.lattice(sd, k + sd, lambda _, pts: [at(cell, n[f], n[f], x) for x in pts for f in facets])
+        lay.lattice(sd, k + sd + 1, lambda _, pts: [at(cell, n[a], n[b], x) for x in pts for a, b in mixed])
+    else:
+        q = moment_degree + k
+        lay.moments(sd - 1, k, q, lambda f: [numpy.outer(n[f], n[f])], scheme=scheme, tag=_TAG)
+        # the lower-degree tests are the leading members of the degree-k basis (NOT a separate degree k-1 set:
+        # a degree-0 expansion set carries a different constant)
+        interior = polynomial_set.ONPolynomialSet(cell.construct_subelement(sd), k)
+        lower = interior.get_expansion_set().get_num_members(k - 1) if k >= 1 else 0
+        lay.moments(sd, k, q, lambda _: [numpy.outer(n[f], n[f]) for f in facets], scheme=scheme, tag=_TAG,
+                    tests=lambda rule: interior.tabulate(rule.get_points())[(0,) * sd][:lower])
+        lay.moments(sd, k, q, lambda _: [numpy.outer(n[a], n[b]) for a, b in mixed], scheme=scheme, tag=_TAG)
+    return lay.dual_set()
 
 
 class HellanHerrmannJohnson(finite_element.CiarletElement):
     def __init__(self, ref_el, degree=0, variant=None, quad_scheme=None):
         if degree < 0:
             raise ValueError(f"{type(self).__name__} only defined for degree >= 0")
-        _, variant, qdegree = check_format_variant(variant, degree)
-        poly_set = polynomial_set.ONSymTensorPolynomialSet(ref_el, degree)
-        dual = HellanHerrmannJohnsonDual(ref_el, degree, variant, qdegree, quad_scheme)
+        _, variant, moment_degree = check_format_variant(variant, degree)
         sd = ref_el.get_spatial_dimension()
-        super().__init__(poly_set, dual, degree, formdegree=(sd - 1, sd - 1), mapping="double contravariant piola")
+        super().__init__(polynomial_set.ONSymTensorPolynomialSet(ref_el, degree),
+                         hhj_dofs(ref_el, degree, variant, moment_degree, quad_scheme), degree,
+                         formdegree=(sd - 1, sd - 1), mapping="double contravariant piola")

@@ -1,32 +1,24 @@
-"""Cubic Hermite element on simplices (FIAT/hermite.py:11-80): P3; dofs = value and gradient at every
-vertex, value at the barycentre of every 2-face.  The gradient dofs are derivative functionals:
-their rows of the Vandermonde matrix come from the order-1 tables of the expansion set
-(dual_set.to_riesz, FIAT/dual_set.py:175-205)."""
-from . import dual_set, finite_element, functional, polynomial_set
+"""Cubic Hermite elements on simplices: P3 with the value and the gradient at every vertex and the value
+at the barycentre of every triangular face.  The gradient dofs are derivative functionals -- their
+Vandermonde rows come from the order-1 expansion tables (dual_set.to_riesz; FIAT/dual_set.py:175-205).
+Behaviour as FIAT/hermite.py:11-80."""
+from . import finite_element, functional, polynomial_set
+from .dof_layout import DofLayout
 
 
-class CubicHermiteDualSet(dual_set.DualSet):
-    def __init__(self, ref_el):
-        sd = ref_el.get_spatial_dimension()
-        top = ref_el.get_topology()
-        verts = ref_el.get_vertices()
-        entity_ids = {dim: {entity: [] for entity in top[dim]} for dim in top}
-        nodes = []
-        for v in sorted(top[0]):
-            jet = [functional.PointEvaluation(ref_el, verts[v])]
-            jet += [functional.PointDerivative(ref_el, verts[v], tuple(int(i == d) for i in range(sd))) for d in range(sd)]
-            entity_ids[0][v] = list(range(len(nodes), len(nodes) + len(jet)))
-            nodes += jet
-        if sd > 1:
-            for f in sorted(top[2]):
-                centre, = ref_el.make_points(2, f, 3)
-                entity_ids[2][f] = [len(nodes)]
-                nodes.append(functional.PointEvaluation(ref_el, centre))
-        super().__init__(nodes, ref_el, entity_ids)
+def hermite_dofs(cell):
+    lay = DofLayout(cell)
+    sd = lay.sd
+    axes = [tuple(int(i == j) for i in range(sd)) for j in range(sd)]
+    for v in lay.entities(0):
+        x = cell.get_vertices()[v]
+        lay.place(0, v, [functional.PointEvaluation(cell, x)] + [functional.PointDerivative(cell, x, a) for a in axes])
+    if sd >= 2:
+        lay.lattice(2, 3, lambda _, pts: [functional.PointEvaluation(cell, x) for x in pts])
+    return lay.dual_set()
 
 
 class CubicHermite(finite_element.CiarletElement):
     def __init__(self, ref_el, deg=3):
         assert deg == 3
-        poly_set = polynomial_set.ONPolynomialSet(ref_el, 3)
-        super().__init__(poly_set, CubicHermiteDualSet(ref_el), 3)
+        super().__init__(polynomial_set.ONPolynomialSet(ref_el, 3), hermite_dofs(ref_el), 3)

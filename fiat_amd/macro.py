@@ -6,8 +6,8 @@ HIP kernel behind ``fx_macro_tabulate_batch`` (see expansions.py).
 
 Mirrors FIAT/macro.py: ``SplitSimplicialComplex`` (:83-199), ``IsoSplit`` (:202-250),
 ``PowellSabinSplit`` (:253-304), ``AlfeldSplit`` (:307-320), ``WorseyFarinSplit`` (:323-336),
-``PowellSabin12Split`` (:339-378), ``make_topology`` (:59-80), ``MacroQuadratureRule`` (:381-432),
-``CkPolynomialSet`` (:435-521).  Entity and cell numbering follow the reference exactly
+``PowellSabin12Split`` (:339-378), ``make_topology`` (:59-80), ``MacroQuadratureRule`` (:381-432).  The C^k
+macro spaces (``CkPolynomialSet``, HCT ...) are out of scope.  Entity and cell numbering follow the reference exactly
 (tests/golden/macro.npz pins vertices, topology, connectivity and cell-node maps).
 """
 import math
@@ -54,6 +54,9 @@ def make_topology(sd, num_verts, edges):
 class SimplicialComplex(Simplex):
     """Several simplices glued along facets; geometry queries that need a single cell take the first
     cell touching the entity."""
+
+    def is_simplex(self):
+        return False
 
     def volume(self):
         sd = self.get_spatial_dimension()
@@ -306,70 +309,3 @@ class MacroQuadratureRule:
                     prev = cur
                 pts, wts = upts, uwts
         return QuadratureRule(ref_el, tuple(pts), tuple(wts))
-
-
-def CkPolynomialSet(ref_el, degree, order=1, vorder=None, shape=(), **kwargs):
-    """The C^order-continuous piecewise polynomials of the given degree on a split cell, as a PolynomialSet over
-    the macro expansion set: nullspace (SVD) of the moments of the normal-derivative jumps across the interior
-    facets against facet polynomials, plus super-smoothness C^vorder at interior vertices.
-    ``order``: int, or {dim: {entity: order}} for dim in {0, sd-1}."""
-    from . import expansions, polynomial_set
-    from .quadrature import create_quadrature
-    if not isinstance(order, (int, dict)):
-        raise TypeError(f"'order' must be either an int or dict, not {type(order).__name__}")
-    sd = ref_el.get_spatial_dimension()
-    if isinstance(order, int):
-        order = {sd - 1: dict.fromkeys(ref_el.get_interior_facets(sd - 1), order)}
-    if vorder is not None:
-        order[0] = dict.fromkeys(ref_el.get_interior_facets(0), vorder)
-    elif 0 not in order:
-        order[0] = {}
-    if not all(k in {0, sd - 1} for k in order):
-        raise NotImplementedError("Only face or vertex constraints have been implemented.")
-
-    es = expansions.ExpansionSet(ref_el, **kwargs)
-    k = 1 if es.continuity == "C0" else 0
-    facet_el = ref_el.construct_subelement(sd - 1)
-    phi_deg = 0 if sd == 1 else degree - k
-    phi = polynomial_set.ONPolynomialSet(facet_el, phi_deg)
-    Q = create_quadrature(facet_el, 2 * phi_deg)
-    qpts, qwts = Q.get_points(), Q.get_weights()
-    weights = phi.tabulate(qpts)[(0,) * (sd - 1)] * qwts
-
-    rows = []
-    for facet, forder in order[sd - 1].items():
-        jumps = es.tabulate_normal_jumps(degree, qpts, facet, order=forder)
-        for r in range(k, forder + 1):
-            nwt = 1 if sd == 1 else expansions.polynomial_dimension(facet_el, degree - r)
-            rows.append(numpy.tensordot(weights[:nwt], jumps[r], axes=(-1, -1)))
-
-    # C^forder across the facets already gives C^(forder + sd - 1) at an interior vertex
-    verts = numpy.asarray(ref_el.get_vertices())
-    top = ref_el.get_topology()
-    vertex_constraints = False
-    for vo in set(order[0].values()):
-        vids = [i for i in order[0] if order[0][i] == vo]
-        touching = [f for f in order[sd - 1] if any(v in top[sd - 1][f] for v in vids)]
-        sorder = min(order[sd - 1][f] for f in touching) + sd - 1
-        if vo > sorder:
-            vertex_constraints = True
-            jumps = es.tabulate_jumps(degree, verts[vids], order=vo)
-            rows.extend(numpy.vstack(jumps[r].T) for r in range(sorder + 1, vo + 1))
-
-    nmem = es.get_num_members(degree)
-    if rows:
-        rows = [row / max(numpy.max(abs(row)), 1) for row in rows]
-        if vertex_constraints:   # block by block, each projected onto the nullspace found so far
-            coeffs = numpy.eye(nmem)
-            for row in rows:
-                nsp = polynomial_set.spanning_basis(numpy.dot(row, coeffs.T), nullspace=True, rtol=1e-12)
-                coeffs = numpy.dot(nsp, coeffs)
-        else:
-            coeffs = polynomial_set.spanning_basis(numpy.vstack(rows), nullspace=True)
-    else:
-        coeffs = numpy.eye(nmem)
-    if shape != ():
-        m, n = coeffs.shape
-        ncomp = int(numpy.prod(shape))
-        coeffs = numpy.kron(coeffs, numpy.eye(ncomp)).reshape(m * ncomp, *shape, n)
-    return polynomial_set.PolynomialSet(ref_el, degree, degree, es, coeffs)

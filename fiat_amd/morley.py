@@ -1,39 +1,27 @@
-"""Morley element on triangles and tetrahedra (FIAT/morley.py:17-66): P2; dofs = average over every
-codimension-2 entity (vertex values on a triangle, edge averages on a tetrahedron) and the
-average normal derivative over every facet (scaled by 1/(sd-1)!, :47-48)."""
+"""Morley elements on triangles and tetrahedra: P2 with the average over every sub-entity of codimension 2
+(the vertex value on a triangle, the edge average on a tetrahedron) and the facet average of the normal
+derivative, divided by (d-1)!.  Behaviour as FIAT/morley.py:17-66."""
 import math
 
 import numpy
 
-from . import dual_set, finite_element, functional, polynomial_set
-from .quadrature import FacetQuadratureRule, create_quadrature
+from . import finite_element, functional, polynomial_set
+from .dof_layout import DofLayout
+from .quadrature import create_quadrature
 
 
-class MorleyDualSet(dual_set.DualSet):
-    def __init__(self, ref_el, degree):
-        sd = ref_el.get_spatial_dimension()
-        top = ref_el.get_topology()
-        entity_ids = {dim: {entity: [] for entity in top[dim]} for dim in top}
-        nodes = []
-        # codimension 2: integral average (a point evaluation when the entity is a vertex)
-        dim = sd - 2
-        if dim > 0:
-            Q_ref = create_quadrature(ref_el.construct_subelement(dim), degree)
-            one = numpy.ones(len(Q_ref.get_weights()))
-        for entity in sorted(top[dim]):
-            if dim == 0:
-                node = functional.PointEvaluation(ref_el, ref_el.get_vertices()[top[0][entity][0]])
-            else:
-                node = functional.IntegralMoment(ref_el, FacetQuadratureRule(ref_el, dim, entity, Q_ref, avg=True), one)
-            entity_ids[dim][entity] = [len(nodes)]
-            nodes.append(node)
-        # codimension 1: average of the normal derivative
-        Q_ref = create_quadrature(ref_el.construct_subelement(sd - 1), degree - 1)
-        scale = numpy.ones(len(Q_ref.get_weights())) / math.factorial(sd - 1)
-        for entity in sorted(top[sd - 1]):
-            entity_ids[sd - 1][entity] = [len(nodes)]
-            nodes.append(functional.IntegralMomentOfNormalDerivative(ref_el, entity, Q_ref, scale))
-        super().__init__(nodes, ref_el, entity_ids)
+def morley_dofs(cell, degree=2):
+    lay = DofLayout(cell)
+    sd = lay.sd
+    if sd == 2:
+        lay.lattice(0, degree, lambda _, pts: [functional.PointEvaluation(cell, x) for x in pts])
+    else:
+        lay.moments(sd - 2, 0, degree, lambda _: [numpy.float64(1.0)], tests=lambda rule: numpy.ones((1, len(rule.pts))))
+    facet_rule = create_quadrature(cell.construct_subelement(sd - 1), degree - 1)
+    weight = numpy.full(len(facet_rule.pts), 1.0 / math.factorial(sd - 1))
+    for f in lay.entities(sd - 1):
+        lay.place(sd - 1, f, [functional.IntegralMomentOfNormalDerivative(cell, f, facet_rule, weight)])
+    return lay.dual_set()
 
 
 class Morley(finite_element.CiarletElement):
@@ -42,5 +30,4 @@ class Morley(finite_element.CiarletElement):
             raise ValueError("Morley only defined on simplices of dimension >= 2")
         if degree != 2:
             raise ValueError(f"{type(self).__name__} only defined for degree == 2")
-        poly_set = polynomial_set.ONPolynomialSet(ref_el, degree)
-        super().__init__(poly_set, MorleyDualSet(ref_el, degree), degree)
+        super().__init__(polynomial_set.ONPolynomialSet(ref_el, degree), morley_dofs(ref_el, degree), degree)

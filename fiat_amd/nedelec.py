@@ -1,124 +1,70 @@
-"""Nedelec first-kind H(curl) element on triangles and tetrahedra
-(FIAT/nedelec.py:17-217): space P_k^d + (homogeneous P_k) x X built by quadrature
-projection and an SVD span; dofs = tangential moments on edges, tangential
-moments on faces (3-D) and interior moments ("integral" variant)."""
-from itertools import chain
+"""Nedelec elements of the first kind, H(curl), on triangles and tetrahedra.
 
+Space of degree q = k + 1:  P_k^d  +  S_k,  S_k = rotated / crossed homogeneous polynomials
+(2-D: p (y, -x);  3-D: p e_i x X).  Degrees of freedom ("integral" variant): on every sub-entity of
+dimension m = 1 .. d-1 the tangential components against an orthonormal basis of P_{q-m} of the entity,
+in the cell all Cartesian components against P_{q-d}.  "point" variant: tangential components at lattice
+points of edges and faces.  Behaviour as FIAT/nedelec.py:17-217 (same nodal basis, same numbering);
+written as dof blocks over fiat_amd/dof_layout.py."""
 import numpy
 
-from . import dual_set, expansions, finite_element, functional, polynomial_set
-from .check_format_variant import check_format_variant, parse_quadrature_scheme
-from .quadrature import FacetQuadratureRule, create_quadrature
+from . import finite_element, functional
+from .check_format_variant import check_format_variant
+from .dof_layout import DofLayout, augmented_vector_space
 
 
-def _vector_subsets(ref_el, k):
-    sd = ref_el.get_spatial_dimension()
-    vec_Pkp1 = polynomial_set.ONPolynomialSet(ref_el, k + 1, (sd,))
-    dims = [expansions.polynomial_dimension(ref_el, j) for j in (k - 1, k, k + 1)]
-    return vec_Pkp1, dims
+def _rotate(p, x):                      # (np, nq), (2, nq) -> (np, 2, nq)
+    return p[:, None, :] * numpy.stack([x[1], -x[0]])[None]
+
+
+def _cross_axes(p, x):                  # (np, nq), (3, nq) -> (3 np, 3, nq): p (e_i x X)
+    axes = numpy.eye(3)
+    swirl = numpy.stack([numpy.cross(axes[i][:, None], x, axis=0) for i in range(3)])
+    return (swirl[:, None] * p[None, :, None, :]).reshape(-1, 3, x.shape[1])
 
 
 def NedelecSpace2D(ref_el, degree):
-    """(P_{degree-1})^2 + P_{degree-1}^hom rot(x)."""
-    sd = ref_el.get_spatial_dimension()
-    if sd != 2:
+    if ref_el.get_spatial_dimension() != 2:
         raise ValueError("NedelecSpace2D requires 2d reference element")
-    k = degree - 1
-    vec_Pkp1, (dimPkm1, dimPk, dimPkp1) = _vector_subsets(ref_el, k)
-    vec_Pk = vec_Pkp1.take(list(chain(*(range(i * dimPkp1, i * dimPkp1 + dimPk) for i in range(sd)))))
-    Pkp1 = polynomial_set.ONPolynomialSet(ref_el, k + 1)
-    PkH = Pkp1.take(list(range(dimPkm1, dimPk)))
-    Q = create_quadrature(ref_el, 2 * (k + 1))
-    Qpts, Qwts = Q.get_points(), Q.get_weights()
-    PkH_at_Qpts = PkH.tabulate(Qpts)[(0,) * sd]
-    Pkp1_at_Qpts = Pkp1.tabulate(Qpts)[(0,) * sd]
-    rot_x = numpy.array([[0.0, 1.0], [-1.0, 0.0]]) @ Qpts.T
-    vals = PkH_at_Qpts[:, None, :] * rot_x[None, :, :]
-    coeffs = numpy.dot(vals * Qwts, Pkp1_at_Qpts.T)
-    PkHrotX = polynomial_set.PolynomialSet(ref_el, k + 1, k + 1, vec_Pkp1.get_expansion_set(), coeffs)
-    return polynomial_set.polynomial_set_union_normalized(vec_Pk, PkHrotX)
+    return augmented_vector_space(ref_el, degree - 1, _rotate)
 
 
 def NedelecSpace3D(ref_el, degree):
-    """(P_{degree-1})^3 + (P_{degree-1}^hom)^3 x X."""
-    sd = ref_el.get_spatial_dimension()
-    if sd != 3:
+    if ref_el.get_spatial_dimension() != 3:
         raise ValueError("NedelecSpace3D requires 3d reference element")
-    k = degree - 1
-    vec_Pkp1, (dimPkm1, dimPk, dimPkp1) = _vector_subsets(ref_el, k)
-    vec_Pk = vec_Pkp1.take(list(chain(*(range(i * dimPkp1, i * dimPkp1 + dimPk) for i in range(sd)))))
-    vec_Pke = vec_Pkp1.take(list(chain(*(range(i * dimPkp1 + dimPkm1, i * dimPkp1 + dimPk)
-                                         for i in range(sd)))))
-    Pkp1 = polynomial_set.ONPolynomialSet(ref_el, k + 1)
-    Q = create_quadrature(ref_el, 2 * (k + 1))
-    Qpts, Qwts = Q.get_points(), Q.get_weights()
-    Pke_at_Qpts = vec_Pke.tabulate(Qpts)[(0,) * sd]
-    Pkp1_at_Qpts = Pkp1.tabulate(Qpts)[(0,) * sd]
-    cross = numpy.cross(Pke_at_Qpts, Qpts.T[None, :, :], axis=1)
-    coeffs = numpy.dot(cross * Qwts, Pkp1_at_Qpts.T)
-    PkCrossX = polynomial_set.PolynomialSet(ref_el, k + 1, k + 1, vec_Pkp1.get_expansion_set(), coeffs)
-    return polynomial_set.polynomial_set_union_normalized(vec_Pk, PkCrossX)
+    return augmented_vector_space(ref_el, degree - 1, _cross_axes)
 
 
-class NedelecDual(dual_set.DualSet):
-    def __init__(self, ref_el, degree, variant, interpolant_deg, quad_scheme):
-        sd = ref_el.get_spatial_dimension()
-        top = ref_el.get_topology()
-        nodes = []
-        entity_ids = {dim: {entity: [] for entity in top[dim]} for dim in top}
-        if variant == "point":  # tangential point evaluations on edge (and face) lattices
-            for e in sorted(top[1]):
-                first = len(nodes)
-                nodes.extend(functional.PointEdgeTangentEvaluation(ref_el, e, pt) for pt in ref_el.make_points(1, e, degree + 1))
-                entity_ids[1][e] = list(range(first, len(nodes)))
-            if sd > 2 and degree > 1:
-                for f in sorted(top[2]):
-                    first = len(nodes)
-                    pts = ref_el.make_points(2, f, degree + 1)
-                    nodes.extend(functional.PointFaceTangentEvaluation(ref_el, f, k, pt) for k in range(2) for pt in pts)
-                    entity_ids[2][f] = list(range(first, len(nodes)))
-        # tangential moments against an orthonormal basis on edges (and faces)
-        for dim in range(1, sd) if variant == "integral" else ():
-            phi_deg = degree - dim
-            if phi_deg < 0:
-                continue
-            facet = ref_el.construct_subelement(dim)
-            Q_ref = parse_quadrature_scheme(facet, interpolant_deg + phi_deg, quad_scheme)
-            Pqmd = polynomial_set.ONPolynomialSet(facet, phi_deg, (dim,))
-            Phis = numpy.transpose(Pqmd.tabulate(Q_ref.get_points())[(0,) * dim], (0, 2, 1))
-            for entity in sorted(top[dim]):
-                first = len(nodes)
-                Q = FacetQuadratureRule(ref_el, dim, entity, Q_ref, avg=True)
-                R = numpy.array(ref_el.compute_tangents(dim, entity))
-                phis = numpy.transpose(numpy.dot(Phis, R), (0, 2, 1))
-                nodes.extend(functional.FrobeniusIntegralMoment(ref_el, Q, phi) for phi in phis)
-                entity_ids[dim][entity] = list(range(first, len(nodes)))
-        # interior moments against P_{degree-sd}^sd
-        phi_deg = degree - sd
-        if phi_deg >= 0:
-            if interpolant_deg is None:
-                interpolant_deg = degree
-            cell = ref_el.construct_subelement(sd)
-            Q_ref = parse_quadrature_scheme(cell, interpolant_deg + phi_deg, quad_scheme)
-            Phis = polynomial_set.ONPolynomialSet(cell, phi_deg).tabulate(Q_ref.get_points())[(0,) * sd]
-            for entity in sorted(top[sd]):
-                Q = FacetQuadratureRule(ref_el, sd, entity, Q_ref)
-                first = len(nodes)
-                nodes.extend(functional.IntegralMoment(ref_el, Q, phi, (d,), (sd,))
-                             for d in range(sd) for phi in Phis)
-                entity_ids[sd][entity] = list(range(first, len(nodes)))
-        super().__init__(nodes, ref_el, entity_ids)
+def nedelec_dofs(cell, q, variant, moment_degree, scheme):
+    lay = DofLayout(cell)
+    sd = lay.sd
+    if variant == "point":
+        lay.lattice(1, q + 1, lambda e, pts: [functional.PointEdgeTangentEvaluation(cell, e, x) for x in pts])
+        if sd == 3 and q > 1:
+            lay.lattice(2, q + 1, lambda f, pts: [functional.PointFaceTangentEvaluation(cell, f, side, x)
+                                                  for side in range(2) for x in pts])
+    else:
+        for m in range(1, sd):
+            lay.moments(m, q - m, moment_degree + q - m, lambda e, m=m: cell.compute_tangents(m, e),
+                        scheme=scheme, frame_major=True)
+    if q >= sd:
+        lay.component_moments(sd, q - sd, (q if moment_degree is None else moment_degree) + q - sd, scheme=scheme)
+    return lay.dual_set()
+
+
+class NedelecDual:
+    """Kept as a constructor-compatible name: ``NedelecDual(ref_el, degree, variant, interpolant_deg, quad_scheme)``."""
+
+    def __new__(cls, ref_el, degree, variant, interpolant_deg, quad_scheme=None):
+        return nedelec_dofs(ref_el, degree, variant, interpolant_deg, quad_scheme)
 
 
 class Nedelec(finite_element.CiarletElement):
     def __init__(self, ref_el, degree, variant=None, quad_scheme=None):
-        _, variant, interpolant_deg = check_format_variant(variant, degree)
+        _, variant, moment_degree = check_format_variant(variant, degree)
+        spaces = {2: NedelecSpace2D, 3: NedelecSpace3D}
         sd = ref_el.get_spatial_dimension()
-        if sd == 3:
-            poly_set = NedelecSpace3D(ref_el, degree)
-        elif sd == 2:
-            poly_set = NedelecSpace2D(ref_el, degree)
-        else:
+        if sd not in spaces:
             raise NotImplementedError("Nedelec needs a triangle or a tetrahedron")
-        dual = NedelecDual(ref_el, degree, variant, interpolant_deg, quad_scheme)
-        super().__init__(poly_set, dual, degree, formdegree=1, mapping="covariant piola")
+        super().__init__(spaces[sd](ref_el, degree), nedelec_dofs(ref_el, degree, variant, moment_degree, quad_scheme),
+                         degree, formdegree=1, mapping="covariant piola")

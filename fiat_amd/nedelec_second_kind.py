@@ -1,62 +1,46 @@
-"""Nedelec second-kind H(curl) element on triangles and tetrahedra
-(FIAT/nedelec_second_kind.py:20-222): the full space P_k^d; dofs on every entity of dimension
-m = 1 .. d are Frobenius moments against the contravariantly mapped vector polynomials of degree
-k - m + 1 of that entity: all of P_k on edges, Raviart-Thomas RT_{k-m+1} on faces and in the cell
-(:107-158); "point" variant: tangential point evaluations on the edges instead of the edge moments.  Tabulation runs on the same kernels as every other
-coeffs x Dubiner element."""
-import numpy
+"""Nedelec elements of the second kind, H(curl), on triangles and tetrahedra: the full space P_k^d.
 
-from . import dual_set, finite_element, functional, polynomial_set, raviart_thomas
-from .check_format_variant import check_format_variant, parse_quadrature_scheme
-from .quadrature import FacetQuadratureRule
+On every sub-entity E of dimension m = 1 .. d: moments against the vector polynomials of degree k - m + 1 of
+the reference entity -- all of P_k on edges, Raviart-Thomas RT_{k-m+1} on faces and in the cell -- pulled to E
+contravariantly.  "point" variant: tangential point values on the edges instead of the edge moments.
+Behaviour as FIAT/nedelec_second_kind.py:20-222; written as dof blocks over fiat_amd/dof_layout.py."""
+from . import finite_element, functional, polynomial_set
+from .check_format_variant import check_format_variant
+from .dof_layout import DofLayout
 
 
-def _entity_test_functions(entity_cell, dim, deg, variant, qpts):
-    """Vector test functions on the reference entity at ``qpts``: (nfun, dim, nq)."""
-    if dim == 1:
-        space = polynomial_set.ONPolynomialSet(entity_cell, deg, (dim,))
-    else:
-        space = raviart_thomas.RaviartThomas(entity_cell, deg, variant).get_nodal_basis()
-    return space.tabulate(qpts)[(0,) * dim]
+def _test_fields(entity_cell, m, degree, variant):
+    if m == 1:
+        return polynomial_set.ONPolynomialSet(entity_cell, degree, (1,))
+    from .raviart_thomas import RaviartThomas
+    return RaviartThomas(entity_cell, degree, variant).get_nodal_basis()
 
 
-class NedelecSecondKindDual(dual_set.DualSet):
-    def __init__(self, cell, degree, variant, interpolant_deg, quad_scheme):
-        d = cell.get_spatial_dimension()
-        assert d in (2, 3), "Second kind Nedelecs only implemented in 2/3D."
-        top = cell.get_topology()
-        ids = {dim: {entity: [] for entity in sorted(top[dim])} for dim in top}
-        dofs = []
-        if interpolant_deg is None:
-            interpolant_deg = degree
-        if variant == "point":  # tangential evaluations at degree + 1 points of every edge (:96-110)
-            for edge in sorted(top[1]):
-                points = cell.make_points(1, edge, degree + 2)
-                ids[1][edge] = list(range(len(dofs), len(dofs) + len(points)))
-                dofs += [functional.PointEdgeTangentEvaluation(cell, edge, pt) for pt in points]
-        for dim in range(2 if variant == "point" else 1, d + 1):
-            test_degree = degree - dim + 1
-            if test_degree < 1:
-                continue
-            entity_cell = cell.construct_subelement(dim)
-            Q_ref = parse_quadrature_scheme(entity_cell, interpolant_deg + test_degree, quad_scheme)
-            Phis = _entity_test_functions(entity_cell, dim, test_degree, variant, Q_ref.get_points())
-            for entity in sorted(top[dim]):
-                Q = FacetQuadratureRule(cell, dim, entity, Q_ref)
-                piola = Q.jacobian() / Q.jacobian_determinant()  # reference entity -> entity of the cell
-                mapped = numpy.einsum("ab,ibq->iaq", piola, Phis)
-                ids[dim][entity] = list(range(len(dofs), len(dofs) + len(mapped)))
-                dofs += [functional.FrobeniusIntegralMoment(cell, Q, phi) for phi in mapped]
-        super().__init__(dofs, cell, ids)
+def n2curl_dofs(cell, k, variant, moment_degree, scheme):
+    lay = DofLayout(cell)
+    if moment_degree is None:
+        moment_degree = k
+    first = 1
+    if variant == "point":
+        lay.lattice(1, k + 2, lambda e, pts: [functional.PointEdgeTangentEvaluation(cell, e, x) for x in pts])
+        first = 2
+    for m in range(first, lay.sd + 1):
+        deg = k - m + 1
+        if deg >= 1:
+            space = _test_fields(cell.construct_subelement(m), m, deg, variant)
+            lay.field_moments(m, lambda x, space=space, m=m: space.tabulate(x)[(0,) * m], moment_degree + deg,
+                              "contravariant", scheme=scheme)
+    return lay.dual_set()
 
 
 class NedelecSecondKind(finite_element.CiarletElement):
-    """N2curl_k, k >= 1; variant in {None, "integral", "integral(q)"}."""
+    """N2curl_k, k >= 1; variant in {None, "integral", "integral(q)", "point"}."""
 
     def __init__(self, ref_el, degree, variant=None, quad_scheme=None):
-        _, variant, interpolant_deg = check_format_variant(variant, degree)
+        _, variant, moment_degree = check_format_variant(variant, degree)
         assert degree >= 1, "Second kind Nedelecs start at 1!"
         d = ref_el.get_spatial_dimension()
-        poly_set = polynomial_set.ONPolynomialSet(ref_el, degree, (d,))
-        dual = NedelecSecondKindDual(ref_el, degree, variant, interpolant_deg, quad_scheme)
-        super().__init__(poly_set, dual, degree, formdegree=1, mapping="covariant piola")
+        assert d in (2, 3), "Second kind Nedelecs only implemented in 2/3D."
+        super().__init__(polynomial_set.ONPolynomialSet(ref_el, degree, (d,)),
+                         n2curl_dofs(ref_el, degree, variant, moment_degree, quad_scheme), degree,
+                         formdegree=1, mapping="covariant piola")

@@ -185,6 +185,10 @@ class Cell:
     def is_macrocell(self):
         return False
 
+    def is_simplex(self):
+        """True for a single simplex only; complexes and product cells say False (FIAT/reference_element.py:327,914)."""
+        return False
+
     def __eq__(self, other):
         return (type(self) is type(other) and self.shape == other.shape
                 and self.vertices == other.vertices and self.topology == other.topology)
@@ -194,6 +198,9 @@ class Cell:
 
 
 class Simplex(Cell):
+    def is_simplex(self):
+        return True
+
     def volume(self):
         v = numpy.asarray(self.vertices)
         sd = self.get_spatial_dimension()
