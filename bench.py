@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """Benchmark of the batched tabulate() hot path on MI355X.
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
-Lagrange P3 tetrahedron, tabulate order 1 (values + gradient), 23 points per
-request (the size of the degree-6 rule), batch of 100 000 independent requests
-per GPU, synthetic uniformly random points (seed 2), fp64.
+Default workload (BASELINE.json configs[1], the configuration the metric is quoted on): Lagrange P3
+tetrahedron, tabulate order 1 (values + gradient), 23 points per request (the size of the degree-6 rule),
+100 000 independent requests per GPU, synthetic uniformly random points (seed 2), fp64.  The other BASELINE
+configs are parity-test cases; ``--workload c3|n2tet|rt2tet|dg6tet|hex ...`` times them with the same line format.
 
-One "step" = one pass of the hot path over the whole batch, inputs and outputs
-resident in HBM.  With N > 1 ranks (one process per GPU, torch.distributed over
-RCCL) every rank tabulates its own 100 000 requests (weak scaling, no data-path
-collective: requests are independent); ``--allgather`` additionally times the
-RCCL all-gather that replicates the tables on every GPU and reports it in a
-separate object.
+One "step" = one pass of the hot path over the whole batch, inputs and outputs resident in HBM.
+
+Multi-GPU (one process per GPU): either launched by ``python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or bare ``python bench.py --gpus N``,
+which starts the N ranks itself BEFORE anything touches the GPU.  Every rank tabulates its own block of requests
+(weak scaling, no data-path collective: requests are independent); ``value`` is that compute-only aggregate.  With
+N > 1 the line also carries ``allgather``: the same step followed by / overlapped with the RCCL exchange that
+replicates all tables on every GPU (fiat_amd/distributed.py -> fx_allgather_tables), timed separately.
 
 Prints ONE JSON line on rank 0.
 """
@@ -19,7 +21,10 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -31,15 +36,18 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # fp64 MFMA: 32 FLOP/clk/SIMD measured (v_mfma_f64_16x16x4 = 64 cycles, tools/ubench2.hip; the fp64 FMA rate)
 # x 1024 SIMDs x 2.4 GHz.  The guide's peak table has no fp64 row.
 F64_PEAK_TFLOPS = 32 * 1024 * 2.4e9 / 1e12
+CLOCK_RAMP_MS = 60.0    # untimed launches before the W warm-up steps: the shader clock needs tens of ms after idle
 
 WORKLOADS = {
-    # name: (family, sd, degree, order, npts, default batch)
-    "p3tet": ("Lagrange", 3, 3, 1, 23, 100_000),
-    "n2tet": ("Nedelec", 3, 2, 1, 23, 25_000),
-    "rt2tet": ("RaviartThomas", 3, 2, 1, 23, 25_000),
-    "dg6tet": ("DiscontinuousLagrange", 3, 6, 2, 23, 20_000),
+    # name: (family, sd, degree, order, npts, default batch per GPU)
+    "p3tet": ("Lagrange", 3, 3, 1, 23, 100_000),                 # BASELINE configs[1] -- the headline
+    "n2tet": ("Nedelec", 3, 2, 1, 23, 25_000),                   # configs[2], first half
+    "rt2tet": ("RaviartThomas", 3, 2, 1, 23, 25_000),            # configs[2], second half
+    "c3": ("Nedelec+RaviartThomas", 3, 2, 1, 23, 50_000),        # configs[2]: 25 000 N2 + 25 000 RT2 per step
+    "dg6tet": ("DiscontinuousLagrange", 3, 6, 2, 23, 125_000),   # configs[3]: 1 M over 8 GPUs = 125 000 per GPU
     "dg6tet122": ("DiscontinuousLagrange", 3, 6, 2, 122, 8_000),  # C4 stress variant: 122 points (823 kB per request)
-    # low-order shapes served by the generic kernel (not BASELINE configs; for tools/kernel_ab.py)
+    "hex": ("P4 x P4 x P4", 3, 4, 1, 125, 200_000 // 8),         # configs[4]: 200 k over 8 GPUs, 5^3 tensor grid
+    # low-order shapes (not BASELINE configs; for tools/kernel_ab.py)
     "p1tet": ("Lagrange", 3, 1, 1, 4, 2_000_000),
     "p2tet": ("Lagrange", 3, 2, 1, 11, 300_000),
     "p4tet": ("Lagrange", 3, 4, 1, 23, 45_000),
@@ -79,64 +87,250 @@ def host_cpu_share():
 
 
 def build_element(name):
-    """Nodal coefficients through the device Vandermonde path; returns the
-    device polynomial set and what the oracle needs for the CPU baseline."""
+    """(element, sd, degree, order, npts, default batch) of a single-family workload (tools/ use this)."""
     import fiat_amd
     fam, sd, deg, order, npts, batch = WORKLOADS[name]
-    el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg)
-    return el, sd, deg, order, npts, batch
+    return getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg), sd, deg, order, npts, batch
 
 
-def cpu_baseline(name, el, sd, deg, order, npts, seconds=12.0):
-    """C restatement of FIAT's algorithm (oracle/fiat_oracle.c, OpenMP over requests) on the
-    host cores of this box, bounded to ~`seconds` of wall time on a sample of the same workload."""
-    from oracle import c_oracle, fiat_oracle as fo
-    coeffs = el.get_coeffs()
-    verts = fo.UFC_SIMPLEX[sd]
-    variant, scale = el._expansion_variant, el._expansion_scale
-    cores = host_cpu_share()
-    chunk = 4096
-    pts = synth_points(sd, chunk, npts, 99)
-    c_oracle.tabulate_batch(verts, deg, coeffs, order, pts[:64], scale=scale, variant=variant, nthreads=cores)  # warm
-    t0 = time.perf_counter()
-    done = 0
-    while time.perf_counter() - t0 < seconds:
-        c_oracle.tabulate_batch(verts, deg, coeffs, order, pts, scale=scale, variant=variant, nthreads=cores)
-        done += chunk
-    dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "tabulations/s", "cores": cores, "kind": "port",
-            "sample": f"{done} requests of the same workload in batches of {chunk}, C/OpenMP restatement "
-                      f"(oracle/fiat_oracle.c) on {cores} host threads, {dt:.1f} s"}
+# ---------------------------------------------------------------------------------------------------
+# workloads: each owns its device buffers and knows its algorithmic bytes, its kernel(s) and its oracle
+class SimplexWorkload:
+    """One or more simplex elements tabulated at per-request random points (or, ``shared``, at one rule pushed
+    forward to per-request cells).  parts = [(element, requests)]; a step launches every part once."""
+
+    def __init__(self, name, batch, rank, shared=False):
+        import fiat_amd
+        import torch
+        fam, sd, deg, order, npts, default = WORKLOADS[name]
+        self.name, self.sd, self.deg, self.order, self.npts = name, sd, deg, order, npts
+        self.batch = batch or default
+        self.shared = shared
+        fams = fam.split("+")
+        share = self.batch // len(fams)
+        self.parts = []
+        for i, f in enumerate(fams):
+            el = getattr(fiat_amd, f)(fiat_amd.ufc_simplex(sd), deg)
+            ps = el.device_polyset()
+            n = share if i + 1 < len(fams) else self.batch - share * (len(fams) - 1)
+            pts_h = synth_points(sd, n, npts, seed=2 + rank + 1000 * i)
+            part = {"family": f, "el": el, "ps": ps, "n": n, "pts_h": pts_h, "verts_h": None,
+                    "out": torch.empty(ps.out_shape(order, n, npts), dtype=torch.float64, device="cuda")}
+            rows = ps.ndof * ps.vdim
+            ntab = ps.out_shape(order, 1, 1)[1]
+            part["rows"], part["ntab"] = rows, ntab
+            if shared:
+                from oracle import fiat_oracle as fo     # vertices of the UFC cell only (bench is allowed to)
+                rng = np.random.default_rng(1000 + rank + i)
+                part["verts_h"] = fo.UFC_SIMPLEX[sd][None] + rng.uniform(-0.2, 0.2, size=(n, sd + 1, sd))
+                ref_h = synth_points(sd, 1, npts, seed=6)[0]
+                bary = np.concatenate([1.0 - ref_h.sum(axis=1, keepdims=True), ref_h], axis=1)
+                part["pts_h"] = np.einsum("pv,rvd->rpd", bary, part["verts_h"])   # the same points, for the check
+                part["verts"] = torch.as_tensor(part["verts_h"]).cuda()
+                part["ref_pts"] = torch.as_tensor(ref_h).cuda()
+                part["bytes_per_req"] = 8 * ((sd + 1) * sd + ntab * rows * npts)
+            else:
+                part["pts"] = torch.as_tensor(pts_h).cuda()
+                part["bytes_per_req"] = 8 * (npts * sd + ntab * rows * npts)      # SURVEY.md 8(d): algorithmic bytes
+            nexp = math.comb(deg + sd, sd)
+            part["flops_per_req"] = 2 * rows * nexp * npts * ntab + nexp * npts * (5 + 21 * (order >= 1) + 60 * (order >= 2))
+            self.parts.append(part)
+
+    def describe(self):
+        cell = "tetrahedron" if self.sd == 3 else "triangle"
+        fam = " + ".join(p["family"] for p in self.parts)
+        return (f"{fam} degree {self.deg} {cell}, order {self.order}, {self.npts} points/request, "
+                f"batch {self.batch} per GPU")
+
+    def step(self):
+        for p in self.parts:
+            if self.shared:
+                p["ps"].tabulate_batch_shared(self.order, p["ref_pts"], p["verts"], mapping=p["el"].mapping()[0], out=p["out"])
+            else:
+                p["ps"].tabulate_batch(self.order, p["pts"], out=p["out"])
+
+    def produce_rows(self, lo, hi, rows):
+        """Tabulate requests [lo, hi) of the (single-part) batch into ``rows`` (a view of a gather buffer)."""
+        p = self.parts[0]
+        p["ps"].tabulate_batch(self.order, p["pts"][lo:hi], out=rows)
+
+    def kernel_times(self, reps, stream):
+        """[(kernel name, ms per launch, algorithmic bytes per launch, flops per launch)] from HIP events on the
+        launch stream."""
+        import torch
+        res = []
+        for p in self.parts:
+            if self.shared:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(reps):
+                    p["ps"].tabulate_batch_shared(self.order, p["ref_pts"], p["verts"], mapping=p["el"].mapping()[0], out=p["out"])
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ms, kern = e0.elapsed_time(e1) / reps, "fxk::shared_points_kernel"   # reference tabulation + streaming kernel
+            else:
+                ms = p["ps"].time_tabulate_batch(self.order, p["pts"], None, p["out"], reps, stream=stream)
+                kern = p["ps"].kernel_name(self.order, p["n"], self.npts)
+            res.append((kern, ms, p["bytes_per_req"] * p["n"], p["flops_per_req"] * p["n"]))
+        return res
+
+    def max_rel_err(self, ncheck):
+        from oracle import c_oracle, fiat_oracle as fo
+        worst = 0.0
+        for p in self.parts:
+            # default: the whole batch while its tables stay below ~2 GB on the host, else the leading requests
+            n = min(p["n"], max(1024, int(2e9 // p["bytes_per_req"]))) if ncheck < 0 else min(ncheck, p["n"])
+            self.checked = getattr(self, "checked", 0) + n
+            el = p["el"]
+            ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[self.sd], self.deg, el.get_coeffs(), self.order, p["pts_h"][:n],
+                                          verts=None if p["verts_h"] is None else p["verts_h"][:n],
+                                          scale=el._expansion_scale, variant=el._expansion_variant)
+            if self.shared and el.mapping()[0] != "affine":     # Piola: phi = M Phi, evaluated in NumPy
+                E = np.swapaxes(p["verts_h"][:n, 1:] - p["verts_h"][:n, :1], 1, 2)       # J for the UFC reference cell
+                M = np.swapaxes(np.linalg.inv(E), 1, 2) if el.mapping()[0].startswith("cov") else E / np.linalg.det(E)[:, None, None]
+                r5 = ref.reshape(n, ref.shape[1], -1, self.sd, self.npts)
+                ref = np.einsum("rce,rtdep->rtdcp", M, r5).reshape(ref.shape)
+            got = p["out"][:n].cpu().numpy().reshape(ref.shape)
+            num = np.abs(got - ref).max(axis=(2, 3))
+            den = np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))
+            worst = max(worst, float((num / den).max()))
+        return worst
+
+    def cpu_baseline(self, seconds=12.0):
+        """C restatement of FIAT's algorithm (oracle/fiat_oracle.c, OpenMP over requests) on the host cores of this
+        box, bounded to ~``seconds`` of wall time on a sample of the same workload."""
+        from oracle import c_oracle, fiat_oracle as fo
+        cores = host_cpu_share()
+        chunk = 4096
+        done, t0 = 0, time.perf_counter()
+        jobs = []
+        for p in self.parts:
+            el = p["el"]
+            pts = synth_points(self.sd, chunk, self.npts, 99)
+            args = (fo.UFC_SIMPLEX[self.sd], self.deg, el.get_coeffs(), self.order)
+            kw = dict(scale=el._expansion_scale, variant=el._expansion_variant, nthreads=cores)
+            c_oracle.tabulate_batch(*args, pts[:64], **kw)      # warm
+            jobs.append((args, pts, kw))
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for args, pts, kw in jobs:                          # the mix of the workload, in equal shares
+                c_oracle.tabulate_batch(*args, pts, **kw)
+                done += chunk
+        dt = time.perf_counter() - t0
+        return {"value": done / dt, "unit": "tabulations/s", "cores": cores, "kind": "port",
+                "sample": f"{done} requests of the same workload in batches of {chunk}, C/OpenMP restatement "
+                          f"(oracle/fiat_oracle.c) on {cores} host threads, {dt:.1f} s"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="p3tet", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=0, help="requests per GPU (default: the workload's)")
-    ap.add_argument("--allgather", action="store_true", help="also time the RCCL all-gather of the tables")
-    ap.add_argument("--shared-points", action="store_true",
-                    help="variant (SURVEY.md 8d): ONE 23-point rule on the reference cell pushed forward to per-request "
-                         "physical cells (fx_tabulate_batch_shared) instead of per-request random points")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check", type=int, default=-1,
-                    help="requests verified against the CPU oracle after timing (-1: the whole batch, 0: none)")
-    args = ap.parse_args()
+class HexWorkload:
+    """configs[4]: P4 x P4 x P4 hexahedron, order 1, per-request 5^3 tensor grid (sum-factorised input:
+    per-request 1-D coordinates), fx_tensor_tabulate_grid_batch."""
 
+    def __init__(self, name, batch, rank, shared=False):
+        import fiat_amd
+        import torch
+        self.name, self.sd, self.deg, self.order, self.npts = name, 3, 4, 1, 125
+        self.batch = batch or WORKLOADS[name][5]
+        P4 = fiat_amd.Lagrange(fiat_amd.ufc_simplex(1), 4)
+        self.P4 = P4
+        self.el = fiat_amd.TensorProductElement(fiat_amd.TensorProductElement(P4, P4), P4)
+        rng = np.random.default_rng(5 + rank)
+        self.grid_h = np.sort(rng.uniform(0, 1, size=(self.batch, 3, 5)), axis=2)
+        self.grid = torch.as_tensor(self.grid_h).cuda()
+        self.out = torch.empty((self.batch, 4, 125, 125), dtype=torch.float64, device="cuda")
+        self.bytes_per_req = 8 * (15 + 4 * 125 * 125)           # SURVEY.md 8(d), factored 1-D inputs
+        self.flops_per_req = 2 * 4 * 125 * 125
+        self.parts = [None]
+
+    def describe(self):
+        return f"P4 x P4 x P4 hexahedron (nested TensorProductElement), order 1, 5^3 tensor grid/request, batch {self.batch} per GPU"
+
+    def step(self):
+        self.el.tabulate_batch(1, self.grid, out=self.out, grid=True)
+
+    def produce_rows(self, lo, hi, rows):
+        self.el.tabulate_batch(1, self.grid[lo:hi], out=rows.view(hi - lo, 4, 125, 125), grid=True)
+
+    def kernel_times(self, reps, stream):
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            self.step()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return [("fxk::tensor_tabulate_kernel<GRID>", e0.elapsed_time(e1) / reps, self.bytes_per_req * self.batch,
+                 self.flops_per_req * self.batch)]
+
+    def _oracle(self, r):
+        from oracle import fiat_oracle as fo
+        g = self.grid_h[r]
+        pts = np.array([[x, y, z] for x in g[0] for y in g[1] for z in g[2]])
+        nodes = np.array(self.P4.get_nodal_basis().get_expansion_set().x)
+        tab = fo.hex_lagrange_tabulate(nodes, 1, pts)
+        return np.stack([tab[a] for a in fo.jet_indices(3, 1)])
+
+    def max_rel_err(self, ncheck):
+        n = 64 if ncheck < 0 else min(ncheck, self.batch)     # NumPy oracle: a sample (full sizes: tests/test_gpu_fullsize.py)
+        idx = np.unique(np.linspace(0, self.batch - 1, n).astype(int))
+        self.checked = len(idx)
+        worst = 0.0
+        for r in idx:
+            ref = self._oracle(r)
+            got = self.out[r].cpu().numpy()
+            worst = max(worst, float((np.abs(got - ref).max(axis=(1, 2)) / np.maximum(1.0, np.abs(ref).max(axis=(1, 2)))).max()))
+        return worst
+
+    def cpu_baseline(self, seconds=12.0):
+        done, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            self._oracle(done % self.batch)
+            done += 1
+        dt = time.perf_counter() - t0
+        return {"value": done / dt, "unit": "tabulations/s", "cores": 1, "kind": "port",
+                "sample": f"{done} requests of the same workload, NumPy restatement (oracle/fiat_oracle.py "
+                          f"hex_lagrange_tabulate) on 1 host thread, {dt:.1f} s"}
+
+
+# ---------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """``bench.py --gpus N`` without a launcher: start the N ranks from a parent that never touches the GPU
+    (torch.cuda.device_count() does not initialise it on this image)."""
+    import torch
+    backend = os.environ.get("FIAT_AMD_BENCH_BACKEND", "nccl")
+    ngpu = torch.cuda.device_count()
+    if backend == "nccl" and ngpu < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {ngpu} GPU(s) visible (RCCL needs one GPU per rank; "
+              f"FIAT_AMD_BENCH_BACKEND=gloo rehearses the multi-rank path on fewer)", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def run(args):
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report n_gpus for a job of another size")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the tabulate path has no CPU fallback")
-    # one process per GPU over RCCL; FIAT_AMD_BENCH_BACKEND=gloo lets several ranks share a GPU to
-    # rehearse the multi-rank path on a one-GPU box (timings are then meaningless)
+    # one process per GPU over RCCL; FIAT_AMD_BENCH_BACKEND=gloo lets several ranks share a GPU to rehearse the
+    # multi-rank path on a one-GPU box (timings are then meaningless)
     backend = os.environ.get("FIAT_AMD_BENCH_BACKEND", "nccl")
     ngpu = torch.cuda.device_count()
     if backend == "nccl" and local_rank >= ngpu:
@@ -149,51 +343,33 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    el, sd, deg, order, npts, batch = build_element(args.workload)
-    if args.batch:
-        batch = args.batch
-    ps = el.device_polyset()
-    ntab = ps.out_shape(order, 1, 1)[1]
-    rows = ps.ndof * ps.vdim
-    bytes_per_req = 8 * (npts * sd + ntab * rows * npts)     # algorithmic bytes
-
-    pts_h = synth_points(sd, batch, npts, seed=2 + rank)
-    pts = torch.as_tensor(pts_h).cuda()
-    out = torch.empty(ps.out_shape(order, batch, npts), dtype=torch.float64, device="cuda")
+    cls = HexWorkload if args.workload == "hex" else SimplexWorkload
+    wl = cls(args.workload, args.batch, rank, shared=args.shared_points)
+    batch = wl.batch
     stream = torch.cuda.current_stream()
-    verts_h = None
-    if args.shared_points:
-        # cells: UFC vertices + U(-0.2, 0.2) per coordinate, the rule: 23 fixed points
-        from oracle import fiat_oracle as fo
-        rng = np.random.default_rng(1000 + rank)
-        verts_h = fo.UFC_SIMPLEX[sd][None] + rng.uniform(-0.2, 0.2, size=(batch, sd + 1, sd))
-        ref_pts_h = synth_points(sd, 1, npts, seed=6)[0]
-        bary = np.concatenate([1.0 - ref_pts_h.sum(axis=1, keepdims=True), ref_pts_h], axis=1)
-        pts_h = np.einsum("pv,rvd->rpd", bary, verts_h)          # the same points, per request (for the check)
-        verts = torch.as_tensor(verts_h).cuda()
-        ref_pts = torch.as_tensor(ref_pts_h).cuda()
-        mapping = el.mapping()[0]
-        bytes_per_req = 8 * ((sd + 1) * sd + ntab * rows * npts)
 
-        def step():
-            ps.tabulate_batch_shared(order, ref_pts, verts, mapping=mapping, out=out)
-    else:
-        def step():
-            ps.tabulate_batch(order, pts, out=out)
-
+    # clock ramp (disclosed in the line, not part of W): the first launches after idle run ~25 % slower
+    t_ramp = time.perf_counter()
+    ramp_steps = 0
+    while (time.perf_counter() - t_ramp) * 1e3 < CLOCK_RAMP_MS:
+        wl.step()
+        ramp_steps += 1
+        if ramp_steps % 8 == 0:
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
-        step()
+        wl.step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        wl.step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -203,28 +379,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant kernel: average launch duration from HIP events on the launch stream
-    if args.shared_points:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        nrep = max(5, args.steps)
-        e0.record(stream)
-        for _ in range(nrep):
-            step()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        kernel_ms = e0.elapsed_time(e1) / nrep      # reference tabulation (1 request) + the streaming kernel
-    else:
-        kernel_ms = ps.time_tabulate_batch(order, pts, None, out, max(5, args.steps), stream=stream)
-    achieved = bytes_per_req * batch / (kernel_ms * 1e-3) / 1e9
+    # dominant kernel(s): average launch duration from HIP events on the launch stream
+    kt = wl.kernel_times(max(5, args.steps), stream)
+    kernel_ms = sum(k[1] for k in kt)
+    abytes = sum(k[2] for k in kt)
+    aflops = sum(k[3] for k in kt)
+    achieved = abytes / (kernel_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "fxk::shared_points_kernel" if args.shared_points else ps.kernel_name(order, batch, npts),
-                "kernel_ms": kernel_ms,
-                "algorithmic_bytes_per_request": bytes_per_req, "requests_per_launch": batch}
-    # context: what this box writes with a plain fill of the same buffer (the attainable write rate
-    # varies between boxes and over time by +-10 %)
+                "kernel": kt[0][0] if len(kt) == 1 else [k[0] for k in kt],
+                "kernel_ms": kernel_ms if len(kt) == 1 else [k[1] for k in kt],
+                "algorithmic_bytes_per_launch": abytes if len(kt) == 1 else [k[2] for k in kt],
+                "requests_per_launch": batch if len(kt) == 1 else [p["n"] for p in wl.parts]}
+    if len(kt) > 1:
+        roofline["per_kernel_frac"] = [k[2] / (k[1] * 1e-3) / 1e9 / HBM_PEAK_GBS for k in kt]
+    # context: what this box writes with a plain fill of the same bytes (the attainable write rate varies
+    # between boxes and over time by +-10 %)
     if rank == 0:
-        scratch = torch.empty_like(out)
+        scratch = torch.empty(int(abytes // 8), dtype=torch.float64, device="cuda")
         for _ in range(3):
             scratch.fill_(1.0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -235,63 +407,30 @@ def main():
         torch.cuda.synchronize()
         roofline["fill_same_bytes_gbs"] = scratch.numel() * 8 / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e9
         del scratch
-    # algorithmic flops: contraction + recurrence; the binding roofline of the large
-    # shapes (DG P6 with Hessians: 21 flop/B) is the fp64 pipe, not HBM
-    nexp = math.comb(deg + sd, sd)
-    flops_per_req = 2 * rows * nexp * npts * ntab + nexp * npts * (5 + 21 * (order >= 1) + 60 * (order >= 2))
-    if flops_per_req / bytes_per_req > F64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS:
-        tf = flops_per_req * batch / (kernel_ms * 1e-3) / 1e12
+    # the binding roofline of the large shapes (DG P6 with Hessians: 21 flop/B) is the fp64 pipe, not HBM
+    if aflops / abytes > F64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS:
+        tf = aflops / (kernel_ms * 1e-3) / 1e12
         roofline = dict(roofline, bound="mfma", achieved=tf, peak=F64_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / F64_PEAK_TFLOPS,
-                        algorithmic_flops_per_request=flops_per_req,
+                        algorithmic_flops_per_launch=aflops,
                         hbm={"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS})
     prof = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-    if not os.path.exists(prof):
-        prof = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(prof):
+    if os.path.exists(prof) and not args.shared_points:
         try:
             with open(prof) as f:
                 tr = json.load(f)
-            if tr.get("workload") == args.workload and tr.get("batch") == batch and not args.shared_points:
+            if tr.get("workload") == args.workload and tr.get("batch") == batch:
                 roofline["traffic"] = tr["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = (f"profiles/traffic_{args.workload}.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                              "of this command on an earlier box, NOT measured in this run")
         except Exception:
             pass
 
-    # parity of the timed output against the CPU oracle, whole batch (never inside the timed region)
+    # parity of the timed output against the CPU oracle (never inside the timed region)
     max_err = None
     if args.check and rank == 0:
-        from oracle import c_oracle, fiat_oracle as fo
-        ncheck = batch if args.check < 0 else min(args.check, batch)
-        ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[sd], deg, el.get_coeffs(), order, pts_h[:ncheck],
-                                      verts=None if verts_h is None else verts_h[:ncheck],
-                                      scale=el._expansion_scale, variant=el._expansion_variant)
-        if args.shared_points and el.mapping()[0] != "affine":     # Piola: phi = M Phi, evaluated in NumPy
-            E = np.swapaxes(verts_h[:ncheck, 1:] - verts_h[:ncheck, :1], 1, 2)          # J for the UFC reference cell
-            M = np.swapaxes(np.linalg.inv(E), 1, 2) if el.mapping()[0].startswith("cov") else E / np.linalg.det(E)[:, None, None]
-            r5 = ref.reshape(ncheck, ref.shape[1], -1, sd, npts)
-            ref = np.einsum("rce,rtdep->rtdcp", M, r5).reshape(ref.shape)
-        got = out[:ncheck].cpu().numpy().reshape(ref.shape)
-        num = np.abs(got - ref).max(axis=(2, 3))
-        den = np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))
-        max_err = float((num / den).max())
+        max_err = wl.max_rel_err(args.check)
 
-    allgather = None
-    if args.allgather and world > 1:
-        gathered = torch.empty((world,) + tuple(out.shape), dtype=torch.float64, device="cuda")
-        dist.all_gather_into_tensor(gathered, out)
-        torch.cuda.synchronize()
-        barrier()
-        t0 = time.perf_counter()
-        reps = max(2, args.steps // 4)
-        for _ in range(reps):
-            ps.tabulate_batch(order, pts, out=out)
-            dist.all_gather_into_tensor(gathered, out)
-        torch.cuda.synchronize()
-        barrier()
-        dt = (time.perf_counter() - t0) / reps
-        allgather = {"ms_per_step_with_allgather": dt * 1e3,
-                     "value_with_allgather": batch * world / dt,
-                     "gathered_bytes_per_gpu": out.numel() * 8 * world}
-
+    line = None
     if rank == 0:
         line = {
             "metric": "element tabulations/sec (basis+grad, fp64) for batched P3 tet"
@@ -307,23 +446,129 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{WORKLOADS[args.workload][0]} degree {deg} "
-                                   f"{'tetrahedron' if sd == 3 else 'triangle'}, order {order}, "
-                                   f"{npts} points/request, batch {batch} per GPU",
-                       "requests_per_gpu": batch, "points_per_request": npts, "order": order,
+            "config": {"workload": wl.describe(), "requests_per_gpu": batch, "points_per_request": wl.npts, "order": wl.order,
                        "points": "one 23-point rule on the reference cell, per-request physical cells" if args.shared_points
                                  else "random per request",
-                       "sharding": "independent requests, contiguous blocks per rank, no data-path collective"},
+                       "sharding": "independent requests, contiguous blocks per rank, no data-path collective",
+                       "world_size": world, "launch": "self-spawned ranks" if os.environ.get("FIAT_AMD_BENCH_SPAWNED") else
+                                     ("torch.distributed.run" if world > 1 else "single process"),
+                       "clock_ramp_ms_before_warmup": CLOCK_RAMP_MS, "clock_ramp_steps": ramp_steps},
             "roofline": roofline,
             "max_rel_err_vs_oracle": max_err,
+            "requests_checked_vs_oracle": getattr(wl, "checked", None),
         }
-        if allgather:
-            line["allgather"] = allgather
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.workload, el, sd, deg, order, npts)
-        print(json.dumps(line), flush=True)
+            line["cpu_baseline"] = wl.cpu_baseline()
+
+    # with-gather leg: after the line is complete, under a watchdog -- a stuck exchange must not cost the
+    # compute-only measurement
+    printed = threading.Event()
+
+    def emit():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            print(json.dumps(line), flush=True)
+
+    if world > 1 and not args.no_allgather and len(wl.parts) == 1 and not args.shared_points:
+        def bail():
+            if rank == 0:
+                line["allgather"] = {"error": f"no result within {args.allgather_timeout} s"}
+            emit()
+            os._exit(0)
+        dog = threading.Timer(args.allgather_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            res = allgather_leg(wl, world, rank, args, barrier)
+            if rank == 0:
+                line["allgather"] = res
+        except Exception as exc:     # report, keep the compute-only result
+            if rank == 0:
+                line["allgather"] = {"error": f"{type(exc).__name__}: {exc}"}
+        dog.cancel()
+    emit()
     if world > 1:
         dist.destroy_process_group()
+
+
+def allgather_leg(wl, world, rank, args, barrier):
+    """Compute + replicate every table on every GPU: (a) tabulate, then one exchange; (b) chunked, the exchange of
+    chunk c on a second stream under the tabulation of chunk c+1.  xGMI budget: 7T/8 bytes into every
+    GPU over 7 x ~153 GB/s."""
+    import torch
+    from fiat_amd import distributed as D
+    gather = D.TableGather(impl=args.allgather_impl, algo=args.allgather_algo)
+    per = wl.batch
+    out = wl.parts[0]["out"] if wl.parts[0] else wl.out
+    tail = tuple(out.shape[1:])
+    full = torch.empty((world * per,) + tail, dtype=torch.float64, device="cuda")
+    mine = full.view(world, per, *tail)[rank]
+    reps = max(2, min(10, args.steps // 4))
+    res = {"impl": gather.impl, "algo": args.allgather_algo if gather.impl == "rccl" else "torch.distributed",
+           "gathered_bytes_per_gpu": full.numel() * 8, "reps": reps}
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        barrier()
+        return (time.perf_counter() - t0) / reps
+
+    def sequential():
+        wl.produce_rows(0, per, mine)
+        gather.all_gather(mine, world * per, out=full)
+
+    dt = timed(sequential)
+    res["ms_per_step_sequential"] = dt * 1e3
+    res["value_sequential"] = per * world / dt
+    chunk = max(1, -(-per // args.allgather_chunks))
+
+    def pipelined():
+        gather.tabulate_allgather(wl.produce_rows, per, per, chunk, full)
+
+    dt = timed(pipelined)
+    res["chunks"] = -(-per // chunk)
+    res["ms_per_step_pipelined"] = dt * 1e3
+    res["value_with_allgather"] = per * world / dt
+    res["ingress_gbs_per_gpu"] = (world - 1) * per * int(np.prod(tail)) * 8 / dt / 1e9
+    # every rank's block must have arrived: compare one foreign request with a local re-tabulation of the same points
+    # (ranks draw different points, so only the sizes and finiteness are checked here; parity is tests/)
+    res["all_finite"] = bool(torch.isfinite(full.view(world, per, -1)[:, :: max(1, per // 16)]).all().item())
+    gather.close()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="p3tet", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="requests per GPU (default: the workload's)")
+    ap.add_argument("--no-allgather", action="store_true", help="N > 1: skip the with-gather leg")
+    ap.add_argument("--allgather", action="store_true", help="(kept for compatibility: the leg runs by default when N > 1)")
+    ap.add_argument("--allgather-impl", default="auto", choices=["auto", "rccl", "torch"],
+                    help="rccl = fx_allgather_tables through the C ABI, torch = torch.distributed collectives")
+    ap.add_argument("--allgather-algo", default="direct", choices=["direct", "ring"])
+    ap.add_argument("--allgather-chunks", type=int, default=8)
+    ap.add_argument("--allgather-timeout", type=float, default=120.0)
+    ap.add_argument("--shared-points", action="store_true",
+                    help="variant (SURVEY.md 8d): ONE 23-point rule on the reference cell pushed forward to per-request "
+                         "physical cells (fx_tabulate_batch_shared) instead of per-request random points")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", type=int, default=-1,
+                    help="requests verified against the CPU oracle after timing (-1: the whole batch, 0: none)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        os.environ["FIAT_AMD_BENCH_SPAWNED"] = "1"
+        sys.exit(spawn_ranks(args))
+    run(args)
 
 
 if __name__ == "__main__":

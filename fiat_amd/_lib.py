@@ -5,7 +5,7 @@ gfx950).  There is no fallback: if the library is missing the import fails, and
 if no GPU is present every compute entry point raises."""
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint, c_void_p
 
 import numpy as np
 # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  Import it
@@ -20,6 +20,10 @@ LIB_PATH = os.environ.get("FIAT_AMD_LIB", os.path.join(_HERE, "csrc", "libfiat_a
 FX_OK = 0
 FX_EINVAL, FX_ENOTIMPL, FX_ESINGULAR, FX_EHIP, FX_ENOMEM = -1, -2, -3, -4, -5
 VARIANTS = {None: 0, "bubble": 1, "dual": 2}
+# kernel-selection policy bits (include/fiat_amd.h FX_POLICY_*)
+POLICY = {"no_fixed": 1 << 0, "no_small": 1 << 1, "no_stacked": 1 << 2, "no_coop": 1 << 3, "stacked_small": 1 << 4,
+          "no_stacked_mix": 1 << 5, "no_shared_wave": 1 << 6, "no_shared_reg": 1 << 7, "no_macro_small": 1 << 8,
+          "kernel_image": 1 << 9, "kernel_stream": 1 << 10}
 
 
 class FiatAmdError(RuntimeError):
@@ -46,6 +50,8 @@ _SIGS = {
     "fx_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
     "fx_ctx_destroy": (c_int, [c_void_p]),
     "fx_ctx_info": (c_int, [c_void_p, _p_i, _p_i, c_char_p, c_int]),
+    "fx_ctx_set_policy": (c_int, [c_void_p, c_uint]),
+    "fx_ctx_get_policy": (c_int, [c_void_p, POINTER(c_uint)]),
     "fx_element_create": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_int, c_int, c_void_p,
                                   POINTER(c_void_p)]),
     "fx_element_destroy": (c_int, [c_void_p]),
@@ -82,6 +88,16 @@ _SIGS = {
     "fx_macro_element_set_coeffs": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "fx_macro_tabulate_batch": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p]),
+    "fx_table_outer_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_void_p, c_void_p, c_void_p]),
+    "fx_map_points": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "fx_jacobi_batch": (c_int, [c_void_p, c_double, c_double, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    "fx_comm_available": (c_int, []),
+    "fx_comm_unique_id": (c_int, [c_void_p]),
+    "fx_comm_create": (c_int, [c_void_p, c_int, c_int, c_void_p, POINTER(c_void_p)]),
+    "fx_comm_destroy": (c_int, [c_void_p]),
+    "fx_allgather_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "fx_ctx_check": (c_int, [c_void_p, c_void_p]),
     "fx_time_tabulate_batch": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, POINTER(c_float)]),
 }

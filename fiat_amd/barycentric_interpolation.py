@@ -91,6 +91,12 @@ class LagrangePolynomialSet(polynomial_set.PolynomialSet):
                 coeffs[(range(c * nexp, (c + 1) * nexp), *idx, range(nexp))] = 1.0
         super().__init__(ref_el, es.degree, es.degree, es, coeffs)
 
+    def device_polyset(self):
+        """Batched device form with the interface of runtime.SimplexPolySet (points (nreq, npts, 1))."""
+        if self.coeffs.ndim != 2 or not numpy.array_equal(self.coeffs, numpy.eye(self.coeffs.shape[0])):
+            raise NotImplementedError("batched tabulation of 1-D Lagrange sets with non-identity coefficients")
+        return _LineBatch(self.expansion_set.device_line())
+
     def tabulate(self, pts, jet_order=0):
         base = self.expansion_set._tabulate(self.embedded_degree, pts, jet_order)
         # the nodal coefficients over the primal Lagrange basis are the identity
@@ -98,3 +104,24 @@ class LagrangePolynomialSet(polynomial_set.PolynomialSet):
         if self.coeffs.ndim == 2 and numpy.array_equal(self.coeffs, numpy.eye(self.coeffs.shape[0])):
             return base
         return {a: numpy.tensordot(self.coeffs, v, axes=(-1, 0)) for a, v in base.items()}
+
+
+class _LineBatch:
+    """fx_line_tabulate_batch behind the calling convention of the simplex polynomial sets."""
+    sd, vdim, value_shape = 1, 1, ()
+
+    def __init__(self, line):
+        self.line = line
+        self.ndof = line.nn
+        self.ctx = line.ctx
+
+    def out_shape(self, order, nreq, npts):
+        return (nreq, order + 1, self.ndof, npts)
+
+    def tabulate_batch(self, order, pts, verts=None, out=None, stream=None, mapping=None):
+        if verts is not None or mapping not in (None, "affine"):
+            raise NotImplementedError("per-request cells for 1-D Lagrange sets")
+        pts = runtime._as_device(pts, self.ctx)
+        if pts.dim() != 3 or pts.shape[2] != 1:
+            raise ValueError(f"points must have shape (nreq, npts, 1), got {tuple(pts.shape)}")
+        return self.line.tabulate_batch(order, pts.reshape(pts.shape[0], pts.shape[1]), out=out, stream=stream)

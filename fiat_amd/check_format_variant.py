@@ -72,10 +72,14 @@ def check_format_variant(variant, degree):
 
 
 def parse_quadrature_scheme(ref_el, degree, quad_scheme=None):
-    scheme = None
-    for opt in (quad_scheme or "").split(","):
-        if opt in _SPLITS or opt.startswith("KMV"):
-            raise NotImplementedError(f"quadrature scheme option {opt!r} is out of scope for fiat_amd")
-        if opt:
+    """Rule from a ``quad_scheme`` string (FIAT/check_format_variant.py:100-136): comma-separated scheme name
+    ("default", "canonical") and/or a splitting ("alfeld", "iso", "powell-sabin", ...) that makes the rule composite."""
+    scheme = "default"
+    for opt in filter(None, (quad_scheme or "").split(",")):
+        if opt in _SPLITS:
+            ref_el = _SPLITS[opt](ref_el)
+        elif opt.startswith("KMV"):
+            raise NotImplementedError("the Kong-Mulder-Veldhuizen lumped rules are out of scope for fiat_amd")
+        else:
             scheme = opt
-    return create_quadrature(ref_el, degree, scheme or "default")
+    return create_quadrature(ref_el, degree, scheme)

@@ -25,8 +25,18 @@
 #include "macro_small.hpp"
 #include "table_kernels.hpp"
 #include "simplex_stacked.hpp"
+#include "jacobi_kernel.hpp"
 
 namespace {
+
+// Measurement scaffolding (ablation bits, verbose launch reports, occupancy caps) is compiled into the A/B build only
+// (make ab-lib: -DFX_AB); the product library never reads the environment on a launch path.  Kernel-selection
+// switches that tests and tools need are an explicit per-context policy (fx_ctx_set_policy).
+#ifdef FX_AB
+inline const char* ab_env(const char* name) { return getenv(name); }
+#else
+inline const char* ab_env(const char*) { return nullptr; }
+#endif
 
 thread_local std::string g_err;
 
@@ -142,10 +152,13 @@ struct fx_ctx {
     double* d_trash = nullptr;  // 64 KB scratch (ablation builds: wave lifetimes, FX_DBG & 512)
     unsigned long long* d_queue = nullptr;  // chunk counters of the dynamically scheduled kernels (work_queue.hpp)
     unsigned int launch_seq = 0;
-    double* d_ref = nullptr;  // reference-cell tables of fx_tabulate_batch_shared (grown on demand)
-    size_t ref_bytes = 0;
+    unsigned policy = 0;      // FX_POLICY_* bits (fx_ctx_set_policy)
 };
 constexpr int FX_QUEUE_SLOTS = 64;  // counters handed to consecutive launches round-robin (128 B apart)
+
+#include "comm.hpp"
+
+constexpr int FX_MAX_ORDER = 8;  // highest derivative order served (orders > 2 through differentiation matrices)
 
 struct fx_element {
     fx_ctx* ctx = nullptr;
@@ -173,6 +186,10 @@ struct fx_element {
     double* d_astack_dm = nullptr;   // order 1, dof-major tiles (tables of 16 dofs consecutive, each table padded): MIXT instances
     int stack_state[3] = {0, 0, 0};  // 0 not built, 1 built, -1 failed
     bool raw_expansion = false;      // internal helper element (identity coefficients): never takes the stacked path
+    // derivative orders 3..FX_MAX_ORDER (ensure_high_order): an internal element whose rows are the stacked matrix
+    // [C D^alpha], |alpha| <= order, tabulated at order 0
+    fx_element* high[FX_MAX_ORDER + 1] = {nullptr};
+    int high_state[FX_MAX_ORDER + 1] = {0};
 };
 
 struct fx_line_element {
@@ -222,7 +239,6 @@ int fx_ctx_create(int device_id, fx_ctx** out) {
 int fx_ctx_destroy(fx_ctx* ctx) {
     if (ctx && ctx->d_trash) (void)hipFree(ctx->d_trash);
     if (ctx && ctx->d_queue) (void)hipFree(ctx->d_queue);
-    if (ctx && ctx->d_ref) (void)hipFree(ctx->d_ref);
     delete ctx;
     return FX_OK;
 }
@@ -235,6 +251,21 @@ int fx_ctx_info(fx_ctx* ctx, int* num_cu, int* lds, char* name, int name_len) {
         strncpy(name, ctx->name.c_str(), name_len - 1);
         name[name_len - 1] = 0;
     }
+    return FX_OK;
+}
+
+int fx_ctx_set_policy(fx_ctx* ctx, unsigned flags) {
+    if (!ctx) return fail(FX_EINVAL, "fx_ctx_set_policy: null context");
+    if (flags & ~(unsigned)FX_POLICY_ALL) return fail(FX_EINVAL, "fx_ctx_set_policy: unknown policy bits 0x%x", flags & ~(unsigned)FX_POLICY_ALL);
+    if ((flags & FX_POLICY_KERNEL_IMAGE) && (flags & FX_POLICY_KERNEL_STREAM))
+        return fail(FX_EINVAL, "fx_ctx_set_policy: KERNEL_IMAGE and KERNEL_STREAM exclude each other");
+    ctx->policy = flags;
+    return FX_OK;
+}
+
+int fx_ctx_get_policy(const fx_ctx* ctx, unsigned* flags) {
+    if (!ctx || !flags) return fail(FX_EINVAL, "fx_ctx_get_policy: null argument");
+    *flags = ctx->policy;
     return FX_OK;
 }
 
@@ -328,6 +359,11 @@ static int upload_coeffs(fx_element* e, int ndof, int vdim, const double* coeffs
     }
     if (e->d_astack_dm) (void)hipFree(e->d_astack_dm);
     e->d_astack_dm = nullptr;
+    for (int o = 0; o <= FX_MAX_ORDER; ++o) {
+        if (e->high[o]) fx_element_destroy(e->high[o]);
+        e->high[o] = nullptr;
+        e->high_state[o] = 0;
+    }
     if (e->d_cmat) {
         HIP_TRY(hipFree(e->d_cmat));
         e->d_cmat = nullptr;
@@ -481,6 +517,8 @@ int fx_element_destroy(fx_element* e) {
     for (int o = 0; o < 3; ++o)
         if (e->d_astack[o]) (void)hipFree(e->d_astack[o]);
     if (e->d_astack_dm) (void)hipFree(e->d_astack_dm);
+    for (int o = 0; o <= FX_MAX_ORDER; ++o)
+        if (e->high[o]) fx_element_destroy(e->high[o]);
     delete e;
     return FX_OK;
 }
@@ -655,7 +693,7 @@ int launch_fixed(const Launch& L, hipStream_t s) {
         const int occ = cached_occ;
         const long long nwg = ((L.fhead.nreq + RPW - 1) / RPW + PAIR_NW - 1) / PAIR_NW;
         const int grid = (int)std::max<long long>(1, std::min<long long>(nwg, (long long)L.ncu * std::max(1, occ)));
-        static const bool verbose = getenv("FIAT_AMD_VERBOSE") != nullptr;
+        static const bool verbose = ab_env("FIAT_AMD_VERBOSE") != nullptr;
         if (verbose) fprintf(stderr, "[fiat_amd] pair kernel: occupancy %d WG/CU, grid %d, lds %d B\n", occ, grid, lds_bytes);
         hipLaunchKernelGGL(kp, dim3(grid), dim3(64 * PAIR_NW), lds_bytes, s, fa, L.trash, reinterpret_cast<unsigned int*>(L.queue));
         HIP_TRY(hipGetLastError());
@@ -765,9 +803,9 @@ int launch_stacked(const Launch& L, hipStream_t s) {
         int q = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, reinterpret_cast<const void*>(kern), 64 * STACKED_NW, (size_t)L.klds_bytes));
         occ = std::max(1, q);
-        static const int cap = getenv("FIAT_AMD_STACKED_WPS") ? atoi(getenv("FIAT_AMD_STACKED_WPS")) : 8;
+        static const int cap = ab_env("FIAT_AMD_STACKED_WPS") ? atoi(ab_env("FIAT_AMD_STACKED_WPS")) : 8;
         occ = std::min(occ, std::max(1, cap));
-        if (getenv("FIAT_AMD_VERBOSE")) fprintf(stderr, "[fiat_amd] stacked kernel <%d,%d,%d,%d>: %d workgroups per CU, lds %d B\n", SD, N, CT, G, occ, L.klds_bytes);
+        if (ab_env("FIAT_AMD_VERBOSE")) fprintf(stderr, "[fiat_amd] stacked kernel <%d,%d,%d,%d>: %d workgroups per CU, lds %d B\n", SD, N, CT, G, occ, L.klds_bytes);
     }
     const long long groups = CHUNK ? L.khead.nreq * ((L.khead.npts + 16 * CT - 1) / (16 * CT)) : (L.khead.nreq + G - 1) / G;
     const int grid = (int)std::max<long long>(1, std::min<long long>((groups + STACKED_NW - 1) / STACKED_NW, (long long)L.ncu * occ));
@@ -775,7 +813,7 @@ int launch_stacked(const Launch& L, hipStream_t s) {
                        reinterpret_cast<unsigned int*>(L.queue));
     HIP_TRY(hipGetLastError());
 #if defined(FX_DBG) && (FX_DBG & 512)
-    if (getenv("FIAT_AMD_VERBOSE")) HIP_TRY(report_wave_lifetimes(L.trash, grid, STACKED_NW));
+    if (ab_env("FIAT_AMD_VERBOSE")) HIP_TRY(report_wave_lifetimes(L.trash, grid, STACKED_NW));
 #endif
 #if defined(FX_DBG) && (FX_DBG & 1024)
     {   // range-check build: report accesses that left their buffers (redirected to the scratch area by the kernel)
@@ -791,7 +829,7 @@ int launch_stacked(const Launch& L, hipStream_t s) {
                         SD, N, CT, G, MIXT, cnt, site[k], rep[4 * k + 1], rep[4 * k + 2], rep[4 * k + 3]);
         }
         HIP_TRY(hipMemset(L.trash + 4096, 0, sizeof rep));
-        if (getenv("FIAT_AMD_VERBOSE")) fprintf(stderr, "[fiat_amd] range check done <%d,%d,%d,%d,mixt %d>\n", SD, N, CT, G, MIXT);
+        if (ab_env("FIAT_AMD_VERBOSE")) fprintf(stderr, "[fiat_amd] range check done <%d,%d,%d,%d,mixt %d>\n", SD, N, CT, G, MIXT);
     }
 #endif
     if (L.khead.verts && L.kmix_order >= 1 && MIXT == 0) {  // chain rule across the derivative tables, in place
@@ -877,6 +915,7 @@ int run_stacked(const Launch& L, hipStream_t s) {
 }
 
 int ensure_stacked(fx_ctx* ctx, fx_element* e, int order);  // defined after the C entry points it uses
+int ensure_high_order(fx_ctx* ctx, fx_element* e, int order);
 
 // ---- registry of cooperative (large-shape) kernels: <SD, ORDER, MT16, M4, TPW> ------
 struct CoopShape {
@@ -1037,7 +1076,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     a.KS = e->KS;
     a.MT = e->MT;
     a.ntab = ntab;
-    if (const char* dbg = getenv("FIAT_AMD_DEBUG")) a.debug = atoi(dbg);  // ablation switches (measurement only)
+    if (const char* dbg = ab_env("FIAT_AMD_DEBUG")) a.debug = atoi(dbg);  // ablation switches (measurement only)
     if (nreq == 0 || npts == 0) {  // empty batch / empty point set: nothing to launch
         a.nitems = 0;
         L.grid = 0;
@@ -1077,12 +1116,12 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     // ---- cooperative kernel for large shapes? ----
     L.coop_id = -1;
     {
-        const char* nocoop = getenv("FIAT_AMD_NO_COOP");
+        const bool nocoop = (ctx->policy & FX_POLICY_NO_COOP) != 0;
         const int rem = rows % 16;
         const bool split = rem != 0 && rem <= 12;
         const int mt16 = split ? rows / 16 : (rows + 15) / 16, m4 = split ? (rem + 3) / 4 : 0;
         const int nt_need = (ntab * npts + 15) / 16;
-        if (!(nocoop && atoi(nocoop)) && npts <= 64 && e->d_coop_eint) {
+        if (!nocoop && npts <= 64 && e->d_coop_eint) {
             for (size_t i = 0; i < sizeof(kCoopShapes) / sizeof(kCoopShapes[0]); ++i) {
                 const CoopShape& c = kCoopShapes[i];
                 if (c.sd != e->sd || c.order != order || c.mt16 != mt16 || c.m4 != m4 || nt_need > 4 * c.tpw) continue;
@@ -1143,10 +1182,10 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     }
     // ---- shape-specialised kernel available? ----
     L.fixed_id = -1;
-    const char* nofixed = getenv("FIAT_AMD_NO_FIXED");
-    const char* stacked_small = getenv("FIAT_AMD_STACKED_SMALL");  // A/B: the stacked kernel's small-shape instances instead
-    const bool ab_small = stacked_small && atoi(stacked_small) && !verts && mapping == FX_MAP_AFFINE;
-    if (!(nofixed && atoi(nofixed)) && !ab_small && npts <= 64) {
+    const bool nofixed = (ctx->policy & FX_POLICY_NO_FIXED) != 0;
+    const bool stacked_small = (ctx->policy & FX_POLICY_STACKED_SMALL) != 0;  // A/B: the stacked kernel's small-shape instances instead
+    const bool ab_small = stacked_small && !verts && mapping == FX_MAP_AFFINE;
+    if (!nofixed && !ab_small && npts <= 64) {
         const int nt_need = (ntab * npts + 15) / 16;
         for (size_t i = 0; i < sizeof(kFixedShapes) / sizeof(kFixedShapes[0]); ++i) {
             const FixedShape& f = kFixedShapes[i];
@@ -1193,9 +1232,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             fa.pts = pts;
             fa.verts = verts;
             fa.out = out;
-            const char* kk = getenv("FIAT_AMD_KERNEL");
+            const char* kk = (ctx->policy & FX_POLICY_KERNEL_IMAGE) ? "image" : (ctx->policy & FX_POLICY_KERNEL_STREAM) ? "stream" : nullptr;
             // default: K-streamed kernel, two requests per wave when the points of two requests fit
-            // one wave (A/B: FIAT_AMD_KERNEL=image|stream|pair)
+            // one wave (A/B: FX_POLICY_KERNEL_IMAGE | _STREAM)
             // (pair kernel: the tables of each output half must fit half of the column tiles)
             const bool pair_ok = npts <= 32 * (3 - f.rpw) && (f.fullimg || ntab == 1 ||
                                                               (f.nt % 2 == 0 && (f.nt / 2) * 16 >= ((ntab + 1) / 2) * npts));
@@ -1261,7 +1300,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     // ---- low-order lane-local kernel? ----
     L.small_id = -1;
     {
-        static const bool nosmall = getenv("FIAT_AMD_NO_SMALL") != nullptr;
+        const bool nosmall = (ctx->policy & FX_POLICY_NO_SMALL) != 0;
         const long long reqbytes8 = (long long)ntab * rows * npts * 8;
         if (!nosmall && order <= 2 && npts <= 64 && rows <= 96 && reqbytes8 <= 16 * 1024 && e->d_cmat) {
             for (size_t i = 0; i < sizeof(kSmallShapes) / sizeof(kSmallShapes[0]); ++i) {
@@ -1302,9 +1341,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     // ---- stacked-matrix kernel (requests on the element's own cell, large shapes)? ----
     L.stacked_id = -1;
     {
-        static const bool nostacked = getenv("FIAT_AMD_NO_STACKED") != nullptr;
+        const bool nostacked = (ctx->policy & FX_POLICY_NO_STACKED) != 0;
         // (fewer stacked rows: the production of the B fragments is no longer amortised over enough row tiles)
-        static const long long stacked_min_rows = getenv("FIAT_AMD_STACKED_MIN_ROWS") ? atoll(getenv("FIAT_AMD_STACKED_MIN_ROWS")) : 48;
+        static const long long stacked_min_rows = ab_env("FIAT_AMD_STACKED_MIN_ROWS") ? atoll(ab_env("FIAT_AMD_STACKED_MIN_ROWS")) : 48;
         const long long R = (long long)ntab * rows;
         const int RT = (int)((R + 15) / 16);
         const bool even = ((R * npts) % 2 == 0) && (((R - 16LL * (RT - 1)) * npts) % 2 == 0);
@@ -1318,11 +1357,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 // small shapes with register-resident fragments: A/B partner of the paired kernel only (measured
                 // equal on C2, 302 vs 303 us -- both sit on the store-path plateau -- and the paired kernel's
                 // recurrence derivatives are two digits more accurate), opt-in with FIAT_AMD_STACKED_SMALL=1
-                const char* small = getenv("FIAT_AMD_STACKED_SMALL");
-                if (k.rtc > 0 ? (RT != k.rtc || verts || !(small && atoi(small))) : R < stacked_min_rows) continue;
+                if (k.rtc > 0 ? (RT != k.rtc || verts || !stacked_small) : R < stacked_min_rows) continue;
                 if (k.rtc == -2) {  // per-request cells, order 1: tables mixed in registers (dof-major tiles)
-                    const char* mixenv = getenv("FIAT_AMD_STACKED_MIX");
-                    const bool nomix = mixenv && !atoi(mixenv);
+                    const bool nomix = (ctx->policy & FX_POLICY_NO_STACKED_MIX) != 0;
                     if (nomix || !verts || order != 1 || ((long long)rows * npts) % 2 || ((long long)(rows - 16 * ((rows + 15) / 16 - 1)) * npts) % 2)
                         continue;
                     const int cap = 16 * k.ct / k.g, lo = 16 * k.ct / (k.g + 1);
@@ -1436,10 +1473,10 @@ bool launch_shared_reg(int np, const fxk::SharedArgs& sa, int grid, hipStream_t 
 }
 
 template <int SD>
-int launch_shared(int order, const fxk::SharedArgs& sa, int grid, hipStream_t s) {
+int launch_shared(int order, const fxk::SharedArgs& sa, int grid, hipStream_t s, unsigned policy) {
     const int table = sa.rows * sa.npts;
     // small affine requests, order <= 1: one wave per request, line-aligned 1 KB stores
-    static const bool nowave = getenv("FIAT_AMD_NO_SHARED_WAVE") != nullptr;
+    const bool nowave = (policy & FX_POLICY_NO_SHARED_WAVE) != 0;
     if (!nowave && sa.kind == 0 && order == 1 && (table & 1) == 0) {
         const int npairs = (1 + SD) * table / 2;
         const int ns = (npairs + 63) / 64;       // 1 KB slots per request
@@ -1453,7 +1490,7 @@ int launch_shared(int order, const fxk::SharedArgs& sa, int grid, hipStream_t s)
             return FX_OK;
         }
     }
-    static const bool noreg = getenv("FIAT_AMD_NO_SHARED_REG") != nullptr;
+    const bool noreg = (policy & FX_POLICY_NO_SHARED_REG) != 0;
     // odd tables: register-resident kernel with one double per slot (order <= 1: NTAB sources per slot)
     if (!noreg && (table & 1) && order <= 1 && (sa.kind == 0 || sa.vdim == SD)) {
         const int np1 = (table + 255) / 256;
@@ -1493,6 +1530,17 @@ extern "C" {
 
 int fx_tabulate_batch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, const double* pts,
                       const double* verts, double* out, void* stream) {
+    if (ctx && e && order > 2) {  // differentiation-matrix route (ensure_high_order)
+        if (order > FX_MAX_ORDER) return fail(FX_ENOTIMPL, "derivative order %d > %d is not implemented on the device", order, FX_MAX_ORDER);
+        if (verts)
+            return fail(FX_ENOTIMPL, "derivative order %d with per-request cells is not implemented (orders <= 2 are; an element "
+                        "built on the physical cell serves any order)", order);
+        if (nreq < 0 || npts < 0) return fail(FX_EINVAL, "negative batch size");
+        if (nreq == 0 || npts == 0) return FX_OK;
+        int rc = ensure_high_order(ctx, const_cast<fx_element*>(e), order);
+        if (rc != FX_OK) return rc;
+        return fx_tabulate_batch(ctx, e->high[order], 0, nreq, npts, pts, nullptr, out, stream);
+    }
     Launch L;
     int rc = plan_launch(ctx, e, order, nreq, npts, pts, verts, out, L);
     if (rc != FX_OK) return rc;
@@ -1566,20 +1614,22 @@ int fx_tabulate_batch_shared(fx_ctx* ctx, const fx_element* e, int mapping, int 
     const int rows = e->ndof * e->vdim;
     const size_t need = (size_t)ntab * rows * npts * sizeof(double);
     hipStream_t s = (hipStream_t)stream;
-    if (need > ctx->ref_bytes) {  // grow the scratch (rare; the old buffer may still be read by queued work)
-        HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipDeviceSynchronize());
-        if (ctx->d_ref) (void)hipFree(ctx->d_ref);
-        ctx->d_ref = nullptr;
-        ctx->ref_bytes = 0;
-        HIP_TRY(hipMalloc(&ctx->d_ref, need));
-        ctx->ref_bytes = need;
-    }
+    // Reference-cell tables: scratch of THIS call, allocated and released in stream order (hipMallocAsync /
+    // hipFreeAsync on the caller's stream), so calls on different streams never share a buffer and the memory
+    // returns to the pool only after the streaming kernel below has read it.
+    HIP_TRY(hipSetDevice(ctx->device));
+    double* d_ref = nullptr;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&d_ref), need, s));
+    struct Release {
+        double* p;
+        hipStream_t s;
+        ~Release() { (void)hipFreeAsync(p, s); }
+    } release{d_ref, s};
     // the element on its own cell at the shared points, once
-    int rc = fx_tabulate_batch(ctx, e, order, 1, npts, ref_pts, nullptr, ctx->d_ref, stream);
+    int rc = fx_tabulate_batch(ctx, e, order, 1, npts, ref_pts, nullptr, d_ref, stream);
     if (rc != FX_OK) return rc;
     fxk::SharedArgs sa;
-    sa.ref = ctx->d_ref;
+    sa.ref = d_ref;
     sa.verts = verts;
     sa.out = out;
     if (!invert_small(e->sd, e->A0, sa.A0inv)) return fail(FX_EINVAL, "degenerate cell");
@@ -1591,9 +1641,9 @@ int fx_tabulate_batch_shared(fx_ctx* ctx, const fx_element* e, int mapping, int 
     // persistent workgroups; the register-resident kernel takes blocks of 256 requests
     const int grid = (int)std::max<long long>(1, std::min<long long>((nreq + fxk::SHARED_RB - 1) / fxk::SHARED_RB, (long long)ctx->num_cu * 8));
     switch (e->sd) {
-        case 1: return launch_shared<1>(order, sa, grid, s);
-        case 2: return launch_shared<2>(order, sa, grid, s);
-        case 3: return launch_shared<3>(order, sa, grid, s);
+        case 1: return launch_shared<1>(order, sa, grid, s, ctx->policy);
+        case 2: return launch_shared<2>(order, sa, grid, s, ctx->policy);
+        case 3: return launch_shared<3>(order, sa, grid, s, ctx->policy);
     }
     return fail(FX_EINVAL, "Invalid number of spatial dimensions");
 }
@@ -1617,18 +1667,19 @@ int fx_collapsed_quadrature(fx_ctx* ctx, int sd, int m, const double* verts, dou
     ra.m = m;
     const size_t need = (size_t)2 * 3 * fxk::GJ_MAX * sizeof(double);
     hipStream_t s = (hipStream_t)stream;
-    if (need > ctx->ref_bytes) {  // the 1-D rules live in the context's scratch buffer
-        HIP_TRY(hipDeviceSynchronize());
-        if (ctx->d_ref) (void)hipFree(ctx->d_ref);
-        ctx->d_ref = nullptr;
-        ctx->ref_bytes = 0;
-        HIP_TRY(hipMalloc(&ctx->d_ref, need));
-        ctx->ref_bytes = need;
-    }
-    ra.rules = ctx->d_ref;
+    // the 1-D rules: per-call scratch in stream order (see fx_tabulate_batch_shared)
+    HIP_TRY(hipSetDevice(ctx->device));
+    double* d_rules = nullptr;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&d_rules), need, s));
+    struct Release {
+        double* p;
+        hipStream_t s;
+        ~Release() { (void)hipFreeAsync(p, s); }
+    } release{d_rules, s};
+    ra.rules = d_rules;
     ra.pts = pts;
     ra.wts = wts;
-    hipLaunchKernelGGL(fxk::gauss_jacobi_kernel, dim3(1), dim3(64), 0, s, m, sd, ctx->d_ref);
+    hipLaunchKernelGGL(fxk::gauss_jacobi_kernel, dim3(1), dim3(64), 0, s, m, sd, d_rules);
     int total = 1;
     for (int d = 0; d < sd; ++d) total *= m;
     const int grid = (total + 255) / 256;
@@ -1998,6 +2049,184 @@ bool solve_dense(int n, std::vector<double> M, int nrhs, std::vector<double>& B)
 // and its derivatives are tabulated ON THE DEVICE (the parity-checked recurrence kernels) at a collapsed
 // Gauss-Jacobi rule of n + 1 points per direction (exact for the degree-2n products), D^alpha = R_alpha M^-1
 // with the mass matrix M = sum w phi phi^T and R_alpha = sum w (d^alpha phi) phi^T.
+// D^alpha of the RAW recurrence basis on the element's own cell, |alpha| = 1..order (order <= 2), by L2 projection:
+// the expansion set and its derivatives are tabulated on the device by the parity-checked recurrence kernels at a
+// collapsed Gauss-Jacobi rule exact for the degree-2n products, D_t = R_t M^-1.  On return (ok) B[k][(t-1) nexp + j]
+// = D_t[j][k], i.e. d^alpha_t phi_j = sum_k D_t[j][k] phi_k.
+int project_derivative_matrices(fx_ctx* ctx, fx_element* e, int order, std::vector<double>& B, bool& ok) {
+    ok = false;
+    const int sd = e->sd, nexp = e->nexp;
+    const int ntab = fx::binom(sd + order, sd);
+    // vertices of the element's cell: preimages of the default simplex's vertices under x -> A0 x + b0
+    double inv[9], verts[12];
+    if (!invert_small(sd, e->A0, inv)) return FX_OK;
+    for (int v = 0; v <= sd; ++v)
+        for (int i = 0; i < sd; ++i) {
+            double t = 0.0;
+            for (int d = 0; d < sd; ++d) t += inv[i * sd + d] * ((v == d + 1 ? 1.0 : -1.0) - e->b0[d]);
+            verts[v * sd + i] = t;
+        }
+    const int m = e->n + 1;
+    int nq = 1;
+    for (int d = 0; d < sd; ++d) nq *= m;
+    double *d_pts = nullptr, *d_wts = nullptr, *d_tab = nullptr;
+    fx_element* raw = new fx_element;
+    raw->ctx = ctx;
+    raw->sd = sd;
+    raw->n = e->n;
+    raw->variant = e->variant;
+    raw->nexp = nexp;
+    raw->scale = e->scale;
+    memcpy(raw->A0, e->A0, sizeof raw->A0);
+    memcpy(raw->b0, e->b0, sizeof raw->b0);
+    raw->prog = e->prog;
+    raw->raw_expansion = true;  // (no C0 transform: the projection is onto the raw recurrence basis)
+    std::vector<double> tab((size_t)ntab * nexp * nq), wts(nq);
+    auto cleanup = [&]() {
+        if (d_pts) (void)hipFree(d_pts);
+        if (d_wts) (void)hipFree(d_wts);
+        if (d_tab) (void)hipFree(d_tab);
+        fx_element_destroy(raw);
+    };
+    int rc = FX_OK;
+    hipError_t he = hipMalloc(&raw->d_steps, std::max<size_t>(1, raw->prog.steps.size()) * sizeof(fxk::Step));
+    if (he == hipSuccess && !raw->prog.steps.empty())
+        he = hipMemcpy(raw->d_steps, raw->prog.steps.data(), raw->prog.steps.size() * sizeof(fxk::Step), hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMalloc(&d_pts, (size_t)nq * sd * sizeof(double));
+    if (he == hipSuccess) he = hipMalloc(&d_wts, (size_t)nq * sizeof(double));
+    if (he == hipSuccess) he = hipMalloc(&d_tab, tab.size() * sizeof(double));
+    if (he != hipSuccess) {
+        cleanup();
+        return fail(FX_EHIP, "stacked matrix: %s", hipGetErrorString(he));
+    }
+    rc = upload_coeffs(raw, nexp, 1, nullptr);
+    if (rc == FX_OK) rc = fx_collapsed_quadrature(ctx, sd, m, verts, d_pts, d_wts, nullptr);
+    if (rc == FX_OK) rc = fx_tabulate_batch(ctx, raw, order, 1, nq, d_pts, nullptr, d_tab, nullptr);
+    if (rc == FX_OK) {
+        he = hipMemcpy(tab.data(), d_tab, tab.size() * sizeof(double), hipMemcpyDeviceToHost);
+        if (he == hipSuccess) he = hipMemcpy(wts.data(), d_wts, wts.size() * sizeof(double), hipMemcpyDeviceToHost);
+        if (he != hipSuccess) rc = fail(FX_EHIP, "stacked matrix: %s", hipGetErrorString(he));
+    }
+    cleanup();
+    if (rc != FX_OK) return rc;
+    // M (symmetric) and the right-hand sides R_alpha^T, side by side
+    const int nrhs = (ntab - 1) * nexp;
+    std::vector<double> M((size_t)nexp * nexp, 0.0), wphi((size_t)nexp * nq);
+    B.assign((size_t)nexp * nrhs, 0.0);
+    for (int k = 0; k < nexp; ++k)
+        for (int q = 0; q < nq; ++q) wphi[(size_t)k * nq + q] = wts[q] * tab[(size_t)k * nq + q];
+    for (int k = 0; k < nexp; ++k)
+        for (int l = 0; l < nexp; ++l) {
+            double t = 0.0;
+            for (int q = 0; q < nq; ++q) t += wphi[(size_t)k * nq + q] * tab[(size_t)l * nq + q];
+            M[(size_t)k * nexp + l] = t;
+        }
+    for (int t = 1; t < ntab; ++t)
+        for (int j = 0; j < nexp; ++j) {
+            const double* dj = &tab[((size_t)t * nexp + j) * nq];
+            for (int k = 0; k < nexp; ++k) {
+                double acc = 0.0;
+                for (int q = 0; q < nq; ++q) acc += dj[q] * wphi[(size_t)k * nq + q];
+                B[(size_t)k * nrhs + (size_t)(t - 1) * nexp + j] = acc;  // R_t^T[k][j]
+            }
+        }
+    ok = solve_dense(nexp, M, nrhs, B);
+    return FX_OK;
+}
+
+// Derivative orders > 2 (FIAT/expansions.py:66-137 carries the Leibniz rule to any order; above its recurrence order the
+// reference itself switches to differentiation matrices, :438-446, 577-599).  On the element's own cell
+// d^alpha phi = D^alpha phi with constant matrices, D^(beta + e_d) = D^beta D^(e_d): the first-order matrices come from
+// the parity-checked order-1 recurrence tables (project_derivative_matrices), the stacked matrix [C D^alpha] over all
+// |alpha| <= order becomes the coefficient matrix of an internal element, and one order-0 tabulation of that element
+// writes every table in place -- [ntab][rows][npts] IS [ntab * rows][npts].
+int ensure_high_order(fx_ctx* ctx, fx_element* e, int order) {
+    static std::mutex build_mutex;
+    std::lock_guard<std::mutex> lock(build_mutex);
+    if (e->high_state[order] == 1) return FX_OK;
+    if (e->high_state[order] < 0) return fail(FX_ENOTIMPL, "derivative order %d: differentiation matrices could not be built", order);
+    e->high_state[order] = -1;
+    const int sd = e->sd, nexp = e->nexp;
+    const int rows = (int)(e->hC.size() / (size_t)nexp);
+    std::vector<double> D1((size_t)sd * nexp * nexp, 0.0);   // D1[d][j][k]
+    if (e->n >= 1) {
+        std::vector<double> B;
+        bool ok = false;
+        int rc = project_derivative_matrices(ctx, e, 1, B, ok);
+        if (rc != FX_OK) return rc;
+        if (!ok) return fail(FX_ENOTIMPL, "derivative order %d: singular mass matrix of the expansion set", order);
+        const int nrhs = sd * nexp;
+        for (int d = 0; d < sd; ++d)
+            for (int j = 0; j < nexp; ++j)
+                for (int k = 0; k < nexp; ++k) D1[((size_t)d * nexp + j) * nexp + k] = B[(size_t)k * nrhs + (size_t)d * nexp + j];
+    }
+    // all multi-indices |alpha| <= order in mis() order, each D^alpha from its predecessor
+    std::vector<std::vector<int>> alphas;
+    for (int k = 0; k <= order; ++k) {
+        std::vector<std::vector<int>> level = fx::multi_indices(sd, k);
+        alphas.insert(alphas.end(), level.begin(), level.end());
+    }
+    const int ntab = (int)alphas.size();
+    std::vector<std::vector<double>> Dm(ntab);
+    std::vector<double> S((size_t)ntab * rows * nexp, 0.0);
+    for (int t = 0; t < ntab; ++t) {
+        std::vector<double>& D = Dm[t];
+        D.assign((size_t)nexp * nexp, 0.0);
+        int d = 0;
+        while (d < sd && alphas[t][d] == 0) ++d;
+        if (d == sd) {
+            for (int i = 0; i < nexp; ++i) D[(size_t)i * nexp + i] = 1.0;
+        } else {
+            std::vector<int> beta = alphas[t];
+            beta[d] -= 1;
+            int tb = 0;
+            while (alphas[tb] != beta) ++tb;
+            const std::vector<double>& P = Dm[tb];
+            const double* E = &D1[(size_t)d * nexp * nexp];
+            for (int i = 0; i < nexp; ++i)
+                for (int l = 0; l < nexp; ++l) {
+                    const double pil = P[(size_t)i * nexp + l];
+                    if (pil == 0.0) continue;
+                    for (int k = 0; k < nexp; ++k) D[(size_t)i * nexp + k] += pil * E[(size_t)l * nexp + k];
+                }
+        }
+        for (int r = 0; r < rows; ++r) {
+            double* srow = &S[((size_t)t * rows + r) * nexp];
+            for (int j = 0; j < nexp; ++j) {
+                const double c = e->hC[(size_t)r * nexp + j];
+                if (c == 0.0) continue;
+                for (int k = 0; k < nexp; ++k) srow[k] += c * D[(size_t)j * nexp + k];
+            }
+        }
+    }
+    // the internal element: same cell, same recurrence, no C0 transform (hC already carries it), rows = all tables
+    fx_element* h = new fx_element;
+    h->ctx = ctx;
+    h->sd = sd;
+    h->n = e->n;
+    h->variant = e->variant;
+    h->nexp = nexp;
+    h->scale = e->scale;
+    memcpy(h->A0, e->A0, sizeof h->A0);
+    memcpy(h->b0, e->b0, sizeof h->b0);
+    h->prog = e->prog;
+    hipError_t he = hipMalloc(&h->d_steps, std::max<size_t>(1, h->prog.steps.size()) * sizeof(fxk::Step));
+    if (he == hipSuccess && !h->prog.steps.empty())
+        he = hipMemcpy(h->d_steps, h->prog.steps.data(), h->prog.steps.size() * sizeof(fxk::Step), hipMemcpyHostToDevice);
+    if (he != hipSuccess) {
+        fx_element_destroy(h);
+        return fail(FX_EHIP, "derivative order %d: %s", order, hipGetErrorString(he));
+    }
+    int rc = upload_coeffs(h, ntab * rows, 1, S.data());
+    if (rc != FX_OK) {
+        fx_element_destroy(h);
+        return rc;
+    }
+    e->high[order] = h;
+    e->high_state[order] = 1;
+    return FX_OK;
+}
+
 int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
     if (order < 0 || order > 2) return FX_OK;
     // built lazily from plan_launch, which may run on several host threads for the same element
@@ -2012,79 +2241,12 @@ int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
     std::vector<double> S((size_t)R * nexp, 0.0);  // stacked matrix
     std::copy(e->hC.begin(), e->hC.end(), S.begin());
     if (ntab > 1) {
-        // vertices of the element's cell: preimages of the default simplex's vertices under x -> A0 x + b0
-        double inv[9], verts[12];
-        if (!invert_small(sd, e->A0, inv)) return FX_OK;
-        for (int v = 0; v <= sd; ++v)
-            for (int i = 0; i < sd; ++i) {
-                double t = 0.0;
-                for (int d = 0; d < sd; ++d) t += inv[i * sd + d] * ((v == d + 1 ? 1.0 : -1.0) - e->b0[d]);
-                verts[v * sd + i] = t;
-            }
-        const int m = e->n + 1;
-        int nq = 1;
-        for (int d = 0; d < sd; ++d) nq *= m;
-        double *d_pts = nullptr, *d_wts = nullptr, *d_tab = nullptr;
-        fx_element* raw = new fx_element;
-        raw->ctx = ctx;
-        raw->sd = sd;
-        raw->n = e->n;
-        raw->variant = e->variant;
-        raw->nexp = nexp;
-        raw->scale = e->scale;
-        memcpy(raw->A0, e->A0, sizeof raw->A0);
-        memcpy(raw->b0, e->b0, sizeof raw->b0);
-        raw->prog = e->prog;
-        raw->raw_expansion = true;  // (no C0 transform: the projection is onto the raw recurrence basis)
-        std::vector<double> tab((size_t)ntab * nexp * nq), wts(nq);
-        auto cleanup = [&]() {
-            if (d_pts) (void)hipFree(d_pts);
-            if (d_wts) (void)hipFree(d_wts);
-            if (d_tab) (void)hipFree(d_tab);
-            fx_element_destroy(raw);
-        };
-        int rc = FX_OK;
-        hipError_t he = hipMalloc(&raw->d_steps, std::max<size_t>(1, raw->prog.steps.size()) * sizeof(fxk::Step));
-        if (he == hipSuccess && !raw->prog.steps.empty())
-            he = hipMemcpy(raw->d_steps, raw->prog.steps.data(), raw->prog.steps.size() * sizeof(fxk::Step), hipMemcpyHostToDevice);
-        if (he == hipSuccess) he = hipMalloc(&d_pts, (size_t)nq * sd * sizeof(double));
-        if (he == hipSuccess) he = hipMalloc(&d_wts, (size_t)nq * sizeof(double));
-        if (he == hipSuccess) he = hipMalloc(&d_tab, tab.size() * sizeof(double));
-        if (he != hipSuccess) {
-            cleanup();
-            return fail(FX_EHIP, "stacked matrix: %s", hipGetErrorString(he));
-        }
-        rc = upload_coeffs(raw, nexp, 1, nullptr);
-        if (rc == FX_OK) rc = fx_collapsed_quadrature(ctx, sd, m, verts, d_pts, d_wts, nullptr);
-        if (rc == FX_OK) rc = fx_tabulate_batch(ctx, raw, order, 1, nq, d_pts, nullptr, d_tab, nullptr);
-        if (rc == FX_OK) {
-            he = hipMemcpy(tab.data(), d_tab, tab.size() * sizeof(double), hipMemcpyDeviceToHost);
-            if (he == hipSuccess) he = hipMemcpy(wts.data(), d_wts, wts.size() * sizeof(double), hipMemcpyDeviceToHost);
-            if (he != hipSuccess) rc = fail(FX_EHIP, "stacked matrix: %s", hipGetErrorString(he));
-        }
-        cleanup();
+        std::vector<double> B;
+        bool ok = false;
+        int rc = project_derivative_matrices(ctx, e, order, B, ok);
         if (rc != FX_OK) return rc;
-        // M (symmetric) and the right-hand sides R_alpha^T, side by side
+        if (!ok) return FX_OK;  // (state stays -1: other kernels serve the element)
         const int nrhs = (ntab - 1) * nexp;
-        std::vector<double> M((size_t)nexp * nexp, 0.0), B((size_t)nexp * nrhs, 0.0), wphi((size_t)nexp * nq);
-        for (int k = 0; k < nexp; ++k)
-            for (int q = 0; q < nq; ++q) wphi[(size_t)k * nq + q] = wts[q] * tab[(size_t)k * nq + q];
-        for (int k = 0; k < nexp; ++k)
-            for (int l = 0; l < nexp; ++l) {
-                double t = 0.0;
-                for (int q = 0; q < nq; ++q) t += wphi[(size_t)k * nq + q] * tab[(size_t)l * nq + q];
-                M[(size_t)k * nexp + l] = t;
-            }
-        for (int t = 1; t < ntab; ++t)
-            for (int j = 0; j < nexp; ++j) {
-                const double* dj = &tab[((size_t)t * nexp + j) * nq];
-                for (int k = 0; k < nexp; ++k) {
-                    double acc = 0.0;
-                    for (int q = 0; q < nq; ++q) acc += dj[q] * wphi[(size_t)k * nq + q];
-                    B[(size_t)k * nrhs + (size_t)(t - 1) * nexp + j] = acc;  // R_t^T[k][j]
-                }
-            }
-        if (!solve_dense(nexp, M, nrhs, B)) return FX_OK;  // (state stays -1: other kernels serve the element)
         // B[k][(t-1) nexp + j] = D_t[j][k];  rows of table t: C D_t
         for (int t = 1; t < ntab; ++t)
             for (int r = 0; r < rows; ++r) {
@@ -2401,7 +2563,7 @@ int fx_macro_tabulate_batch(fx_ctx* ctx, const fx_macro_element* e, int order, i
     const int rows = e->ndof * e->vdim;
     HIP_TRY(hipSetDevice(ctx->device));
     {   // lane-local kernel for the registered low-order shapes
-        static const bool nosmall = getenv("FIAT_AMD_NO_MACRO_SMALL") != nullptr;
+        const bool nosmall = (ctx->policy & FX_POLICY_NO_MACRO_SMALL) != 0;
         const long long cmat_doubles = ((long long)e->ncell * rows * e->nexp + 1) & ~1LL;
         for (size_t i = 0; !nosmall && i < sizeof(kMacroSmallShapes) / sizeof(kMacroSmallShapes[0]); ++i) {
             const MacroSmallShape& m = kMacroSmallShapes[i];
@@ -2450,7 +2612,7 @@ int fx_macro_tabulate_batch(fx_ctx* ctx, const fx_macro_element* e, int order, i
             sa.vec2 = vec2;
             sa.stage_doubles = (int)stage_doubles;
             sa.cmat_doubles = (int)cmat_doubles;
-            if (const char* dbg = getenv("FIAT_AMD_DEBUG")) sa.debug = atoi(dbg);  // ablation switches (measurement only)
+            if (const char* dbg = ab_env("FIAT_AMD_DEBUG")) sa.debug = atoi(dbg);  // ablation switches (measurement only)
             const int wg_per_cu = std::max(1, std::min(8, ctx->lds_per_cu / (int)lds_bytes));
             const long long nwg = (sa.nitems + MACRO_SMALL_NW - 1) / MACRO_SMALL_NW;
             const int grid = (int)std::max<long long>(1, std::min<long long>(nwg, (long long)ctx->num_cu * wg_per_cu * 2));
@@ -2513,6 +2675,213 @@ int fx_macro_tabulate_batch(fx_ctx* ctx, const fx_macro_element* e, int order, i
         case 3: return launch_macro_sd<3>(order, a, grid, lds_bytes, (hipStream_t)stream);
     }
     return fail(FX_EINVAL, "Invalid number of spatial dimensions");
+}
+
+// ---------------------------------------------------------------------------------
+// multi-GPU: RCCL over xGMI behind the C ABI (comm.hpp; SURVEY.md 8b fx_allgather_tables, 8e)
+#define NCCL_TRY(expr)                                                                          \
+    do {                                                                                        \
+        ncclResult_t r_ = (expr);                                                               \
+        if (r_ != ncclSuccess) return fail(FX_EHIP, "%s: %s", #expr, fxcomm::api().GetErrorString(r_)); \
+    } while (0)
+
+int fx_comm_available(void) {
+    const fxcomm::Api& a = fxcomm::api();
+    if (!a.handle) return fail(FX_EHIP, "RCCL is not available: %s", a.why);
+    return FX_OK;
+}
+
+int fx_comm_unique_id(unsigned char* id) {
+    if (!id) return fail(FX_EINVAL, "fx_comm_unique_id: null buffer");
+    if (fx_comm_available() != FX_OK) return FX_EHIP;
+    static_assert(sizeof(ncclUniqueId) == FX_COMM_ID_BYTES, "FX_COMM_ID_BYTES must match ncclUniqueId");
+    ncclUniqueId u;
+    NCCL_TRY(fxcomm::api().GetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return FX_OK;
+}
+
+int fx_comm_create(fx_ctx* ctx, int nranks, int rank, const unsigned char* id, fx_comm** out) {
+    if (!ctx || !id || !out) return fail(FX_EINVAL, "fx_comm_create: null argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(FX_EINVAL, "fx_comm_create: rank %d of %d", rank, nranks);
+    if (fx_comm_available() != FX_OK) return FX_EHIP;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclComm_t c = nullptr;
+    NCCL_TRY(fxcomm::api().CommInitRank(&c, nranks, u, rank));
+    fx_comm* fc = new fx_comm;
+    fc->ctx = ctx;
+    fc->comm = c;
+    fc->nranks = nranks;
+    fc->rank = rank;
+    *out = fc;
+    return FX_OK;
+}
+
+int fx_comm_destroy(fx_comm* c) {
+    if (c && c->comm) (void)fxcomm::api().CommDestroy(c->comm);
+    delete c;
+    return FX_OK;
+}
+
+int fx_allgather_tables(fx_comm* c, const double* send, double* recv, int64_t count, int64_t stride, int64_t offset,
+                        int algo, void* stream) {
+    if (!c || !c->comm) return fail(FX_EINVAL, "fx_allgather_tables: null communicator");
+    if (count < 0 || stride < 0 || offset < 0 || offset + count > stride)
+        return fail(FX_EINVAL, "fx_allgather_tables: block [%lld, %lld) does not fit the stride %lld", (long long)offset,
+                    (long long)(offset + count), (long long)stride);
+    if (count == 0) return FX_OK;
+    if (!send || !recv) return fail(FX_EINVAL, "fx_allgather_tables: null device pointer");
+    const fxcomm::Api& a = fxcomm::api();
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    if (algo == FX_GATHER_RING) {
+        if (stride != count || offset != 0)
+            return fail(FX_EINVAL, "fx_allgather_tables: FX_GATHER_RING needs blocks that tile the buffer (stride == count, offset == 0)");
+        NCCL_TRY(a.AllGather(send, recv, (size_t)count, ncclDouble, c->comm, s));
+        return FX_OK;
+    }
+    if (algo != FX_GATHER_DIRECT) return fail(FX_EINVAL, "fx_allgather_tables: unknown algorithm %d", algo);
+    double* mine = recv + (size_t)c->rank * stride + offset;
+    if (mine != send) HIP_TRY(hipMemcpyAsync(mine, send, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (c->nranks == 1) return FX_OK;
+    NCCL_TRY(a.GroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int d = 1; d < c->nranks && bad == ncclSuccess; ++d) {
+        // peer order rotated by the rank: at step d every GPU sends to rank + d and receives from rank - d,
+        // so the 7 steps use 7 different links on every GPU
+        const int to = (c->rank + d) % c->nranks, from = (c->rank - d + c->nranks) % c->nranks;
+        bad = a.Send(send, (size_t)count, ncclDouble, to, c->comm, s);
+        if (bad == ncclSuccess) bad = a.Recv(recv + (size_t)from * stride + offset, (size_t)count, ncclDouble, from, c->comm, s);
+    }
+    const ncclResult_t end = a.GroupEnd();  // always closed, also after a failed call inside the group
+    if (bad != ncclSuccess) return fail(FX_EHIP, "ncclSend/ncclRecv: %s", a.GetErrorString(bad));
+    if (end != ncclSuccess) return fail(FX_EHIP, "ncclGroupEnd: %s", a.GetErrorString(end));
+    return FX_OK;
+}
+
+// TensorProductElement.tabulate for ANY two tabulated factors (table_kernels.hpp table_outer_kernel)
+int fx_table_outer_batch(fx_ctx* ctx, int order, int sdA, int sdB, int64_t nreq, int npts, int rowsA, int vdimA, int rowsB,
+                         int vdimB, const double* tabA, const double* tabB, double* out, void* stream) {
+    if (!ctx) return fail(FX_EINVAL, "fx_table_outer_batch: null context");
+    if (order < 0 || sdA < 0 || sdB < 0 || sdA + sdB < 1 || nreq < 0 || npts < 0 || rowsA < 1 || rowsB < 1 || vdimA < 1 || vdimB < 1)
+        return fail(FX_EINVAL, "fx_table_outer_batch: bad argument");
+    if (vdimA > 1 && vdimB > 1) return fail(FX_ENOTIMPL, "tabulate does not support two vector-valued inputs");
+    if (nreq == 0 || npts == 0) return FX_OK;
+    if (!tabA || !tabB || !out) return fail(FX_EINVAL, "fx_table_outer_batch: null device pointer");
+    const int vdim = std::max(vdimA, vdimB);
+    if ((long long)rowsA * rowsB * vdim * npts >= (1LL << 24)) return fail(FX_ENOTIMPL, "fx_table_outer_batch: table of %lld entries is too large", (long long)rowsA * rowsB * vdim * npts);
+    // tables of a factor: all multi-indices of order <= `order` in mis() order (a 0-dimensional factor has one table)
+    auto tables = [&](int sd) {
+        std::vector<std::vector<int>> all;
+        for (int k = 0; k <= order; ++k) {
+            if (sd == 0) {
+                if (k == 0) all.push_back({});
+                continue;
+            }
+            std::vector<std::vector<int>> level = fx::multi_indices(sd, k);
+            all.insert(all.end(), level.begin(), level.end());
+        }
+        return all;
+    };
+    const std::vector<std::vector<int>> TA = tables(sdA), TB = tables(sdB), T = tables(sdA + sdB);
+    if ((int)T.size() > fxk::OUTER_MAXTAB || TA.size() > 255 || TB.size() > 255) return fail(FX_ENOTIMPL, "fx_table_outer_batch: too many derivative tables (%d)", (int)T.size());
+    fxk::OuterArgs a;
+    memset(&a, 0, sizeof a);
+    a.A = tabA;
+    a.B = tabB;
+    a.out = out;
+    a.nreq = nreq;
+    a.ntab = (int)T.size();
+    a.ntabA = (int)TA.size();
+    a.ntabB = (int)TB.size();
+    a.rowsA = rowsA;
+    a.rowsB = rowsB;
+    a.vdimA = vdimA;
+    a.vdimB = vdimB;
+    a.npts = npts;
+    for (size_t t = 0; t < T.size(); ++t) {
+        const std::vector<int> aa(T[t].begin(), T[t].begin() + sdA), bb(T[t].begin() + sdA, T[t].end());
+        a.tA[t] = (unsigned char)(std::find(TA.begin(), TA.end(), aa) - TA.begin());
+        a.tB[t] = (unsigned char)(std::find(TB.begin(), TB.end(), bb) - TB.begin());
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const long long units = nreq * a.ntab;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(units, (long long)ctx->num_cu * 16));
+    hipLaunchKernelGGL(fxk::table_outer_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+// entity coordinates -> cell coordinates for a whole batch of points (table_kernels.hpp map_points_kernel)
+int fx_map_points(fx_ctx* ctx, int din, int dout, const double* M, const double* b, int64_t n, const double* in, double* out,
+                  void* stream) {
+    if (!ctx) return fail(FX_EINVAL, "fx_map_points: null context");
+    if (din < 0 || din > 3 || dout < 1 || dout > 3 || n < 0) return fail(FX_EINVAL, "fx_map_points: bad dimensions (%d -> %d)", din, dout);
+    if (n == 0) return FX_OK;
+    if (!b || (din > 0 && (!M || !in)) || !out) return fail(FX_EINVAL, "fx_map_points: null pointer");
+    fxk::MapPointsArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = in;
+    a.out = out;
+    a.n = n;
+    a.din = din;
+    a.dout = dout;
+    for (int i = 0; i < dout * din; ++i) a.M[i] = M[i];
+    for (int i = 0; i < dout; ++i) a.b[i] = b[i];
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int grid = (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, (long long)ctx->num_cu * 16));
+    hipLaunchKernelGGL(fxk::map_points_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+// FIAT/jacobi.py eval_jacobi_batch / eval_jacobi_deriv_batch on the device (jacobi_kernel.hpp)
+int fx_jacobi_batch(fx_ctx* ctx, double a, double b, int n, int order, int64_t npts, const double* xs, double* out,
+                    void* stream) {
+    if (!ctx) return fail(FX_EINVAL, "fx_jacobi_batch: null context");
+    if (n < 0 || order < 0 || npts < 0) return fail(FX_EINVAL, "fx_jacobi_batch: negative degree, order or point count");
+    if (n > fxk::JACOBI_MAXN) return fail(FX_ENOTIMPL, "fx_jacobi_batch: degree %d > %d", n, fxk::JACOBI_MAXN);
+    if (npts == 0) return FX_OK;
+    if (!xs || !out) return fail(FX_EINVAL, "fx_jacobi_batch: null device pointer");
+    fxk::JacobiArgs A;
+    memset(&A, 0, sizeof A);
+    A.xs = xs;
+    A.out = out;
+    A.npts = npts;
+    A.n = n;
+    A.order = order;
+    const double as = a + order, bs = b + order, apb = as + bs;  // weights of the shifted family
+    A.p1c = 0.5 * (as - bs);
+    A.p1x = 0.5 * (apb + 2.0);
+    for (int k = 2; k <= n - order; ++k) {  // jacobi.py:62-71, same expression order
+        const double a1 = 2.0 * k * (k + apb) * (2.0 * k + apb - 2.0);
+        A.a2[k] = (2.0 * k + apb - 1.0) * (as * as - bs * bs) / a1;
+        A.a3[k] = (2.0 * k + apb - 2.0) * (2.0 * k + apb - 1.0) * (2.0 * k + apb) / a1;
+        A.a4[k] = 2.0 * (k + as - 1.0) * (k + bs - 1.0) * (2.0 * k + apb) / a1;
+    }
+    for (int j = order; j <= n; ++j) {      // jacobi.py:96-101
+        double z = 1.0;
+        const double f = a + b + j + 1;
+        for (int l = 0; l < order; ++l) z *= 0.5 * (f + l);
+        A.z[j] = z;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const long long want = (npts + 255) / 256;
+    const int grid = (int)std::max<long long>(1, std::min<long long>(want, (long long)ctx->num_cu * 16));
+    hipLaunchKernelGGL(fxk::jacobi_batch_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, A);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
+// after a synchronisation: did a dynamically scheduled kernel of this context give up waiting for a chunk
+// id (work_queue.hpp)?  Synchronises `stream` first.
+int fx_ctx_check(fx_ctx* ctx, void* stream) {
+    if (!ctx) return fail(FX_EINVAL, "fx_ctx_check: null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return check_work_queues(ctx);
 }
 
 }  // extern "C"

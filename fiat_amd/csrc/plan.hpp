@@ -41,6 +41,20 @@ inline int binom(int n, int k) {
     return (int)r;
 }
 
+// All m-tuples of non-negative integers summing to n, in the order of FIAT's mis() (polynomial_set.py:23-32): the
+// first entry descends from n, the rest recursively -- (2,0,0) (1,1,0) (1,0,1) (0,2,0) (0,1,1) (0,0,2).
+inline std::vector<std::vector<int>> multi_indices(int m, int n) {
+    if (m == 1) return {{n}};
+    std::vector<std::vector<int>> out;
+    for (int i = 0; i <= n; ++i)
+        for (const std::vector<int>& rest : multi_indices(m - 1, i)) {
+            std::vector<int> a{n - i};
+            a.insert(a.end(), rest.begin(), rest.end());
+            out.push_back(a);
+        }
+    return out;
+}
+
 inline void jacobi_abc(double a, double b, int n, double& an, double& bn, double& cn) {
     double s = a + b;
     an = (2 * n + 1 + s) * (2 * n + 2 + s) / (2 * (n + 1) * (n + 1 + s));

@@ -165,4 +165,83 @@ __global__ __launch_bounds__(256) void table_mix_kernel(const TableMixArgs a) {
     }
 }
 
+// ---- tensor products of ANY two tabulated factors (TensorProductElement.tabulate, FIAT/tensor_product.py:231-336) ----
+// out[r][t][a * rowsB + b][c][p] = A[r][tA(t)][a][cA][p] * B[r][tB(t)][b][cB][p]   for alpha_t = (alpha_A, alpha_B):
+// scalar x scalar (:274-292), vector x scalar (:293-317) and scalar x vector (:318-335) are the same formula with the
+// component index c riding on whichever factor is vector-valued.  The factor tables come from the factors' own kernels
+// (simplex elements, 1-D Lagrange, nested products); this pass is write-bound: 8 * rowsA * rowsB * vdim * npts bytes per
+// table against 8 * (rowsA * vdimA + rowsB * vdimB) * npts read (L2 hits: every factor entry is reused rowsB / rowsA times).
+constexpr int OUTER_MAXTAB = 220;  // tables per request: C(sd + order, sd) for sd = 3, order = 9
+
+struct OuterArgs {
+    const double* A;  // [nreq][ntabA][rowsA][vdimA][npts]
+    const double* B;  // [nreq][ntabB][rowsB][vdimB][npts]
+    double* out;      // [nreq][ntab][rowsA * rowsB][vdim][npts]
+    long long nreq;
+    int ntab, ntabA, ntabB, rowsA, rowsB, vdimA, vdimB, npts;
+    unsigned char tA[OUTER_MAXTAB], tB[OUTER_MAXTAB];
+};
+
+// x / d and x % d for x < 2^24 (single-precision reciprocal + correction)
+__device__ __forceinline__ void divmod24(unsigned x, unsigned d, float inv, unsigned& q, unsigned& r) {
+    q = (unsigned)((float)x * inv);
+    int rem = (int)x - (int)(q * d);
+    if (rem < 0) {
+        --q;
+        rem += (int)d;
+    } else if (rem >= (int)d) {
+        ++q;
+        rem -= (int)d;
+    }
+    r = (unsigned)rem;
+}
+
+__global__ __launch_bounds__(256) void table_outer_kernel(const OuterArgs a) {
+    const int vdim = a.vdimA > a.vdimB ? a.vdimA : a.vdimB;
+    const unsigned npts = (unsigned)a.npts;
+    const unsigned perB = (unsigned)(a.rowsB * vdim) * npts;   // elements of one `a` block
+    const unsigned table = (unsigned)a.rowsA * perB;           // elements of one output table (< 2^24, checked on the host)
+    const float inv_perB = 1.0f / (float)perB, inv_npts = 1.0f / (float)npts, inv_vdim = 1.0f / (float)vdim;
+    const long long units = a.nreq * a.ntab;
+    for (long long u = blockIdx.x; u < units; u += gridDim.x) {
+        const long long r = u / a.ntab;
+        const int t = (int)(u - r * a.ntab);
+        const double* At = a.A + ((size_t)r * a.ntabA + a.tA[t]) * (size_t)(a.rowsA * a.vdimA) * npts;
+        const double* Bt = a.B + ((size_t)r * a.ntabB + a.tB[t]) * (size_t)(a.rowsB * a.vdimB) * npts;
+        double* o = a.out + (size_t)u * table;
+        for (unsigned j = threadIdx.x; j < table; j += 256) {
+            unsigned ia, rem, bc, p, ib, c;
+            divmod24(j, perB, inv_perB, ia, rem);
+            divmod24(rem, npts, inv_npts, bc, p);
+            divmod24(bc, (unsigned)vdim, inv_vdim, ib, c);
+            const double x = a.vdimA > 1 ? At[((size_t)ia * a.vdimA + c) * npts + p] : At[(size_t)ia * npts + p];
+            const double y = a.vdimB > 1 ? Bt[((size_t)ib * a.vdimB + c) * npts + p] : Bt[(size_t)ib * npts + p];
+            __builtin_nontemporal_store(x * y, o + j);
+        }
+    }
+}
+
+// ---- affine map of points: entity coordinates -> cell coordinates (reference_element.py:570-609) -----------------
+// out[i] = M in[i] + b with M (dout x din, din may be 0: every point becomes the vertex b), for `n` points.
+struct MapPointsArgs {
+    const double* in;  // [n][din]
+    double* out;       // [n][dout]
+    long long n;
+    int din, dout;
+    double M[9], b[3];
+};
+
+__global__ __launch_bounds__(256) void map_points_kernel(const MapPointsArgs a) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        double x[3] = {0.0, 0.0, 0.0};
+        for (int d = 0; d < a.din; ++d) x[d] = a.in[(size_t)i * a.din + d];
+        for (int e = 0; e < a.dout; ++e) {
+            double y = a.b[e];
+            for (int d = 0; d < a.din; ++d) y += a.M[e * a.din + d] * x[d];
+            a.out[(size_t)i * a.dout + e] = y;
+        }
+    }
+}
+
 }  // namespace fxk

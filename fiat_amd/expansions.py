@@ -183,20 +183,9 @@ class ExpansionSet:
                 verts=numpy.asarray(self.ref_el.get_vertices_of_subcomplex(top[sd][cell])))
         sd = self.ref_el.get_spatial_dimension()
         P = numpy.asarray(pts, dtype=float).reshape(1, -1, sd)
-        dev_order = min(order, 2)
-        out = self._dev[key].tabulate_batch(dev_order, P).cpu().numpy()[0]
-        keys = [a for k in range(dev_order + 1) for a in mis(sd, k)]
-        result = {a: out[t] for t, a in enumerate(keys)}
-        if order > 2:
-            # derivative orders beyond the kernels (super-smoothness constraints of C^k spaces, construction only):
-            # D^(beta + e_d) phi = dmat_d . D^beta phi with the differentiation matrices of the sub-cell
-            dmats = self.get_dmats(n, cell=cell)
-            for r in range(3, order + 1):
-                for alpha in mis(sd, r):
-                    d = next(i for i, a in enumerate(alpha) if a > 0)
-                    beta = tuple(a - (i == d) for i, a in enumerate(alpha))
-                    result[alpha] = dmats[d] @ result[beta]
-        return result
+        out = runtime.fetch(self._dev[key].tabulate_batch(order, P))[0]
+        keys = [a for k in range(order + 1) for a in mis(sd, k)]
+        return {a: out[t] for t, a in enumerate(keys)}
 
     def get_dmats(self, degree, cell=0):
         """dmats[d][j, i]: d/dx_d phi_j = sum_i dmats[d][j, i] phi_i on one sub-cell (FIAT/expansions.py:576-600,
@@ -219,7 +208,7 @@ class ExpansionSet:
         sd = self.ref_el.get_spatial_dimension()
         single = pts.ndim == 1
         P = pts.reshape(1, -1, sd)
-        out = self._device_set(n).tabulate_batch(order, P).cpu().numpy()[0]
+        out = runtime.fetch(self._device_set(n).tabulate_batch(order, P))[0]
         keys = [a for k in range(order + 1) for a in mis(sd, k)]
         result = {a: numpy.ascontiguousarray(out[t]) for t, a in enumerate(keys)}
         if single:

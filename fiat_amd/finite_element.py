@@ -8,7 +8,7 @@ reference (:151-156)."""
 import numpy
 
 from . import runtime
-from .polynomial_set import PolynomialSet
+from .polynomial_set import PolynomialSet, mis
 
 
 class FiniteElement:
@@ -109,28 +109,63 @@ class CiarletElement(FiniteElement):
         """Device-resident nodal basis for the batched API (fx_tabulate_batch)."""
         return self.poly_set.device_polyset()
 
-    def tabulate(self, order, points, entity=None):
-        """{alpha: (ndof, *value_shape, npts)} of all derivatives up to ``order``."""
-        if entity is None:
-            entity = (self.ref_el.get_spatial_dimension(), 0)
-        entity_dim, entity_id = entity
-        transform = self.ref_el.get_entity_transform(entity_dim, entity_id)
-        return self.poly_set.tabulate(transform(numpy.asarray(points, dtype=float)), order)
+    def entity_map(self, entity):
+        """(M, b) of the affine map from the coordinates of the reference sub-entity ``(dim, id)`` into this
+        element's cell, x = M xi + b (reference_element.py:570-609); None for the cell itself."""
+        sd = self.ref_el.get_spatial_dimension()
+        if entity is None or entity[0] == sd:
+            if entity is not None and entity[1] != 0:
+                raise ValueError("a simplex has a single cell")
+            return None
+        dim, number = entity
+        f = self.ref_el.get_entity_transform(dim, number)
+        b = numpy.asarray(f(numpy.zeros((1, dim))), dtype=float).reshape(sd)
+        M = numpy.zeros((sd, dim))
+        for i in range(dim):
+            unit = numpy.zeros((1, dim))
+            unit[0, i] = 1.0
+            M[:, i] = numpy.asarray(f(unit), dtype=float).reshape(sd) - b
+        return M, b
 
-    def tabulate_batch(self, order, points, verts=None, out=None, stream=None, pushforward=False):
+    def tabulate(self, order, points, entity=None):
+        """{alpha: (ndof, *value_shape, npts)} of all derivatives up to ``order``; ``entity=(dim, id)``: the points
+        are given in the coordinates of that reference sub-entity (FIAT/finite_element.py:181-197)."""
+        points = numpy.asarray(points, dtype=float)
+        emap = self.entity_map(entity)
+        if emap is None:
+            return self.poly_set.tabulate(points, order)
+        sd = self.ref_el.get_spatial_dimension()
+        single = points.ndim == 1 and entity[0] > 0
+        npts = (len(points) if points.ndim == 2 else 1) if entity[0] == 0 else points.size // entity[0]
+        dev = self.tabulate_batch(order, points.reshape(1, npts, entity[0]), entity=entity)
+        out = runtime.fetch(dev)[0]
+        keys = [a for k in range(order + 1) for a in mis(sd, k)]
+        return {a: (numpy.ascontiguousarray(out[t][..., 0]) if single else numpy.ascontiguousarray(out[t]))
+                for t, a in enumerate(keys)}
+
+    def tabulate_batch(self, order, points, verts=None, out=None, stream=None, pushforward=False, entity=None):
         """Batched form of tabulate(): points (nreq, npts, sd) [+ per-request cell
         vertices (nreq, sd+1, sd)] -> device tensor (nreq, ntab, ndof, *value_shape, npts)
         with tables in mis() order.  ``pushforward=True`` (needs ``verts``) applies this element's
         mapping() -- affine pull-back, covariant or contravariant Piola -- so that the tables are
-        the basis functions ON the physical cells."""
+        the basis functions ON the physical cells.  ``entity=(dim, id)``: points (nreq, npts, dim) in the
+        coordinates of that reference sub-entity, mapped into the cell on the device (fx_map_points)."""
+        emap = self.entity_map(entity)
+        if emap is not None:
+            if verts is not None:
+                raise NotImplementedError("sub-entity points with per-request cells: use tabulate_cells(..., entity=)")
+            points = runtime.map_points(*emap, points, stream=stream)
         mapping = self._mapping if pushforward else None
         return self.device_polyset().tabulate_batch(order, points, verts=verts, out=out, stream=stream, mapping=mapping)
 
-    def tabulate_cells(self, order, ref_points, verts, out=None, stream=None):
-        """The quadrature-rule case: ONE point set on this element's reference cell, pushed
-        forward (with mapping()) to the physical cells ``verts`` (nreq, sd+1, sd) -> device
-        tensor (nreq, ntab, ndof, *value_shape, npts).  Same result as
+    def tabulate_cells(self, order, ref_points, verts, out=None, stream=None, entity=None):
+        """The quadrature-rule case: ONE point set on this element's reference cell (or, ``entity=(dim, id)``, on one
+        of its reference sub-entities: a facet rule), pushed forward (with mapping()) to the physical cells ``verts``
+        (nreq, sd+1, sd) -> device tensor (nreq, ntab, ndof, *value_shape, npts).  Same result as
         ``tabulate_batch(order, F_r(ref_points), verts, pushforward=True)``."""
+        emap = self.entity_map(entity)
+        if emap is not None:
+            ref_points = runtime.map_points(*emap, ref_points, stream=stream)
         return self.device_polyset().tabulate_batch_shared(order, ref_points, verts, mapping=self._mapping, out=out,
                                                            stream=stream)
 

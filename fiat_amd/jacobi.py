@@ -1,34 +1,49 @@
-"""Jacobi polynomials on the host (FIAT/jacobi.py:47-102), used only while a dual set is being built: the
-edge-moment weight functions of the Argyris element are Jacobi(2, 2) polynomials along the edge.  (The tabulation
-hot path evaluates its 1-D recurrences on the device.)"""
+"""1-D Jacobi polynomials, evaluated on the device (fx_jacobi_batch, csrc/jacobi_kernel.hpp).
+
+Same call signatures and return shapes as FIAT/jacobi.py: ``eval_jacobi_batch(a, b, n, xs)`` (:47-74) returns the
+(n + 1, npts) table of P_k^{(a,b)} at the points ``xs`` of shape (npts, 1); ``eval_jacobi_deriv_batch`` (:85-102) the
+table of their derivatives of a given order; the scalar twins evaluate one polynomial.  ``jacobi_table`` is the
+batched form that stays on the GPU."""
 import numpy
+import torch
+
+from . import runtime
+
+
+def jacobi_table(a, b, n, xs, order=0, out=None, stream=None):
+    """Device tensor (n + 1, npts): row k = d^order/dx^order P_k^{(a,b)} at the points ``xs`` (any shape, flattened)."""
+    ctx = runtime.Context.get()
+    x = runtime._as_device(xs, ctx).reshape(-1)
+    if out is None:
+        out = torch.empty((n + 1, x.shape[0]), dtype=torch.float64, device=ctx.device)
+    runtime.check(runtime.lib.fx_jacobi_batch(ctx.handle, float(a), float(b), int(n), int(order), x.shape[0],
+                                              runtime._dev_ptr(x), runtime._dev_ptr(out), runtime._stream_ptr(stream)))
+    return out
+
+
+def _points(xs):
+    xs = numpy.asarray(xs, dtype=float)
+    return xs, (xs.shape[:-1] if xs.ndim > 1 else xs.shape)
 
 
 def eval_jacobi_batch(a, b, n, xs):
-    """P_k^{(a,b)}(x), k = 0..n, by the three-term recurrence: (n + 1, npts) for xs of shape (npts, 1)."""
-    xs = numpy.asarray(xs, dtype=float)
-    x = xs.reshape(xs.shape[:-1])
-    out = numpy.zeros((n + 1, *x.shape))
-    out[0] = 1.0
-    if n >= 1:
-        out[1] = 0.5 * (a - b + (a + b + 2.0) * x)
-    s = a + b
-    for k in range(2, n + 1):
-        den = 2.0 * k * (k + s) * (2.0 * k + s - 2.0)
-        lin = (2.0 * k + s - 1.0) * (a * a - b * b) / den
-        slope = (2.0 * k + s - 2.0) * (2.0 * k + s - 1.0) * (2.0 * k + s) / den
-        back = 2.0 * (k + a - 1.0) * (k + b - 1.0) * (2.0 * k + s) / den
-        out[k] = (lin + slope * x) * out[k - 1] - back * out[k - 2]
-    return out
+    xs, shape = _points(xs)
+    return runtime.fetch(jacobi_table(a, b, n, xs)).reshape((n + 1, *shape))
 
 
 def eval_jacobi_deriv_batch(a, b, n, xs, order=1):
-    """order-th derivatives of P_k^{(a,b)}, k = 0..n: d^m P_k^{(a,b)} = prod_{l<m} (k + a + b + 1 + l)/2 P_{k-m}^{(a+m,b+m)}."""
     xs = numpy.asarray(xs, dtype=float)
-    out = numpy.zeros((n + 1, len(xs)))
-    if n + 1 <= order:
-        return out
-    out[order:] = eval_jacobi_batch(a + order, b + order, n - order, xs)
-    for k in range(order, n + 1):
-        out[k] *= numpy.prod([0.5 * (a + b + k + 1 + l) for l in range(order)])
-    return out
+    return runtime.fetch(jacobi_table(a, b, n, xs, order=order)).reshape(n + 1, len(xs))
+
+
+def eval_jacobi(a, b, n, x):
+    """P_n^{(a,b)} at a point or an array of points (result has the shape of ``x``)."""
+    x = numpy.asarray(x, dtype=float)
+    row = runtime.fetch(jacobi_table(a, b, n, x))[n].reshape(x.shape)
+    return float(row) if x.ndim == 0 else row
+
+
+def eval_jacobi_deriv(a, b, n, x):
+    x = numpy.asarray(x, dtype=float)
+    row = runtime.fetch(jacobi_table(a, b, n, x, order=1))[n].reshape(x.shape)
+    return float(row) if x.ndim == 0 else row

@@ -35,7 +35,7 @@ class PolynomialSet:
         pts = numpy.asarray(pts, dtype=float)
         sd = self.ref_el.get_spatial_dimension()
         single = pts.ndim == 1
-        out = self.device_polyset().tabulate_batch(jet_order, pts.reshape(1, -1, sd)).cpu().numpy()[0]
+        out = runtime.fetch(self.device_polyset().tabulate_batch(jet_order, pts.reshape(1, -1, sd)))[0]
         keys = [a for k in range(jet_order + 1) for a in mis(sd, k)]
         result = {a: numpy.ascontiguousarray(out[t]) for t, a in enumerate(keys)}
         if single:

@@ -4,11 +4,11 @@ integral-moment degrees of freedom.  Host-side input producers.
 Mirrors FIAT/quadrature.py (QuadratureRule :47-93, GaussJacobiQuadratureLineRule
 :96-110, CollapsedQuadratureSimplexRule :171-181, FacetQuadratureRule :198-224,
 make_quadrature :227-255, make_tensor_product_quadrature :258-268) and
-FIAT/quadrature_schemes.py create_quadrature (:46-106).  The reference's
-"default" scheme uses tabulated Xiao-Gimbutas rules on triangles/tetrahedra
-(data tables that are not restated here): every scheme below is the collapsed
-Gauss-Jacobi ("canonical") rule of the same exactness, so moments integrate
-identically but the point sets differ from the reference's default ones.
+FIAT/quadrature_schemes.py create_quadrature (:46-106): the "default" scheme serves the
+tabulated Xiao-Gimbutas / classical rules on triangles and tetrahedra (data:
+fiat_amd/data/simplex_rules.npz, tools/make_rule_tables.py), "canonical" the collapsed
+Gauss-Jacobi rule; ``QuadratureRule.device_points()`` keeps a rule resident on the GPU for
+``element.tabulate_cells``.
 """
 import itertools
 
@@ -51,6 +51,14 @@ class QuadratureRule:
 
     def get_weights(self):
         return numpy.array(self.wts)
+
+    def device_points(self):
+        """(points, weights) as device tensors, uploaded once per rule: the input of ``element.tabulate_cells``."""
+        if getattr(self, "_device", None) is None:
+            from . import runtime
+            ctx = runtime.Context.get()
+            self._device = (runtime._as_device(self.get_points(), ctx), runtime._as_device(self.get_weights(), ctx))
+        return self._device
 
     def integrate(self, f):
         return sum(w * f(x) for x, w in zip(self.pts, self.wts))
@@ -144,26 +152,67 @@ def make_tensor_product_quadrature(*quad_rules):
     return QuadratureRule(ref_el, pts, wts)
 
 
+_TABLES = None
+
+
+def _rule_tables():
+    """fiat_amd/data/simplex_rules.npz: the Xiao-Gimbutas tables (symmetric simplex) and the classical low-degree
+    rules (UFC simplex) behind the reference's default scheme; plain arrays produced by tools/make_rule_tables.py."""
+    global _TABLES
+    if _TABLES is None:
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "simplex_rules.npz")
+        with numpy.load(path) as data:
+            _TABLES = {k: data[k] for k in data.files}
+    return _TABLES
+
+
+def tabulated_rule(sd, degree):
+    """(cell vertices, points, weights) of the tabulated rule the default scheme uses for this dimension and
+    degree, or None when it falls back to the collapsed Gauss-Jacobi rule (FIAT/quadrature_schemes.py:356-419:
+    classical rules for triangle degree <= 3 / tetrahedron degree <= 2, Xiao-Gimbutas up to 50 / 15)."""
+    if sd not in (2, 3):
+        return None
+    T = _rule_tables()
+    degree = max(int(degree), 0)
+    for family in ("classical", "xg"):
+        degrees = T[f"{family}{sd}_degrees"]
+        hit = numpy.nonzero(degrees == degree)[0]
+        if len(hit):
+            lo, hi = T[f"{family}{sd}_offsets"][hit[0]:hit[0] + 2]
+            return T[f"{family}{sd}_cell"], T[f"{family}{sd}_points"][lo:hi], T[f"{family}{sd}_weights"][lo:hi]
+    return None
+
+
+class _TabulatedSimplexRule(QuadratureRule):
+    def __init__(self, ref_el, source_verts, pts, wts):
+        source = reference_element.physical_simplex(source_verts)
+        super().__init__(ref_el, *map_quadrature(pts, wts, source, ref_el))
+
+
 def create_quadrature(ref_el, degree, scheme="default", entity=None):
-    """Rule exact for polynomials of the given degree on ref_el (or on one of its
-    sub-entities)."""
+    """Rule exact for polynomials of the given degree on ref_el, or on one of its sub-entities; the same
+    points and weights as FIAT/quadrature_schemes.py:46-106 for "default" and "canonical"."""
     if entity is not None:
-        dimension, entity_id = entity
-        Q_ref = create_quadrature(ref_el.construct_subelement(dimension), degree, scheme=scheme)
-        return FacetQuadratureRule(ref_el, dimension, entity_id, Q_ref)
-    if ref_el.is_macrocell():     # composite rule that respects the splitting (FIAT/quadrature_schemes.py:71-75)
+        dim, number = entity
+        return FacetQuadratureRule(ref_el, dim, number, create_quadrature(ref_el.construct_subelement(dim), degree, scheme=scheme))
+    if ref_el.is_macrocell():     # composite rule that respects the splitting
         from .macro import MacroQuadratureRule
         sub = ref_el.construct_subelement(ref_el.get_spatial_dimension())
         return MacroQuadratureRule(ref_el, create_quadrature(sub, degree, scheme=scheme))
     if isinstance(ref_el, reference_element.TensorProductCell):
-        try:
-            degree = tuple(degree)
-        except TypeError:
-            degree = (degree,) * len(ref_el.cells)
-        return make_tensor_product_quadrature(*[create_quadrature(c, d, scheme)
-                                                for c, d in zip(ref_el.cells, degree)])
+        degrees = tuple(degree) if numpy.ndim(degree) else (degree,) * len(ref_el.cells)
+        assert len(degrees) == len(ref_el.cells)
+        return make_tensor_product_quadrature(*(create_quadrature(c, d, scheme) for c, d in zip(ref_el.cells, degrees)))
     if degree < 0:
         raise ValueError("Need positive degree, not %d" % degree)
+    if scheme == "KMV":
+        raise NotImplementedError("the Kong-Mulder-Veldhuizen lumped rules are out of scope for fiat_amd")
     if scheme not in ("default", "canonical"):
         raise ValueError("Unknown quadrature scheme: %s." % scheme)
+    if scheme == "default":
+        table = tabulated_rule(ref_el.get_spatial_dimension(), degree) \
+            if ref_el.get_shape() in (reference_element.TRIANGLE, reference_element.TETRAHEDRON) else None
+        if table is not None:
+            return _TabulatedSimplexRule(ref_el, *table)
     return make_quadrature(ref_el, (degree + 2) // 2)

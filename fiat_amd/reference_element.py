@@ -7,6 +7,7 @@ Mirrors the parts of FIAT/reference_element.py the path uses: cell classes
 (:64-76), entity transforms (:570-609), ``make_affine_mapping`` (:1621-1654),
 ``ufc_simplex``/``default_simplex`` (:1680-1715).
 """
+import itertools
 import math
 
 import numpy
@@ -425,23 +426,57 @@ def physical_simplex(vertices):
 
 
 class TensorProductCell(Cell):
-    """Product of interval cells (quadrilateral / hexahedron)."""
+    """Product of cells -- intervals (quadrilateral, hexahedron), triangle x interval (prism), or products of
+    products: ``cells`` are kept as given, so a nested element (A x B) x C lives on a nested cell whose entity
+    dimensions are nested tuples, ((1, 1), 1).  Vertices: concatenated coordinates, the last factor fastest.
+    Topology: entities of dimension (d_0, d_1, ...) are products of the factors' entities, numbered row-major over the
+    factors' (sorted) entity numbers -- the numbering ``TensorProductElement.tabulate(entity=...)`` unravels."""
 
     def __init__(self, *cells):
         self.cells = tuple(cells)
-        import itertools
-        verts = [sum((tuple(v) for v in combo), ()) for combo in
-                 itertools.product(*[c.get_vertices() for c in cells])]
         self.shape = TENSORPRODUCT
-        self.vertices = tuple(verts)
-        self.topology = None
+        self.vertices = tuple(sum((tuple(v) for v in combo), ()) for combo in
+                              itertools.product(*[c.get_vertices() for c in cells]))
+        self._topology = None
         self.sub_entities = None
+
+    @property
+    def topology(self):
+        if self._topology is None:
+            counts = [len(c.get_vertices()) for c in self.cells]
+            tops = [c.get_topology() for c in self.cells]
+            topo = {}
+            for dims in itertools.product(*[sorted(t, key=repr) for t in tops]):
+                entities = {}
+                for number, picks in enumerate(itertools.product(*[sorted(t[d]) for t, d in zip(tops, dims)])):
+                    corner_sets = [t[d][e] for t, d, e in zip(tops, dims, picks)]
+                    entities[number] = tuple(int(numpy.ravel_multi_index(corner, counts))
+                                             for corner in itertools.product(*corner_sets))
+                topo[dims] = entities
+            self._topology = topo
+        return self._topology
+
+    def get_topology(self):
+        return self.topology
 
     def get_spatial_dimension(self):
         return sum(c.get_spatial_dimension() for c in self.cells)
 
     def get_dimension(self):
         return tuple(c.get_dimension() for c in self.cells)
+
+    def construct_subelement(self, dimension):
+        return TensorProductCell(*[c.construct_subelement(d) for c, d in zip(self.cells, dimension)])
+
+    def flat_cells(self):
+        """The simplex factors, left to right, with nesting removed."""
+        out = []
+        for c in self.cells:
+            out.extend(c.flat_cells() if isinstance(c, TensorProductCell) else [c])
+        return out
+
+    def is_simplex(self):
+        return False
 
     def __eq__(self, other):
         return isinstance(other, TensorProductCell) and self.cells == other.cells

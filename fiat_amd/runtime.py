@@ -3,6 +3,7 @@
 PyTorch-ROCm is used only as the owner of device memory and streams; every
 computation goes through the C ABI (include/fiat_amd.h) into the HIP kernels.
 """
+import contextlib
 import ctypes
 import math
 from ctypes import c_float, c_int, c_void_p
@@ -30,6 +31,32 @@ class Context:
         check(lib.fx_ctx_info(h, ctypes.byref(ncu), ctypes.byref(lds), name, 64))
         self.num_cu, self.lds_per_cu, self.arch = ncu.value, lds.value, name.value.decode()
 
+    def check(self, stream=None):
+        """Synchronise ``stream`` and raise FiatAmdError if a kernel of this context reported a scheduling failure."""
+        check(lib.fx_ctx_check(self.handle, _stream_ptr(stream)))
+
+    def set_policy(self, *names):
+        """Kernel-selection policy (fx_ctx_set_policy): names from ``_lib.POLICY``; no names = the default."""
+        flags = 0
+        for n in names:
+            flags |= _lib.POLICY[n]
+        check(lib.fx_ctx_set_policy(self.handle, flags))
+
+    def get_policy(self):
+        flags = ctypes.c_uint(0)
+        check(lib.fx_ctx_get_policy(self.handle, ctypes.byref(flags)))
+        return {n for n, bit in _lib.POLICY.items() if flags.value & bit}
+
+    @contextlib.contextmanager
+    def policy(self, *names):
+        """``with ctx.policy("no_fixed"): ...`` -- reach an A/B partner kernel through the same entry points."""
+        before = self.get_policy()
+        self.set_policy(*names)
+        try:
+            yield self
+        finally:
+            self.set_policy(*before)
+
     @staticmethod
     def get(device=None):
         if device is None:
@@ -43,6 +70,15 @@ class Context:
         if idx not in _contexts:
             _contexts[idx] = Context(idx)
         return _contexts[idx]
+
+
+def fetch(tensor, stream=None):
+    """Device tensor -> NumPy array, then ``fx_ctx_check``: a dynamically scheduled kernel that gave up waiting for its
+    work queue (csrc/work_queue.hpp) leaves incomplete tables -- the facade raises instead of returning them."""
+    host = tensor.cpu().numpy()
+    if tensor.is_cuda:
+        Context.get(tensor.device).check(stream)
+    return host
 
 
 def _stream_ptr(stream):
@@ -279,9 +315,8 @@ class MacroPolySet:
 
     def kernel_name(self, order, nreq, npts, has_verts=False):
         """Kernel a request shape maps to (mirrors the selection in fx_macro_tabulate_batch)."""
-        import os
         small = (order <= self._SMALL.get((self.sd, self.n), -1) and npts <= 64
-                 and "FIAT_AMD_NO_MACRO_SMALL" not in os.environ)
+                 and "no_macro_small" not in self.ctx.get_policy())
         return "fxk::tabulate_macro_small" if small else "fxk::tabulate_simplex_kernel<MACRO>"
 
 
@@ -332,6 +367,59 @@ def tables_point_major(tables, out=None, ctx=None, stream=None):
         out = torch.empty(lead + (npts, rows), dtype=torch.float64, device=ctx.device)
     check(lib.fx_tables_point_major(ctx.handle, ntables, int(rows), int(npts), _dev_ptr(tables), _dev_ptr(out),
                                     _stream_ptr(stream)))
+    return out
+
+
+def map_points(M, b, pts, ctx=None, stream=None):
+    """Affine image of a batch of points on the device: pts (..., din) -> (..., dout) = pts M^T + b
+    (fx_map_points; the entity transform of ``tabulate(..., entity=)``)."""
+    ctx = ctx or Context.get()
+    b = np.ascontiguousarray(b, dtype=np.float64).reshape(-1)
+    dout = b.shape[0]
+    M = np.ascontiguousarray(M, dtype=np.float64).reshape(dout, -1)
+    din = M.shape[1]
+    if isinstance(pts, torch.Tensor):
+        lead = tuple(pts.shape[:-1])
+        if pts.shape[-1] != din:
+            raise ValueError(f"points must have {din} coordinates, got {pts.shape[-1]}")
+        src = _as_device(pts, ctx) if din else None
+    else:
+        pts = np.asarray(pts, dtype=np.float64)
+        lead = tuple(pts.shape[:-1])
+        if pts.shape[-1] != din:
+            raise ValueError(f"points must have {din} coordinates, got {pts.shape[-1]}")
+        src = _as_device(pts, ctx) if din else None
+    n = int(np.prod(lead, dtype=np.int64)) if lead else 1
+    out = torch.empty(lead + (dout,), dtype=torch.float64, device=ctx.device)
+    check(lib.fx_map_points(ctx.handle, din, dout, host_ptr(M) if din else None, host_ptr(b), n,
+                            None if src is None else _dev_ptr(src), _dev_ptr(out), _stream_ptr(stream)))
+    return out
+
+
+def table_outer(order, sdA, sdB, tabA, tabB, out=None, ctx=None, stream=None):
+    """Tensor product of two tabulated factors (fx_table_outer_batch): tabA (nreq, ntabA, ndofA, [vdimA,] npts),
+    tabB (nreq, ntabB, ndofB, [vdimB,] npts) -> (nreq, ntab, ndofA * ndofB, [vdim,] npts), the tables of all
+    |alpha| <= order of the product in mis() order."""
+    ctx = ctx or Context.get()
+    tabA, tabB = _as_device(tabA, ctx), _as_device(tabB, ctx)
+    nreq, npts = tabA.shape[0], tabA.shape[-1]
+    if tabB.shape[0] != nreq or tabB.shape[-1] != npts:
+        raise ValueError("factor tables must share the request and point axes")
+    vdimA = tabA.shape[3] if tabA.dim() == 5 else 1
+    vdimB = tabB.shape[3] if tabB.dim() == 5 else 1
+    if vdimA > 1 and vdimB > 1:
+        raise NotImplementedError("tabulate does not support two vector-valued inputs")
+    rowsA, rowsB = tabA.shape[2], tabB.shape[2]
+    if tabA.shape[1] != num_tables(sdA, order) or tabB.shape[1] != num_tables(sdB, order):
+        raise ValueError("factor tables must hold all derivative tables up to the product's order")
+    vshape = (max(vdimA, vdimB),) if max(tabA.dim(), tabB.dim()) == 5 else ()
+    shape = (nreq, num_tables(sdA + sdB, order), rowsA * rowsB) + vshape + (npts,)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float64, device=ctx.device)
+    elif tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError("out has the wrong shape/layout")
+    check(lib.fx_table_outer_batch(ctx.handle, int(order), int(sdA), int(sdB), nreq, npts, rowsA, vdimA, rowsB, vdimB,
+                                   _dev_ptr(tabA), _dev_ptr(tabB), _dev_ptr(out), _stream_ptr(stream)))
     return out
 
 

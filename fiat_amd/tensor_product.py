@@ -1,9 +1,15 @@
-"""TensorProductElement facade (FIAT/tensor_product.py:26-360, tabulate :231-336;
-FlattenedDimensions :363-434) for products of 1-D Lagrange elements: quadrilateral
-and hexahedral Lagrange/DG elements.  The per-point outer products are formed by
-the HIP tensor kernel; nested products (A x B) x C flatten to a list of interval
-factors whose basis index is row-major over the factors, exactly the reference's
-f1g1, f1g2, ... ordering."""
+"""Tensor products of elements: quadrilateral / hexahedral elements from interval factors, prisms from a
+triangle and an interval, H(div) / H(curl)-style products with ONE vector-valued factor, nested products.
+
+Behaviour as FIAT/tensor_product.py (TensorProductElement :26-360, tabulate :231-336, FlattenedDimensions :363-434):
+basis function (i, j) of A x B has index i * dim(B) + j, the table of the derivative alpha = (alpha_A, alpha_B) is
+the per-point product of A's table alpha_A and B's table alpha_B, the value component rides on the vector-valued
+factor, ``entity=((dA, dB), id)`` picks a product of sub-entities.
+
+Two device routes: products of scalar 1-D Lagrange / DG factors (BASELINE config 5, the hexahedron) run on the fused
+tensor kernel, which evaluates the 1-D bases itself (fx_tensor_tabulate_batch, optionally from per-request 1-D grid
+coordinates); every other product tabulates its two factors with their own kernels and multiplies the tables
+(fx_table_outer_batch)."""
 import numpy
 
 from . import runtime
@@ -11,74 +17,144 @@ from .polynomial_set_util import mis
 from .reference_element import LINE, TensorProductCell
 
 
+def _first_point(node):
+    return tuple(node.get_point_dict().keys())[0]
+
+
+def _is_line_lagrange(element):
+    if isinstance(element, (TensorProductElement, FlattenedDimensions)):
+        return False
+    es = element.get_nodal_basis().get_expansion_set()
+    return element.get_reference_element().get_shape() == LINE and hasattr(es, "device_line") and element.value_shape() == ()
+
+
 def _line_factors(element):
-    """Interval factors of a (nested) tensor-product element, left to right."""
-    if isinstance(element, TensorProductElement):
-        return _line_factors(element.A) + _line_factors(element.B)
+    """The interval factors of a (nested) product of scalar 1-D Lagrange elements, left to right, or None."""
     if isinstance(element, FlattenedDimensions):
         return _line_factors(element.element)
-    es = element.get_nodal_basis().get_expansion_set()
-    if element.get_reference_element().get_shape() != LINE or not hasattr(es, "device_line"):
-        raise NotImplementedError("fiat_amd tensor products take 1-D Lagrange/DG factors")
-    return [element]
+    if isinstance(element, TensorProductElement):
+        left, right = _line_factors(element.A), _line_factors(element.B)
+        return None if left is None or right is None else left + right
+    return [element] if _is_line_lagrange(element) else None
+
+
+def _unravel(cell, entity_dim, entity_id):
+    """Entity numbers of the factors: entities of dimension (dA, dB, ...) are numbered row-major."""
+    counts = tuple(len(c.get_topology()[d]) for c, d in zip(cell.cells, entity_dim))
+    return tuple(int(i) for i in numpy.unravel_index(entity_id, counts))
 
 
 class TensorProductElement:
     def __init__(self, A, B):
         self.A, self.B = A, B
-        cells = []
-        for e in (A, B):
-            c = e.get_reference_element()
-            cells.extend(c.cells if isinstance(c, TensorProductCell) else [c])
-        self.ref_el = TensorProductCell(*cells)
-        self._factors = _line_factors(self)
-        if any(len(f.value_shape()) for f in self._factors):
-            raise NotImplementedError("tabulate does not support vector-valued factors in fiat_amd")
-        self.order = max(A.get_order(), B.get_order()) if hasattr(A, "get_order") else None
+        self.ref_el = TensorProductCell(A.get_reference_element(), B.get_reference_element())
+        if len(A.value_shape()) + len(B.value_shape()) > 1:
+            raise NotImplementedError("tabulate does not support two vector-valued inputs")
+        kinds = [f.mapping()[0] for f in (A, B)]
+        if kinds[0] != "affine" and kinds[1] != "affine":
+            raise ValueError("check tensor product mappings - at least one must be affine")
+        self._mapping = kinds[0] if kinds[0] != "affine" else kinds[1]
+        self._lines = _line_factors(self)
+        fa, fb = (getattr(f, "get_formdegree", lambda: None)() for f in (A, B))
+        self.formdegree = None if fa is None or fb is None else fa + fb
 
+    # -- accessors of the reference's FiniteElement interface -----------------------------------------------
     def get_reference_element(self):
         return self.ref_el
 
     def get_order(self):
-        return max(f.get_order() for f in self._factors)
+        return min(self.A.get_order(), self.B.get_order())
+
+    def get_formdegree(self):
+        return self.formdegree
 
     def degree(self):
-        return sum(f.degree() for f in self._factors)
+        return self.A.degree() + self.B.degree()
 
     def space_dimension(self):
-        return int(numpy.prod([f.space_dimension() for f in self._factors]))
+        return self.A.space_dimension() * self.B.space_dimension()
 
     def value_shape(self):
-        return ()
+        return tuple(self.A.value_shape()) or tuple(self.B.value_shape())
 
     def mapping(self):
-        return ["affine"] * self.space_dimension()
+        return [self._mapping] * self.space_dimension()
 
     def get_coeffs(self):
         raise NotImplementedError("get_coeffs not implemented")
 
+    def entity_dofs(self):
+        """{(dA, dB): {entity: dofs}}: dofs of entity (eA, eB) are i * dim(B) + j over the factors' entity dofs,
+        entities numbered row-major (FIAT/tensor_product.py:52-68)."""
+        a, b = self.A.entity_dofs(), self.B.entity_dofs()
+        nb = self.B.space_dimension()
+        out = {}
+        for da in a:
+            for db in b:
+                pairs = [(ea, eb) for ea in a[da] for eb in b[db]]
+                out[(da, db)] = {k: [i * nb + j for i in a[da][ea] for j in b[db][eb]] for k, (ea, eb) in enumerate(pairs)}
+        return out
+
+    # -- tabulation -----------------------------------------------------------------------------------------
     def device_factors(self):
-        return [f.get_nodal_basis().get_expansion_set().device_line() for f in self._factors]
+        return [f.get_nodal_basis().get_expansion_set().device_line() for f in self._lines]
+
+    def _split(self, entity):
+        """(entity of A, entity of B, point columns of A, point columns of B)."""
+        if entity is None:
+            entity = (self.ref_el.get_dimension(), 0)
+        dims, number = entity
+        ea, eb = _unravel(self.ref_el, dims, number)
+        sub = self.ref_el.construct_subelement(dims)
+        ca, cb = (c.get_spatial_dimension() for c in sub.cells)
+        return (dims[0], ea), (dims[1], eb), ca, cb
+
+    def tabulate_batch(self, order, points, out=None, stream=None, grid=False, entity=None):
+        """points (nreq, npts, sd) -> (nreq, ntab, ndof, [vdim,] npts) on the device.  ``grid=True`` (products of 1-D
+        Lagrange factors): per-request 1-D coordinates (nreq, nf, q) of a tensor grid instead of explicit points.
+        ``entity=((dA, dB), id)``: points in the coordinates of that reference sub-entity."""
+        whole = entity is None or tuple(entity[0]) == tuple(self.ref_el.get_dimension())
+        if self._lines is not None and whole:
+            return runtime.tensor_tabulate_batch(self.device_factors(), order, points, out=out, stream=stream, grid=grid)
+        if grid:
+            raise NotImplementedError("grid input is served for products of 1-D Lagrange factors only")
+        ctx = runtime.Context.get()
+        points = runtime._as_device(points, ctx)
+        ea, eb, ca, cb = self._split(entity)
+        if points.dim() != 3 or points.shape[2] != ca + cb:
+            raise ValueError(f"points must have shape (nreq, npts, {ca + cb}), got {tuple(points.shape)}")
+        tabs = []
+        for factor, ent, cols in ((self.A, ea, points[..., :ca]), (self.B, eb, points[..., ca:ca + cb])):
+            tabs.append(factor.tabulate_batch(order, cols.contiguous(), stream=stream, entity=ent))
+        sda, sdb = (f.get_reference_element().get_spatial_dimension() for f in (self.A, self.B))
+        return runtime.table_outer(order, sda, sdb, tabs[0], tabs[1], out=out, ctx=ctx, stream=stream)
 
     def tabulate(self, order, points, entity=None):
-        """{alpha: (ndof, npts)} for all derivative multi-indices up to ``order``."""
-        if entity is not None and tuple(entity[0]) != tuple(self.ref_el.get_dimension()):
-            raise NotImplementedError("sub-entity tabulation of tensor-product elements")
-        nf = len(self._factors)
-        pts = numpy.asarray(points, dtype=float).reshape(-1, nf)
-        out = runtime.tensor_tabulate_batch(self.device_factors(), order, pts[None]).cpu().numpy()[0]
-        keys = [a for k in range(order + 1) for a in mis(nf, k)]
-        return {a: numpy.ascontiguousarray(out[t]) for t, a in enumerate(keys)}
+        """{alpha: (ndof, [vdim,] npts)} for all derivative multi-indices up to ``order``."""
+        _, _, ca, cb = self._split(entity)
+        pts = numpy.asarray(points, dtype=float).reshape(-1, ca + cb)
+        dev = self.tabulate_batch(order, pts[None], entity=entity)
+        host = runtime.fetch(dev)[0]
+        sd = self.ref_el.get_spatial_dimension()
+        keys = [a for k in range(order + 1) for a in mis(sd, k)]
+        return {a: numpy.ascontiguousarray(host[t]) for t, a in enumerate(keys)}
 
-    def tabulate_batch(self, order, points, out=None, stream=None, grid=False):
-        """Batched: points (nreq, npts, nf) -- or, with grid=True, per-request 1-D
-        coordinates (nreq, nf, q) of a tensor grid -- -> (nreq, ntab, ndof, npts) on the device."""
-        return runtime.tensor_tabulate_batch(self.device_factors(), order, points, out=out, stream=stream, grid=grid)
+    def dual_basis(self):
+        """Point evaluations at the concatenated nodes for products of point-evaluation factors
+        (FIAT/tensor_product.py:70-190, scalar x scalar case)."""
+        from . import functional
+        nodes = []
+        for na in self.A.dual_basis():
+            for nb in self.B.dual_basis():
+                if not (isinstance(na, functional.PointEvaluation) and isinstance(nb, functional.PointEvaluation)):
+                    raise NotImplementedError("dual basis of products of non-point-evaluation factors")
+                nodes.append(functional.PointEvaluation(self.ref_el, _first_point(na) + _first_point(nb)))
+        return nodes
 
 
 class FlattenedDimensions:
-    """A tensor-product element viewed on the flattened quadrilateral/hexahedron;
-    tabulation is unchanged (FIAT/tensor_product.py:396-407)."""
+    """A tensor-product element viewed on the flattened quadrilateral / hexahedron: same tables, entity dimensions
+    summed (FIAT/tensor_product.py:363-434; tabulate :396-407 passes the cell itself as the entity)."""
 
     def __init__(self, element):
         self.element = element
@@ -95,6 +171,9 @@ class FlattenedDimensions:
 
     def degree(self):
         return self.element.degree()
+
+    def mapping(self):
+        return self.element.mapping()
 
     def tabulate(self, order, points, entity=None):
         return self.element.tabulate(order, points, None)

@@ -52,6 +52,27 @@ int fx_ctx_destroy(fx_ctx* ctx);
 /* Device facts used by the benchmark: CU count and bytes of LDS per CU. */
 int fx_ctx_info(fx_ctx* ctx, int* num_cu, int* lds_bytes_per_cu, char* name, int name_len);
 
+/* Kernel-selection policy of a context (no reference counterpart: FIAT has one NumPy path,
+ * FIAT/expansions.py:449-490).  Several kernels can serve a request shape; fx_tabulate_batch picks the
+ * fastest registered one.  The bits below take a kernel family out of the selection (or opt into an A/B
+ * partner) so that parity tests and tools can reach every kernel through the same entry points.  Results
+ * are identical to the stated tolerance under every policy; 0 is the default.  Not read from the
+ * environment: launch paths make no getenv calls. */
+#define FX_POLICY_NO_FIXED (1u << 0)       /* shape-specialised paired / K-streamed / LDS-image kernels */
+#define FX_POLICY_NO_SMALL (1u << 1)       /* lane-local low-order kernel */
+#define FX_POLICY_NO_STACKED (1u << 2)     /* stacked-matrix kernel */
+#define FX_POLICY_NO_COOP (1u << 3)        /* cooperative producer/consumer kernel */
+#define FX_POLICY_STACKED_SMALL (1u << 4)  /* opt in: register-resident stacked instances on the small shapes */
+#define FX_POLICY_NO_STACKED_MIX (1u << 5) /* chain rule of per-request cells as a second pass, not in the kernel */
+#define FX_POLICY_NO_SHARED_WAVE (1u << 6) /* fx_tabulate_batch_shared: wave-per-request kernel */
+#define FX_POLICY_NO_SHARED_REG (1u << 7)  /* fx_tabulate_batch_shared: register-resident kernel */
+#define FX_POLICY_NO_MACRO_SMALL (1u << 8) /* fx_macro_tabulate_batch: lane-local kernel */
+#define FX_POLICY_KERNEL_IMAGE (1u << 9)   /* shape-specialised family: LDS-image variant */
+#define FX_POLICY_KERNEL_STREAM (1u << 10) /* shape-specialised family: one request per wave, K-streamed */
+#define FX_POLICY_ALL ((1u << 11) - 1)
+int fx_ctx_set_policy(fx_ctx* ctx, unsigned flags);
+int fx_ctx_get_policy(const fx_ctx* ctx, unsigned* flags);
+
 /* ---- simplex elements ------------------------------------------------------
  * A polynomial set over the Dubiner expansion set of one simplex cell:
  *   coeffs[ndof][vdim][nexp]  (FIAT/polynomial_set.py:42-66, PolynomialSet),
@@ -252,6 +273,62 @@ int fx_macro_element_set_coeffs(fx_macro_element* elem, int ndof, int vdim, cons
 int fx_macro_tabulate_batch(fx_ctx* ctx, const fx_macro_element* elem, int order,
                             int64_t nreq, int npts, const double* pts,
                             const double* verts, double* out, void* stream);
+
+/* ---- general tensor products and sub-entities --------------------------
+ * TensorProductElement.tabulate (FIAT/tensor_product.py:231-336) for ANY two factors whose tables are on
+ * the device -- simplex elements (fx_tabulate_batch), 1-D Lagrange (fx_line_tabulate_batch), products
+ * themselves:  out[r][t][a*rowsB + b][c][p] = A[r][tA][a][cA][p] * B[r][tB][b][cB][p], alpha_t =
+ * (alpha_A, alpha_B) over all |alpha| <= order in mis() order; at most one factor is vector-valued
+ * (two: FX_ENOTIMPL, as the reference :271-272).  tabA device [nreq][C(sdA+order,sdA)][rowsA][vdimA][npts]
+ * (all of the factor's tables up to `order`; sd 0 = a point factor with one table), tabB likewise,
+ * out device [nreq][C(sdA+sdB+order, sdA+sdB)][rowsA*rowsB][max(vdimA,vdimB)][npts]. */
+int fx_table_outer_batch(fx_ctx* ctx, int order, int sdA, int sdB, int64_t nreq, int npts, int rowsA,
+                         int vdimA, int rowsB, int vdimB, const double* tabA, const double* tabB,
+                         double* out, void* stream);
+/* The affine map behind ``tabulate(order, points, entity=(dim, id))`` (FIAT/finite_element.py:181-197,
+ * reference_element.py:570-609) for a whole batch: out[i] = M in[i] + b, M host [dout][din] (din = 0: every
+ * point is the vertex b), in device [n][din], out device [n][dout]. */
+int fx_map_points(fx_ctx* ctx, int din, int dout, const double* M, const double* b, int64_t n,
+                  const double* in, double* out, void* stream);
+
+/* ---- 1-D Jacobi polynomials ---------------------------------------------
+ * FIAT/jacobi.py eval_jacobi_batch (:47-74) for order == 0 and eval_jacobi_deriv_batch (:85-102)
+ * for order >= 1:  out[k][p] = d^order/dx^order P_k^{(a,b)}(xs[p]),  k = 0..n  (rows k < order are zero).
+ * xs device [npts], out device [n+1][npts].  n <= 96. */
+int fx_jacobi_batch(fx_ctx* ctx, double a, double b, int n, int order, int64_t npts, const double* xs,
+                    double* out, void* stream);
+
+/* ---- multi-GPU: reassembling the tables ----------------------------------
+ * No reference counterpart (the reference is single-process NumPy): requests are independent, rank g of
+ * N (one process per GPU, one fx_ctx each) tabulates a contiguous block, and only if the consumer wants all
+ * tables on every GPU are the blocks exchanged -- RCCL over xGMI, bound at run time (no link dependency).
+ *   fx_comm_available   FX_OK if RCCL could be loaded (call on every rank and agree BEFORE fx_comm_create:
+ *                       communicator creation is collective and blocks until all ranks have joined);
+ *   fx_comm_unique_id   one rank produces the 128-byte id and hands it to the others out of band
+ *                       (torch.distributed store, MPI, a file);
+ *   fx_comm_create      collective over the nranks processes.
+ * fx_allgather_tables: rank p's block send[count] (device doubles) arrives at recv[p*stride + offset] on
+ * every rank; recv holds nranks*stride doubles.  stride == count, offset == 0 is the plain all-gather of
+ * equal blocks; a chunked, compute-overlapped gather passes the chunk's offset inside each rank's block
+ * (offset + count <= stride).  send may alias the caller's own block of recv (in place).
+ *   FX_GATHER_RING    ncclAllGather (blocks must tile recv);
+ *   FX_GATHER_DIRECT  grouped send/recv with every peer: all 7 xGMI links of a GPU at once.
+ * Enqueued on `stream`; nothing synchronises. */
+typedef struct fx_comm fx_comm;
+#define FX_COMM_ID_BYTES 128
+#define FX_GATHER_RING 0
+#define FX_GATHER_DIRECT 1
+int fx_comm_available(void);
+int fx_comm_unique_id(unsigned char* id /* host [FX_COMM_ID_BYTES] */);
+int fx_comm_create(fx_ctx* ctx, int nranks, int rank, const unsigned char* id, fx_comm** comm);
+int fx_comm_destroy(fx_comm* comm);
+int fx_allgather_tables(fx_comm* comm, const double* send, double* recv, int64_t count, int64_t stride,
+                        int64_t offset, int algo, void* stream);
+
+/* Synchronises `stream` and reports a scheduling failure of the dynamically scheduled kernels (their
+ * work queue gives up after ~1 s instead of hanging the GPU; the affected launch's output is then
+ * incomplete and this returns FX_EHIP).  The facade calls it wherever it copies tables to the host. */
+int fx_ctx_check(fx_ctx* ctx, void* stream);
 
 /* ---- measurement helpers ---------------------------------------------------------
  * Time `reps` launches of fx_tabulate_batch with HIP events on `stream`;

@@ -27,3 +27,13 @@ def golden():
                 self._cache[name] = np.load(os.path.join(GOLDEN, name + ".npz"))
             return self._cache[name]
     return _Golden()
+
+
+@pytest.fixture
+def kernel_policy():
+    """``kernel_policy("no_fixed", ...)`` sets the context's kernel-selection policy (fx_ctx_set_policy) for the rest
+    of the test; the default policy is restored afterwards."""
+    from fiat_amd import runtime
+    ctx = runtime.Context.get()
+    yield ctx.set_policy
+    ctx.set_policy()

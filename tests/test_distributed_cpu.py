@@ -1,6 +1,7 @@
-"""world_size-2 gloo test of the request sharding + all-gather plumbing (CPU).
-The per-rank compute is the oracle here (tests may use it as the stand-in); on the
-GPU box the same plumbing carries the HIP path's device tensors over RCCL."""
+"""world_size-2 gloo tests of the request sharding and of the three gather patterns of fiat_amd/distributed.py
+(one-shot, chunked + overlapped, staging ring) on CPU.  The per-rank compute is the oracle here (tests may use it
+as the stand-in); on a GPU node the same code carries the HIP path's device tensors over RCCL through the C ABI
+(fx_allgather_tables)."""
 import os
 import socket
 import sys
@@ -34,57 +35,71 @@ def _oracle_tabulate(pts, verts):
     return torch.as_tensor(np.stack(out))
 
 
-def _worker(rank, world, port, nreq, q):
+def _worker(rank, world, port, nreq, chunk, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from fiat_amd_dist_shim import distributed as D
+    from fiat_amd import distributed as D
     rng = np.random.default_rng(0)
     e = rng.exponential(size=(nreq, 4, 3))
     pts = torch.as_tensor((e / e.sum(-1, keepdims=True))[..., 1:].copy())
+    ref = _oracle_tabulate(pts, None)
+    gather = D.TableGather()
+    assert gather.impl == "torch" and gather.world == world
+    # 1. one exchange of (padded) equal blocks
     local, (lo, hi) = D.tabulate_sharded(_oracle_tabulate, pts)
     assert local.shape[0] == hi - lo
-    full = D.allgather_tables(local, nreq)
-    ref = _oracle_tabulate(pts, None)
-    ok = bool(torch.equal(full, ref))
+    ok = [bool(torch.equal(gather.all_gather(local, nreq), ref))]
+    ok.append(bool(torch.equal(D.allgather_tables(local, nreq), ref)))
+    # 2. chunked gather, a chunk exchanged as soon as it is produced
+    per = -(-nreq // world)
+    full = torch.full((world * per,) + tuple(ref.shape[1:]), float("nan"), dtype=torch.float64)
+    calls = []
+
+    def produce(c0, c1, rows):
+        calls.append((c0, c1))
+        rows.copy_(_oracle_tabulate(pts[lo + c0:lo + c1], None))
+
+    gather.tabulate_allgather(produce, hi - lo, per, chunk, full)
+    ok.append(bool(torch.equal(full[:nreq], ref)))
+    ok.append(calls == [(c, min(c + chunk, hi - lo)) for c in range(0, hi - lo, chunk)])
+    # 3. staging ring for outputs too large to replicate: the consumer sees every chunk of every rank once
+    padded = torch.zeros((per,) + tuple(ref.shape[1:]), dtype=torch.float64)
+    padded[: hi - lo] = local
+    seen = torch.full_like(full, float("nan")).view(world, per, *ref.shape[1:])
+    nchunks = 0
+    for c0, c1, staged in gather.iter_gathered_chunks(padded, chunk, ring=2):
+        assert staged.shape[:2] == (world, c1 - c0)
+        seen[:, c0:c1] = staged
+        nchunks += 1
+    ok.append(nchunks == -(-per // chunk))
+    ok.append(bool(torch.equal(seen.reshape(world * per, *ref.shape[1:])[:nreq], ref)))
+    gather.close()
     q.put((rank, lo, hi, ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nreq", [8, 7, 1])
-def test_shard_and_allgather_world2(nreq, tmp_path):
-    # import fiat_amd.distributed without importing the package __init__ (which
-    # needs the built HIP library; here only the plumbing is under test)
-    shim = tmp_path / "fiat_amd_dist_shim"
-    shim.mkdir()
-    (shim / "__init__.py").write_text("")
-    src = open(os.path.join(ROOT, "fiat_amd", "distributed.py")).read()
-    (shim / "distributed.py").write_text(src)
-    sys.path.insert(0, str(tmp_path))
-    os.environ["PYTHONPATH"] = str(tmp_path) + os.pathsep + os.environ.get("PYTHONPATH", "")
+@pytest.mark.parametrize("nreq,chunk", [(8, 2), (7, 3), (1, 1), (13, 4)])
+def test_shard_and_gather_world2(nreq, chunk):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, nreq, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, nreq, chunk, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     res.sort()
-    assert [r[3] for r in res] == [True, True]
+    assert all(all(r[3]) for r in res), res
     assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == nreq
 
 
 def test_shard_bounds():
-    sys.path.insert(0, ROOT)
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("d", os.path.join(ROOT, "fiat_amd", "distributed.py"))
-    D = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(D)
+    from fiat_amd import distributed as D
     for n in (0, 1, 7, 8, 100000, 1000003):
         for w in (1, 2, 4, 8):
             b = [D.shard_bounds(n, r, w) for r in range(w)]

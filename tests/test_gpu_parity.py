@@ -92,7 +92,9 @@ def test_bad_arguments(rt):
         rt.SimplexPolySet(2, 0, variant="bubble")
     ps = rt.SimplexPolySet(2, 2)
     with pytest.raises(NotImplementedError):
-        ps.tabulate_batch(3, np.zeros((1, 2, 2)))
+        ps.tabulate_batch(9, np.zeros((1, 2, 2)))          # orders 3..8 run through differentiation matrices
+    with pytest.raises(NotImplementedError):
+        ps.tabulate_batch(3, np.zeros((1, 2, 2)), verts=np.array([[[0.0, 0], [1, 0], [0, 1]]]))
     with pytest.raises(ValueError):
         ps.tabulate_batch(1, np.zeros((1, 2, 3)))
     # empty batches are fine
@@ -514,11 +516,11 @@ def test_stacked_matrix_kernel_families(fam, deg, order, npts):
 
 
 @pytest.mark.parametrize("npts,nreq", [(23, 4001), (17, 3), (28, 500), (40, 77)])
-def test_stacked_matrix_kernel_small_shape_ab(rt, golden, monkeypatch, npts, nreq):
+def test_stacked_matrix_kernel_small_shape_ab(rt, golden, kernel_policy, npts, nreq):
     """The register-resident instances of the stacked-matrix kernel (P3 tetrahedron, values + gradient: the A/B
-    partner of the paired kernel on the benchmark shape, FIAT_AMD_STACKED_SMALL=1) against the C oracle."""
+    partner of the paired kernel on the benchmark shape, policy "stacked_small") against the C oracle."""
     from oracle import c_oracle
-    monkeypatch.setenv("FIAT_AMD_STACKED_SMALL", "1")  # (read at every launch)
+    kernel_policy("stacked_small")
     g = golden("elements")
     co = g["c2_p3tet_q6_coeffs"]
     ps = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=co)
@@ -530,7 +532,7 @@ def test_stacked_matrix_kernel_small_shape_ab(rt, golden, monkeypatch, npts, nre
     axes = tuple(range(2, out.ndim))
     err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)
     assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), err
-    monkeypatch.delenv("FIAT_AMD_STACKED_SMALL")
+    kernel_policy()
     assert ps.kernel_name(1, nreq, npts) == "fxk::tabulate_simplex_pair"
 
 
@@ -564,14 +566,14 @@ def test_stacked_matrix_kernel_triangles(fam, deg, order, npts):
                                                    ("DiscontinuousLagrange", 2, 5, 1, 30), ("Lagrange", 2, 5, 1, 44),
                                                    ("Nedelec", 2, 6, 1, 22)])
 @pytest.mark.parametrize("mix", ["1", "0"])
-def test_stacked_matrix_kernel_with_per_request_cells(monkeypatch, mix, fam, sd, deg, order, npts):
+def test_stacked_matrix_kernel_with_per_request_cells(kernel_policy, mix, fam, sd, deg, order, npts):
     """Per-request cells on the stacked-matrix kernel: points mapped through the request's cell in the kernel,
     chain rule across the derivative tables by the in-place mixing pass (table_mix_kernel), against the C
     oracle's recurrence on the physical cells; one negatively oriented cell."""
     import fiat_amd
     from oracle import c_oracle
-    # order 1: chain rule inside the kernel (MIXT instances) or, FIAT_AMD_STACKED_MIX=0, the mixing pass
-    monkeypatch.setenv("FIAT_AMD_STACKED_MIX", mix)
+    # order 1: chain rule inside the kernel (MIXT instances) or, policy "no_stacked_mix", the mixing pass
+    kernel_policy(*(["no_stacked_mix"] if mix == "0" else []))
     el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg)
     ps = el.device_polyset()
     nreq = 131 if mix == "0" else 4133   # (several groups per wave for the in-kernel variant)

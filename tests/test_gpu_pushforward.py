@@ -150,13 +150,13 @@ def test_shared_points_against_the_reference_on_physical_cells(rt, golden):
 @pytest.mark.parametrize("name,n,mapping", [("n2", 2, "covariant piola"), ("rt2", 2, "contravariant piola")])
 @pytest.mark.parametrize("npts", [22, 23, 24])
 @pytest.mark.parametrize("kernel", ["wave", "cooperative"])
-def test_fused_pushforward_equals_second_pass(rt, golden, monkeypatch, name, n, mapping, npts, kernel):
+def test_fused_pushforward_equals_second_pass(rt, golden, kernel_policy, name, n, mapping, npts, kernel):
     """N2 / RT2 tetrahedra at benchmark-like sizes: the push-forward fused into the kernel (applied to
     the LDS image of the one-request-per-wave kernel; in the output rounds of the cooperative kernel,
     several rounds per request, odd table sizes for RT2 at 23 points) against tabulation followed by
     the separate pass, and both against the oracle's evaluation of the formula."""
     if kernel == "cooperative":
-        monkeypatch.setenv("FIAT_AMD_NO_FIXED", "1")  # (read at every launch)
+        kernel_policy("no_fixed")
     g = golden("piola")
     co = g[f"{name}_sd3_refcoeffs"]
     ps = rt.SimplexPolySet(3, n, coeffs=co, value_shape=(3,))

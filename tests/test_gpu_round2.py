@@ -1,0 +1,369 @@
+"""Round-2 device entries: fx_jacobi_batch, the kernel-selection policy, per-call scratch of the
+shared-point path on concurrent streams, the work-queue check, and the RCCL gather behind the C ABI (world size 1
+here: a one-GPU box; the multi-rank logic is covered on CPU by tests/test_distributed_cpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ab", [(0, 0), (1, 1), (2, 2), (3, 0), (5, 1)])
+def test_jacobi_kernel_vs_reference(golden, ab):
+    """Device tables equal FIAT's eval_jacobi_batch / eval_jacobi_deriv_batch (tests/golden/jacobi.npz, generated from
+    the reference): 1e-12 relative on values, 1e-10 on derivatives."""
+    from fiat_amd import jacobi
+    g = golden("jacobi")
+    a, b = ab
+    xs = g["jacobi_x"]
+    vals = jacobi.eval_jacobi_batch(a, b, 7, xs)
+    ref = g[f"jacobi_{a}_{b}"]
+    assert vals.shape == ref.shape
+    assert np.abs(vals - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    der = jacobi.eval_jacobi_deriv_batch(a, b, 7, xs)
+    dref = g[f"jacobi_deriv_{a}_{b}"]
+    assert der.shape == dref.shape
+    assert np.abs(der - dref).max() <= 1e-10 * max(1.0, np.abs(dref).max())
+    # scalar twins (jacobi.py:15-44, :77-82)
+    assert abs(jacobi.eval_jacobi(a, b, 5, 0.3) - float(jacobi.eval_jacobi_batch(a, b, 5, np.array([[0.3]]))[5, 0])) < 1e-14
+    assert abs(jacobi.eval_jacobi_deriv(a, b, 5, 0.3) - float(jacobi.eval_jacobi_deriv_batch(a, b, 5, np.array([[0.3]]))[5, 0])) < 1e-13
+    assert jacobi.eval_jacobi_deriv(a, b, 0, 0.3) == 0.0
+
+
+def test_jacobi_kernel_higher_orders_and_large_batches(golden):
+    """Derivative orders 2-4 (golden: the reference's own eval_jacobi_deriv_batch(order=...)), orders beyond the degree
+    (all zero, jacobi.py:92-93), a batch of 1e6 points against the oracle's recurrence, degree 0."""
+    from fiat_amd import jacobi
+    from oracle import fiat_oracle as fo
+    g = golden("round2")
+    xs = g["jacobi_x"]
+    for a, b in [(0, 0), (2, 1), (0.5, 1.5)]:
+        for order in (2, 3, 4):
+            ref = g[f"jacobi_deriv{order}_{a}_{b}"]
+            got = jacobi.eval_jacobi_deriv_batch(a, b, 9, xs, order=order)
+            assert np.abs(got - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), (a, b, order)
+    assert not jacobi.eval_jacobi_deriv_batch(1, 1, 3, xs, order=4).any()
+    assert not jacobi.eval_jacobi_deriv_batch(1, 1, 3, xs, order=7).any()
+    assert np.array_equal(jacobi.eval_jacobi_batch(2, 3, 0, xs), np.ones((1, len(xs))))
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, size=1_000_003)
+    dev = jacobi.jacobi_table(1, 2, 12, torch.as_tensor(x).cuda())
+    ref = fo.jacobi_table(1, 2, 12, x)
+    assert np.abs(dev.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+    with pytest.raises(ValueError):
+        jacobi.jacobi_table(0, 0, -1, xs)
+    with pytest.raises(NotImplementedError):
+        jacobi.jacobi_table(0, 0, 200, xs)
+
+
+def test_policy_reaches_every_kernel_family(golden, kernel_policy):
+    """fx_ctx_set_policy replaces the per-launch environment switches: the same element and request shape run on the
+    paired, K-streamed, LDS-image, stacked, cooperative and generic kernels and give the same tables."""
+    from fiat_amd import runtime
+    g = golden("elements")
+    ps = runtime.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=g["c2_p3tet_q6_coeffs"])
+    rng = np.random.default_rng(5)
+    e = rng.exponential(size=(257, 23, 4))
+    pts = (e / e.sum(-1, keepdims=True))[..., 1:].copy()
+    ctx = runtime.Context.get()
+    assert ctx.get_policy() == set()
+    base = ps.tabulate_batch(1, pts).cpu().numpy()
+    seen = {ps.kernel_name(1, 257, 23)}
+    for names in (["kernel_stream"], ["kernel_image"], ["stacked_small"], ["no_fixed"], ["no_fixed", "no_stacked"],
+                  ["no_fixed", "no_stacked", "no_coop", "no_small"]):
+        kernel_policy(*names)
+        assert ctx.get_policy() == set(names)
+        seen.add(ps.kernel_name(1, 257, 23))
+        out = ps.tabulate_batch(1, pts).cpu().numpy()
+        assert np.abs(out - base).max() <= 1e-11 * max(1.0, np.abs(base).max()), names
+    kernel_policy()
+    assert {"fxk::tabulate_simplex_pair", "fxk::tabulate_simplex_stream", "fxk::tabulate_simplex_fixed",
+            "fxk::tabulate_simplex_stacked", "fxk::tabulate_simplex_kernel"} <= seen, seen
+    with pytest.raises(ValueError):
+        kernel_policy("kernel_stream", "kernel_image")
+    with pytest.raises(KeyError):
+        kernel_policy("no_such_policy")
+    with ctx.policy("no_stacked"):
+        assert ctx.get_policy() == {"no_stacked"}
+    assert ctx.get_policy() == set()
+
+
+def test_shared_point_tabulation_on_concurrent_streams():
+    """Two elements tabulated at one rule in many cells on two streams at once, plus a quadrature call in between: every
+    call owns its reference-table scratch (stream-ordered allocation), so the results equal the serial ones."""
+    import fiat_amd
+    from fiat_amd import runtime
+    rng = np.random.default_rng(9)
+    sd, nreq, npts = 3, 20_000, 23
+    ref = np.array(fiat_amd.ufc_simplex(sd).get_vertices(), dtype=float)
+    verts = torch.as_tensor(ref[None] + rng.uniform(-0.15, 0.15, size=(nreq, sd + 1, sd))).cuda()
+    e = rng.exponential(size=(2, npts, sd + 1))
+    rules = [torch.as_tensor((x / x.sum(-1, keepdims=True))[:, 1:].copy()).cuda() for x in e]
+    els = [fiat_amd.Lagrange(fiat_amd.ufc_simplex(sd), 3), fiat_amd.Nedelec(fiat_amd.ufc_simplex(sd), 2)]
+    serial = [el.tabulate_cells(1, r, verts).clone() for el, r in zip(els, rules)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.empty_like(s) for s in serial]
+    for rep in range(6):
+        for el, r, s, o in zip(els, rules, streams, outs):
+            with torch.cuda.stream(s):
+                el.tabulate_cells(1, r, verts, out=o, stream=s)
+        runtime.collapsed_quadrature(3, 4)
+    torch.cuda.synchronize()
+    for got, want in zip(outs, serial):
+        assert torch.equal(got, want)
+    runtime.Context.get().check()
+
+
+def test_work_queue_check_is_clean_after_dynamic_launches(golden):
+    from fiat_amd import runtime
+    g = golden("elements")
+    ps = runtime.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=g["c2_p3tet_q6_coeffs"])
+    rng = np.random.default_rng(1)
+    e = rng.exponential(size=(30_001, 23, 4))
+    out = ps.tabulate_batch(1, (e / e.sum(-1, keepdims=True))[..., 1:].copy())
+    assert ps.kernel_name(1, 30_001, 23) == "fxk::tabulate_simplex_pair"
+    host = runtime.fetch(out)          # .cpu() + fx_ctx_check
+    assert np.isfinite(host).all()
+
+
+@pytest.mark.parametrize("algo", ["direct", "ring"])
+def test_rccl_gather_through_the_c_abi_world1(algo, tmp_path):
+    """fx_comm_* / fx_allgather_tables with one rank: RCCL is loaded at run time, the communicator is created from the
+    128-byte id, the block lands at recv[rank * stride + offset] (in place and out of place, chunked offsets)."""
+    import torch.distributed as dist
+    from fiat_amd import distributed as D
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1)
+    try:
+        gather = D.TableGather(impl="rccl", algo=algo)
+        assert gather.impl == "rccl" and gather.world == 1
+        local = torch.arange(7 * 3 * 5, dtype=torch.float64, device="cuda").reshape(7, 3, 5)
+        full = gather.all_gather(local, 7)
+        torch.cuda.synchronize()
+        assert torch.equal(full, local)
+        # chunked, in place: rows produced chunk by chunk into the rank's block of the full buffer
+        big = torch.full((10, 3, 5), float("nan"), dtype=torch.float64, device="cuda")
+
+        def produce(lo, hi, rows):
+            rows.copy_(local[lo:hi] if hi <= 7 else torch.cat([local[lo:7], torch.zeros(hi - 7, 3, 5, device="cuda", dtype=torch.float64)]))
+
+        gather.tabulate_allgather(produce, 7, 10, 4, big)
+        torch.cuda.synchronize()
+        assert torch.equal(big[:7], local)
+        seen = []
+        for c0, c1, staged in gather.iter_gathered_chunks(local, 3, ring=2):
+            seen.append(staged[0].clone())
+        torch.cuda.synchronize()
+        assert torch.equal(torch.cat(seen), local)
+        gather.close()
+    finally:
+        dist.destroy_process_group()
+
+
+# ---- derivative orders 3 and 4 (differentiation-matrix route, csrc/api.hip ensure_high_order) ---------------------
+def _rel(x, ref):
+    return np.abs(x - ref).max() / max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("sd", [1, 2, 3])
+@pytest.mark.parametrize("variant", [None, "bubble"])
+@pytest.mark.parametrize("n", [2, 4])
+def test_expansion_sets_to_order_4(golden, sd, variant, n):
+    """ExpansionSet._tabulate(n, pts, order=4) against the reference (FIAT/expansions.py:66-137 at orders 3 and 4; the
+    relation test/FIAT/unit/test_polynomial.py:87-109 checks to 1e-10); orders above the degree are exact zeros there."""
+    import fiat_amd
+    g = golden("round2")
+    es = fiat_amd.ExpansionSet(fiat_amd.ufc_simplex(sd), variant=variant)
+    tab = es._tabulate(n, g[f"hi_pts_sd{sd}"], order=4)
+    ref = g[f"hi_exp_sd{sd}_{variant}_n{n}"]
+    keys = [a for k in range(5) for a in fiat_amd.mis(sd, k)]
+    assert list(tab) == keys
+    for t, a in enumerate(keys):
+        tol = 1e-12 if sum(a) == 0 else 1e-10
+        assert _rel(tab[a], ref[t]) <= tol, (a, _rel(tab[a], ref[t]))
+
+
+@pytest.mark.parametrize("name,make,sd", [("p3tet", lambda fa, c: fa.Lagrange(c, 3), 3), ("dg4tri", lambda fa, c: fa.DiscontinuousLagrange(c, 4), 2),
+                                          ("n2tet", lambda fa, c: fa.Nedelec(c, 2), 3), ("p5line", lambda fa, c: fa.Lagrange(c, 5), 1),
+                                          ("rt3tri", lambda fa, c: fa.RaviartThomas(c, 3), 2),
+                                          ("dg6tet", lambda fa, c: fa.DiscontinuousLagrange(c, 6), 3)])
+def test_elements_to_order_4(golden, name, make, sd):
+    """element.tabulate(3, .) and (4, .) -- what test/FIAT/regression/test_regression.py:283-299 tabulates -- against
+    the reference, single call and batched (two requests, ragged to the kernels: 9 points)."""
+    import fiat_amd
+    g = golden("round2")
+    el = make(fiat_amd, fiat_amd.ufc_simplex(sd))
+    pts = g[f"hi_pts_sd{sd}"]
+    for order in (3, 4):
+        ref = g[f"hi_{name}_o{order}"]
+        tab = el.tabulate(order, pts)
+        keys = [a for k in range(order + 1) for a in fiat_amd.mis(sd, k)]
+        assert list(tab) == keys
+        for t, a in enumerate(keys):
+            assert tab[a].shape == ref[t].shape
+            assert _rel(tab[a], ref[t]) <= (1e-12 if t == 0 else 1e-10), (order, a, _rel(tab[a], ref[t]))
+        if sd > 1:
+            dev = el.tabulate_batch(order, np.stack([pts, pts[::-1]])).cpu().numpy()
+            assert _rel(dev[0], ref) <= 1e-10 and _rel(dev[1][..., ::-1], ref) <= 1e-10
+
+
+def test_order_3_on_a_physical_cell_and_limits(golden):
+    import fiat_amd
+    g = golden("round2")
+    cell = fiat_amd.physical_simplex(g["hi_phys_verts"])
+    el = fiat_amd.Lagrange(cell, 3)
+    tab = el.tabulate(3, g["hi_phys_pts"])
+    ref = g["hi_phys_p3tet_o3"]
+    for t, a in enumerate([a for k in range(4) for a in fiat_amd.mis(3, k)]):
+        assert _rel(tab[a], ref[t]) <= (1e-12 if t == 0 else 1e-10), (a, _rel(tab[a], ref[t]))
+    # all third derivatives of a cubic are constant over the points, fourth derivatives vanish
+    t4 = el.tabulate(4, g["hi_phys_pts"])
+    for a in fiat_amd.mis(3, 3):
+        assert np.abs(t4[a] - t4[a][:, :1]).max() <= 1e-9 * max(1.0, np.abs(t4[a]).max())
+    for a in fiat_amd.mis(3, 4):
+        assert np.abs(t4[a]).max() <= 1e-8
+    with pytest.raises(NotImplementedError):
+        el.tabulate(9, g["hi_phys_pts"])
+    with pytest.raises(NotImplementedError):   # per-request cells: orders <= 2 only
+        el.tabulate_batch(3, g["hi_phys_pts"][None], verts=g["hi_phys_verts"][None])
+
+
+def test_order_3_full_batch_consistency():
+    """100 000 requests, P3 tetrahedron, order 3: tables 0..9 equal the order-2 path's (recurrence) to 1e-10, the ten
+    third-derivative tables are constant per request and sum to zero over the dofs (partition of unity)."""
+    import fiat_amd
+    rng = np.random.default_rng(12)
+    e = rng.exponential(size=(100_000, 23, 4))
+    pts = torch.as_tensor((e / e.sum(-1, keepdims=True))[..., 1:].copy()).cuda()
+    el = fiat_amd.Lagrange(fiat_amd.ufc_simplex(3), 3)
+    lo = el.tabulate_batch(2, pts)
+    hi = el.tabulate_batch(3, pts)
+    assert hi.shape == (100_000, 20, 20, 23)
+    scale = float(lo.abs().max())
+    assert float((hi[:, :10] - lo).abs().max()) <= 1e-10 * scale
+    third = hi[:, 10:]
+    assert float((third - third[..., :1]).abs().max()) <= 1e-9 * float(third.abs().max())
+    assert float(third.sum(dim=2).abs().max()) <= 1e-8 * float(third.abs().max())
+
+
+# ---- general tensor products (csrc/table_kernels.hpp table_outer_kernel) ----------------------------------------
+def _tp(fa, key):
+    T, I = fa.ufc_simplex(2), fa.ufc_simplex(1)
+    return {"p2tri_p1": lambda: fa.TensorProductElement(fa.Lagrange(T, 2), fa.Lagrange(I, 1)),
+            "dg1tri_p2": lambda: fa.TensorProductElement(fa.DiscontinuousLagrange(T, 1), fa.Lagrange(I, 2)),
+            "rt1tri_dg0": lambda: fa.TensorProductElement(fa.RaviartThomas(T, 1), fa.DiscontinuousLagrange(I, 0)),
+            "n1tri_p1": lambda: fa.TensorProductElement(fa.Nedelec(T, 1), fa.Lagrange(I, 1)),
+            "rt2tri_dg1": lambda: fa.TensorProductElement(fa.RaviartThomas(T, 2), fa.DiscontinuousLagrange(I, 1))}[key]()
+
+
+@pytest.mark.parametrize("key", ["p2tri_p1", "dg1tri_p2", "rt1tri_dg0", "n1tri_p1", "rt2tri_dg1"])
+def test_prism_elements_vs_reference(golden, key):
+    """Triangle x interval products, scalar and with a vector-valued triangle factor (FIAT/tensor_product.py:274-317),
+    orders 0-2, against the reference; batched = single."""
+    import fiat_amd
+    g = golden("round2")
+    el = _tp(fiat_amd, key)
+    pts = g["tp_prism_pts"]
+    for order in (0, 1, 2):
+        ref = g[f"tp_{key}_o{order}"]
+        tab = el.tabulate(order, pts)
+        keys = [a for k in range(order + 1) for a in fiat_amd.mis(3, k)]
+        assert list(tab) == keys
+        for t, a in enumerate(keys):
+            assert tab[a].shape == ref[t].shape, (tab[a].shape, ref[t].shape)
+            assert _rel(tab[a], ref[t]) <= (1e-12 if t == 0 else 1e-10), (order, a)
+    dev = el.tabulate_batch(1, np.stack([pts] * 3)).cpu().numpy()
+    assert _rel(dev[2], g[f"tp_{key}_o1"]) <= 1e-10
+    assert el.space_dimension() == ref.shape[1]
+    assert el.value_shape() == (() if ref.ndim == 3 else (2,))
+
+
+def test_scalar_times_vector_and_entities(golden):
+    import fiat_amd as fa
+    g = golden("round2")
+    T, I = fa.ufc_simplex(2), fa.ufc_simplex(1)
+    for key, el in (("tp_p1_rt1tri_o1", fa.TensorProductElement(fa.Lagrange(I, 1), fa.RaviartThomas(T, 1))),
+                    ("tp_p2_dg1tri_o1", fa.TensorProductElement(fa.Lagrange(I, 2), fa.DiscontinuousLagrange(T, 1)))):
+        tab = el.tabulate(1, g["tp_it_pts"])
+        for t, a in enumerate([a for k in range(2) for a in fa.mis(3, k)]):
+            assert tab[a].shape == g[key][t].shape
+            assert _rel(tab[a], g[key][t]) <= 1e-10, (key, a)
+    el = fa.TensorProductElement(fa.Lagrange(T, 2), fa.Lagrange(I, 1))
+    keys = [a for k in range(2) for a in fa.mis(3, k)]
+    for k in (0, 1):       # bottom / top triangle
+        tab = el.tabulate(1, g["tp_tri_pts"], entity=((2, 0), k))
+        for t, a in enumerate(keys):
+            assert _rel(tab[a], g[f"tp_p2tri_p1_ent20_{k}"][t]) <= 1e-10, (k, a)
+    for k in (0, 1, 2):    # side quadrilaterals
+        tab = el.tabulate(1, g["tp_quad_pts"], entity=((1, 1), k))
+        for t, a in enumerate(keys):
+            assert _rel(tab[a], g[f"tp_p2tri_p1_ent11_{k}"][t]) <= 1e-10, (k, a)
+    with pytest.raises(NotImplementedError):
+        fa.TensorProductElement(fa.RaviartThomas(T, 1), fa.RaviartThomas(T, 1))
+    # the hexahedron of BASELINE config 5 stays on the fused kernel; the general route gives the same tables
+    P2 = fa.Lagrange(I, 2)
+    hexel = fa.TensorProductElement(fa.TensorProductElement(P2, P2), P2)
+    pts = np.random.default_rng(3).uniform(0, 1, size=(2, 11, 3))
+    fused = hexel.tabulate_batch(1, pts)
+    left = hexel.A.tabulate_batch(1, pts[..., :2])
+    right = P2.tabulate_batch(1, pts[..., 2:])
+    from fiat_amd import runtime
+    assert _rel(runtime.table_outer(1, 2, 1, left, right).cpu().numpy(), fused.cpu().numpy()) <= 1e-13
+
+
+# ---- sub-entity tabulation on the device (fx_map_points) ------------------------------------------------------------
+def test_entity_tabulation_vs_reference(golden):
+    """tabulate(order, points, entity=(dim, id)): facet, edge and vertex entities of a tetrahedron, edges of a triangle
+    for a Piola-mapped element (FIAT/finite_element.py:181-197, reference_element.py:570-609); batched facet tabulation
+    and one facet rule in many cells."""
+    import fiat_amd as fa
+    g = golden("round2")
+    el = fa.Lagrange(fa.ufc_simplex(3), 3)
+    keys = [a for k in range(2) for a in fa.mis(3, k)]
+    for f in range(4):
+        tab = el.tabulate(1, g["ent_facet_pts"], entity=(2, f))
+        for t, a in enumerate(keys):
+            assert _rel(tab[a], g[f"ent_p3tet_facet{f}"][t]) <= 1e-10, (f, a)
+    for e in range(6):
+        tab = el.tabulate(1, g["ent_edge_pts"], entity=(1, e))
+        for t, a in enumerate(keys):
+            assert _rel(tab[a], g[f"ent_p3tet_edge{e}"][t]) <= 1e-10, (e, a)
+    tab = el.tabulate(1, np.zeros((1, 0)), entity=(0, 2))
+    for t, a in enumerate(keys):
+        assert tab[a].shape == g["ent_p3tet_vertex2"][t].shape
+        assert _rel(tab[a], g["ent_p3tet_vertex2"][t]) <= 1e-10
+    rt = fa.RaviartThomas(fa.ufc_simplex(2), 2)
+    for e in range(3):
+        tab = rt.tabulate(1, g["ent_edge_pts"], entity=(1, e))
+        for t, a in enumerate([a for k in range(2) for a in fa.mis(2, k)]):
+            assert _rel(tab[a], g[f"ent_rt2tri_edge{e}"][t]) <= 1e-10, (e, a)
+    # batch of facet point sets, and a facet quadrature rule pushed to many physical cells
+    batch = np.stack([g["ent_facet_pts"], g["ent_facet_pts"][::-1]])
+    dev = el.tabulate_batch(1, batch, entity=(2, 3)).cpu().numpy()
+    assert _rel(dev[0], g["ent_p3tet_facet3"]) <= 1e-10 and _rel(dev[1][..., ::-1], g["ent_p3tet_facet3"]) <= 1e-10
+    Q = fa.create_quadrature(fa.ufc_simplex(2), 4)
+    rng = np.random.default_rng(4)
+    ref = np.array(fa.ufc_simplex(3).get_vertices(), dtype=float)
+    verts = ref[None] + rng.uniform(-0.1, 0.1, size=(50, 4, 3))
+    got = el.tabulate_cells(1, Q.device_points()[0], verts, entity=(2, 1)).cpu().numpy()
+    M, b = el.entity_map((2, 1))
+    ref_pts = Q.get_points() @ M.T + b
+    bary = np.concatenate([1 - ref_pts.sum(1, keepdims=True), ref_pts], axis=1)
+    phys = np.einsum("pv,rvd->rpd", bary, verts)
+    want = el.tabulate_batch(1, phys, verts=verts).cpu().numpy()
+    assert _rel(got, want) <= 1e-10
+
+
+def test_default_rule_on_device_feeds_tabulate_cells(golden):
+    """create_quadrature(tet, 6) is the 23-point Xiao-Gimbutas rule of BASELINE config 2; resident on the device it feeds
+    tabulate_cells, whose tables on the reference cell equal the reference's c2_p3tet_q6_tab."""
+    import fiat_amd as fa
+    g = golden("elements")
+    Q = fa.create_quadrature(fa.ufc_simplex(3), 6)
+    pts_d, wts_d = Q.device_points()
+    assert pts_d.is_cuda and pts_d.shape == (23, 3) and abs(float(wts_d.sum()) - 1 / 6) < 1e-14
+    el = fa.Lagrange(fa.ufc_simplex(3), 3)
+    ref = np.array(fa.ufc_simplex(3).get_vertices(), dtype=float)
+    out = el.tabulate_cells(1, pts_d, np.stack([ref, ref])).cpu().numpy()
+    assert _rel(out[0], g["c2_p3tet_q6_tab"]) <= 1e-10 and _rel(out[1], g["c2_p3tet_q6_tab"]) <= 1e-10

@@ -1,0 +1,74 @@
+"""create_quadrature against the reference's own output (tests/golden/round2.npz, make_golden_round2.py): default
+scheme = classical / Xiao-Gimbutas tables on triangles (degree <= 50) and tetrahedra (<= 15), collapsed Gauss-Jacobi
+beyond and for "canonical"; exactness as in test/FIAT/unit/test_quadrature.py:110-125.  Host logic only."""
+import math
+
+import numpy as np
+import pytest
+
+import fiat_amd
+from fiat_amd import quadrature
+from fiat_amd.check_format_variant import parse_quadrature_scheme
+
+
+@pytest.mark.parametrize("sd,degrees", [(1, range(0, 12)), (2, range(0, 54)), (3, range(0, 19))])
+def test_default_scheme_equals_reference(golden, sd, degrees):
+    g = golden("round2")
+    cell = fiat_amd.ufc_simplex(sd)
+    counts = []
+    for d in degrees:
+        Q = fiat_amd.create_quadrature(cell, d)
+        counts.append(len(Q.get_weights()))
+        assert Q.get_points().shape == g[f"quad_sd{sd}_deg{d}_pts"].shape, d
+        assert np.abs(Q.get_points() - g[f"quad_sd{sd}_deg{d}_pts"]).max() <= 1e-14, d
+        assert np.abs(Q.get_weights() - g[f"quad_sd{sd}_deg{d}_wts"]).max() <= 1e-14, d
+    assert counts == list(g[f"quad_sd{sd}_counts"])
+    for d in (2, 5):
+        Q = fiat_amd.create_quadrature(cell, d, "canonical")
+        assert np.abs(Q.get_points() - g[f"quadcanon_sd{sd}_deg{d}_pts"]).max() <= 1e-14
+        assert np.abs(Q.get_weights() - g[f"quadcanon_sd{sd}_deg{d}_wts"]).max() <= 1e-14
+
+
+def test_headline_rule_and_other_cells(golden):
+    g = golden("round2")
+    Q = fiat_amd.create_quadrature(fiat_amd.ufc_simplex(3), 6)
+    assert len(Q.get_weights()) == 23                     # the rule BASELINE configs[1] is defined on
+    assert np.array_equal(Q.get_points(), golden("elements")["tet_q6_pts"])
+    cell = fiat_amd.physical_simplex(g["quad_phys_tri_verts"])
+    Q = fiat_amd.create_quadrature(cell, 7)
+    assert np.abs(Q.get_points() - g["quad_phys_tri_pts"]).max() <= 1e-14
+    assert np.abs(Q.get_weights() - g["quad_phys_tri_wts"]).max() <= 1e-14
+    Q = fiat_amd.create_quadrature(fiat_amd.ufc_simplex(3), 5, entity=(2, 1))
+    assert np.abs(Q.get_points() - g["quad_tet_facet1_deg5_pts"]).max() <= 1e-14
+    assert np.abs(Q.get_weights() - g["quad_tet_facet1_deg5_wts"]).max() <= 1e-14
+    assert quadrature.tabulated_rule(2, 51) is None and quadrature.tabulated_rule(3, 16) is None
+    assert quadrature.tabulated_rule(1, 3) is None
+
+
+@pytest.mark.parametrize("sd,maxdeg", [(2, 50), (3, 15)])
+def test_exactness_of_the_tabulated_rules(sd, maxdeg):
+    """Every monomial x^a y^b (z^c) of total degree <= d integrates to a! b! c! / (a + b + c + sd)!."""
+    cell = fiat_amd.ufc_simplex(sd)
+    for d in list(range(0, maxdeg + 1, 3)) + [maxdeg]:
+        Q = fiat_amd.create_quadrature(cell, d)
+        x, w = Q.get_points(), Q.get_weights()
+        for alpha in fiat_amd.mis(sd, d):
+            exact = math.prod(math.factorial(a) for a in alpha) / math.factorial(sum(alpha) + sd)
+            got = float(np.sum(w * np.prod(x ** np.array(alpha), axis=1)))
+            assert abs(got - exact) <= 2e-13 * max(exact, 1e-3), (d, alpha)
+
+
+def test_scheme_strings():
+    tri = fiat_amd.ufc_simplex(2)
+    with pytest.raises(ValueError):
+        fiat_amd.create_quadrature(tri, 2, "no-such-scheme")
+    with pytest.raises(ValueError):
+        fiat_amd.create_quadrature(tri, -1)
+    with pytest.raises(NotImplementedError):
+        fiat_amd.create_quadrature(tri, 2, "KMV")
+    assert len(parse_quadrature_scheme(tri, 4).get_weights()) == 6
+    assert len(parse_quadrature_scheme(tri, 4, "canonical").get_weights()) == 9
+    Q = parse_quadrature_scheme(tri, 4, "default,alfeld")      # composite rule on the Alfeld split: 3 sub-triangles
+    assert len(Q.get_weights()) == 18 and abs(Q.get_weights().sum() - 0.5) < 1e-15
+    with pytest.raises(NotImplementedError):
+        parse_quadrature_scheme(tri, 4, "KMV(2)")

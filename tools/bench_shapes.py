@@ -8,7 +8,7 @@ import fiat_amd, bench
 CASES = [("Lagrange", 2, 1, 3), ("Lagrange", 2, 2, 6), ("Lagrange", 2, 3, 12), ("Lagrange", 3, 1, 4), ("Lagrange", 3, 2, 11),
          ("Lagrange", 3, 2, 14), ("Lagrange", 3, 3, 23), ("Lagrange", 3, 3, 14), ("Lagrange", 2, 4, 12), ("Lagrange", 2, 5, 16), ("Lagrange", 3, 4, 23), ("DiscontinuousLagrange", 3, 1, 4),
          ("Nedelec", 3, 1, 4), ("RaviartThomas", 3, 1, 4), ("Nedelec", 2, 1, 3)]
-# (family, sd, degree, points, order): larger shapes, FIAT_AMD_NO_STACKED=1 for the A/B partner
+# (family, sd, degree, points, order): larger shapes, --no-stacked / --no-fixed / --no-small for the A/B partners
 BIG = [("Lagrange", 3, 4, 23, 2), ("Lagrange", 3, 5, 23, 1), ("Lagrange", 3, 5, 23, 2), ("DiscontinuousLagrange", 3, 5, 30, 1),
        ("DiscontinuousLagrange", 3, 6, 23, 1), ("DiscontinuousLagrange", 3, 6, 40, 2), ("Lagrange", 3, 6, 23, 2),
        ("Nedelec", 3, 4, 23, 1), ("Nedelec", 3, 3, 23, 1), ("BrezziDouglasMarini", 3, 3, 23, 1)]
@@ -23,6 +23,8 @@ if "--big" in sys.argv:
     CASES = BIG
 if "--mid" in sys.argv:
     CASES = MID
+from fiat_amd import runtime
+runtime.Context.get().set_policy(*[f[2:].replace("-", "_") for f in sys.argv if f in ("--no-stacked", "--no-fixed", "--no-small", "--no-coop")])
 for case in CASES:
     fam, sd, deg, npts = case[:4]
     el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg)

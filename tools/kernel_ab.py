@@ -57,9 +57,9 @@ def main():
         kt = {k: [] for k in ks}
         for _ in range(args.rounds):
             for k in ks:
-                os.environ["FIAT_AMD_KERNEL"] = k
+                ps.ctx.set_policy(*({"image": ["kernel_image"], "stream": ["kernel_stream"]}.get(k, [])))
                 kt[k].append(ps.time_tabulate_batch(order, pts, verts, out, args.reps))
-        os.environ.pop("FIAT_AMD_KERNEL", None)
+        ps.ctx.set_policy()
         cl = statistics.median(ceiling() for _ in range(args.rounds))
         print(f"fill_ of the output buffer on this box: {cl * 1e3:9.1f} us")
         for k in ks:
