@@ -2156,9 +2156,18 @@ int ensure_high_order(fx_ctx* ctx, fx_element* e, int order) {
         if (rc != FX_OK) return rc;
         if (!ok) return fail(FX_ENOTIMPL, "derivative order %d: singular mass matrix of the expansion set", order);
         const int nrhs = sd * nexp;
+        // members are graded by total degree (Morton order: degree s starts at C(s - 1 + sd, sd)) and differentiation
+        // lowers the degree: entries with deg(k) >= deg(j) are structural zeros -- whatever the projection left there
+        // is round-off, and dropping it makes D^alpha vanish exactly for |alpha| > degree
+        std::vector<int> deg(nexp, 0);
+        for (int j = 0, s = 0; j < nexp; ++j) {
+            while (fx::binom(s + sd, sd) <= j) ++s;
+            deg[j] = s;
+        }
         for (int d = 0; d < sd; ++d)
             for (int j = 0; j < nexp; ++j)
-                for (int k = 0; k < nexp; ++k) D1[((size_t)d * nexp + j) * nexp + k] = B[(size_t)k * nrhs + (size_t)d * nexp + j];
+                for (int k = 0; k < nexp; ++k)
+                    D1[((size_t)d * nexp + j) * nexp + k] = deg[k] < deg[j] ? B[(size_t)k * nrhs + (size_t)d * nexp + j] : 0.0;
     }
     // all multi-indices |alpha| <= order in mis() order, each D^alpha from its predecessor
     std::vector<std::vector<int>> alphas;
