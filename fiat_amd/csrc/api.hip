@@ -594,7 +594,7 @@ const FixedShape kFixedShapes[] = {
     {3, 3, 1, 20, 12, true, 1, false, 8, false}, // ... 41..48 points
     {3, 2, 1, 45, 6, true, 1, false, 8, true},   // RT2 tetrahedron (15 x 3 rows), 21..24 points: one request per wave, half image
     {3, 4, 1, 35, 6, true, 1, false, 8, false},  // Lagrange P4 tetrahedron, 21..24 points
-    {3, 2, 1, 60, 6, true, 1, false, 6, true},   // N2 tetrahedron (20 x 3 rows), 21..24 points: 22 KB half images, six waves
+    {3, 2, 1, 60, 6, true, 1, false, 4, true},   // N2 tetrahedron (20 x 3 rows), 21..24 points: 22 KB half images, four waves (one per SIMD: 180 accumulator registers)
 };
 
 template <int SD, int N>
@@ -1013,7 +1013,7 @@ int run_fixed(const Launch& L, hipStream_t s) {
         case 6: return launch_fixed<3, 3, 1, 20, 12, true, 1, false>(L, s);
         case 7: return launch_fixed<3, 2, 1, 45, 6, true, 1, false, 8, true>(L, s);
         case 8: return launch_fixed<3, 4, 1, 35, 6, true, 1, false>(L, s);
-        case 9: return launch_fixed<3, 2, 1, 60, 6, true, 1, false, 6, true>(L, s);
+        case 9: return launch_fixed<3, 2, 1, 60, 6, true, 1, false, 4, true>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown fixed kernel %d", L.fixed_id);
 }

@@ -39,7 +39,7 @@ namespace fxk {
 // is copied out -- lane <-> (dof, point), the SD components of a dof are SD rows of the image.
 template <int SD, int N, int ORDER, int ROWS, int NT, int NW, bool UNIFORM, int RPW = 2, bool FULLIMG = (FX_PAIR_FULLIMG != 0),
           bool PIOLA = false>
-__global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(const FixedArgs<FixedNC<SD, N>::value> a,
+__global__ __launch_bounds__(64 * NW, NW <= 4 ? 1 : FX_PAIR_WAVES) void tabulate_simplex_pair(const FixedArgs<FixedNC<SD, N>::value> a,
                                                                                 double* __restrict__ trash,
                                                                                 unsigned int* __restrict__ gqueue) {
     constexpr int NTAB = NTab<SD, ORDER>::value;
@@ -342,17 +342,27 @@ __global__ __launch_bounds__(64 * NW, FX_PAIR_WAVES) void tabulate_simplex_pair(
             v2d* g2 = reinterpret_cast<v2d*>(a.out + (size_t)req * (NTAB * ROWS * enpts) + (size_t)half * TH * ROWS * enpts);
             // in batches of 8 x 16 B per lane (32 VGPRs in flight)
             constexpr int FB = 8;
+            // Requests whose size is not a multiple of the 128-byte line (RT2, P4 at 21-23 points) start anywhere in a
+            // line.  Every store instruction then covers WHOLE lines: lane i of instruction `it` takes the 16-byte chunk
+            // 64 it + i - shift, shift = chunks between the last line boundary and the start of the image (wave uniform,
+            // from the address); chunks before the start / past the end are clamped (the same bytes written twice).
+            // Non-temporal stores of partial lines cost ~10 % of the launch (tools/ubench6.hip: 173 -> 156 us per 0.84 GB);
+            // only the first and the last line of an image stay partial.
+            constexpr bool SHIFT = (ROWS * 8 * (FULLIMG ? NTAB : 1)) % 128 != 0;
+            constexpr int NFLS = SHIFT ? NFL + 1 : NFL;
+            int shift = 0;
+            if constexpr (SHIFT) shift = (int)((reinterpret_cast<unsigned long long>(g2) >> 4) & 7ull);
 #pragma unroll
-            for (int b0 = 0; b0 < NFL; b0 += FB) {
+            for (int b0 = 0; b0 < NFLS; b0 += FB) {
                 v2d buf[FB];
 #pragma unroll
-                for (int it = b0; it < NFL && it < b0 + FB; ++it) {
-                    const int i = min(it * 64 + elane, nch - 1);
+                for (int it = b0; it < NFLS && it < b0 + FB; ++it) {
+                    const int i = SHIFT ? max(0, min(it * 64 + elane - shift, nch - 1)) : min(it * 64 + elane, nch - 1);
                     buf[it - b0] = s2[i];
                 }
 #pragma unroll
-                for (int it = b0; it < NFL && it < b0 + FB; ++it) {
-                    const int i = min(it * 64 + elane, nch - 1);
+                for (int it = b0; it < NFLS && it < b0 + FB; ++it) {
+                    const int i = SHIFT ? max(0, min(it * 64 + elane - shift, nch - 1)) : min(it * 64 + elane, nch - 1);
                     stream_store(&g2[i], buf[it - b0]);
                 }
             }
