@@ -205,3 +205,27 @@ def test_dual_basis_rejects_derivative_nodes(fa):
     fe = ad.FiatElement(fiat_amd.CubicHermite(fiat_amd.ufc_simplex(2)))
     with pytest.raises(NotImplementedError):
         fe.dual_basis
+
+
+@pytest.mark.parametrize("variant", ["equispaced,iso(2)", "equispaced,alfeld"])
+def test_macro_elements_are_not_cellwise_constant(fa, variant):
+    """On a macro element the derivative == degree table is only PIECEWISE constant: finat/fiat_elements.py:101 asks
+    ``complex.is_simplex()`` before dropping the point axis (FIAT/reference_element.py:327,914: False for complexes).
+    P1-iso-P2 and Alfeld P1 with points in several sub-cells: the first-derivative tables stay pointwise, in the
+    single-point-set and in the batch path."""
+    fiat_amd, ad = fa
+    el = fiat_amd.Lagrange(fiat_amd.ufc_simplex(2), 1, variant=variant)
+    assert not el.get_reference_complex().is_simplex() and fiat_amd.ufc_simplex(2).is_simplex()
+    fe = ad.FiatElement(el)
+    pts = simplex_points(2, 12, 21)
+    res = fe.basis_evaluation(1, ad.PointSet(pts))
+    raw = el.tabulate(1, pts)
+    for alpha in ((1, 0), (0, 1)):
+        assert res[alpha].kind == ad.POINTWISE
+        np.testing.assert_array_equal(res[alpha].array, raw[alpha])
+        assert np.abs(raw[alpha] - raw[alpha][:, :1]).max() > 0.5      # the gradient really differs between sub-cells
+    batch = np.stack([pts, pts[::-1]])
+    bres = fe.basis_evaluation_batch(1, batch)
+    for alpha in ((1, 0), (0, 1)):
+        assert bres[alpha].kind == ad.POINTWISE
+        np.testing.assert_allclose(bres[alpha].array.cpu().numpy()[0], raw[alpha], atol=1e-12)

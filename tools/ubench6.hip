@@ -60,6 +60,20 @@ __global__ __launch_bounds__(512) void store_blocks(double* out, long long nblk,
                 st<NT>(g + i, val);
             }
         }
+    } else if (pattern >= 20 && pattern < 30) {  // as 0, but at most (pattern - 20) KB... of stores in flight per wave: wait after every k stores
+        const long long gw = (long long)blockIdx.x * nw + wv, tw = (long long)gridDim.x * nw;
+        const int k = 1 << (pattern - 20);
+        for (long long b = gw; b < nblk; b += tw) {
+            v2d* g = base + b * stride16;
+            int cnt = 0;
+            for (int i = lane; i < blk16; i += 64) {
+                st<NT>(g + i, val);
+                if (++cnt == k) {
+                    cnt = 0;
+                    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0) only
+                }
+            }
+        }
     } else if (pattern == 5) {  // as 4, but the waves of a workgroup store ONE AFTER THE OTHER: a workgroup writes its run of NW
                                 // adjacent blocks as one sequential stream (256 streams on the chip instead of 2048)
         const long long ngroups = (nblk + nw - 1) / nw;
@@ -119,13 +133,15 @@ int main(int argc, char** argv) {
     const double total = (double)nblk * bytes;
     double us = timeit([&] { hipMemsetAsync(out, 0, (size_t)total, 0); });
     printf("memset of the same bytes: %7.1f us %6.0f GB/s\n", us, total / us / 1e3);
+    const bool quick = argc > 3;
     for (int pad : {0}) {
         const int stride = pad ? (bytes + 127) / 128 * 128 : bytes;
         for (int nt : {0, 1})
-            for (int nw : {4, 8})
+            for (int nw : {2, 4, 8})
                 for (int wgs : {1, 2, 4})
-                    for (int pattern : {0, 9}) {
+                    for (int pattern : {0, 2, 21, 22, 23, 24}) {
                         if (nw * wgs > 16) continue;
+                        if (quick && (wgs != 1)) continue;
                         const int grid = 256 * wgs;
                         auto fn = [&] {
                             if (nt) store_blocks<1><<<grid, 64 * nw>>>(out, nblk, bytes / 16, stride / 16, pattern);
