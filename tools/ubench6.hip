@@ -74,6 +74,18 @@ __global__ __launch_bounds__(512) void store_blocks(double* out, long long nblk,
                 }
             }
         }
+    } else if (pattern >= 40 && pattern < 60) {  // as 0, but the 1 KB pieces of a block are visited with a stride of (pattern - 40):
+                                                 // consecutive store instructions go to different 4 KB / 8 KB ... stripes
+        const long long gw = (long long)blockIdx.x * nw + wv, tw = (long long)gridDim.x * nw;
+        const int npieces = (blk16 + 63) / 64, strd = pattern - 40;
+        for (long long b = gw; b < nblk; b += tw) {
+            v2d* g = base + b * stride16;
+            for (int r = 0; r < strd; ++r)
+                for (int pc = r; pc < npieces; pc += strd) {
+                    const int i = pc * 64 + lane;
+                    if (i < blk16) st<NT>(g + i, val);
+                }
+        }
     } else if (pattern == 5) {  // as 4, but the waves of a workgroup store ONE AFTER THE OTHER: a workgroup writes its run of NW
                                 // adjacent blocks as one sequential stream (256 streams on the chip instead of 2048)
         const long long ngroups = (nblk + nw - 1) / nw;
@@ -137,9 +149,9 @@ int main(int argc, char** argv) {
     for (int pad : {0}) {
         const int stride = pad ? (bytes + 127) / 128 * 128 : bytes;
         for (int nt : {0, 1})
-            for (int nw : {2, 4, 8})
+            for (int nw : {4, 8})
                 for (int wgs : {1, 2, 4})
-                    for (int pattern : {0, 2, 21, 22, 23, 24}) {
+                    for (int pattern : {0, 42, 44, 48, 2}) {
                         if (nw * wgs > 16) continue;
                         if (quick && (wgs != 1)) continue;
                         const int grid = 256 * wgs;
