@@ -4,8 +4,8 @@
     PYTHONPATH=oracle/restated_deps:/root/reference OMP_NUM_THREADS=1 \
         python -B tests/golden/make_golden_families.py
 
-Brezzi-Douglas-Marini, second-kind Nedelec, cubic Hermite, Morley and Crouzeix-Raviart elements on
-the UFC interval / triangle / tetrahedron:
+Brezzi-Douglas-Marini, second-kind Nedelec, Regge, Hellan-Herrmann-Johnson, point variants of Nedelec / Raviart-Thomas,
+cubic Hermite and Morley elements on the UFC interval / triangle / tetrahedron:
 nodal coefficients, entity -> dof map, the tables of tabulate(1, points) at seeded points.
 Plain numbers only."""
 import json
@@ -13,9 +13,8 @@ import os
 
 import numpy as np
 
-from FIAT import (Argyris, HellanHerrmannJohnson, Regge, BrezziDouglasFortinMarini, BrezziDouglasMarini, Bubble, CrouzeixRaviart, CubicHermite,
-                  DiscontinuousRaviartThomas, FacetBubble, Lagrange, Morley, Nedelec, NedelecSecondKind, RaviartThomas,
-                  NodalEnrichedElement, RestrictedElement, ufc_simplex)
+from FIAT import (BrezziDouglasMarini, CubicHermite, HellanHerrmannJohnson, Morley, Nedelec, NedelecSecondKind, RaviartThomas,
+                  Regge, ufc_simplex)
 from FIAT.polynomial_set import mis
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -24,8 +23,7 @@ CASES = [("bdm", BrezziDouglasMarini, 2, (1, 2, 3)), ("bdm", BrezziDouglasMarini
          # derivative functionals in the dual set (FIAT/dual_set.py:175-205)
          ("hermite", CubicHermite, 1, (3,)), ("hermite", CubicHermite, 2, (3,)), ("hermite", CubicHermite, 3, (3,)),
          ("morley", Morley, 2, (2,)), ("morley", Morley, 3, (2,)),
-         ("cr", CrouzeixRaviart, 2, (1, 3)), ("cr", CrouzeixRaviart, 3, (1,)),
-         # point variants (normal / tangential point evaluations) and restricted elements
+         # point variants (normal / tangential point evaluations)
          ("rtpt", lambda c, k: RaviartThomas(c, k, variant="point"), 2, (1, 2)),
          ("rtpt", lambda c, k: RaviartThomas(c, k, variant="point"), 3, (1, 2)),
          ("nedpt", lambda c, k: Nedelec(c, k, variant="point"), 2, (1, 2)),
@@ -34,22 +32,11 @@ CASES = [("bdm", BrezziDouglasMarini, 2, (1, 2, 3)), ("bdm", BrezziDouglasMarini
          ("bdmpt", lambda c, k: BrezziDouglasMarini(c, k, variant="point"), 3, (1, 2)),
          ("n2curlpt", lambda c, k: NedelecSecondKind(c, k, variant="point"), 2, (1, 2)),
          ("n2curlpt", lambda c, k: NedelecSecondKind(c, k, variant="point"), 3, (1, 2)),
-         ("drt", DiscontinuousRaviartThomas, 2, (1, 2)), ("drt", DiscontinuousRaviartThomas, 3, (1, 2)),
-         ("bubble", Bubble, 2, (3, 4)), ("bubble", Bubble, 3, (4,)),
-         ("facetbubble", FacetBubble, 2, (2, 3)), ("facetbubble", FacetBubble, 3, (3,)),
-         ("bdfm", BrezziDouglasFortinMarini, 2, (2,)), ("bdfm", BrezziDouglasFortinMarini, 3, (2,)),
          # symmetric-matrix-valued elements (ONSymTensorPolynomialSet)
          ("regge", Regge, 2, (0, 1, 2)), ("regge", Regge, 3, (0, 1)),
          ("reggept", lambda c, k: Regge(c, k, variant="point"), 2, (1,)), ("reggept", lambda c, k: Regge(c, k, variant="point"), 3, (1,)),
          ("hhj", HellanHerrmannJohnson, 2, (0, 1, 2)), ("hhj", HellanHerrmannJohnson, 3, (0, 1)),
-         ("hhjpt", lambda c, k: HellanHerrmannJohnson(c, k, variant="point"), 3, (1,)),
-         ("argyris", Argyris, 2, (5, 6)), ("argyrispt", lambda c, k: Argyris(c, k, variant="point"), 2, (5, 6)),
-         ("mini", lambda c, k: NodalEnrichedElement(Lagrange(c, 1), Bubble(c, k)), 2, (3,)),
-         ("mini", lambda c, k: NodalEnrichedElement(Lagrange(c, 1), Bubble(c, k)), 3, (4,)),
-         ("p2facetbubble", lambda c, k: NodalEnrichedElement(Lagrange(c, 2), FacetBubble(c, k)), 3, (3,)),
-         ("bdfmpt", lambda c, k: BrezziDouglasFortinMarini(c, k, variant="point"), 2, (2,)),
-         ("lagfacet", lambda c, k: RestrictedElement(Lagrange(c, k), restriction_domain="facet"), 2, (3,)),
-         ("lagedge", lambda c, k: RestrictedElement(Lagrange(c, k), restriction_domain="edge", take_closure=False), 3, (3,))]
+         ("hhjpt", lambda c, k: HellanHerrmannJohnson(c, k, variant="point"), 3, (1,))]
 
 
 def main():
