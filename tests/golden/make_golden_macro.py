@@ -6,8 +6,7 @@
         python -B tests/golden/make_golden_macro.py
 
 Writes tests/golden/macro.npz (plain numbers: vertices, topologies, cell-node maps,
-seeded points and the reference's tables/coefficients) and tests/golden/hct.npz (C1 spaces as
-projectors, Hsieh-Clough-Tocher tables, composite quadrature rules).  Covered reference code:
+seeded points and the reference's tables/coefficients).  Covered reference code:
 FIAT/macro.py:83-379 (splits), FIAT/expansions.py:449-490 (macro scatter), :744-811
 (cell-node map, point binning), FIAT/lagrange.py:75-88 and
 FIAT/discontinuous_lagrange.py:225-241 with a splitting in the variant.
@@ -130,39 +129,5 @@ def main():
     print("macro.npz:", len(out), "arrays")
 
 
-def hct_main():
-    """C1 macro element (FIAT/hct.py, FIAT/macro.py:435-521) -> tests/golden/hct.npz."""
-    from FIAT.hct import HsiehCloughTocher
-    from FIAT.macro import CkPolynomialSet, MacroQuadratureRule
-    from FIAT import create_quadrature
-    rng = np.random.default_rng(20261005)
-    out = {}
-    T = ufc_simplex(2)
-    for name, kw in {"hct3": dict(degree=3), "hct3_reduced": dict(degree=3, reduced=True), "hct4": dict(degree=4),
-                     "hct5": dict(degree=5)}.items():
-        e = HsiehCloughTocher(T, **kw)
-        out[f"{name}/coeffs"] = np.asarray(e.get_coeffs())
-        ids = e.entity_dofs()
-        flat = [(d, ent, dof) for d in sorted(ids) for ent in sorted(ids[d]) for dof in ids[d][ent]]
-        out[f"{name}/entity_dofs"] = np.asarray(flat, dtype=np.int64).reshape(-1, 3)
-        pts = np.vstack([rand_points(rng, 2, 25), [[1 / 3, 1 / 3], [0.5, 0.5], [0.0, 0.0], [1 / 6, 1 / 6]]])
-        out[f"{name}/pts"] = pts
-        out[f"{name}/tab2"] = stack(e.tabulate(2, pts), 2, 2)
-    # the C1 spaces themselves: orthogonal projectors onto their spans (the SVD basis is not unique)
-    for sd, S, deg in ((2, AlfeldSplit(ufc_simplex(2)), 3), (2, AlfeldSplit(ufc_simplex(2)), 4), (3, AlfeldSplit(ufc_simplex(3)), 3),
-                       (2, PowellSabinSplit(ufc_simplex(2)), 2)):
-        for variant in (None, "bubble"):
-            P = CkPolynomialSet(S, deg, order=1, variant=variant)
-            C = np.asarray(P.get_coeffs())
-            out[f"ck/{type(S).__name__}{sd}/deg{deg}/{variant or 'none'}/projector"] = C.T @ np.linalg.solve(C @ C.T, C)
-    Q = create_quadrature(AlfeldSplit(T), 3)
-    out["mq/alfeld_tri/pts"], out["mq/alfeld_tri/wts"] = Q.get_points(), Q.get_weights()
-    Q = MacroQuadratureRule(IsoSplit(T), create_quadrature(ufc_simplex(1), 2), parent_facets=[0, 2])
-    out["mq/iso_tri_facets/pts"], out["mq/iso_tri_facets/wts"] = Q.get_points(), Q.get_weights()
-    np.savez_compressed(os.path.join(HERE, "hct.npz"), **out)
-    print("hct.npz:", len(out), "arrays")
-
-
 if __name__ == "__main__":
     main()
-    hct_main()

@@ -62,6 +62,14 @@ def main():
     out["quad_phys_tri_verts"], out["quad_phys_tri_pts"], out["quad_phys_tri_wts"] = np.array(phys.get_vertices()), Q.get_points(), Q.get_weights()
     Q = create_quadrature(ufc_simplex(3), 5, entity=(2, 1))
     out["quad_tet_facet1_deg5_pts"], out["quad_tet_facet1_deg5_wts"] = Q.get_points(), Q.get_weights()
+    # composite rules on split cells (FIAT/macro.py:381-432; quadrature_schemes.py:71-75)
+    from FIAT.macro import AlfeldSplit, IsoSplit, MacroQuadratureRule
+    Q = create_quadrature(AlfeldSplit(ufc_simplex(2)), 3)
+    out["mq_alfeld_tri_pts"], out["mq_alfeld_tri_wts"] = Q.get_points(), Q.get_weights()
+    Q = create_quadrature(IsoSplit(ufc_simplex(3)), 4)
+    out["mq_iso_tet_pts"], out["mq_iso_tet_wts"] = Q.get_points(), Q.get_weights()
+    Q = MacroQuadratureRule(IsoSplit(ufc_simplex(2)), create_quadrature(ufc_simplex(1), 2), parent_facets=[0, 2])
+    out["mq_iso_tri_facets_pts"], out["mq_iso_tri_facets_wts"] = Q.get_points(), Q.get_weights()
     # ---- derivative orders 3, 4 ----------------------------------------------------------------------
     for sd in (1, 2, 3):
         pts = simplex_points(rng, sd, 9)

@@ -72,3 +72,23 @@ def test_scheme_strings():
     assert len(Q.get_weights()) == 18 and abs(Q.get_weights().sum() - 0.5) < 1e-15
     with pytest.raises(NotImplementedError):
         parse_quadrature_scheme(tri, 4, "KMV(2)")
+
+
+def test_composite_rules_on_split_cells(golden):
+    """create_quadrature on a macro cell and MacroQuadratureRule on the children of parent facets
+    (FIAT/macro.py:381-432, quadrature_schemes.py:71-75): the same point sets (as sets: the merge order of coincident
+    points is an implementation detail) and weights as the reference."""
+    g = golden("round2")
+
+    def same(Q, key):
+        pts, wts = np.asarray(Q.get_points()), np.asarray(Q.get_weights())
+        rp, rw = g[key + "_pts"], g[key + "_wts"]
+        assert pts.shape == rp.shape and abs(wts.sum() - rw.sum()) < 1e-14
+        order, rorder = np.lexsort(np.round(pts, 12).T), np.lexsort(np.round(rp, 12).T)
+        assert np.abs(pts[order] - rp[rorder]).max() < 1e-13 and np.abs(wts[order] - rw[rorder]).max() < 1e-14
+
+    same(fiat_amd.create_quadrature(fiat_amd.AlfeldSplit(fiat_amd.ufc_simplex(2)), 3), "mq_alfeld_tri")
+    same(fiat_amd.create_quadrature(fiat_amd.IsoSplit(fiat_amd.ufc_simplex(3)), 4), "mq_iso_tet")
+    from fiat_amd.macro import MacroQuadratureRule
+    same(MacroQuadratureRule(fiat_amd.IsoSplit(fiat_amd.ufc_simplex(2)), fiat_amd.create_quadrature(fiat_amd.ufc_simplex(1), 2),
+                             parent_facets=[0, 2]), "mq_iso_tri_facets")
