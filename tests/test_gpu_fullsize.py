@@ -92,3 +92,33 @@ def test_c5_full_size(rt, golden):
             assert np.abs(got[t] - ref[al]).max() <= (1e-12 if t == 0 else 1e-10) * max(1.0, np.abs(ref[al]).max())
     del out
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("family,degree,order,nreq,key", [("Nedelec", 2, 1, 25000, "c3_n2tet_q6"), ("RaviartThomas", 2, 1, 25000, "c3_rt2tet_q6"),
+                                                          ("DiscontinuousLagrange", 6, 2, 125000, "c4_dg6tet_q6")])
+def test_full_size_with_device_constructed_elements(rt, golden, family, degree, order, nreq, key):
+    """The same full-size batches through the façade element whose nodal coefficients were BUILT on the device
+    (Riesz assembly + Vandermonde solve), not injected from the reference: coefficients equal the reference's, a sample
+    of requests equals the C oracle evaluated with the reference's coefficients, every request is finite and -- DG --
+    sums to one / zero over the basis."""
+    import fiat_amd
+    import torch
+    from oracle import c_oracle
+    el = getattr(fiat_amd, family)(fiat_amd.ufc_simplex(3), degree)
+    ref_co = golden("elements")[key + "_coeffs"]
+    assert np.abs(el.get_coeffs() - ref_co).max() <= 1e-11 * max(1.0, np.abs(ref_co).max())
+    rng = np.random.default_rng(17 + degree + order)
+    pts = simplex_points(rng, 3, (nreq, 23))
+    out = el.tabulate_batch(order, pts)
+    assert bool(torch.isfinite(out).all())
+    if family == "DiscontinuousLagrange":
+        s = out.sum(dim=2)
+        assert float((s[:, 0] - 1.0).abs().max()) <= 1e-11 and float(s[:, 1:4].abs().max()) <= 1e-9
+    idx = rng.choice(nreq, 300, replace=False)
+    got = out[torch.as_tensor(idx).cuda()].cpu().numpy()
+    ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[3], degree, ref_co, order, pts[idx]).reshape(got.shape)
+    axes = tuple(range(2, got.ndim))
+    err = (np.abs(got - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)
+    assert err[0] <= 1e-12 and err[1:].max() <= 1e-10, err
+    del out
+    torch.cuda.empty_cache()
