@@ -2816,6 +2816,27 @@ int fx_table_outer_batch(fx_ctx* ctx, int order, int sdA, int sdB, int64_t nreq,
         a.tB[t] = (unsigned char)(std::find(TB.begin(), TB.end(), bb) - TB.begin());
     }
     HIP_TRY(hipSetDevice(ctx->device));
+    // factor tables of a group of requests staged in LDS when they fit a 16 KB tile (and the group's output < 2^24 entries)
+    const long long sizeA = (long long)a.ntabA * rowsA * vdimA * npts, sizeB = (long long)a.ntabB * rowsB * vdimB * npts;
+    const long long nrows = (long long)a.ntab * rowsA * rowsB * vdim, S = nrows * npts;
+    if (sizeA + sizeB <= fxk::OUTER_TILE && nrows <= 8192 && S < (1LL << 22)) {
+        fxk::OuterLdsArgs la;
+        la.o = a;
+        la.sizeA = (int)sizeA;
+        la.sizeB = (int)sizeB;
+        la.nrows = (int)nrows;
+        const long long by_tile = fxk::OUTER_TILE / (sizeA + sizeB), by_out = std::max<long long>(1, 16384 / S);
+        la.G = (int)std::max<long long>(1, std::min<long long>(std::min(by_tile, by_out), 64));
+        const size_t lds = ((size_t)((2 * nrows + 1) / 2 + 1) / 2 * 2 + 2 * fxk::OUTER_TILE) * sizeof(double);
+        const long long ngroups = (nreq + la.G - 1) / la.G;
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)ctx->lds_per_cu / lds));
+        const int grid = (int)std::max<long long>(1, std::min<long long>(ngroups, (long long)ctx->num_cu * per_cu));
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fxk::table_outer_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(fxk::table_outer_lds_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, la);
+        HIP_TRY(hipGetLastError());
+        return FX_OK;
+    }
     const long long units = nreq * a.ntab;
     const int grid = (int)std::max<long long>(1, std::min<long long>(units, (long long)ctx->num_cu * 16));
     hipLaunchKernelGGL(fxk::table_outer_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);

@@ -221,6 +221,98 @@ __global__ __launch_bounds__(256) void table_outer_kernel(const OuterArgs a) {
     }
 }
 
+// The same product with the factor tables of a group of requests staged in LDS (the default; the kernel above is the
+// fallback for factor tables that do not fit).  A persistent workgroup takes groups of G requests: the A and B tables of the
+// NEXT group are fetched into registers while the current group is multiplied out of LDS, a row table (LDS offsets of the
+// A row and the B row of every output row, built once per workgroup) replaces the per-element index decoding, and the
+// output leaves as coalesced 8-byte stores of consecutive elements (a group's output is one contiguous block).
+constexpr int OUTER_TILE = 4096;   // doubles of factor tables per group and buffer (32 KB; two buffers)
+constexpr int OUTER_PF = OUTER_TILE / 256;
+
+struct OuterLdsArgs {
+    OuterArgs o;
+    int G;            // requests per group
+    int sizeA, sizeB; // doubles of one request's A / B tables
+    int nrows;        // output rows of one request: ntab * rowsA * rowsB * vdim
+};
+
+__global__ __launch_bounds__(256) void table_outer_lds_kernel(const OuterLdsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double olds[];
+    const OuterArgs& o = a.o;
+    const int vdim = o.vdimA > o.vdimB ? o.vdimA : o.vdimB;
+    const int npts = o.npts;
+    int* rowtab = reinterpret_cast<int*>(olds);                 // [nrows][2]
+    double* buf0 = olds + ((2 * a.nrows + 1) / 2 + 1) / 2 * 2;   // 16-byte aligned
+    double* buf1 = buf0 + OUTER_TILE;
+    // row table: output row (t, ia, ib, c) -> start of its A row and its B row inside one request's staged tables
+    for (int r = threadIdx.x; r < a.nrows; r += 256) {
+        int rest = r;
+        const int c = rest % vdim;
+        rest /= vdim;
+        const int ib = rest % o.rowsB;
+        rest /= o.rowsB;
+        const int ia = rest % o.rowsA;
+        const int t = rest / o.rowsA;
+        rowtab[2 * r] = ((o.tA[t] * o.rowsA + ia) * o.vdimA + (o.vdimA > 1 ? c : 0)) * npts;
+        rowtab[2 * r + 1] = a.sizeA + ((o.tB[t] * o.rowsB + ib) * o.vdimB + (o.vdimB > 1 ? c : 0)) * npts;
+    }
+    const int per = a.sizeA + a.sizeB;                // staged doubles per request
+    const long long ngroups = (o.nreq + a.G - 1) / a.G;
+    const int S = a.nrows * npts;                     // output elements per request
+    const float inv_S = 1.0f / (float)S, inv_npts = 1.0f / (float)npts, inv_per = 1.0f / (float)per;
+    double pf[OUTER_PF];
+#pragma unroll
+    for (int k = 0; k < OUTER_PF; ++k) pf[k] = 0.0;
+    auto fetch = [&](long long grp) {                 // factor tables of group `grp` -> registers
+        const long long r0 = grp * a.G;
+        const int g_here = (int)(o.nreq - r0 < a.G ? o.nreq - r0 : a.G);
+        const unsigned total = (unsigned)(g_here * per);
+#pragma unroll
+        for (int k = 0; k < OUTER_PF; ++k) {
+            const unsigned e = (unsigned)(k * 256 + threadIdx.x);
+            double v = 0.0;
+            if (e < total) {
+                unsigned g, w;
+                divmod24(e, (unsigned)per, inv_per, g, w);
+                v = (int)w < a.sizeA ? o.A[(size_t)(r0 + g) * a.sizeA + w] : o.B[(size_t)(r0 + g) * a.sizeB + (w - a.sizeA)];
+            }
+            pf[k] = v;
+        }
+    };
+    long long grp = blockIdx.x;
+    if (grp < ngroups) fetch(grp);
+    double* cur = buf0;
+    double* nxt = buf1;
+#pragma unroll
+    for (int k = 0; k < OUTER_PF; ++k) cur[k * 256 + threadIdx.x] = pf[k];
+    __syncthreads();
+    for (; grp < ngroups; grp += gridDim.x) {
+        const long long gnext = grp + gridDim.x;
+        if (gnext < ngroups) fetch(gnext);
+        const long long r0 = grp * a.G;
+        const int g_here = (int)(o.nreq - r0 < a.G ? o.nreq - r0 : a.G);
+        const unsigned total = (unsigned)g_here * (unsigned)S;
+        double* out = o.out + (size_t)r0 * S;
+        for (unsigned e = threadIdx.x; e < total; e += 256) {
+            unsigned g, j, row, p;
+            divmod24(e, (unsigned)S, inv_S, g, j);
+            divmod24(j, (unsigned)npts, inv_npts, row, p);
+            const double* base = cur + g * per;
+            const double x = base[rowtab[2 * row] + p];
+            const double y = base[rowtab[2 * row + 1] + p];
+            __builtin_nontemporal_store(x * y, out + e);
+        }
+        if (gnext < ngroups) {
+#pragma unroll
+            for (int k = 0; k < OUTER_PF; ++k) nxt[k * 256 + threadIdx.x] = pf[k];
+        }
+        __syncthreads();
+        double* tmp = cur;
+        cur = nxt;
+        nxt = tmp;
+    }
+}
+
 // ---- affine map of points: entity coordinates -> cell coordinates (reference_element.py:570-609) -----------------
 // out[i] = M in[i] + b with M (dout x din, din may be 0: every point becomes the vertex b), for `n` points.
 struct MapPointsArgs {

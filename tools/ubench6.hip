@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 template <int NT>
@@ -146,12 +148,17 @@ int main(int argc, char** argv) {
     double us = timeit([&] { hipMemsetAsync(out, 0, (size_t)total, 0); });
     printf("memset of the same bytes: %7.1f us %6.0f GB/s\n", us, total / us / 1e3);
     const bool quick = argc > 3;
+    std::vector<int> pats = {0, 1, 2};
+    if (argc > 4) {
+        pats.clear();
+        for (char* tok = strtok(argv[4], ","); tok; tok = strtok(nullptr, ",")) pats.push_back(atoi(tok));
+    }
     for (int pad : {0}) {
         const int stride = pad ? (bytes + 127) / 128 * 128 : bytes;
         for (int nt : {0, 1})
             for (int nw : {4, 8})
                 for (int wgs : {1, 2, 4})
-                    for (int pattern : {0, 42, 44, 48, 2}) {
+                    for (int pattern : pats) {
                         if (nw * wgs > 16) continue;
                         if (quick && (wgs != 1)) continue;
                         const int grid = 256 * wgs;
