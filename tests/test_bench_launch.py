@@ -1,0 +1,52 @@
+"""bench.py as a launcher: `--gpus N` without WORLD_SIZE starts its own ranks before anything touches the GPU, never
+reports an n_gpus other than the world size it ran with, and refuses when the GPUs are not there."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_refuses_more_ranks_than_gpus():
+    import torch
+    if torch.cuda.device_count() >= 4:
+        pytest.skip("this box has the GPUs")
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         env=_env(), timeout=300)
+    assert res.returncode == 2 and "GPU(s) visible" in res.stderr and not res.stdout.strip()
+
+
+def test_world_size_mismatch_is_an_error():
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         env=_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in (res.stderr + res.stdout)
+
+
+@pytest.mark.gpu
+def test_bare_two_rank_launch_on_one_gpu():
+    """FIAT_AMD_BENCH_BACKEND=gloo lets two ranks share the one GPU of this box: the parent spawns them, both tabulate their
+    own block, the with-gather leg runs through fiat_amd/distributed.py, rank 0 prints ONE line with n_gpus = 2."""
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4000",
+                          "--allgather-chunks", "4"], capture_output=True, text=True,
+                         env=_env(FIAT_AMD_BENCH_BACKEND="gloo"), timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["launch"] == "self-spawned ranks"
+    assert line["value"] > 0 and line["max_rel_err_vs_oracle"] < 1e-12
+    ag = line["allgather"]
+    assert "error" not in ag, ag
+    assert ag["impl"] == "torch" and ag["all_finite"] and ag["chunks"] == 4
+    assert ag["gathered_bytes_per_gpu"] == 2 * 4000 * 4 * 20 * 23 * 8
