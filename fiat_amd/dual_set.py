@@ -119,7 +119,8 @@ class DualSet:
     def riesz_derivative_weights(self):
         """(points, order, D): the derivative part (FIAT/dual_set.py:175-205).  D[node, *target_shape, t, point]
         weights the t-th derivative table (mis() order over all orders <= ``order``; t = 0, the values, stays
-        zero) at the sorted unique derivative points; (None, 0, None) without derivative functionals."""
+        zero) at the sorted unique derivative points; (None, 0, None) without derivative functionals.  Any order the
+        device tabulates (<= 8: orders above 2 through differentiation matrices)."""
         order = max(ell.max_deriv_order for ell in self.nodes)
         if order == 0:
             return None, 0, None
@@ -159,8 +160,6 @@ class DualSet:
             mat += runtime.riesz_assemble(Wd, ev, ctx)
         dpts, order, D = self.riesz_derivative_weights()
         if dpts is not None:
-            if order > 2:
-                raise NotImplementedError("derivative functionals of order > 2 are not supported on the device")
             tabs = self._expansion_tables(es, ed, dpts, order)                      # (ntab, nexp, npts)
             ntab, _, npts = tabs.shape
             # the (table, point) pairs play the role of quadrature points

@@ -367,3 +367,26 @@ def test_default_rule_on_device_feeds_tabulate_cells(golden):
     ref = np.array(fa.ufc_simplex(3).get_vertices(), dtype=float)
     out = el.tabulate_cells(1, pts_d, np.stack([ref, ref])).cpu().numpy()
     assert _rel(out[0], g["c2_p3tet_q6_tab"]) <= 1e-10 and _rel(out[1], g["c2_p3tet_q6_tab"]) <= 1e-10
+
+
+def test_third_order_derivative_functionals():
+    """DualSet.to_riesz with derivative functionals of order 3 (FIAT/dual_set.py:175-205 at orders the round-1 device path
+    refused): the septic Hermite element on the interval -- value and the first three derivatives at both end points -- built
+    through the device Riesz assembly.  Independent check: the basis function dual to the value at 0 is
+    (1 - x)^4 (1 + 4x + 10x^2 + 20x^3); every dof applied to every basis function is the identity."""
+    import fiat_amd as fa
+    from fiat_amd import dual_set, finite_element, functional, polynomial_set
+    cell = fa.ufc_simplex(1)
+    nodes = []
+    for x in (0.0, 1.0):
+        nodes.append(functional.PointEvaluation(cell, (x,)))
+        nodes += [functional.PointDerivative(cell, (x,), (k,)) for k in (1, 2, 3)]
+    ids = {0: {0: [0, 1, 2, 3], 1: [4, 5, 6, 7]}, 1: {0: []}}
+    el = finite_element.CiarletElement(polynomial_set.ONPolynomialSet(cell, 7), dual_set.DualSet(nodes, cell, ids), 7)
+    x = np.linspace(0.05, 0.95, 13)
+    tab = el.tabulate(3, x[:, None])
+    want = (1 - x) ** 4 * (1 + 4 * x + 10 * x ** 2 + 20 * x ** 3)
+    assert np.abs(tab[(0,)][0] - want).max() <= 1e-12
+    ends = el.tabulate(3, np.array([[0.0], [1.0]]))
+    V = np.stack([ends[(k,)][:, e] for e in (0, 1) for k in (0, 1, 2, 3)])       # dof i applied to basis function j
+    assert np.abs(V - np.eye(8)).max() <= 1e-9
