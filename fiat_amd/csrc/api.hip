@@ -916,6 +916,7 @@ int run_stacked(const Launch& L, hipStream_t s) {
 
 int ensure_stacked(fx_ctx* ctx, fx_element* e, int order);  // defined after the C entry points it uses
 int ensure_high_order(fx_ctx* ctx, fx_element* e, int order);
+int mix_high_order(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, const double* verts, double* out, hipStream_t s);
 
 // ---- registry of cooperative (large-shape) kernels: <SD, ORDER, MT16, M4, TPW> ------
 struct CoopShape {
@@ -1532,14 +1533,18 @@ int fx_tabulate_batch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq,
                       const double* verts, double* out, void* stream) {
     if (ctx && e && order > 2) {  // differentiation-matrix route (ensure_high_order)
         if (order > FX_MAX_ORDER) return fail(FX_ENOTIMPL, "derivative order %d > %d is not implemented on the device", order, FX_MAX_ORDER);
-        if (verts)
-            return fail(FX_ENOTIMPL, "derivative order %d with per-request cells is not implemented (orders <= 2 are; an element "
+        if (verts && order > 4)
+            return fail(FX_ENOTIMPL, "derivative order %d with per-request cells is not implemented (orders <= 4 are; an element "
                         "built on the physical cell serves any order)", order);
         if (nreq < 0 || npts < 0) return fail(FX_EINVAL, "negative batch size");
         if (nreq == 0 || npts == 0) return FX_OK;
         int rc = ensure_high_order(ctx, const_cast<fx_element*>(e), order);
         if (rc != FX_OK) return rc;
-        return fx_tabulate_batch(ctx, e->high[order], 0, nreq, npts, pts, nullptr, out, stream);
+        // with per-request cells the order-0 kernels map the points into the element's cell: the tables are derivatives
+        // with respect to the ELEMENT's coordinates, and the chain rule follows as a pass over the tables
+        rc = fx_tabulate_batch(ctx, e->high[order], 0, nreq, npts, pts, verts, out, stream);
+        if (rc != FX_OK || !verts) return rc;
+        return mix_high_order(ctx, e, order, nreq, npts, verts, out, (hipStream_t)stream);
     }
     Launch L;
     int rc = plan_launch(ctx, e, order, nreq, npts, pts, verts, out, L);
@@ -2131,6 +2136,50 @@ int project_derivative_matrices(fx_ctx* ctx, fx_element* e, int order, std::vect
             }
         }
     ok = solve_dense(nexp, M, nrhs, B);
+    return FX_OK;
+}
+
+// chain rule across the tables of orders 1..order (3 or 4) for per-request cells (table_mix_high_kernel)
+int mix_high_order(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, const double* verts, double* out, hipStream_t s) {
+    const int sd = e->sd;
+    fxk::TableMixHighArgs ma;
+    memset(&ma, 0, sizeof ma);
+    ma.out = out;
+    ma.verts = verts;
+    if (!invert_small(sd, e->A0, ma.A0inv)) return fail(FX_EINVAL, "degenerate cell");
+    ma.n = e->ndof * e->vdim * npts;
+    ma.slices = std::max(1, std::min(8, (ma.n + 2047) / 2048));
+    if (nreq * ma.slices > 0x7fffffffLL) return fail(FX_EINVAL, "batch too large for the table-mixing pass");
+    // where alpha - e_c sits within the previous order (mis() order inside each order)
+    std::vector<std::vector<int>> prev = fx::multi_indices(sd, 0);
+    int t = 1;
+    for (int k = 1; k <= order; ++k) {
+        const std::vector<std::vector<int>> cur = fx::multi_indices(sd, k);
+        for (const std::vector<int>& al : cur) {
+            if (t >= fxk::MIXH_MAXT) return fail(FX_ENOTIMPL, "too many derivative tables for the mixing pass");
+            int lead = 0;
+            while (al[lead] == 0) ++lead;
+            ma.lead[t] = (unsigned char)lead;
+            for (int c = 0; c < 3; ++c) {
+                ma.down[t][c] = -1;
+                if (c < sd && al[c] > 0) {
+                    std::vector<int> be = al;
+                    be[c] -= 1;
+                    ma.down[t][c] = (signed char)(std::find(prev.begin(), prev.end(), be) - prev.begin());
+                }
+            }
+            ++t;
+        }
+        prev = cur;
+    }
+    const dim3 grid((unsigned)(nreq * ma.slices));
+    if (sd == 1 && order == 3) hipLaunchKernelGGL((fxk::table_mix_high_kernel<1, 3>), grid, dim3(256), 0, s, ma);
+    else if (sd == 1) hipLaunchKernelGGL((fxk::table_mix_high_kernel<1, 4>), grid, dim3(256), 0, s, ma);
+    else if (sd == 2 && order == 3) hipLaunchKernelGGL((fxk::table_mix_high_kernel<2, 3>), grid, dim3(256), 0, s, ma);
+    else if (sd == 2) hipLaunchKernelGGL((fxk::table_mix_high_kernel<2, 4>), grid, dim3(256), 0, s, ma);
+    else if (order == 3) hipLaunchKernelGGL((fxk::table_mix_high_kernel<3, 3>), grid, dim3(256), 0, s, ma);
+    else hipLaunchKernelGGL((fxk::table_mix_high_kernel<3, 4>), grid, dim3(256), 0, s, ma);
+    HIP_TRY(hipGetLastError());
     return FX_OK;
 }
 

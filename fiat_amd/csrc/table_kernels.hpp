@@ -165,6 +165,94 @@ __global__ __launch_bounds__(256) void table_mix_kernel(const TableMixArgs a) {
     }
 }
 
+// ---- chain rule across the derivative tables for orders 3 and 4 (per-request cells on the differentiation-matrix route) ----
+// The order-0 tabulation of the stacked element [C D^alpha] at points mapped into the element's cell yields derivatives with
+// respect to the ELEMENT's coordinates X; with x the request's coordinates and K = dX/dx = A0^-1 A_req,
+//   d^alpha_x = sum_beta M_k[alpha][beta] d^beta_X,   M_1[e_d][e_c] = K[c][d],
+//   M_k[alpha][beta] = sum_{c: beta_c >= 1} K[c][d] M_{k-1}[alpha - e_d][beta - e_c]   (d = first non-zero entry of alpha)
+// -- the symmetric k-th tensor power of K on multi-indices in mis() order.  One workgroup slice per request builds M_1..M_ORDER
+// in LDS (host-made index tables say where alpha - e_c sits in the previous order) and mixes every (row, point) entry in place,
+// all tables of one order in registers.
+constexpr int MIXH_MAXT = 35;  // tables up to order 4 in 3-D
+struct TableMixHighArgs {
+    double* out;          // [nreq][ntab][n]   n = rows * npts
+    const double* verts;  // [nreq][SD+1][SD]
+    double A0inv[9];
+    int n;
+    int slices;
+    signed char down[MIXH_MAXT][3];  // index, within the previous order, of alpha_t - e_c (-1: alpha_t[c] == 0)
+    unsigned char lead[MIXH_MAXT];   // first non-zero entry of alpha_t
+};
+
+template <int SD, int K>
+struct MisCount {
+    static constexpr int value = K == 0 ? 1 : (SD == 1 ? 1 : SD == 2 ? K + 1 : (K + 1) * (K + 2) / 2);
+};
+
+template <int SD, int ORDER, int K>
+__device__ __forceinline__ void mix_one_order(double* base, int n, int i, const double* M, int first) {
+    constexpr int CNT = MisCount<SD, K>::value;
+    double in[CNT];
+#pragma unroll
+    for (int s = 0; s < CNT; ++s) in[s] = base[(size_t)(first + s) * n + i];
+#pragma unroll
+    for (int t = 0; t < CNT; ++t) {
+        double acc = 0.0;
+#pragma unroll
+        for (int s = 0; s < CNT; ++s) acc += M[t * CNT + s] * in[s];
+        base[(size_t)(first + t) * n + i] = acc;
+    }
+}
+
+template <int SD, int ORDER>
+__global__ __launch_bounds__(256) void table_mix_high_kernel(const TableMixHighArgs a) {
+    static_assert(ORDER == 3 || ORDER == 4, "orders 3 and 4");
+    constexpr int C1 = MisCount<SD, 1>::value, C2 = MisCount<SD, 2>::value, C3 = MisCount<SD, 3>::value, C4 = MisCount<SD, 4>::value;
+    constexpr int F1 = 1, F2 = F1 + C1, F3 = F2 + C2, F4 = F3 + C3;   // first table of each order
+    constexpr int NTAB = ORDER == 3 ? F4 : F4 + C4;
+    __shared__ double sK[SD * SD];
+    __shared__ double M1[C1 * C1], M2[C2 * C2], M3[C3 * C3], M4[ORDER >= 4 ? C4 * C4 : 1];
+    const size_t req = blockIdx.x / a.slices;
+    const int slice = blockIdx.x % a.slices;
+    if (threadIdx.x == 0) {
+        double A[SD][SD], b[SD];
+        cell_map<SD>(a.verts + req * (SD + 1) * SD, A, b);
+        for (int c = 0; c < SD; ++c)
+            for (int d = 0; d < SD; ++d) {
+                double t = 0.0;
+                for (int k = 0; k < SD; ++k) t += a.A0inv[c * SD + k] * A[k][d];
+                sK[c * SD + d] = t;
+            }
+    }
+    __syncthreads();
+    // M_k[t][s] from M_{k-1}; tables of order k are first..first+cnt-1
+    auto build = [&](double* Mk, const double* Mp, int first, int cnt, int pcnt) {
+        for (int e = threadIdx.x; e < cnt * cnt; e += 256) {
+            const int t = e / cnt, s2 = e - t * cnt;
+            const int d = a.lead[first + t];
+            const int tp = a.down[first + t][d];
+            double acc = 0.0;
+            for (int c = 0; c < SD; ++c) {
+                const int sp = a.down[first + s2][c];
+                if (sp >= 0) acc += sK[c * SD + d] * (Mp ? Mp[tp * pcnt + sp] : 1.0);
+            }
+            Mk[e] = acc;
+        }
+        __syncthreads();
+    };
+    build(M1, nullptr, F1, C1, 1);
+    build(M2, M1, F2, C2, C1);
+    build(M3, M2, F3, C3, C2);
+    if constexpr (ORDER >= 4) build(M4, M3, F4, C4, C3);
+    double* base = a.out + req * (size_t)NTAB * a.n;
+    for (int i = slice * 256 + threadIdx.x; i < a.n; i += a.slices * 256) {
+        mix_one_order<SD, ORDER, 1>(base, a.n, i, M1, F1);
+        mix_one_order<SD, ORDER, 2>(base, a.n, i, M2, F2);
+        mix_one_order<SD, ORDER, 3>(base, a.n, i, M3, F3);
+        if constexpr (ORDER >= 4) mix_one_order<SD, ORDER, 4>(base, a.n, i, M4, F4);
+    }
+}
+
 // ---- tensor products of ANY two tabulated factors (TensorProductElement.tabulate, FIAT/tensor_product.py:231-336) ----
 // out[r][t][a * rowsB + b][c][p] = A[r][tA(t)][a][cA][p] * B[r][tB(t)][b][cB][p]   for alpha_t = (alpha_A, alpha_B):
 // scalar x scalar (:274-292), vector x scalar (:293-317) and scalar x vector (:318-335) are the same formula with the

@@ -103,7 +103,9 @@ int fx_num_tables(int sd, int order);
  *                                    request uses the element's own cell
  *   out   device [nreq][ntab][ndof][vdim][npts],  ntab = fx_num_tables(sd, order);
  *         table t of request r is exactly tabulate(order, pts[r])[alpha_t].
- * order <= 2.  Derivatives are with respect to the caller's coordinates. */
+ * order <= 2 by the recurrence (FIAT/expansions.py:140-267); orders 3..8 through differentiation matrices
+ * (expansions.py:438-446, 577-599), with per-request cells up to order 4.  Derivatives are with respect to the
+ * caller's coordinates. */
 int fx_tabulate_batch(fx_ctx* ctx, const fx_element* elem, int order,
                       int64_t nreq, int npts, const double* pts,
                       const double* verts, double* out, void* stream);

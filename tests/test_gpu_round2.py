@@ -225,26 +225,66 @@ def test_order_3_on_a_physical_cell_and_limits(golden):
         assert np.abs(t4[a]).max() <= 1e-8
     with pytest.raises(NotImplementedError):
         el.tabulate(9, g["hi_phys_pts"])
-    with pytest.raises(NotImplementedError):   # per-request cells: orders <= 2 only
-        el.tabulate_batch(3, g["hi_phys_pts"][None], verts=g["hi_phys_verts"][None])
+    with pytest.raises(NotImplementedError):   # per-request cells: orders <= 4
+        el.tabulate_batch(5, g["hi_phys_pts"][None], verts=g["hi_phys_verts"][None])
 
 
-def test_order_3_full_batch_consistency():
-    """100 000 requests, P3 tetrahedron, order 3: tables 0..9 equal the order-2 path's (recurrence) to 1e-10, the ten
-    third-derivative tables are constant per request and sum to zero over the dofs (partition of unity)."""
-    import fiat_amd
-    rng = np.random.default_rng(12)
-    e = rng.exponential(size=(100_000, 23, 4))
-    pts = torch.as_tensor((e / e.sum(-1, keepdims=True))[..., 1:].copy()).cuda()
-    el = fiat_amd.Lagrange(fiat_amd.ufc_simplex(3), 3)
-    lo = el.tabulate_batch(2, pts)
-    hi = el.tabulate_batch(3, pts)
-    assert hi.shape == (100_000, 20, 20, 23)
-    scale = float(lo.abs().max())
-    assert float((hi[:, :10] - lo).abs().max()) <= 1e-10 * scale
-    third = hi[:, 10:]
-    assert float((third - third[..., :1]).abs().max()) <= 1e-9 * float(third.abs().max())
-    assert float(third.sum(dim=2).abs().max()) <= 1e-8 * float(third.abs().max())
+def _chain_rule_tables(fa, ref_tab, sd, order, Kt):
+    """Derivatives with respect to x from the tables with respect to X (reference cell), Kt[c, d] = dX_c / dx_d:
+    d^alpha_x = sum over ordered source directions of prod Kt[c_m, d_m] d^beta_X -- NumPy, independent of the device pass."""
+    import itertools
+    out = []
+    for alpha in [a for k in range(order + 1) for a in fa.mis(sd, k)]:
+        dirs = [d for d, m in enumerate(alpha) for _ in range(m)]
+        acc = 0.0
+        for src in itertools.product(range(sd), repeat=len(dirs)):
+            beta = tuple(src.count(c) for c in range(sd))
+            acc = acc + float(np.prod([Kt[c, d] for c, d in zip(src, dirs)])) * ref_tab[beta]
+        out.append(acc)
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("order", [3, 4])
+def test_high_orders_with_per_request_cells(golden, order):
+    """Orders 3 and 4 with per-request cells (table_mix_high_kernel: symmetric tensor powers of K = dX/dx across the tables).
+    (a) The reference's P3 element built ON a physical tetrahedron (round2.npz) equals the UFC-cell element tabulated with that
+    cell as the request's cell; (b) random cells incl. a negatively oriented one, sd = 1, 2, 3, scalar and vector-valued sets:
+    equal to the chain rule applied in NumPy to the reference-cell tables, and -- affine families -- to elements built
+    directly on the physical cells."""
+    import fiat_amd as fa
+    g = golden("round2")
+    if order == 3:
+        el = fa.Lagrange(fa.ufc_simplex(3), 3)
+        got = el.tabulate_batch(3, g["hi_phys_pts"][None], verts=g["hi_phys_verts"][None]).cpu().numpy()[0]
+        for t in range(got.shape[0]):
+            assert _rel(got[t], g["hi_phys_p3tet_o3"][t]) <= (1e-12 if t == 0 else 1e-10), t
+    rng = np.random.default_rng(40 + order)
+    cases = [(3, lambda c: fa.Lagrange(c, 4), True), (3, lambda c: fa.DiscontinuousLagrange(c, 5), True),
+             (2, lambda c: fa.Lagrange(c, 5), True), (2, lambda c: fa.RaviartThomas(c, 3), False),
+             (1, lambda c: fa.ONPolynomialSet(c, 6), False)]
+    for sd, make, rebuild in cases:
+        ref = np.array(fa.ufc_simplex(sd).get_vertices(), dtype=float)
+        ncell, npts = 3, 11
+        A = np.eye(sd) + 0.25 * rng.standard_normal((ncell, sd, sd))
+        A[-1, :, 0] *= -1.0                                          # one negatively oriented cell
+        verts = np.einsum("vd,red->rve", ref, A) + rng.standard_normal((ncell, 1, sd))
+        e = rng.exponential(size=(ncell, npts, sd + 1))
+        bary = e / e.sum(-1, keepdims=True)
+        pts, ref_pts = np.einsum("rpv,rvd->rpd", bary, verts), np.einsum("rpv,vd->rpd", bary, ref)
+        base = make(fa.ufc_simplex(sd))
+        is_element = hasattr(base, "dual_basis")
+        dev = base if is_element else base.device_polyset()
+        got = dev.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+        for r in range(ncell):
+            ref_tab = base.tabulate(order, ref_pts[r]) if is_element else base.tabulate(ref_pts[r], order)
+            J = (verts[r][1:] - verts[r][0]).T @ np.linalg.inv((ref[1:] - ref[0]).T)          # dx/dX
+            want = _chain_rule_tables(fa, ref_tab, sd, order, np.linalg.inv(J))
+            assert got[r].shape == want.shape
+            assert _rel(got[r], want) <= 1e-9, (sd, r, _rel(got[r], want))
+            if rebuild:
+                tab = make(fa.physical_simplex(verts[r])).tabulate(order, pts[r])
+                direct = np.stack([tab[a] for k in range(order + 1) for a in fa.mis(sd, k)])
+                assert _rel(got[r], direct) <= 1e-9, (sd, r)
 
 
 # ---- general tensor products (csrc/table_kernels.hpp table_outer_kernel) ----------------------------------------
