@@ -88,6 +88,25 @@ __global__ __launch_bounds__(512) void store_blocks(double* out, long long nblk,
                     if (i < blk16) st<NT>(g + i, val);
                 }
         }
+    } else if (pattern >= 200 && pattern < 300) {  // as 0, but every wave starts its block at the piece that contains the first
+                                                    // (pattern - 200) KB-aligned address inside the block and wraps around: waves in
+                                                    // lock step then write the same phase of that period at the same time
+        const long long gw = (long long)blockIdx.x * nw + wv, tw = (long long)gridDim.x * nw;
+        const int npieces = (blk16 + 63) / 64;
+        const unsigned long long P = (unsigned long long)(pattern - 200) * 1024ull;
+        for (long long b = gw; b < nblk; b += tw) {
+            v2d* g = base + b * stride16;
+            const unsigned long long a0 = reinterpret_cast<unsigned long long>(g);
+            const unsigned long long to_boundary = (P - a0 % P) % P;          // bytes from the block start to the next multiple of P
+            int rot = (int)(to_boundary >> 10);
+            if (rot >= npieces) rot = 0;
+            for (int j = 0; j < npieces; ++j) {
+                int pc = j + rot;
+                if (pc >= npieces) pc -= npieces;
+                const int i = pc * 64 + lane;
+                if (i < blk16) st<NT>(g + i, val);
+            }
+        }
     } else if (pattern == 5) {  // as 4, but the waves of a workgroup store ONE AFTER THE OTHER: a workgroup writes its run of NW
                                 // adjacent blocks as one sequential stream (256 streams on the chip instead of 2048)
         const long long ngroups = (nblk + nw - 1) / nw;
@@ -101,7 +120,7 @@ __global__ __launch_bounds__(512) void store_blocks(double* out, long long nblk,
                 __syncthreads();
             }
         }
-    } else if (pattern >= 100) {  // segments of (pattern - 100) KB: wave w writes segments w, w + W, ... of the whole output
+    } else if (pattern >= 100 && pattern < 200) {  // segments of (pattern - 100) KB: wave w writes segments w, w + W, ... of the whole output
         const long long gw = (long long)blockIdx.x * nw + wv, tw = (long long)gridDim.x * nw;
         const long long seg16 = (long long)(pattern - 100) * 64, total16 = nblk * (long long)stride16;
         for (long long s0 = gw * seg16; s0 < total16; s0 += tw * seg16)
