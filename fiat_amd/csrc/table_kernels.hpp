@@ -195,11 +195,13 @@ __device__ __forceinline__ void mix_one_order(double* base, int n, int i, const 
     double in[CNT];
 #pragma unroll
     for (int s = 0; s < CNT; ++s) in[s] = base[(size_t)(first + s) * n + i];
-#pragma unroll
+    // (target loop NOT unrolled: unrolled, hipcc hoists all CNT^2 matrix entries out of the element loop and spills 300 registers)
+#pragma unroll 1
     for (int t = 0; t < CNT; ++t) {
+        const double* Mt = M + t * CNT;
         double acc = 0.0;
 #pragma unroll
-        for (int s = 0; s < CNT; ++s) acc += M[t * CNT + s] * in[s];
+        for (int s = 0; s < CNT; ++s) acc += Mt[s] * in[s];
         base[(size_t)(first + t) * n + i] = acc;
     }
 }
