@@ -1449,26 +1449,22 @@ int run_tabulate(fx_ctx* ctx, const fx_element* e, int order, const Launch& L, h
 }  // namespace
 
 namespace {
-template <int SD, int ORDER, bool PIOLA>
-bool launch_shared_reg1(int np, const fxk::SharedArgs& sa, int grid, hipStream_t s) {  // single doubles (odd tables)
+// register-resident shared-point kernel: NP units (pairs, or single doubles for odd tables) per thread and table slice; NP is
+// capped so that the reference values stay in registers (NP * EL * NTAB * NE doubles), larger tables take more slices
+template <int SD, int ORDER, bool PIOLA, int EL>
+bool launch_shared_reg_sliced(int units, const fxk::SharedArgs& sa, int grid, hipStream_t s) {
+    constexpr int NTAB = fxk::NTab<SD, ORDER>::value;
+    constexpr int PER = EL * NTAB * (PIOLA ? SD : 1);                       // doubles per unit slot
+    constexpr int NPMAX = PER >= 80 ? 1 : PER >= 40 ? 2 : PER >= 27 ? 3 : 4;  // <= ~120 doubles of reference values per thread
+    const int need = (units + 255) / 256;
+    const int np = std::min(need, NPMAX);
+    const int slices = (need + np - 1) / np;
+    const dim3 g((unsigned)std::max(1, grid / slices), (unsigned)slices);
     switch (np) {
-        case 1: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 1, PIOLA, 1>), dim3(grid), dim3(256), 0, s, sa); return true;
-        case 2: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 2, PIOLA, 1>), dim3(grid), dim3(256), 0, s, sa); return true;
-        case 3: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 3, PIOLA, 1>), dim3(grid), dim3(256), 0, s, sa); return true;
-        case 4: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 4, PIOLA, 1>), dim3(grid), dim3(256), 0, s, sa); return true;
-        case 5: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 5, PIOLA, 1>), dim3(grid), dim3(256), 0, s, sa); return true;
-        case 6: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 6, PIOLA, 1>), dim3(grid), dim3(256), 0, s, sa); return true;
-    }
-    return false;
-}
-
-template <int SD, int ORDER, bool PIOLA>
-bool launch_shared_reg(int np, const fxk::SharedArgs& sa, int grid, hipStream_t s) {
-    switch (np) {
-        case 1: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 1, PIOLA>), dim3(grid), dim3(256), 0, s, sa); return true;
-        case 2: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 2, PIOLA>), dim3(grid), dim3(256), 0, s, sa); return true;
-        case 3: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 3, PIOLA>), dim3(grid), dim3(256), 0, s, sa); return true;
-        case 4: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 4, PIOLA>), dim3(grid), dim3(256), 0, s, sa); return true;
+        case 1: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 1, PIOLA, EL>), g, dim3(256), 0, s, sa); return true;
+        case 2: if constexpr (NPMAX >= 2) { hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 2, PIOLA, EL>), g, dim3(256), 0, s, sa); return true; } break;
+        case 3: if constexpr (NPMAX >= 3) { hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 3, PIOLA, EL>), g, dim3(256), 0, s, sa); return true; } break;
+        case 4: if constexpr (NPMAX >= 4) { hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 4, PIOLA, EL>), g, dim3(256), 0, s, sa); return true; } break;
     }
     return false;
 }
@@ -1493,25 +1489,19 @@ int launch_shared(int order, const fxk::SharedArgs& sa, int grid, hipStream_t s,
     }
     const bool noreg = (policy & FX_POLICY_NO_SHARED_REG) != 0;
     // odd tables: register-resident kernel with one double per slot (order <= 1: NTAB sources per slot)
-    if (!noreg && (table & 1) && order <= 1 && (sa.kind == 0 || sa.vdim == SD)) {
-        const int np1 = (table + 255) / 256;
+    // register-resident kernel: reference values of each thread's fixed output positions in registers; tables of odd size go
+    // double by double (order <= 1), even ones pair by pair; any table size (sliced)
+    if (!noreg && (sa.kind == 0 || sa.vdim == SD) && ((table & 1) == 0 || order <= 1)) {
         const bool piola = sa.kind != 0;
         bool ok = false;
-        if (order == 0) ok = piola ? launch_shared_reg1<SD, 0, true>(np1, sa, grid, s) : launch_shared_reg1<SD, 0, false>(np1, sa, grid, s);
-        if (order == 1) ok = piola ? launch_shared_reg1<SD, 1, true>(np1, sa, grid, s) : launch_shared_reg1<SD, 1, false>(np1, sa, grid, s);
-        if (ok) {
-            HIP_TRY(hipGetLastError());
-            return FX_OK;
+        if (table & 1) {
+            if (order == 0) ok = piola ? launch_shared_reg_sliced<SD, 0, true, 1>(table, sa, grid, s) : launch_shared_reg_sliced<SD, 0, false, 1>(table, sa, grid, s);
+            if (order == 1) ok = piola ? launch_shared_reg_sliced<SD, 1, true, 1>(table, sa, grid, s) : launch_shared_reg_sliced<SD, 1, false, 1>(table, sa, grid, s);
+        } else {
+            if (order == 0) ok = piola ? launch_shared_reg_sliced<SD, 0, true, 2>(table / 2, sa, grid, s) : launch_shared_reg_sliced<SD, 0, false, 2>(table / 2, sa, grid, s);
+            if (order == 1) ok = piola ? launch_shared_reg_sliced<SD, 1, true, 2>(table / 2, sa, grid, s) : launch_shared_reg_sliced<SD, 1, false, 2>(table / 2, sa, grid, s);
+            if (order == 2) ok = piola ? launch_shared_reg_sliced<SD, 2, true, 2>(table / 2, sa, grid, s) : launch_shared_reg_sliced<SD, 2, false, 2>(table / 2, sa, grid, s);
         }
-    }
-    // register-resident kernel when a table is even-sized and at most 4 pairs per thread
-    const int np = (table / 2 + 255) / 256;
-    if (!noreg && (table & 1) == 0 && np >= 1 && np <= 4 && (sa.kind == 0 || sa.vdim == SD)) {
-        bool ok = false;
-        const bool piola = sa.kind != 0;
-        if (order == 0) ok = piola ? launch_shared_reg<SD, 0, true>(np, sa, grid, s) : launch_shared_reg<SD, 0, false>(np, sa, grid, s);
-        if (order == 1) ok = piola ? launch_shared_reg<SD, 1, true>(np, sa, grid, s) : launch_shared_reg<SD, 1, false>(np, sa, grid, s);
-        if (order == 2) ok = piola ? launch_shared_reg<SD, 2, true>(np, sa, grid, s) : launch_shared_reg<SD, 2, false>(np, sa, grid, s);
         if (ok) {
             HIP_TRY(hipGetLastError());
             return FX_OK;

@@ -128,9 +128,12 @@ __global__ __launch_bounds__(256) void shared_points_reg_kernel(const SharedArgs
     // reference values: [slot][element of the pair][source table][component]
     double rv[NP][EL][NTAB][NE];
     int comp[NP][EL];  // component (row % SD) of each element, for the Piola matrix row
+    // blockIdx.y = slice of the table: this workgroup owns the units [pair0, pair0 + 256 NP) of every table, so that the
+    // register-resident reference values stay within budget for any table size (NP * EL * NTAB * NE doubles per thread)
+    const int pair0 = (int)blockIdx.y * NP * 256;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int pr = min((int)threadIdx.x + 256 * i, npairs - 1);
+        const int pr = min(pair0 + (int)threadIdx.x + 256 * i, npairs - 1);
 #pragma unroll
         for (int el = 0; el < EL; ++el) {
             const int q = EL * pr + el;
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256) void shared_points_reg_kernel(const SharedArgs
         (void)o2;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int pr = (int)threadIdx.x + 256 * i;
+            const int pr = pair0 + (int)threadIdx.x + 256 * i;
             if (pr < npairs) {
                 // source values after the Piola mix: m[el][s]
                 double m[EL][NTAB];
