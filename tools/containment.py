@@ -2,7 +2,6 @@
 (build container only), the share of this file's code tokens (comments and docstrings removed) that appear,
 in order, in the reference file (longest common subsequence / own length).  Independent restatements of a
 shared API land around 0.3-0.5 (fiat_amd/dual_set.py: 0.34); a condensed copy scores > 0.75."""
-import io
 import os
 import sys
 import tokenize
