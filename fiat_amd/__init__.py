@@ -31,6 +31,7 @@ from .morley import Morley  # noqa: F401
 from .regge import Regge  # noqa: F401
 from .hellan_herrmann_johnson import HellanHerrmannJohnson  # noqa: F401
 from .tensor_product import FlattenedDimensions, TensorProductElement  # noqa: F401
+from .batch import Request, tabulate_requests  # noqa: F401
 
 # the element registry of the reference (FIAT/__init__.py:72-131), in-scope subset
 supported_elements = {

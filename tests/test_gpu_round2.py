@@ -430,3 +430,47 @@ def test_third_order_derivative_functionals():
     ends = el.tabulate(3, np.array([[0.0], [1.0]]))
     V = np.stack([ends[(k,)][:, e] for e in (0, 1) for k in (0, 1, 2, 3)])       # dof i applied to basis function j
     assert np.abs(V - np.eye(8)).max() <= 1e-9
+
+
+# ---- a list of heterogeneous requests (fiat_amd/batch.py) ---------------------------------------------------------------
+def test_request_list_is_grouped_and_batched():
+    """600 requests over seven elements, orders 0-2, 3-23 points, some on their own cells, in random order: every result equals
+    the one-request-at-a-time ``element.tabulate`` / ``tabulate_batch`` of the same request; results are views of a few group
+    tensors; with rank / world each rank returns its contiguous share of every group."""
+    import fiat_amd as fa
+    rng = np.random.default_rng(99)
+    T2, T3 = fa.ufc_simplex(2), fa.ufc_simplex(3)
+    elements = [fa.Lagrange(T2, 1), fa.Lagrange(T2, 3), fa.Lagrange(T3, 2), fa.Lagrange(T3, 3), fa.DiscontinuousLagrange(T3, 1),
+                fa.Nedelec(T3, 1), fa.RaviartThomas(T2, 2)]
+    requests = []
+    for _ in range(600):
+        el = elements[rng.integers(len(elements))]
+        sd = el.get_reference_element().get_spatial_dimension()
+        npts = int(rng.choice([3, 6, 11, 23]))
+        e = rng.exponential(size=(npts, sd + 1))
+        bary = e / e.sum(-1, keepdims=True)
+        ref = np.array(el.get_reference_element().get_vertices(), dtype=float)
+        if rng.random() < 0.3:
+            verts = ref @ (np.eye(sd) + 0.2 * rng.standard_normal((sd, sd))).T + rng.standard_normal(sd)
+            requests.append(fa.Request(el, int(rng.integers(0, 3)), bary @ verts, verts))
+        else:
+            requests.append(fa.Request(el, int(rng.integers(0, 3)), bary @ ref))
+    results = fa.tabulate_requests(requests)
+    torch.cuda.synchronize()
+    assert len(results) == 600 and all(r is not None for r in results)
+    assert len({r.untyped_storage().data_ptr() for r in results}) < 200       # views of the group tensors, not 600 allocations
+    for req, got in zip(requests[::7], results[::7]):
+        sd = req.element.get_reference_element().get_spatial_dimension()
+        if req.verts is None:
+            tab = req.element.tabulate(req.order, req.points)
+            want = np.stack([tab[a] for k in range(req.order + 1) for a in fa.mis(sd, k)])
+        else:
+            want = req.element.tabulate_batch(req.order, req.points[None], verts=req.verts[None]).cpu().numpy()[0]
+        assert got.shape == want.shape
+        assert _rel(got.cpu().numpy(), want) <= 1e-10
+    # two ranks: disjoint shares covering everything, equal to the single-rank results
+    halves = [fa.tabulate_requests(requests, rank=r, world=2) for r in (0, 1)]
+    torch.cuda.synchronize()
+    for i in range(600):
+        owners = [h[i] for h in halves if h[i] is not None]
+        assert len(owners) == 1 and torch.equal(owners[0], results[i])
