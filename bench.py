@@ -501,11 +501,40 @@ def allgather_leg(wl, world, rank, args, barrier):
     per = wl.batch
     out = wl.parts[0]["out"] if wl.parts[0] else wl.out
     tail = tuple(out.shape[1:])
-    full = torch.empty((world * per,) + tail, dtype=torch.float64, device="cuda")
-    mine = full.view(world, per, *tail)[rank]
     reps = max(2, min(10, args.steps // 4))
     res = {"impl": gather.impl, "algo": args.allgather_algo if gather.impl == "rccl" else "torch.distributed",
-           "gathered_bytes_per_gpu": full.numel() * 8, "reps": reps}
+           "gathered_bytes_per_gpu": world * out.numel() * 8, "reps": reps}
+    free_bytes, _ = torch.cuda.mem_get_info()
+    if args.allgather_mode == "ring" or (args.allgather_mode == "auto" and world * out.numel() * 8 > 0.6 * free_bytes):
+        # too large to replicate (C4: 8 x 19 GB, at 122 points 8 x 103 GB): every table still visits every GPU, chunk by chunk,
+        # through a ring of staging buffers the consumer drains (here: a reduction that touches every gathered byte)
+        chunk = max(1, -(-per // max(args.allgather_chunks, 32)))
+        res["mode"] = f"staging ring of 2 x {world} x {chunk} requests"
+        sink = torch.zeros((), dtype=torch.float64, device="cuda")
+
+        def ring():
+            wl.produce_rows(0, per, out)
+            for _, _, staged in gather.iter_gathered_chunks(out, chunk, ring=2):
+                sink.add_(staged.sum())
+
+        ring()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ring()
+        torch.cuda.synchronize()
+        barrier()
+        dt = (time.perf_counter() - t0) / reps
+        res["ms_per_step_pipelined"] = dt * 1e3
+        res["value_with_allgather"] = per * world / dt
+        res["ingress_gbs_per_gpu"] = (world - 1) * out.numel() * 8 / dt / 1e9
+        res["all_finite"] = bool(torch.isfinite(sink).item())
+        gather.close()
+        return res
+    res["mode"] = "replicated"
+    full = torch.empty((world * per,) + tail, dtype=torch.float64, device="cuda")
+    mine = full.view(world, per, *tail)[rank]
 
     def timed(fn):
         fn()
@@ -555,6 +584,8 @@ def main():
                     help="rccl = fx_allgather_tables through the C ABI, torch = torch.distributed collectives")
     ap.add_argument("--allgather-algo", default="direct", choices=["direct", "ring"])
     ap.add_argument("--allgather-chunks", type=int, default=8)
+    ap.add_argument("--allgather-mode", default="auto", choices=["auto", "replicated", "ring"],
+                    help="replicated: every GPU ends with all tables; ring: tables too large to replicate pass through staging buffers")
     ap.add_argument("--allgather-timeout", type=float, default=120.0)
     ap.add_argument("--shared-points", action="store_true",
                     help="variant (SURVEY.md 8d): ONE 23-point rule on the reference cell pushed forward to per-request "

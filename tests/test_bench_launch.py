@@ -50,3 +50,16 @@ def test_bare_two_rank_launch_on_one_gpu():
     assert "error" not in ag, ag
     assert ag["impl"] == "torch" and ag["all_finite"] and ag["chunks"] == 4
     assert ag["gathered_bytes_per_gpu"] == 2 * 4000 * 4 * 20 * 23 * 8
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_the_staging_ring():
+    """Outputs too large to replicate travel through the ring of staging buffers (forced here on a small batch)."""
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "3000", "--check", "100",
+                          "--allgather-mode", "ring", "--allgather-chunks", "4"], capture_output=True, text=True,
+                         env=_env(FIAT_AMD_BENCH_BACKEND="gloo"), timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    ag = line["allgather"]
+    assert "error" not in ag, ag
+    assert line["n_gpus"] == 2 and ag["mode"].startswith("staging ring") and ag["all_finite"] and ag["value_with_allgather"] > 0
