@@ -119,6 +119,15 @@ def main():
         out[f"tp_p2tri_p1_ent20_{k}"] = stack(el.tabulate(1, tri_pts, entity=((2, 0), k)), 3, 1)
     for k in (0, 1, 2):
         out[f"tp_p2tri_p1_ent11_{k}"] = stack(el.tabulate(1, quad_pts, entity=((1, 1), k)), 3, 1)
+    # facets of a nested (hexahedral) product: entity dimensions are nested tuples, ((1, 1), 0) = bottom / top faces
+    P2 = Lagrange(I, 2)
+    hexel = TensorProductElement(TensorProductElement(P2, Lagrange(I, 1)), P2)
+    out["tp_hex_quad_pts"] = quad_pts
+    for dims, count in ((((1, 1), 0), 2), (((1, 0), 1), 2), (((0, 1), 1), 2), (((1, 0), 0), 4)):
+        for k in range(count):
+            pts_e = quad_pts if sum(dims[0]) + dims[1] == 2 else quad_pts[:, :1]
+            key = "".join(str(x) for x in (*dims[0], dims[1]))
+            out[f"tp_hex_ent{key}_{k}"] = stack(hexel.tabulate(1, pts_e, entity=(dims, k)), 3, 1)
     # ---- sub-entity tabulation ------------------------------------------------------------------------
     fpts, epts = simplex_points(rng, 2, 6), rng.uniform(0, 1, size=(6, 1))
     out["ent_facet_pts"], out["ent_edge_pts"] = fpts, epts

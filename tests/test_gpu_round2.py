@@ -474,3 +474,50 @@ def test_request_list_is_grouped_and_batched():
     for i in range(600):
         owners = [h[i] for h in halves if h[i] is not None]
         assert len(owners) == 1 and torch.equal(owners[0], results[i])
+
+
+def test_hexahedron_facets_and_edges(golden):
+    """Nested products: the entity dimensions of (P2 x P1) x P2 are nested tuples; faces ((1,1),0), ((1,0),1), ((0,1),1) and
+    edges ((1,0),0) of the hexahedron against the reference (FIAT/tensor_product.py:231-258 unravels the entity number over the
+    factors' entities)."""
+    import fiat_amd as fa
+    g = golden("round2")
+    I = fa.ufc_simplex(1)
+    P2 = fa.Lagrange(I, 2)
+    hexel = fa.TensorProductElement(fa.TensorProductElement(P2, fa.Lagrange(I, 1)), P2)
+    assert hexel.get_reference_element().get_dimension() == ((1, 1), 1)
+    keys = [a for k in range(2) for a in fa.mis(3, k)]
+    quad = g["tp_hex_quad_pts"]
+    for dims, count in ((((1, 1), 0), 2), (((1, 0), 1), 2), (((0, 1), 1), 2), (((1, 0), 0), 4)):
+        pts = quad if sum(dims[0]) + dims[1] == 2 else quad[:, :1]
+        name = "".join(str(x) for x in (*dims[0], dims[1]))
+        for k in range(count):
+            tab = hexel.tabulate(1, pts, entity=(dims, k))
+            ref = g[f"tp_hex_ent{name}_{k}"]
+            for t, a in enumerate(keys):
+                assert tab[a].shape == ref[t].shape
+                assert _rel(tab[a], ref[t]) <= 1e-10, (dims, k, a)
+    # the cell itself still runs on the fused kernel and agrees with the general route
+    pts = np.random.default_rng(8).uniform(0, 1, size=(9, 3))
+    whole = hexel.tabulate(1, pts)
+    same = hexel.tabulate(1, pts, entity=(((1, 1), 1), 0))
+    for a in keys:
+        assert _rel(whole[a], same[a]) <= 1e-13
+
+
+def test_jacobi_kernel_extremes():
+    """Chebyshev weights (a = b = -1/2), the highest degree the kernel-argument table takes (96) with derivative order 8, against
+    the oracle's recurrence / the closed form T_n(cos t) = cos(n t)."""
+    from fiat_amd import jacobi
+    from oracle import fiat_oracle as fo
+    t = np.linspace(0.05, 3.0, 41)
+    x = np.cos(t)
+    tab = jacobi.eval_jacobi_batch(-0.5, -0.5, 20, x[:, None])
+    for n in (1, 5, 20):      # P_n^(-1/2,-1/2) = binom(n - 1/2, n) T_n
+        scale = np.prod([(k - 0.5) / k for k in range(1, n + 1)])
+        assert np.abs(tab[n] - scale * np.cos(n * t)).max() <= 1e-12
+    xs = np.linspace(-1, 1, 17)
+    dev = jacobi.eval_jacobi_deriv_batch(1.0, 2.0, 96, xs[:, None], order=8)
+    ref = fo.jacobi_deriv_table(1.0, 2.0, 96, xs, order=8)
+    assert dev.shape == ref.shape == (97, 17)
+    assert np.abs(dev - ref).max() <= 1e-10 * np.abs(ref).max()
