@@ -152,13 +152,34 @@ class TensorProductElement:
         return nodes
 
 
+def _dimension_total(dims):
+    return sum(_dimension_total(d) if isinstance(d, tuple) else d for d in dims) if isinstance(dims, tuple) else dims
+
+
+def flat_entity_map(cell):
+    """{(flat dimension, flat number): (product dimension tuple, product number)}: the entities of a product cell whose
+    dimensions sum to d, taken in the sorted order of their dimension tuples and then by number, are the entities 0, 1, ...
+    of dimension d of the quadrilateral / hexahedron (FIAT/reference_element.py:1852-1866)."""
+    counters, out = {}, {}
+    topology = cell.get_topology()
+    for dims in sorted(topology):
+        flat = _dimension_total(dims)
+        for number in sorted(topology[dims]):
+            out[(flat, counters.get(flat, 0))] = (dims, number)
+            counters[flat] = counters.get(flat, 0) + 1
+    return out
+
+
 class FlattenedDimensions:
-    """A tensor-product element viewed on the flattened quadrilateral / hexahedron: same tables, entity dimensions
-    summed (FIAT/tensor_product.py:363-434; tabulate :396-407 passes the cell itself as the entity)."""
+    """A tensor-product element viewed on the flattened quadrilateral / hexahedron: same tables, entities numbered by their
+    total dimension (FIAT/tensor_product.py:363-434)."""
 
     def __init__(self, element):
         self.element = element
         self.ref_el = element.get_reference_element()
+        if self.ref_el.get_spatial_dimension() not in (2, 3):
+            raise ValueError("Illegal element dimension %s" % self.ref_el.get_spatial_dimension())
+        self.unflattening_map = flat_entity_map(self.ref_el)
 
     def get_reference_element(self):
         return self.ref_el
@@ -175,8 +196,21 @@ class FlattenedDimensions:
     def mapping(self):
         return self.element.mapping()
 
-    def tabulate(self, order, points, entity=None):
-        return self.element.tabulate(order, points, None)
+    def entity_dofs(self):
+        """{flat dimension: {flat number: dofs}} of the product element's entity dofs."""
+        product = self.element.entity_dofs()
+        out = {}
+        for (flat, number), (dims, entity) in self.unflattening_map.items():
+            out.setdefault(flat, {})[number] = product[dims][entity]
+        return out
 
-    def tabulate_batch(self, *args, **kwargs):
-        return self.element.tabulate_batch(*args, **kwargs)
+    def _product_entity(self, entity):
+        if entity is None:
+            entity = (self.ref_el.get_spatial_dimension(), 0)
+        return self.unflattening_map[tuple(entity)]
+
+    def tabulate(self, order, points, entity=None):
+        return self.element.tabulate(order, points, self._product_entity(entity))
+
+    def tabulate_batch(self, order, points, entity=None, **kwargs):
+        return self.element.tabulate_batch(order, points, entity=self._product_entity(entity), **kwargs)

@@ -128,6 +128,14 @@ def main():
             pts_e = quad_pts if sum(dims[0]) + dims[1] == 2 else quad_pts[:, :1]
             key = "".join(str(x) for x in (*dims[0], dims[1]))
             out[f"tp_hex_ent{key}_{k}"] = stack(hexel.tabulate(1, pts_e, entity=(dims, k)), 3, 1)
+    # the same element on the flattened hexahedron: entities (d, i) numbered by total dimension (tensor_product.py:363-434)
+    from FIAT.tensor_product import FlattenedDimensions
+    flat = FlattenedDimensions(hexel)
+    for k in range(6):
+        out[f"tp_flathex_face{k}"] = stack(flat.tabulate(1, quad_pts, entity=(2, k)), 3, 1)
+    for k in range(12):
+        out[f"tp_flathex_edge{k}"] = stack(flat.tabulate(1, quad_pts[:, :1], entity=(1, k)), 3, 1)
+    out["tp_flathex_cell"] = stack(flat.tabulate(1, prism_pts), 3, 1)
     # ---- sub-entity tabulation ------------------------------------------------------------------------
     fpts, epts = simplex_points(rng, 2, 6), rng.uniform(0, 1, size=(6, 1))
     out["ent_facet_pts"], out["ent_edge_pts"] = fpts, epts

@@ -521,3 +521,29 @@ def test_jacobi_kernel_extremes():
     ref = fo.jacobi_deriv_table(1.0, 2.0, 96, xs, order=8)
     assert dev.shape == ref.shape == (97, 17)
     assert np.abs(dev - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+def test_flattened_hexahedron_entities(golden):
+    """FlattenedDimensions: faces (2, 0..5) and edges (1, 0..11) of the hexahedron map to the product entities as in the
+    reference (FIAT/tensor_product.py:396-407, reference_element.py:1852-1866)."""
+    import fiat_amd as fa
+    g = golden("round2")
+    I = fa.ufc_simplex(1)
+    P2 = fa.Lagrange(I, 2)
+    flat = fa.FlattenedDimensions(fa.TensorProductElement(fa.TensorProductElement(P2, fa.Lagrange(I, 1)), P2))
+    keys = [a for k in range(2) for a in fa.mis(3, k)]
+    quad = g["tp_hex_quad_pts"]
+    for k in range(6):
+        tab = flat.tabulate(1, quad, entity=(2, k))
+        for t, a in enumerate(keys):
+            assert _rel(tab[a], g[f"tp_flathex_face{k}"][t]) <= 1e-10, (k, a)
+    for k in range(12):
+        tab = flat.tabulate(1, quad[:, :1], entity=(1, k))
+        for t, a in enumerate(keys):
+            assert _rel(tab[a], g[f"tp_flathex_edge{k}"][t]) <= 1e-10, (k, a)
+    tab = flat.tabulate(1, g["tp_prism_pts"])
+    for t, a in enumerate(keys):
+        assert _rel(tab[a], g["tp_flathex_cell"][t]) <= 1e-10
+    dofs = flat.entity_dofs()
+    assert sorted(dofs) == [0, 1, 2, 3] and [len(dofs[d]) for d in range(4)] == [8, 12, 6, 1]
+    assert sum(len(v) for d in dofs.values() for v in d.values()) == flat.space_dimension() == 18
