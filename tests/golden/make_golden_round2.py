@@ -128,6 +128,7 @@ def main():
             pts_e = quad_pts if sum(dims[0]) + dims[1] == 2 else quad_pts[:, :1]
             key = "".join(str(x) for x in (*dims[0], dims[1]))
             out[f"tp_hex_ent{key}_{k}"] = stack(hexel.tabulate(1, pts_e, entity=(dims, k)), 3, 1)
+    out["tp_hex_o3"] = stack(hexel.tabulate(3, prism_pts), 3, 3)
     # the same element on the flattened hexahedron: entities (d, i) numbered by total dimension (tensor_product.py:363-434)
     from FIAT.tensor_product import FlattenedDimensions
     flat = FlattenedDimensions(hexel)

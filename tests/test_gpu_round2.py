@@ -544,6 +544,10 @@ def test_flattened_hexahedron_entities(golden):
     tab = flat.tabulate(1, g["tp_prism_pts"])
     for t, a in enumerate(keys):
         assert _rel(tab[a], g["tp_flathex_cell"][t]) <= 1e-10
+    # order 3 on the hexahedron: beyond the fused kernel, through the factor tables (1-D Lagrange derivatives of any order)
+    tab3 = flat.tabulate(3, g["tp_prism_pts"])
+    for t, a in enumerate([a for k in range(4) for a in fa.mis(3, k)]):
+        assert _rel(tab3[a], g["tp_hex_o3"][t]) <= 1e-10, a
     dofs = flat.entity_dofs()
     assert sorted(dofs) == [0, 1, 2, 3] and [len(dofs[d]) for d in range(4)] == [8, 12, 6, 1]
     assert sum(len(v) for d in dofs.values() for v in d.values()) == flat.space_dimension() == 18
