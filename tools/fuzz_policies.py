@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the kernel families (measurement / debugging tooling): for random elements, orders, point counts,
+batch sizes and optional per-request cells, the default kernel selection must agree with the generic kernel
+(policy no_fixed + no_small + no_stacked + no_coop).  python tools/fuzz_policies.py [seconds] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import fiat_amd as fa
+from fiat_amd import runtime
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+ctx = runtime.Context.get()
+FAMS = [("Lagrange", 1, 6), ("DiscontinuousLagrange", 0, 6), ("Nedelec", 1, 4), ("RaviartThomas", 1, 4), ("BrezziDouglasMarini", 1, 3)]
+cache = {}
+t0, n, worst = time.time(), 0, 0.0
+while time.time() - t0 < budget:
+    fam, lo, hi = FAMS[rng.integers(len(FAMS))]
+    sd = int(rng.integers(2, 4))
+    deg = int(rng.integers(lo, hi + 1))
+    if fam in ("Nedelec", "RaviartThomas", "BrezziDouglasMarini") and sd == 3 and deg > 3:
+        deg = 3
+    key = (fam, sd, deg)
+    if key not in cache:
+        cache[key] = getattr(fa, fam)(fa.ufc_simplex(sd), deg)
+    el = cache[key]
+    order = int(rng.integers(0, 3))
+    npts = int(rng.choice([1, 2, 3, 4, 6, 11, 12, 13, 16, 17, 21, 23, 24, 25, 31, 32, 33, 40, 48, 49, 64, 65, 70, 122]))
+    nreq = int(rng.choice([1, 2, 3, 7, 63, 64, 65, 257, 1000, 4097]))
+    rows = el.space_dimension() * int(np.prod(el.value_shape() or (1,)))
+    if nreq * npts * rows * (1 + sd + sd * (sd + 1) // 2) * 8 > 2e9:
+        nreq = 7
+    e = rng.exponential(size=(nreq, npts, sd + 1))
+    bary = e / e.sum(-1, keepdims=True)
+    ref = np.array(fa.ufc_simplex(sd).get_vertices(), dtype=float)
+    verts = None
+    if rng.random() < 0.4:
+        A = np.eye(sd) + 0.2 * rng.standard_normal((nreq, sd, sd))
+        verts = np.einsum("vd,red->rve", ref, A) + rng.standard_normal((nreq, 1, sd))
+        pts = np.einsum("rpv,rvd->rpd", bary, verts)
+    else:
+        pts = np.einsum("rpv,vd->rpd", bary, ref)
+    ctx.set_policy()
+    kern = el.device_polyset().kernel_name(order, nreq, npts, has_verts=verts is not None)
+    a = el.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    ctx.set_policy("no_fixed", "no_small", "no_stacked", "no_coop")
+    b = el.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    ctx.set_policy()
+    axes = tuple(range(2, a.ndim))
+    err = float((np.abs(a - b).max(axis=axes) / np.maximum(1.0, np.abs(b).max(axis=axes))).max())
+    worst = max(worst, err)
+    n += 1
+    if not np.isfinite(a).all() or err > 1e-9:
+        print("MISMATCH", key, "order", order, "npts", npts, "nreq", nreq, "verts", verts is not None, kern, err, flush=True)
+ctx.check()
+print(f"{n} random cases, worst relative difference {worst:.2e}")
