@@ -1,6 +1,8 @@
 """Round-2 device entries: fx_jacobi_batch, the kernel-selection policy, per-call scratch of the
 shared-point path on concurrent streams, the work-queue check, and the RCCL gather behind the C ABI (world size 1
 here: a one-GPU box; the multi-rank logic is covered on CPU by tests/test_distributed_cpu.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
