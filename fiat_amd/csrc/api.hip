@@ -767,6 +767,17 @@ const StackedShape kStackedShapes[] = {
     {2, 5, 3, 3, 0}, {2, 5, 4, 1, 0},
     {3, 2, 3, 2, 0}, {3, 2, 2, 1, 0}, {3, 2, 3, 1, 0}, {3, 2, 3, 3, 0}, {3, 2, 4, 1, 0},  // degree-2 tetrahedron (N2, RT2, BDM2 ...)
     {3, 6, 3, 1, -1}, {3, 5, 3, 1, -1}, {3, 4, 3, 1, -1}, {3, 3, 3, 1, -1}, {3, 2, 3, 1, -1}, {2, 6, 3, 1, -1}, {2, 5, 3, 1, -1},  // point-chunked
+    // round 2 (tools/coverage_map.py): the quadrature sizes of the mid-degree vector-valued elements that were left to the
+    // lane-local / generic kernels at 8-30 % of the HBM peak
+    {3, 2, 3, 4, 0},                                   // degree-2 tetrahedron, 9..12 points (the 11-point degree-4 rule)
+    {2, 4, 3, 3, 0}, {2, 4, 3, 2, 0}, {2, 4, 2, 1, 0}, {2, 4, 3, 1, 0},  // degree-4 triangle (N4 / RT4 / BDM3 ...): 13..16, 17..24, 25..32, 33..48 points
+    {2, 3, 3, 4, 0}, {2, 3, 3, 3, 0}, {2, 3, 3, 2, 0}, {2, 3, 2, 1, 0},  // degree-3 triangle: 9..12, 13..16, 17..24, 25..32 points
+    {3, 2, 3, 6, 0}, {3, 2, 3, 8, 0}, {3, 2, 3, 12, 0},                  // few points: 7..8, 5..6, <= 4 (six / eight / twelve requests per group)
+    {2, 3, 3, 6, 0}, {2, 3, 3, 8, 0}, {2, 4, 3, 4, 0}, {2, 4, 3, 6, 0},
+    {2, 4, 3, 1, -1}, {2, 3, 3, 1, -1},                                  // point-chunked: odd table sizes, more points
+    // per-request cells, values + gradient, chain rule inside the kernel (as the rtc -2 block above)
+    {3, 2, 3, 4, -2}, {3, 2, 3, 3, -2}, {3, 2, 3, 2, -2}, {3, 2, 2, 1, -2},
+    {2, 3, 3, 4, -2}, {2, 3, 3, 3, -2}, {2, 3, 3, 2, -2}, {2, 4, 3, 3, -2}, {2, 4, 3, 2, -2}, {2, 4, 2, 1, -2},
 };
 constexpr int STACKED_NW = 4;  // one wave per SIMD
 
@@ -910,6 +921,34 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 57: return launch_stacked<3, 2, 3, 1, 0, 1, true>(L, s);
         case 58: return launch_stacked<2, 6, 3, 1, 0, 1, true>(L, s);
         case 59: return launch_stacked<2, 5, 3, 1, 0, 1, true>(L, s);
+        case 60: return launch_stacked<3, 2, 3, 4>(L, s);
+        case 61: return launch_stacked<2, 4, 3, 3>(L, s);
+        case 62: return launch_stacked<2, 4, 3, 2>(L, s);
+        case 63: return launch_stacked<2, 4, 2, 1>(L, s);
+        case 64: return launch_stacked<2, 4, 3, 1>(L, s);
+        case 65: return launch_stacked<2, 3, 3, 4>(L, s);
+        case 66: return launch_stacked<2, 3, 3, 3>(L, s);
+        case 67: return launch_stacked<2, 3, 3, 2>(L, s);
+        case 68: return launch_stacked<2, 3, 2, 1>(L, s);
+        case 69: return launch_stacked<3, 2, 3, 6>(L, s);
+        case 70: return launch_stacked<3, 2, 3, 8>(L, s);
+        case 71: return launch_stacked<3, 2, 3, 12>(L, s);
+        case 72: return launch_stacked<2, 3, 3, 6>(L, s);
+        case 73: return launch_stacked<2, 3, 3, 8>(L, s);
+        case 74: return launch_stacked<2, 4, 3, 4>(L, s);
+        case 75: return launch_stacked<2, 4, 3, 6>(L, s);
+        case 76: return launch_stacked<2, 4, 3, 1, 0, 1, true>(L, s);
+        case 77: return launch_stacked<2, 3, 3, 1, 0, 1, true>(L, s);
+        case 78: return launch_stacked<3, 2, 3, 4, 0, 1, false, 4>(L, s);
+        case 79: return launch_stacked<3, 2, 3, 3, 0, 1, false, 4>(L, s);
+        case 80: return launch_stacked<3, 2, 3, 2, 0, 1, false, 4>(L, s);
+        case 81: return launch_stacked<3, 2, 2, 1, 0, 1, false, 4>(L, s);
+        case 82: return launch_stacked<2, 3, 3, 4, 0, 1, false, 3>(L, s);
+        case 83: return launch_stacked<2, 3, 3, 3, 0, 1, false, 3>(L, s);
+        case 84: return launch_stacked<2, 3, 3, 2, 0, 1, false, 3>(L, s);
+        case 85: return launch_stacked<2, 4, 3, 3, 0, 1, false, 3>(L, s);
+        case 86: return launch_stacked<2, 4, 3, 2, 0, 1, false, 3>(L, s);
+        case 87: return launch_stacked<2, 4, 2, 1, 0, 1, false, 3>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown stacked kernel %d", L.stacked_id);
 }
@@ -1309,6 +1348,10 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 if (!small_table_matches((int)i, e->prog) || (int)e->prog.steps.size() > fxk::SMALL_MAXSTEPS) continue;
                 int P = std::max(1, 64 / npts);
                 while (P > 1 && P * reqbytes8 > 12 * 1024) --P;  // per-wave image: several workgroups per CU
+                // many rows (vector-valued elements): the MFMA contraction of the generic / stacked kernels wins over
+                // rows x members FMAs per lane (tools/coverage_map.py: 30+ rows 15-30 % here against 26-48 % there; 17-24 rows
+                // only while several requests share a wave)
+                if (rows > 24 || (rows > 16 && P == 1)) break;
                 fxk::SmallArgs& sa = L.sargs;
                 memset(&sa, 0, sizeof sa);
                 sa.pts = pts;
@@ -1344,14 +1387,30 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     {
         const bool nostacked = (ctx->policy & FX_POLICY_NO_STACKED) != 0;
         // (fewer stacked rows: the production of the B fragments is no longer amortised over enough row tiles)
-        static const long long stacked_min_rows = ab_env("FIAT_AMD_STACKED_MIN_ROWS") ? atoll(ab_env("FIAT_AMD_STACKED_MIN_ROWS")) : 48;
+        // (measured, tools/coverage_map.py: values-only requests of P3 / P4 tetrahedra, 20 / 35 rows, run at 45 / 30 % of the HBM
+        // peak here against 23 / 13 % on the generic kernel; below one row tile nothing is left to amortise)
+        static const long long stacked_min_rows = ab_env("FIAT_AMD_STACKED_MIN_ROWS") ? atoll(ab_env("FIAT_AMD_STACKED_MIN_ROWS")) : 16;
         const long long R = (long long)ntab * rows;
         const int RT = (int)((R + 15) / 16);
         const bool even = ((R * npts) % 2 == 0) && (((R - 16LL * (RT - 1)) * npts) % 2 == 0);
         // (after the shape-specialised registries: the tuned paired instances and the lane-local kernel keep their shapes)
         // (per-request cells: the kernel maps the points through the request's cell and a second pass applies the
         // chain rule across the derivative tables, table_mix_kernel; a Piola map is left to fx_pushforward_batch)
-        if (!nostacked && L.fixed_id < 0 && L.small_id < 0 && !L.fused_mapping && !e->raw_expansion && order <= 2) {
+        // (the lane-local kernel keeps the shapes no stacked instance takes -- degrees 1 and 2 on triangles, degree 1 on
+        // tetrahedra, fewer than 16 stacked rows -- and per-request cells, where it applies the chain rule itself; elsewhere
+        // the MFMA contraction wins: tools/coverage_map.py, P3 / P4 triangles and P2 tetrahedra with derivatives 26-52 % -> 50-69 %)
+        if (!nostacked && L.fixed_id < 0 && (L.small_id < 0 || !verts) && !L.fused_mapping && !e->raw_expansion && order <= 2) {
+            // among the instances of one kind that hold the request, the one with the fewest padding columns
+            auto tighter_instance = [&](const StackedShape& k) {
+                for (const StackedShape& o : kStackedShapes)
+                    if (o.sd == k.sd && o.n == k.n && o.rtc == k.rtc && 16 * o.ct / o.g >= npts &&
+                        (16 * o.ct / o.g < 16 * k.ct / k.g || (16 * o.ct / o.g == 16 * k.ct / k.g && o.ct < k.ct)))
+                        return true;
+                return false;
+            };
+            // ... and only when the group's points fill more than two thirds of its column tiles (measured: at 16 of 48
+            // columns the in-kernel chain-rule instance runs at 18 % where the generic kernel reaches 43 %)
+            auto fills_tiles = [&](const StackedShape& k) { return 3LL * k.g * npts > 2LL * 16 * k.ct; };
             for (size_t i = 0; i < sizeof(kStackedShapes) / sizeof(kStackedShapes[0]); ++i) {
                 const StackedShape& k = kStackedShapes[i];
                 if (k.sd != e->sd || k.n != e->n) continue;
@@ -1359,19 +1418,19 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 // equal on C2, 302 vs 303 us -- both sit on the store-path plateau -- and the paired kernel's
                 // recurrence derivatives are two digits more accurate), opt-in with FIAT_AMD_STACKED_SMALL=1
                 if (k.rtc > 0 ? (RT != k.rtc || verts || !stacked_small) : R < stacked_min_rows) continue;
+                // (per-request cells with derivatives on the low-degree shapes: the second pass over the tables costs more
+                // than the generic kernel's in-kernel chain rule -- tools/small_vs_stacked.py --verts, 18-29 % against 25-48 %)
+                if (k.rtc != -2 && verts && order >= 1 && (k.n <= 2 || (k.sd == 2 && k.n <= 4))) continue;
                 if (k.rtc == -2) {  // per-request cells, order 1: tables mixed in registers (dof-major tiles)
                     const bool nomix = (ctx->policy & FX_POLICY_NO_STACKED_MIX) != 0;
                     if (nomix || !verts || order != 1 || ((long long)rows * npts) % 2 || ((long long)(rows - 16 * ((rows + 15) / 16 - 1)) * npts) % 2)
                         continue;
-                    const int cap = 16 * k.ct / k.g, lo = 16 * k.ct / (k.g + 1);
-                    if (npts > cap || npts <= lo) continue;
+                    if (npts > 16 * k.ct / k.g || tighter_instance(k) || !fills_tiles(k)) continue;
                 } else if (k.rtc < 0) {  // point-chunked: whatever the whole-request instances above did not take
                     if (npts < 13 || nreq * (long long)((npts + 16 * k.ct - 1) / (16 * k.ct)) > 0x7fffffffLL) continue;
                 } else {
                     if (!even) continue;  // (16-byte stores of whole request chunks)
-                    const int cap = 16 * k.ct / k.g;              // points one request may have
-                    const int lo = 16 * k.ct / (k.g + 1);         // below: one more request fits the tiles
-                    if (npts > cap || npts <= lo) continue;
+                    if (npts > 16 * k.ct / k.g || tighter_instance(k) || !fills_tiles(k)) continue;  // 16 ct / g: points one request may have
                 }
                 bool ok = false;
                 if (e->sd == 3 && e->n == 6) ok = table_matches<3, 6>(e->prog);
@@ -1381,6 +1440,8 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 if (e->sd == 2 && e->n == 6) ok = table_matches<2, 6>(e->prog);
                 if (e->sd == 2 && e->n == 5) ok = table_matches<2, 5>(e->prog);
                 if (e->sd == 3 && e->n == 2) ok = table_matches<3, 2>(e->prog);
+                if (e->sd == 2 && e->n == 4) ok = table_matches<2, 4>(e->prog);
+                if (e->sd == 2 && e->n == 3) ok = table_matches<2, 3>(e->prog);
                 if (!ok) continue;
                 int rc = ensure_stacked(ctx, const_cast<fx_element*>(e), order);
                 if (rc != FX_OK) return rc;
@@ -1422,6 +1483,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 L.queue = ctx->d_queue + (size_t)(ctx->launch_seq++ % FX_QUEUE_SLOTS) * 16;
                 L.kmix_order = order;
                 L.stacked_id = (int)i;
+                L.small_id = -1;
                 break;
             }
         }

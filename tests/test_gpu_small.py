@@ -68,10 +68,16 @@ def test_small_kernel_is_selected(rt, sd, n):
     import math
     nexp = math.comb(n + sd, sd)
     ps = rt.SimplexPolySet(sd, n, coeffs=np.eye(nexp))
-    assert ps.kernel_name(1, 1000, 4) == "fxk::tabulate_simplex_small"
-    assert ps.kernel_name(0, 1000, 11, has_verts=True) == "fxk::tabulate_simplex_small"
-    assert ps.kernel_name(2, 1000, 4) == "fxk::tabulate_simplex_small"        # Hessians too
-    assert ps.kernel_name(1, 1000, 65) == "fxk::tabulate_simplex_kernel"      # more points than lanes: generic kernel
+    # shapes the stacked-matrix kernel also serves (round 2: degree-2 tetrahedra, degree-3 / 4 triangles) go there once the
+    # derivative tables give it 16+ stacked rows and the points fill its column tiles (tools/small_vs_stacked.py)
+    stacked_too = (sd, n) in ((3, 2), (2, 3), (2, 4))
+    small, stacked, generic = ("fxk::tabulate_simplex_" + k for k in ("small", "stacked", "kernel"))
+    assert ps.kernel_name(0, 1000, 4) == small
+    assert ps.kernel_name(1, 1000, 4) == (stacked if (sd, n) == (3, 2) else small)    # twelve 4-point requests per group
+    assert ps.kernel_name(0, 1000, 11, has_verts=True) == small
+    assert ps.kernel_name(1, 1000, 11, has_verts=True) in ((small, stacked) if stacked_too else (small,))
+    assert ps.kernel_name(2, 1000, 2) == small                               # Hessians too
+    assert ps.kernel_name(1, 1000, 65) == (stacked if stacked_too else generic)  # more points than lanes
 
 
 def test_small_kernel_vector_valued_and_bubble(rt, golden):
@@ -82,7 +88,7 @@ def test_small_kernel_vector_valued_and_bubble(rt, golden):
     for fam, sd, deg in (("Nedelec", 3, 1), ("RaviartThomas", 2, 1), ("Lagrange", 3, 2), ("Lagrange", 2, 3)):
         el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg)
         pts = simplex_points(rng, sd, (501, 7))
-        assert el.device_polyset().kernel_name(1, 501, 7) == "fxk::tabulate_simplex_small"
+        assert el.device_polyset().kernel_name(1, 501, 7) == ("fxk::tabulate_simplex_small" if deg == 1 else "fxk::tabulate_simplex_stacked")
         out = el.tabulate_batch(1, pts).cpu().numpy()
         ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[sd], el.get_nodal_basis().get_embedded_degree() if hasattr(el.get_nodal_basis(), "get_embedded_degree") else deg,
                                       el.get_coeffs(), 1, pts, scale=el._expansion_scale, variant=el._expansion_variant)

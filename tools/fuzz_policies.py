@@ -25,7 +25,7 @@ while time.time() - t0 < budget:
         cache[key] = getattr(fa, fam)(fa.ufc_simplex(sd), deg)
     el = cache[key]
     order = int(rng.integers(0, 3))
-    npts = int(rng.choice([1, 2, 3, 4, 6, 11, 12, 13, 16, 17, 21, 23, 24, 25, 31, 32, 33, 40, 48, 49, 64, 65, 70, 122]))
+    npts = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 21, 23, 24, 25, 31, 32, 33, 40, 48, 49, 64, 65, 70, 122]))
     nreq = int(rng.choice([1, 2, 3, 7, 63, 64, 65, 257, 1000, 4097]))
     rows = el.space_dimension() * int(np.prod(el.value_shape() or (1,)))
     if nreq * npts * rows * (1 + sd + sd * (sd + 1) // 2) * 8 > 2e9:
