@@ -253,8 +253,14 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                         mem[TBL.dst[s]] = v;
                         return v;
                     };
+#if FX_DBG & 1  // ablation: no recurrence
+#pragma unroll
+                    for (int slot = 0; slot < 4 * KS; ++slot) phi[slot * PWP + lane] = X[0] + slot;
+                    (void)produce;
+#else
 #pragma unroll
                     for (int slot = 0; slot < 4 * KS; ++slot) phi[slot * PWP + lane] = produce(slot);
+#endif
                 }
                 wave_lds_fence();
 #pragma unroll
@@ -336,7 +342,10 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
 #if FX_DBG & 1024
                 if (dst == a.out && !(oreq[0] == 0 && rowbase + row == 0 && p0 + (i - row * pc) == 0)) dst = trash;
 #endif
-                stream_store(dst, fbuf1[r]);
+                // plain stores: the chunks of a request are pieces of its rows (16 CT points out of npts), which start anywhere
+                // in a 128-byte line; the neighbouring chunk completes the line in L2 (non-temporal stores of partial lines are
+                // expensive)
+                *dst = fbuf1[r];
             } else {
                 const int g = r / NST, it = r % NST;
                 const int nch = (nrows * enpts) >> 1;
@@ -353,6 +362,13 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
             }
         };
         auto mfma_steps = [&](v4d (&acc)[CT], const double (&af)[KS], int k0, int k1) {
+#if FX_DBG & 2  // ablation: no MFMAs (one add keeps the operands alive)
+#pragma unroll
+            for (int ks = k0; ks < k1; ++ks)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[c][0] += af[ks] + bf[ks][c];
+            return;
+#endif
 #pragma unroll
             for (int ks = k0; ks < k1; ++ks)
 #pragma unroll
@@ -366,7 +382,10 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
         // reads (second third) or output stores (last third); the scheduler may not move anything across a K-step.
         constexpr int NWR = 4 * CT, T3 = KS / 3;
         constexpr int LPK = (KS + 2 * T3 - 1) / (2 * T3);
-        constexpr int WPK = (NWR + T3 - 1) / T3, RPK = (NRD + T3 - 1) / T3, SPK = (NRD + (KS - 2 * T3) - 1) / (KS - 2 * T3);
+        // (image stores and image reads are packed into the first TP K-steps of their thirds: the LDS fence between them and
+        // the first output store then find their operands complete instead of stalling the only wave of the SIMD)
+        constexpr int TP = T3 > 3 ? T3 - 2 : T3;
+        constexpr int WPK = (NWR + TP - 1) / TP, RPK = (NRD + TP - 1) / TP, SPK = (NRD + (KS - 2 * T3) - 1) / (KS - 2 * T3);
         auto stage = [&](v4d (&cur)[CT], const v4d (&prev)[CT], int rt, const double (&af)[KS], double (&an)[KS]) {
             const double* anp = ap + (size_t)(rt + 1) * KS * 64;  // (the buffer ends with a zero tile)
 #pragma unroll
@@ -381,13 +400,14 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                     for (int q = ks * LPK; q < (ks + 1) * LPK && q < KS; ++q)
                         an[q] = anp[FX_CHK(q * 64 + (anp - a.afrag), a.lim_afrag, 3) - (anp - a.afrag)];
                 }
-                if (ks < T3) {
+                if (ks < TP) {
 #pragma unroll
                     for (int w = ks * WPK; w < (ks + 1) * WPK && w < NWR; ++w) image_put(prev, w, 16);
-                } else if (ks < 2 * T3) {
+                } else if (ks >= T3 && ks < T3 + TP) {
                     if (ks == T3) wave_lds_fence();
 #pragma unroll
                     for (int r = (ks - T3) * RPK; r < (ks - T3 + 1) * RPK && r < NRD; ++r) image_get(r, 16);
+                } else if (ks < 2 * T3) {
                 } else {
 #pragma unroll
                     for (int r = (ks - 2 * T3) * SPK; r < (ks - 2 * T3 + 1) * SPK && r < NRD; ++r) image_out(r, 16 * (rt - 1), 16);
