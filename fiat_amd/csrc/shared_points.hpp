@@ -301,11 +301,9 @@ template <int SD, int NS> __global__ __launch_bounds__(256) void shared_points_w
             for (int c = 0; c < SD; ++c) rv[i][el][c] = t == 0 ? (c == 0 ? a.ref[q + el] : 0.0) : a.ref[(size_t)(1 + c) * table + q + el];
     }
     __shared__ double sK[4][64][SD * SD];  // per wave: K of its team's next 64 requests
-    // request rb of a team's block kb is (64 kb + rb) * nteams + team: at any time the teams of the chip write one
-    // contiguous window of the output that moves forward (blocks of 64 consecutive requests per team measured 4.5 TB/s)
-    for (long long kb = 0; kb * 64 * nteams + team < a.nreq; ++kb) {
+    for (long long base = (long long)team * 64; base < a.nreq; base += nteams * 64) {
         {
-            const long long rq = min((kb * 64 + lane) * nteams + team, a.nreq - 1);
+            const long long rq = min(base + lane, a.nreq - 1);
             double A[SD][SD], b[SD];
             cell_map<SD>(a.verts + (size_t)rq * (SD + 1) * SD, A, b);
 #pragma unroll
@@ -321,15 +319,14 @@ template <int SD, int NS> __global__ __launch_bounds__(256) void shared_points_w
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-        for (int rb = 0; rb < 64; ++rb) {
-            const long long req = (kb * 64 + rb) * nteams + team;
-            if (req >= a.nreq) break;
+        const int nblk = (int)min(64LL, a.nreq - base);
+        for (int rb = 0; rb < nblk; ++rb) {
             double K[SD][SD];
 #pragma unroll
             for (int c = 0; c < SD; ++c)
 #pragma unroll
                 for (int d = 0; d < SD; ++d) K[c][d] = sK[wave][rb][c * SD + d];
-            v2d_t* o2 = reinterpret_cast<v2d_t*>(a.out + (size_t)req * NTAB * table);
+            v2d_t* o2 = reinterpret_cast<v2d_t*>(a.out + (size_t)(base + rb) * NTAB * table);
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const int f = 64 * (NS * part + i) + lane;
