@@ -595,6 +595,9 @@ const FixedShape kFixedShapes[] = {
     {3, 2, 1, 45, 6, true, 1, false, 8, true},   // RT2 tetrahedron (15 x 3 rows), 21..24 points: one request per wave, half image
     {3, 4, 1, 35, 6, true, 1, false, 8, false},  // Lagrange P4 tetrahedron, 21..24 points
     {3, 2, 1, 60, 6, true, 1, false, 4, true},   // N2 tetrahedron (20 x 3 rows), 21..24 points: 22 KB half images, four waves (one per SIMD: 180 accumulator registers)
+    {3, 3, 0, 20, 2, true, 2, true, 8, false},   // Lagrange P3 tetrahedron, values only, 17..32 points (45 % on the stacked kernel -> 56 %)
+    {3, 3, 0, 20, 3, true, 1, true, 8, false},   // ... 33..48 points (40 -> 54-58 %; <= 16 points: the stacked kernel is faster)
+    // (P4 values-only instances <3, 4, 0, 35, 2 | 3> computed wrong tables in a first try -- cause not found, not registered)
 };
 
 template <int SD, int N>
@@ -1054,6 +1057,8 @@ int run_fixed(const Launch& L, hipStream_t s) {
         case 7: return launch_fixed<3, 2, 1, 45, 6, true, 1, false, 8, true>(L, s);
         case 8: return launch_fixed<3, 4, 1, 35, 6, true, 1, false>(L, s);
         case 9: return launch_fixed<3, 2, 1, 60, 6, true, 1, false, 4, true>(L, s);
+        case 10: return launch_fixed<3, 3, 0, 20, 2, true>(L, s);
+        case 11: return launch_fixed<3, 3, 0, 20, 3, true, 1>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown fixed kernel %d", L.fixed_id);
 }
