@@ -597,7 +597,8 @@ const FixedShape kFixedShapes[] = {
     {3, 2, 1, 60, 6, true, 1, false, 4, true},   // N2 tetrahedron (20 x 3 rows), 21..24 points: 22 KB half images, four waves (one per SIMD: 180 accumulator registers)
     {3, 3, 0, 20, 2, true, 2, true, 8, false},   // Lagrange P3 tetrahedron, values only, 17..32 points (45 % on the stacked kernel -> 56 %)
     {3, 3, 0, 20, 3, true, 1, true, 8, false},   // ... 33..48 points (40 -> 54-58 %; <= 16 points: the stacked kernel is faster)
-    // (P4 values-only instances <3, 4, 0, 35, 2 | 3> computed wrong tables in a first try -- cause not found, not registered)
+    {3, 4, 0, 35, 2, true, 2, true, 8, false},   // Lagrange P4 tetrahedron, values only, 17..32 points (even point counts: 35 rows)
+    {3, 4, 0, 35, 3, true, 1, true, 8, false},   // ... 33..48 points (the 44-point degree-8 rule: 31 -> 46 %)
 };
 
 template <int SD, int N>
@@ -1059,6 +1060,8 @@ int run_fixed(const Launch& L, hipStream_t s) {
         case 9: return launch_fixed<3, 2, 1, 60, 6, true, 1, false, 4, true>(L, s);
         case 10: return launch_fixed<3, 3, 0, 20, 2, true>(L, s);
         case 11: return launch_fixed<3, 3, 0, 20, 3, true, 1>(L, s);
+        case 12: return launch_fixed<3, 4, 0, 35, 2, true>(L, s);
+        case 13: return launch_fixed<3, 4, 0, 35, 3, true, 1>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown fixed kernel %d", L.fixed_id);
 }
@@ -1237,6 +1240,10 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             // (half-image shapes keep the tables of each half in their own tiles: one spare tile is fine)
             const bool nt_ok = f.nt == nt_need || (!f.fullimg && f.nt == nt_need + 1);
             if (f.sd != e->sd || f.n != e->n || f.order != order || f.rows != rows || !nt_ok) continue;
+            {   // the image of a flush round leaves as 16-byte pieces: an even number of doubles per round (and so per request)
+                const int th = f.fullimg ? ntab : (ntab + 1) / 2;
+                if (((long long)th * rows * npts) % 2 || ((long long)(ntab - th) * rows * npts) % 2) continue;
+            }
             const bool want_piola = mapping == FX_MAP_COVARIANT_PIOLA || mapping == FX_MAP_CONTRAVARIANT_PIOLA;
             const bool fuse_here = want_piola && f.can_piola && verts && e->vdim == e->sd;
             if (L.fused_mapping && !fuse_here) continue;  // the cooperative kernel fuses the map, this one cannot

@@ -565,3 +565,37 @@ def test_random_shapes_default_kernels_match_generic():
                          text=True, timeout=300, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "MISMATCH" not in out.stdout and "random cases" in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.parametrize("n,npts", [(3, 17), (3, 23), (3, 32), (3, 33), (3, 48), (4, 23), (4, 24), (4, 31), (4, 33), (4, 44), (4, 47)])
+@pytest.mark.parametrize("cells", [False, True])
+def test_values_only_paired_instances_vs_c_oracle(n, npts, cells):
+    """Values-only (order 0) instances of the paired kernel for P3 / P4 tetrahedra.  35 rows x an odd point count is an odd
+    number of doubles per request: the 16-byte flush cannot serve it, and the selection must send it elsewhere (a first
+    version of the P4 instances lacked that guard and wrote wrong tables for odd point counts)."""
+    import math
+    from oracle import c_oracle, fiat_oracle as fo
+    from fiat_amd import runtime
+    rng = np.random.default_rng(100 * n + npts)
+    nexp = math.comb(n + 3, 3)
+    co = rng.standard_normal((nexp, nexp))
+    ps = runtime.SimplexPolySet(3, n, coeffs=co)
+    ref_cell = fo.UFC_SIMPLEX[3]
+    for nreq in (1, 2, 5, 257):
+        e = rng.exponential(size=(nreq, npts, 4))
+        bary = e / e.sum(-1, keepdims=True)
+        verts = None
+        pts = np.einsum("rpv,vd->rpd", bary, ref_cell)
+        if cells:
+            A = np.eye(3) + 0.2 * rng.standard_normal((nreq, 3, 3))
+            verts = np.einsum("vd,red->rve", ref_cell, A) + rng.standard_normal((nreq, 1, 3))
+            pts = np.einsum("rpv,rvd->rpd", bary, verts)
+        kern = ps.kernel_name(0, nreq, npts, has_verts=cells)
+        if (nexp * npts) % 2 == 0 and 17 <= npts <= 48:
+            assert kern == "fxk::tabulate_simplex_pair", kern
+        else:
+            assert kern != "fxk::tabulate_simplex_pair", kern
+        out = ps.tabulate_batch(0, pts, verts=verts).cpu().numpy()
+        ref = c_oracle.tabulate_batch(ref_cell, n, co, 0, pts, verts=verts).reshape(out.shape)
+        err = np.abs(out - ref).max() / max(1.0, np.abs(ref).max())
+        assert err <= 1e-12, (n, npts, nreq, cells, kern, err)
