@@ -26,6 +26,7 @@
 #include "table_kernels.hpp"
 #include "simplex_stacked.hpp"
 #include "jacobi_kernel.hpp"
+#include "tensor_small.hpp"
 
 namespace {
 
@@ -1591,6 +1592,61 @@ int launch_shared(int order, const fxk::SharedArgs& sa, int grid, hipStream_t s,
 }
 }  // namespace
 
+namespace {
+// ---- lane-local kernel for small tensor-product requests (tensor_small.hpp): <NF, NN, ORDER> ----
+template <int NF, int NN, int ORDER>
+static void launch_tensor_small(bool grid_mode, const fxk::TensorArgs& a, int P, int img_doubles, int grid, size_t lds, hipStream_t s) {
+    if (grid_mode) {
+        auto kern = fxk::tensor_small_kernel<NF, NN, ORDER, true>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, P, img_doubles);
+    } else {
+        auto kern = fxk::tensor_small_kernel<NF, NN, ORDER, false>;
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a, P, img_doubles);
+    }
+}
+
+// registered shapes: every factor with the same NN nodes; true if launched
+static bool try_tensor_small(fx_ctx* ctx, bool grid_mode, const fxk::TensorArgs& a, hipStream_t s) {
+    if ((ctx->policy & FX_POLICY_NO_SMALL) != 0 || a.nf < 2 || a.npts > 64) return false;
+    const int nn = a.L[0].nn;
+    for (int f = 1; f < a.nf; ++f)
+        if (a.L[f].nn != nn) return false;
+    long long ndof = 1;
+    for (int f = 0; f < a.nf; ++f) ndof *= nn;
+    const long long total = (long long)a.ntab * ndof * a.npts;  // doubles per request
+    constexpr long long IMG_BYTES = 16 * 1024;                  // per wave: four waves per workgroup, two workgroups per CU
+    if (total * 8 > IMG_BYTES) return false;
+    const int P = (int)std::max<long long>(1, std::min<long long>(64 / a.npts, IMG_BYTES / (total * 8)));
+    const int img_doubles = (int)((P * total + 1) & ~1LL);
+    const size_t lds = (size_t)img_doubles * 8 * 4;
+    const long long items = (a.nreq + P - 1) / P;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)ctx->lds_per_cu / std::max<size_t>(lds, 1)));
+    const int grid = (int)std::max<long long>(1, std::min<long long>((items + 3) / 4, (long long)ctx->num_cu * per_cu * 2));
+    const int key = a.nf * 100 + nn * 10 + a.order;
+    switch (key) {
+        case 220: launch_tensor_small<2, 2, 0>(grid_mode, a, P, img_doubles, grid, lds, s); return true;
+        case 221: launch_tensor_small<2, 2, 1>(grid_mode, a, P, img_doubles, grid, lds, s); return true;
+        case 222: launch_tensor_small<2, 2, 2>(grid_mode, a, P, img_doubles, grid, lds, s); return true;
+        case 230: launch_tensor_small<2, 3, 0>(grid_mode, a, P, img_doubles, grid, lds, s); return true;
+        case 231: launch_tensor_small<2, 3, 1>(grid_mode, a, P, img_doubles, grid, lds, s); return true;
+        case 232: launch_tensor_small<2, 3, 2>(grid_mode, a, P, img_doubles, grid, lds, s); return true;
+        case 240: launch_tensor_small<2, 4, 0>(grid_mode, a, P, img_doubles, grid, lds, s); return true;
+        case 241: launch_tensor_small<2, 4, 1>(grid_mode, a, P, img_doubles, grid, lds, s); return true;
+        case 242: launch_tensor_small<2, 4, 2>(grid_mode, a, P, img_doubles, grid, lds, s); return true;
+        case 250: launch_tensor_small<2, 5, 0>(grid_mode, a, P, img_doubles, grid, lds, s); return true;
+        case 251: launch_tensor_small<2, 5, 1>(grid_mode, a, P, img_doubles, grid, lds, s); return true;
+        case 320: launch_tensor_small<3, 2, 0>(grid_mode, a, P, img_doubles, grid, lds, s); return true;
+        case 321: launch_tensor_small<3, 2, 1>(grid_mode, a, P, img_doubles, grid, lds, s); return true;
+        case 322: launch_tensor_small<3, 2, 2>(grid_mode, a, P, img_doubles, grid, lds, s); return true;
+        case 330: launch_tensor_small<3, 3, 0>(grid_mode, a, P, img_doubles, grid, lds, s); return true;
+    }
+    return false;
+}
+
+}  // namespace
+
 extern "C" {
 
 int fx_tabulate_batch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, const double* pts,
@@ -2040,7 +2096,6 @@ static int tensor_launch(fx_ctx* ctx, int nf, const fx_line_element* const* fact
         for (int f = 0; f < nf; ++f) nbf *= factors[f]->nn;
         lds += (size_t)fx::binom(nf + order, nf) * nbf * 16;
     }
-    if (lds > 150 * 1024) return fail(FX_ENOTIMPL, "factor tables exceed LDS (%zu bytes)", lds);
     a.nf = nf;
     a.order = order;
     fill_alpha(nf, order, a);
@@ -2049,19 +2104,30 @@ static int tensor_launch(fx_ctx* ctx, int nf, const fx_line_element* const* fact
     a.q = q;
     a.pts = pts;
     a.out = out;
-    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)ctx->lds_per_cu / std::max<size_t>(lds, 1)));
-    int grid = (int)std::min<long long>(nreq, (long long)ctx->num_cu * per_cu * 2);
-    if (grid_mode) {
-        auto kern = fxk::tensor_tabulate_kernel<true>;
-        if (lds > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
-    } else {
-        auto kern = fxk::tensor_tabulate_kernel<false>;
-        if (lds > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+    if (try_tensor_small(ctx, grid_mode, a, (hipStream_t)stream)) {
+        HIP_TRY(hipGetLastError());
+        return FX_OK;
     }
+    if (lds > 150 * 1024) return fail(FX_ENOTIMPL, "factor tables exceed LDS (%zu bytes)", lds);
+    int block = 256;
+    if (const char* e = ab_env("FIAT_AMD_TENSOR_BLOCK")) block = atoi(e);
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)(8 * 256 / block), (size_t)ctx->lds_per_cu / std::max<size_t>(lds, 1)));
+    int grid = (int)std::min<long long>(nreq, (long long)ctx->num_cu * per_cu * 2);
+    // every factor with the same node count (Q_k elements): instances with compile-time loops in the factor phase
+    int nnc = factors[0]->nn;
+    for (int f = 1; f < nf; ++f)
+        if (factors[f]->nn != nnc) nnc = 0;
+    using TensorKern = void (*)(fxk::TensorArgs);
+    TensorKern kern = grid_mode ? (TensorKern)fxk::tensor_tabulate_kernel<true> : (TensorKern)fxk::tensor_tabulate_kernel<false>;
+    switch (nnc) {
+        case 2: kern = grid_mode ? (TensorKern)fxk::tensor_tabulate_kernel<true, 2> : (TensorKern)fxk::tensor_tabulate_kernel<false, 2>; break;
+        case 3: kern = grid_mode ? (TensorKern)fxk::tensor_tabulate_kernel<true, 3> : (TensorKern)fxk::tensor_tabulate_kernel<false, 3>; break;
+        case 4: kern = grid_mode ? (TensorKern)fxk::tensor_tabulate_kernel<true, 4> : (TensorKern)fxk::tensor_tabulate_kernel<false, 4>; break;
+        case 5: kern = grid_mode ? (TensorKern)fxk::tensor_tabulate_kernel<true, 5> : (TensorKern)fxk::tensor_tabulate_kernel<false, 5>; break;
+    }
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return FX_OK;
 }

@@ -191,6 +191,33 @@ __device__ __forceinline__ void lagrange_diff(const LineDesc& L, const double* i
     }
 }
 
+// the same with a compile-time node count: every index is a constant, the node data are uniform loads
+template <int NN> __device__ __forceinline__ void lagrange_values_n(const LineDesc& L, double x, double (&phi)[NN]) {
+    double sum = 0.0;
+    int hit = -1;
+#pragma unroll
+    for (int i = 0; i < NN; ++i) {
+        const double d = x - L.nodes[i];
+        if (d == 0.0) hit = i;
+        const double t = L.wts[i] / d;
+        phi[i] = t;
+        sum += t;
+    }
+    const double inv = 1.0 / sum;
+#pragma unroll
+    for (int i = 0; i < NN; ++i) phi[i] = hit >= 0 ? (i == hit ? 1.0 : 0.0) : phi[i] * inv;
+}
+
+template <int NN> __device__ __forceinline__ void lagrange_diff_n(const LineDesc& L, const double (&in)[NN], double (&out)[NN]) {
+#pragma unroll
+    for (int i = 0; i < NN; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < NN; ++j) s += L.dmat[i * NN + j] * in[j];
+        out[i] = s;
+    }
+}
+
 // out[r][k][i][p], one thread per (r, p)
 __global__ void line_tabulate_kernel(LineDesc L, int order, long long nreq, int npts,
                                      const double* __restrict__ pts, double* __restrict__ out) {
@@ -234,7 +261,8 @@ struct TensorArgs {
 
 constexpr int TP_NIT = 2;  // 16-byte chunks per lane and row group in the fast path (row groups <= 256 doubles)
 
-template <bool GRID>
+// NNC > 0: every factor has NNC nodes (compile-time loops in the factor phase); 0: any node counts
+template <bool GRID, int NNC = 0>
 __global__ __launch_bounds__(256) void tensor_tabulate_kernel(TensorArgs a) {
     extern __shared__ __attribute__((aligned(16))) double T[];  // [f][k][i][w]
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -305,6 +333,20 @@ __global__ __launch_bounds__(256) void tensor_tabulate_kernel(TensorArgs a) {
             int f = e / w, p = e - f * w;
             const LineDesc& L = a.L[f];
             double x = GRID ? a.pts[((size_t)r * a.nf + f) * a.q + p] : a.pts[((size_t)r * a.npts + p) * a.nf + f];
+            if constexpr (NNC > 0) {
+                double ta[NNC], tb[NNC];
+                lagrange_values_n<NNC>(L, x, ta);
+                for (int k = 0; k < K; ++k) {
+                    if (k > 0) {
+                        lagrange_diff_n<NNC>(L, ta, tb);
+#pragma unroll
+                        for (int i = 0; i < NNC; ++i) ta[i] = tb[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < NNC; ++i) T[fofs[f] + (k * NNC + i) * w + p] = ta[i];
+                }
+                continue;
+            }
             double va[NN_MAX], vb[NN_MAX];
             lagrange_values(L, x, va);
             for (int k = 0; k < K; ++k) {

@@ -599,3 +599,47 @@ def test_values_only_paired_instances_vs_c_oracle(n, npts, cells):
         ref = c_oracle.tabulate_batch(ref_cell, n, co, 0, pts, verts=verts).reshape(out.shape)
         err = np.abs(out - ref).max() / max(1.0, np.abs(ref).max())
         assert err <= 1e-12, (n, npts, nreq, cells, kern, err)
+
+
+def _tensor_oracle(nodes, dim, order, pts):
+    from oracle import fiat_oracle as fo
+    t = [fo.lagrange_line_tabulate(nodes, pts[:, d:d + 1], order) for d in range(dim)]
+    tab = fo.tensor_product_tabulate(t[0], 1, t[1], 1, order)
+    if dim == 3:
+        tab = fo.tensor_product_tabulate(tab, 2, t[2], 1, order)
+    return np.stack([tab[a] for a in fo.jet_indices(dim, order)])
+
+
+@pytest.mark.parametrize("dim,nn,order", [(2, 2, 0), (2, 2, 1), (2, 2, 2), (2, 3, 0), (2, 3, 1), (2, 3, 2), (2, 4, 0), (2, 4, 1), (2, 4, 2),
+                                          (2, 5, 0), (2, 5, 1), (3, 2, 0), (3, 2, 1), (3, 2, 2), (3, 3, 0)])
+def test_lane_local_tensor_kernel_vs_oracle(dim, nn, order):
+    """tensor_small_kernel (Q1..Q4 quadrilaterals, Q1 / Q2 hexahedra: requests up to 16 KB) against the restated
+    TensorProductElement.tabulate (FIAT/tensor_product.py:231-292 over barycentric_interpolation.py:22-93): scattered points and
+    tensor grids, ragged batches, a point on a node (exact Kronecker delta), and equality with the one-workgroup-per-request kernel."""
+    from fiat_amd import runtime
+    ctx = runtime.Context.get()
+    rng = np.random.default_rng(1000 * dim + 10 * nn + order)
+    nodes = np.concatenate([[0.0, 1.0], np.linspace(0, 1, nn)[1:-1]])          # FIAT's entity order: vertices first
+    L = runtime.LineLagrange(nodes)
+    for q in (1, 2, nn, nn + 1):
+        npts = q ** dim
+        if npts > 64:
+            continue
+        for nreq in (1, 3, 17, 1000):
+            grid = rng.uniform(0, 1, size=(nreq, dim, q))
+            grid[0, 0, 0] = nodes[-1]                                               # a coordinate exactly on a node
+            pts = np.stack([np.stack(np.meshgrid(*g, indexing="ij"), axis=-1).reshape(-1, dim) for g in grid])
+            a = runtime.tensor_tabulate_batch([L] * dim, order, grid, grid=True).cpu().numpy()
+            b = runtime.tensor_tabulate_batch([L] * dim, order, pts).cpu().numpy()
+            assert np.array_equal(a, b)
+            ctx.set_policy("no_small")
+            try:
+                c = runtime.tensor_tabulate_batch([L] * dim, order, pts).cpu().numpy()
+            finally:
+                ctx.set_policy()
+            assert np.array_equal(a, c), "lane-local and per-request kernels multiply the same factors"
+            for r in sorted({0, nreq // 2, nreq - 1}):
+                ref = _tensor_oracle(nodes, dim, order, pts[r])
+                err = np.abs(a[r] - ref).max(axis=(1, 2)) / np.maximum(1.0, np.abs(ref).max(axis=(1, 2)))
+                assert err[0] <= 1e-12 and err.max() <= 1e-10, (dim, nn, order, q, nreq, r, err)
+    ctx.check()
