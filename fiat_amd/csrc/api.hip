@@ -1566,12 +1566,15 @@ int launch_shared(int order, const fxk::SharedArgs& sa, int grid, hipStream_t s,
     // odd tables: register-resident kernel with one double per slot (order <= 1: NTAB sources per slot)
     // register-resident kernel: reference values of each thread's fixed output positions in registers; tables of odd size go
     // double by double (order <= 1), even ones pair by pair; any table size (sliced)
-    if (!noreg && (sa.kind == 0 || sa.vdim == SD) && ((table & 1) == 0 || order <= 1)) {
+    if (!noreg && (sa.kind == 0 || sa.vdim == SD)) {
         const bool piola = sa.kind != 0;
         bool ok = false;
         if (table & 1) {
             if (order == 0) ok = piola ? launch_shared_reg_sliced<SD, 0, true, 1>(table, sa, grid, s) : launch_shared_reg_sliced<SD, 0, false, 1>(table, sa, grid, s);
             if (order == 1) ok = piola ? launch_shared_reg_sliced<SD, 1, true, 1>(table, sa, grid, s) : launch_shared_reg_sliced<SD, 1, false, 1>(table, sa, grid, s);
+            // (odd tables with Hessians -- N3 / RT2 tetrahedra, P5 triangles at their default rules -- ran on the
+            // one-workgroup-per-request fallback at 1-20 % of the HBM peak: tools/coverage_map_cells.py)
+            if (order == 2) ok = piola ? launch_shared_reg_sliced<SD, 2, true, 1>(table, sa, grid, s) : launch_shared_reg_sliced<SD, 2, false, 1>(table, sa, grid, s);
         } else {
             if (order == 0) ok = piola ? launch_shared_reg_sliced<SD, 0, true, 2>(table / 2, sa, grid, s) : launch_shared_reg_sliced<SD, 0, false, 2>(table / 2, sa, grid, s);
             if (order == 1) ok = piola ? launch_shared_reg_sliced<SD, 1, true, 2>(table / 2, sa, grid, s) : launch_shared_reg_sliced<SD, 1, false, 2>(table / 2, sa, grid, s);

@@ -643,3 +643,31 @@ def test_lane_local_tensor_kernel_vs_oracle(dim, nn, order):
                 err = np.abs(a[r] - ref).max(axis=(1, 2)) / np.maximum(1.0, np.abs(ref).max(axis=(1, 2)))
                 assert err[0] <= 1e-12 and err.max() <= 1e-10, (dim, nn, order, q, nreq, r, err)
     ctx.check()
+
+
+@pytest.mark.parametrize("family,sd,deg,qdeg", [("Lagrange", 2, 1, 2), ("Lagrange", 2, 5, 10), ("RaviartThomas", 3, 2, 4),
+                                                 ("Nedelec", 3, 3, 6)])
+def test_one_rule_many_cells_with_hessians_odd_tables(family, sd, deg, qdeg):
+    """tabulate_cells (fx_tabulate_batch_shared) at order 2 for tables with an odd number of doubles (rows x points): these ran on
+    the one-workgroup-per-request fallback; now the register-resident kernel with one double per slot.  Reference: the
+    per-request-point path with the same cells and the rule mapped into them (itself pinned against the reference elements
+    built on physical cells, tests/test_gpu_pushforward.py)."""
+    import fiat_amd
+    cell = fiat_amd.ufc_simplex(sd)
+    el = getattr(fiat_amd, family)(cell, deg)
+    rule = np.asarray(fiat_amd.create_quadrature(cell, qdeg).get_points())
+    rows = el.space_dimension() * int(np.prod(el.value_shape() or (1,)))
+    assert (rows * len(rule)) % 2 == 1
+    rng = np.random.default_rng(7)
+    ref = np.array(cell.get_vertices(), dtype=float)
+    for nreq in (1, 37, 1000):
+        A = np.eye(sd) + 0.2 * rng.standard_normal((nreq, sd, sd))
+        verts = np.einsum("vd,red->rve", ref, A) + rng.standard_normal((nreq, 1, sd))
+        # the rule's points in every physical cell: x = v0 + sum_i xi_i (v_i - v0) on the UFC simplex
+        pts = verts[:, :1, :] + np.einsum("pi,rid->rpd", rule, verts[:, 1:, :] - verts[:, :1, :])
+        for order in (0, 1, 2):
+            a = el.tabulate_cells(order, rule, verts).cpu().numpy()
+            b = el.tabulate_batch(order, pts, verts=verts, pushforward=True).cpu().numpy()
+            axes = tuple(range(2, a.ndim))
+            err = (np.abs(a - b).max(axis=axes) / np.maximum(1.0, np.abs(b).max(axis=axes))).max()
+            assert err <= 1e-10, (family, sd, deg, nreq, order, err)
