@@ -1013,6 +1013,20 @@ constexpr int SMALL_NW = 4;
 
 template <int SD, int N>
 int launch_small(int order, const Launch& L, hipStream_t s) {
+    if (L.sargs.piola) {  // Piola map of the request's cell fused into the contraction
+        if constexpr (SD >= 2) {
+            if (order == 0)
+                hipLaunchKernelGGL((fxk::tabulate_simplex_small<SD, N, 0, SMALL_NW, true>), dim3(L.sgrid), dim3(64 * SMALL_NW), L.slds_bytes, s, L.sargs);
+            else if (order == 1)
+                hipLaunchKernelGGL((fxk::tabulate_simplex_small<SD, N, 1, SMALL_NW, true>), dim3(L.sgrid), dim3(64 * SMALL_NW), L.slds_bytes, s, L.sargs);
+            else if constexpr (!(SD == 3 && N == 2))
+                hipLaunchKernelGGL((fxk::tabulate_simplex_small<SD, N, 2, SMALL_NW, true>), dim3(L.sgrid), dim3(64 * SMALL_NW), L.slds_bytes, s, L.sargs);
+            else
+                return fail(FX_EINVAL, "internal: no fused push-forward for this lane-local shape");
+            HIP_TRY(hipGetLastError());
+            return FX_OK;
+        }
+    }
     if (order == 0)
         hipLaunchKernelGGL((fxk::tabulate_simplex_small<SD, N, 0, SMALL_NW>), dim3(L.sgrid), dim3(64 * SMALL_NW), L.slds_bytes, s, L.sargs);
     else if (order == 1)
@@ -1364,9 +1378,19 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 // many rows (vector-valued elements): the MFMA contraction of the generic / stacked kernels wins over
                 // rows x members FMAs per lane (tools/coverage_map.py: 30+ rows 15-30 % here against 26-48 % there; 17-24 rows
                 // only while several requests share a wave)
-                if (rows > 24 || (rows > 16 && P == 1)) break;
+                // ... unless the Piola map of a vector-valued element on per-request cells fuses here (one pass instead of
+                // tabulation + read-modify-write of every table: tools/coverage_map.py --verts --pushforward)
+                const bool fuse_small = (mapping == FX_MAP_COVARIANT_PIOLA || mapping == FX_MAP_CONTRAVARIANT_PIOLA) && verts &&
+                                        e->vdim == e->sd && rows % e->sd == 0 && L.fixed_id < 0 && L.coop_id < 0 && !L.fused_mapping &&
+                                        !(e->sd == 3 && e->n == 2 && order == 2);  // (that instance spills 39 registers)
+                if (fuse_small ? rows > 36 : (rows > 24 || (rows > 16 && P == 1))) break;
                 fxk::SmallArgs& sa = L.sargs;
                 memset(&sa, 0, sizeof sa);
+                if (fuse_small) {
+                    sa.piola = mapping;
+                    for (int q = 0; q < 9; ++q) sa.G[q] = 0.5 * e->A0[q];
+                    L.fused_mapping = true;
+                }
                 sa.pts = pts;
                 sa.verts = verts;
                 sa.out = out;
@@ -1718,11 +1742,16 @@ int fx_pushforward_batch(fx_ctx* ctx, const fx_element* e, int mapping, int orde
     pa.ndof = e->ndof;
     pa.npts = npts;
     pa.kind = mapping;
-    if (nreq > 0x7fffffffLL) return fail(FX_EINVAL, "batch too large");
+    pa.nreq = nreq;
+    const long long per = (long long)pa.ntab * pa.ndof * npts;  // elements (vectors / matrices) per request
+    if (per > 0x3fffffffLL / fxk::PIOLA_RB) return fail(FX_EINVAL, "request too large for the push-forward pass");
+    pa.rb = (int)std::max<long long>(1, std::min<long long>(fxk::PIOLA_RB, 2048 / std::max<long long>(per, 1)));
+    const long long blocks = (nreq + pa.rb - 1) / pa.rb;
+    const unsigned pgrid = (unsigned)std::max<long long>(1, std::min<long long>(blocks, (long long)ctx->num_cu * 16));
     if (e->sd == 2)
-        hipLaunchKernelGGL(fxk::piola_apply_kernel<2>, dim3((unsigned)nreq), dim3(256), 0, (hipStream_t)stream, pa);
+        hipLaunchKernelGGL(fxk::piola_apply_kernel<2>, dim3(pgrid), dim3(256), 0, (hipStream_t)stream, pa);
     else
-        hipLaunchKernelGGL(fxk::piola_apply_kernel<3>, dim3((unsigned)nreq), dim3(256), 0, (hipStream_t)stream, pa);
+        hipLaunchKernelGGL(fxk::piola_apply_kernel<3>, dim3(pgrid), dim3(256), 0, (hipStream_t)stream, pa);
     HIP_TRY(hipGetLastError());
     return FX_OK;
 }

@@ -453,109 +453,136 @@ __global__ __launch_bounds__(256) void tensor_tabulate_kernel(TensorArgs a) {
 // edge matrix (columns v_i - v_0) and G = A0 / 2 (host constant, A0 = map of the element's
 // cell to the default simplex).  The derivative tables were taken w.r.t. physical x already
 // (fx_tabulate_batch with verts), J is constant per cell: every table gets the same matrix.
-// One workgroup per request; out[t][dof][c][p], vdim == SD.
+// out[t][dof][c][p], vdim == SD.
 struct PiolaArgs {
     const double* verts;  // [nreq][SD+1][SD]
     double* out;          // [nreq][ntab][ndof][SD][npts]
     double G[9];
     int ntab, ndof, npts, kind;  // kind 1 covariant, 2 contravariant; 3 / 4: the double maps of matrix-valued functions
+    long long nreq;
+    int rb;  // requests per workgroup pass (<= PIOLA_RB)
 };
 
-template <int SD> __global__ __launch_bounds__(256) void piola_apply_kernel(const PiolaArgs a) {
-    __shared__ double M[SD * SD];
-    const size_t req = blockIdx.x;
-    if (threadIdx.x == 0) {
-        const double* v = a.verts + req * (SD + 1) * SD;
-        double E[SD][SD], J[SD][SD];
-        for (int c = 0; c < SD; ++c)
-            for (int r = 0; r < SD; ++r) E[r][c] = v[(c + 1) * SD + r] - v[r];
-        for (int r = 0; r < SD; ++r)
-            for (int c = 0; c < SD; ++c) {
-                double t = 0.0;
-                for (int k = 0; k < SD; ++k) t += E[r][k] * a.G[k * SD + c];
-                J[r][c] = t;
-            }
-        double det, inv[SD][SD];
-        if constexpr (SD == 2) {
-            det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-            inv[0][0] = J[1][1] / det;
-            inv[0][1] = -J[0][1] / det;
-            inv[1][0] = -J[1][0] / det;
-            inv[1][1] = J[0][0] / det;
-        } else {
-            const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-            const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-            const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-            det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
-            inv[0][0] = c00 / det;
-            inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
-            inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
-            inv[1][0] = c01 / det;
-            inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
-            inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
-            inv[2][0] = c02 / det;
-            inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
-            inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
-        }
-        for (int r = 0; r < SD; ++r)
-            for (int c = 0; c < SD; ++c) M[r * SD + c] = (a.kind == 1 || a.kind == 3) ? inv[c][r] : J[r][c] / det;
-    }
-    __syncthreads();
-    double m[SD][SD];
+// The matrix of the Piola maps of one cell: J = E G (E: edge matrix of the physical cell, columns v_i - v_0; G = A0 / 2),
+// kind 1 / 3 (covariant, double covariant): J^-T, kind 2 / 4 (contravariant): J / det J.
+template <int SD> __device__ __forceinline__ void piola_matrix(const double* v, const double* G, int kind, double (&M)[SD][SD]) {
+    double E[SD][SD], J[SD][SD];
+#pragma unroll
+    for (int c = 0; c < SD; ++c)
+#pragma unroll
+        for (int r = 0; r < SD; ++r) E[r][c] = v[(c + 1) * SD + r] - v[r];
 #pragma unroll
     for (int r = 0; r < SD; ++r)
 #pragma unroll
-        for (int c = 0; c < SD; ++c) m[r][c] = M[r * SD + c];
-    const int groups = a.ntab * a.ndof;  // (table, dof) pairs: SD rows of npts each
-    if (a.kind >= 3) {
-        // matrix-valued functions (value shape (SD, SD), row-major: SD*SD rows per dof): M Phi M^T with the same M
-        // -- double covariant J^-T Phi J^-1, double contravariant J Phi J^T / det^2 (Regge, Hellan-Herrmann-Johnson)
-        double* o2 = a.out + req * (size_t)groups * SD * SD * a.npts;
-        for (int e = threadIdx.x; e < groups * a.npts; e += blockDim.x) {
-            const int g = e / a.npts, p = e - g * a.npts;
-            double* q = o2 + (size_t)g * SD * SD * a.npts + p;
-            double X[SD][SD], T[SD][SD];
-#pragma unroll
-            for (int i = 0; i < SD; ++i)
-#pragma unroll
-                for (int j = 0; j < SD; ++j) X[i][j] = q[(i * SD + j) * a.npts];
-#pragma unroll
-            for (int i = 0; i < SD; ++i)
-#pragma unroll
-                for (int j = 0; j < SD; ++j) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int k = 0; k < SD; ++k) t += m[i][k] * X[k][j];
-                    T[i][j] = t;
-                }
-#pragma unroll
-            for (int i = 0; i < SD; ++i)
-#pragma unroll
-                for (int j = 0; j < SD; ++j) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int k = 0; k < SD; ++k) t += T[i][k] * m[j][k];
-                    q[(i * SD + j) * a.npts] = t;
-                }
-        }
-        return;
-    }
-    double* o = a.out + req * (size_t)groups * SD * a.npts;
-    for (int e = threadIdx.x; e < groups * a.npts; e += blockDim.x) {
-        const int g = e / a.npts, p = e - g * a.npts;
-        double* q = o + (size_t)g * SD * a.npts + p;
-        double x[SD], y[SD];
-#pragma unroll
-        for (int c = 0; c < SD; ++c) x[c] = q[c * a.npts];
-#pragma unroll
-        for (int r = 0; r < SD; ++r) {
+        for (int c = 0; c < SD; ++c) {
             double t = 0.0;
 #pragma unroll
-            for (int c = 0; c < SD; ++c) t += m[r][c] * x[c];
-            y[r] = t;
+            for (int k = 0; k < SD; ++k) t += E[r][k] * G[k * SD + c];
+            J[r][c] = t;
         }
+    double det, inv[SD][SD];
+    if constexpr (SD == 2) {
+        det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+        inv[0][0] = J[1][1] / det;
+        inv[0][1] = -J[0][1] / det;
+        inv[1][0] = -J[1][0] / det;
+        inv[1][1] = J[0][0] / det;
+    } else {
+        const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+        const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+        const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+        inv[0][0] = c00 / det;
+        inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+        inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
+        inv[1][0] = c01 / det;
+        inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
+        inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+        inv[2][0] = c02 / det;
+        inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+        inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+    }
 #pragma unroll
-        for (int c = 0; c < SD; ++c) q[c * a.npts] = y[c];
+    for (int r = 0; r < SD; ++r)
+#pragma unroll
+        for (int c = 0; c < SD; ++c) M[r][c] = (kind == 1 || kind == 3) ? inv[c][r] : J[r][c] / det;
+}
+
+constexpr int PIOLA_RB = 64;  // requests a workgroup takes at a time (small requests: several per pass)
+
+template <int SD> __global__ __launch_bounds__(256) void piola_apply_kernel(const PiolaArgs a) {
+    // Persistent workgroups over blocks of `rb` requests (host: rb * elements per request ~ 2048, <= PIOLA_RB): the first rb
+    // threads build the maps of the block's requests, then all threads walk the block's (request, table, dof, point)
+    // elements.  (One workgroup per request left 250 of 256 threads idle on N1 / RT1 requests of 18 elements: 5-9 % of
+    // the HBM peak for the whole mapped tabulation, tools/coverage_map.py --verts --pushforward.)
+    __shared__ double sM[PIOLA_RB][SD * SD];
+    const int rb = a.rb;
+    const int groups = a.ntab * a.ndof;  // (table, dof) pairs: SD (or SD * SD) rows of npts each
+    const int per = groups * a.npts;     // elements per request
+    const int rowsper = a.kind >= 3 ? SD * SD : SD;
+    for (long long base = (long long)blockIdx.x * rb; base < a.nreq; base += (long long)gridDim.x * rb) {
+        __syncthreads();  // the maps of the previous block are no longer read
+        if ((int)threadIdx.x < rb && base + threadIdx.x < a.nreq) {
+            double m0[SD][SD];
+            piola_matrix<SD>(a.verts + (size_t)(base + threadIdx.x) * (SD + 1) * SD, a.G, a.kind, m0);
+#pragma unroll
+            for (int r = 0; r < SD; ++r)
+#pragma unroll
+                for (int c = 0; c < SD; ++c) sM[threadIdx.x][r * SD + c] = m0[r][c];
+        }
+        __syncthreads();
+        const int nb = (int)min((long long)rb, a.nreq - base);
+        double* o = a.out + (size_t)base * per * rowsper;
+        for (int e = threadIdx.x; e < nb * per; e += blockDim.x) {
+            const int rl = e / per, rem = e - rl * per;
+            const int g = rem / a.npts, p = rem - g * a.npts;
+            double m[SD][SD];
+#pragma unroll
+            for (int r = 0; r < SD; ++r)
+#pragma unroll
+                for (int c = 0; c < SD; ++c) m[r][c] = sM[rl][r * SD + c];
+            double* q = o + ((size_t)rl * groups + g) * rowsper * a.npts + p;
+            if (a.kind >= 3) {
+                // matrix-valued functions (value shape (SD, SD), row-major: SD*SD rows per dof): M Phi M^T with the same M
+                // -- double covariant J^-T Phi J^-1, double contravariant J Phi J^T / det^2 (Regge, Hellan-Herrmann-Johnson)
+                double X[SD][SD], T[SD][SD];
+#pragma unroll
+                for (int i = 0; i < SD; ++i)
+#pragma unroll
+                    for (int j = 0; j < SD; ++j) X[i][j] = q[(i * SD + j) * a.npts];
+#pragma unroll
+                for (int i = 0; i < SD; ++i)
+#pragma unroll
+                    for (int j = 0; j < SD; ++j) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int k = 0; k < SD; ++k) t += m[i][k] * X[k][j];
+                        T[i][j] = t;
+                    }
+#pragma unroll
+                for (int i = 0; i < SD; ++i)
+#pragma unroll
+                    for (int j = 0; j < SD; ++j) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int k = 0; k < SD; ++k) t += T[i][k] * m[j][k];
+                        q[(i * SD + j) * a.npts] = t;
+                    }
+            } else {
+                double x[SD], y[SD];
+#pragma unroll
+                for (int c = 0; c < SD; ++c) x[c] = q[c * a.npts];
+#pragma unroll
+                for (int r = 0; r < SD; ++r) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int c = 0; c < SD; ++c) t += m[r][c] * x[c];
+                    y[r] = t;
+                }
+#pragma unroll
+                for (int c = 0; c < SD; ++c) q[c * a.npts] = y[c];
+            }
+        }
     }
 }
 

@@ -9,6 +9,7 @@
 // results go through a per-wave LDS image of the item's P whole requests, which is contiguous in
 // HBM, and leave as 16-byte-per-lane full-line stores.
 #pragma once
+#include "aux_kernels.hpp"
 #include "simplex_fixed.hpp"
 #include "store.hpp"
 
@@ -30,9 +31,13 @@ struct SmallArgs {
     int P;              // whole requests per wave item (P * npts <= 64)
     int stage_doubles;  // per-wave LDS doubles (>= P * ntab * rows * npts, even)
     int debug;
+    int piola;          // PIOLA instances: 1 covariant, 2 contravariant map of the request's cell (rows = dofs x SD components)
+    double G[9];        // A0 / 2 (piola_matrix, aux_kernels.hpp)
 };
 
-template <int SD, int N, int ORDER, int NW>
+// PIOLA: vector-valued functions on per-request cells leave already pushed forward (phi = M Phi per dof, M from
+// piola_matrix) -- the separate pass over the tables (read + write) costs twice the tabulation itself for these shapes.
+template <int SD, int N, int ORDER, int NW, bool PIOLA = false>
 __global__ __launch_bounds__(64 * NW) void tabulate_simplex_small(const SmallArgs a) {
     constexpr int NTAB = NTab<SD, ORDER>::value;
     constexpr StepTable<SD, N> TBL{};
@@ -112,7 +117,44 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_small(const SmallArg
         }
 
         // ---------------- lane-local contraction -> LDS image of the item ----------------
-        if (!(a.debug & 2)) {
+        if constexpr (PIOLA) {
+            double M[SD][SD];
+            piola_matrix<SD>(a.verts + (size_t)req * (SD + 1) * SD, a.G, a.piola, M);
+            double* sp = stage + (size_t)(active ? rl : 0) * reqsize + (active ? pl : 0);
+            for (int dof = 0; dof < rows / SD; ++dof) {
+                double acc[SD][NTAB];
+#pragma unroll
+                for (int c = 0; c < SD; ++c) {
+                    const double* crow = a.cmat + (size_t)(dof * SD + c) * NEXP;   // uniform address: scalar loads
+#pragma unroll
+                    for (int t = 0; t < NTAB; ++t) acc[c][t] = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NEXP; ++k) {
+                        const double cf = crow[k];
+                        acc[c][0] += cf * mem[k].v;
+                        if constexpr (ORDER >= 1) {
+#pragma unroll
+                            for (int d = 0; d < SD; ++d) acc[c][1 + d] += cf * mem[k].g[d];
+                        }
+                        if constexpr (ORDER >= 2) {
+#pragma unroll
+                            for (int h = 0; h < SD * (SD + 1) / 2; ++h) acc[c][1 + SD + h] += cf * mem[k].h[h];
+                        }
+                    }
+                }
+                if (active) {
+#pragma unroll
+                    for (int t = 0; t < NTAB; ++t)
+#pragma unroll
+                        for (int r = 0; r < SD; ++r) {
+                            double y = 0.0;
+#pragma unroll
+                            for (int c = 0; c < SD; ++c) y += M[r][c] * acc[c][t];
+                            sp[(size_t)t * table + (dof * SD + r) * npts] = y;
+                        }
+                }
+            }
+        } else if (!(a.debug & 2)) {
             double* sp = stage + (size_t)(active ? rl : 0) * reqsize + (active ? pl : 0);
             for (int row = 0; row < rows; ++row) {
                 const double* crow = a.cmat + (size_t)row * NEXP;   // uniform address: scalar loads

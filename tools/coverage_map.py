@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Which kernel serves which realistic request shape, and how close to the HBM / fp64 rooflines it runs (measurement tooling):
 families x cell x degree x derivative order, points = the default quadrature rule of degree 2 * degree (what a mass /
-stiffness assembly asks for).  python tools/coverage_map.py [--verts] [--order K] [--policy no_small,no_stacked] [--only "Lagrange sd3"]"""
+stiffness assembly asks for).  python tools/coverage_map.py [--verts [--pushforward]] [--order K] [--policy no_small,no_stacked] [--only "Lagrange sd3"]"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -40,7 +40,19 @@ for sd in (2, 3):
                     verts = (torch.einsum("vd,red->rve", ref, A) + b).contiguous()
                     pts = (torch.einsum("rpd,red->rpe", pts, A) + b).contiguous()
                 out = torch.empty(ps.out_shape(order, nreq, npts), dtype=torch.float64, device="cuda")
-                t = statistics.median(ps.time_tabulate_batch(order, pts, verts, out, 5) for _ in range(3))
+                if "--pushforward" in sys.argv:   # + the element's Piola map (fx_tabulate_batch_mapped): the basis ON the physical cells
+                    def run():
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(5):
+                            el.tabulate_batch(order, pts, verts=verts, out=out, pushforward=True)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        return e0.elapsed_time(e1) / 5
+                    run()
+                    t = statistics.median(run() for _ in range(3))
+                else:
+                    t = statistics.median(ps.time_tabulate_batch(order, pts, verts, out, 5) for _ in range(3))
                 nexp = ps.coeffs.shape[-1] if hasattr(ps, "coeffs") else 0
                 frac = per_req * nreq / t / 1e6 / 80
                 kern = ps.kernel_name(order, nreq, npts, has_verts=verts is not None)
