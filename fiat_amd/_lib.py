@@ -70,6 +70,7 @@ _SIGS = {
                                          c_void_p, c_void_p]),
     "fx_tensor_tabulate_grid_batch": (c_int, [c_void_p, c_int, POINTER(c_void_p), c_int, c_int64, c_int, c_void_p,
                                               c_void_p, c_void_p]),
+    "fx_prism_tabulate_batch": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "fx_plan_steps": (c_int, [c_int, c_int, c_int, c_double, c_int, _p_i, _p_d, c_void_p, c_void_p]),
     "fx_plan_c0_transform": (c_int, [c_int, c_int, c_void_p]),
     "fx_plan_coop": (c_int, [c_int, c_int, c_int, c_double, c_int, _p_i, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

@@ -27,6 +27,7 @@
 #include "simplex_stacked.hpp"
 #include "jacobi_kernel.hpp"
 #include "tensor_small.hpp"
+#include "prism_small.hpp"
 
 namespace {
 
@@ -1620,6 +1621,35 @@ int launch_shared(int order, const fxk::SharedArgs& sa, int grid, hipStream_t s,
 }  // namespace
 
 namespace {
+// ---- fused prism kernel (prism_small.hpp): <N (degree of the triangle factor's expansion set), NN (nodes of the interval factor), ORDER> ----
+template <int N, int NN, int ORDER>
+void launch_prism_small(const fxk::PrismArgs& a, int grid, size_t lds, hipStream_t s) {
+    auto kern = fxk::prism_small_kernel<N, NN, ORDER, 4>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+}
+template <int N, int NN>
+bool launch_prism_small_order(int order, const fxk::PrismArgs& a, int grid, size_t lds, hipStream_t s) {
+    if (order == 0) launch_prism_small<N, NN, 0>(a, grid, lds, s);
+    else if (order == 1) launch_prism_small<N, NN, 1>(a, grid, lds, s);
+    else if (order == 2 && N <= 2 && NN <= 3) {
+        if constexpr (N <= 2 && NN <= 3) launch_prism_small<N, NN, 2>(a, grid, lds, s);
+    } else return false;
+    return true;
+}
+template <int N>
+bool launch_prism_small_nn(int nn, int order, const fxk::PrismArgs& a, int grid, size_t lds, hipStream_t s) {
+    switch (nn) {
+        case 1: return launch_prism_small_order<N, 1>(order, a, grid, lds, s);
+        case 2: return launch_prism_small_order<N, 2>(order, a, grid, lds, s);
+        case 3: return launch_prism_small_order<N, 3>(order, a, grid, lds, s);
+        case 4: return launch_prism_small_order<N, 4>(order, a, grid, lds, s);
+    }
+    return false;
+}
+}  // namespace
+
+namespace {
 // ---- lane-local kernel for small tensor-product requests (tensor_small.hpp): <NF, NN, ORDER> ----
 template <int NF, int NN, int ORDER>
 static void launch_tensor_small(bool grid_mode, const fxk::TensorArgs& a, int P, int img_doubles, int grid, size_t lds, hipStream_t s) {
@@ -2167,6 +2197,64 @@ static int tensor_launch(fx_ctx* ctx, int nf, const fx_line_element* const* fact
 int fx_tensor_tabulate_batch(fx_ctx* ctx, int nf, const fx_line_element* const* factors, int order, int64_t nreq,
                              int npts, const double* pts, double* out, void* stream) {
     return tensor_launch(ctx, nf, factors, order, nreq, npts, 0, pts, out, stream, false);
+}
+
+// (element on a triangle) x (1-D Lagrange element), fused (prism_small.hpp).  FX_ENOTIMPL: shape not registered -- the caller
+// takes the general route (factor tables + fx_table_outer_batch).
+int fx_prism_tabulate_batch(fx_ctx* ctx, const fx_element* tri, const fx_line_element* line, int order, int64_t nreq, int npts,
+                            const double* pts, double* out, void* stream) {
+    if (!ctx || !tri || !line) return fail(FX_EINVAL, "fx_prism_tabulate_batch: null context/element");
+    if (order < 0 || nreq < 0 || npts < 0) return fail(FX_EINVAL, "fx_prism_tabulate_batch: bad argument");
+    if (tri->sd != 2) return fail(FX_EINVAL, "fx_prism_tabulate_batch: the first factor must live on a triangle");
+    if (nreq == 0 || npts == 0) return FX_OK;
+    if (!pts || !out) return fail(FX_EINVAL, "fx_prism_tabulate_batch: null device pointer");
+    const int rows = (int)(tri->hC.size() / (size_t)tri->nexp);
+    const int ntab = fx::binom(3 + order, 3);
+    const long long reqsize = (long long)ntab * rows * line->nn * npts;
+    if ((ctx->policy & FX_POLICY_NO_SMALL) != 0 || order > 2 || npts > 64 || tri->n < 1 || tri->n > 3 || line->nn < 1 || line->nn > 4 ||
+        !tri->d_cmat || tri->raw_expansion || (int)tri->prog.steps.size() > fxk::SMALL_MAXSTEPS || reqsize * 8 > 20 * 1024 || rows > 24 ||
+        (order == 2 && (tri->n > 2 || line->nn > 3)))
+        return fail(FX_ENOTIMPL, "fx_prism_tabulate_batch: shape not registered (degree %d x %d nodes, order %d, %d points, %d rows)",
+                    tri->n, line->nn, order, npts, rows);
+    bool match = false;
+    if (tri->n == 1) match = table_matches<2, 1>(tri->prog);
+    if (tri->n == 2) match = table_matches<2, 2>(tri->prog);
+    if (tri->n == 3) match = table_matches<2, 3>(tri->prog);
+    if (!match) return fail(FX_ENOTIMPL, "fx_prism_tabulate_batch: the triangle factor's recurrence is not the registered one");
+    fxk::PrismArgs a;
+    memset(&a, 0, sizeof a);
+    a.pts = pts;
+    a.out = out;
+    a.cmat = tri->d_cmat;
+    for (size_t k = 0; k < tri->prog.steps.size(); ++k) {
+        a.coef[3 * k + 0] = tri->prog.steps[k].A;
+        a.coef[3 * k + 1] = tri->prog.steps[k].B;
+        a.coef[3 * k + 2] = tri->prog.steps[k].C;
+    }
+    a.phi0 = tri->prog.phi0;
+    for (int i = 0; i < 4; ++i) a.A0[i] = tri->A0[i];
+    a.b0[0] = tri->b0[0];
+    a.b0[1] = tri->b0[1];
+    a.L = line_desc(line);
+    a.nreq = nreq;
+    a.npts = npts;
+    a.rowsA = rows;
+    a.vdimA = tri->vdim;
+    int P = std::max(1, 64 / npts);
+    while (P > 1 && P * reqsize * 8 > 20 * 1024) --P;  // 20 KB per wave: two four-wave workgroups per CU
+    a.P = P;
+    a.nitems = (nreq + P - 1) / P;
+    a.stage_doubles = (int)((P * reqsize + 1) & ~1LL);
+    const size_t lds = (size_t)a.stage_doubles * 8 * 4;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)ctx->lds_per_cu / std::max<size_t>(lds, 1)));
+    const int grid = (int)std::max<long long>(1, std::min<long long>((a.nitems + 3) / 4, (long long)ctx->num_cu * per_cu * 2));
+    bool ok = false;
+    if (tri->n == 1) ok = launch_prism_small_nn<1>(line->nn, order, a, grid, lds, (hipStream_t)stream);
+    if (tri->n == 2) ok = launch_prism_small_nn<2>(line->nn, order, a, grid, lds, (hipStream_t)stream);
+    if (tri->n == 3) ok = launch_prism_small_nn<3>(line->nn, order, a, grid, lds, (hipStream_t)stream);
+    if (!ok) return fail(FX_ENOTIMPL, "fx_prism_tabulate_batch: no instance for degree %d x %d nodes, order %d", tri->n, line->nn, order);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
 }
 
 int fx_tensor_tabulate_grid_batch(fx_ctx* ctx, int nf, const fx_line_element* const* factors, int order, int64_t nreq,

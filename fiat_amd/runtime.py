@@ -488,6 +488,29 @@ class LineLagrange:
         return out
 
 
+def prism_tabulate_batch(tri, line, order, pts, out=None, stream=None):
+    """(element on a triangle) x (1-D Lagrange element) on the fused prism kernel (fx_prism_tabulate_batch): ``tri`` a
+    SimplexPolySet of spatial dimension 2, ``line`` a LineLagrange, pts (nreq, npts, 3) ->
+    (nreq, ntab, ndofA * ndofB, [vdim,] npts); None when the shape has no instance (the caller takes the general route)."""
+    ctx = tri.ctx
+    pts = _as_device(pts, ctx)
+    if pts.dim() != 3 or pts.shape[2] != 3:
+        raise ValueError(f"points must have shape (nreq, npts, 3), got {tuple(pts.shape)}")
+    nreq, npts = int(pts.shape[0]), int(pts.shape[1])
+    shapeA = tri.out_shape(order, nreq, npts)                      # (nreq, ntabA, ndofA, [vdim,] npts)
+    shape = (nreq, num_tables(3, order), shapeA[2] * line.nn) + tuple(shapeA[3:])
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float64, device=ctx.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float64 or not out.is_contiguous():
+        raise ValueError("out has the wrong shape/dtype/layout")
+    rc = lib.fx_prism_tabulate_batch(ctx.handle, tri.handle, line.handle, int(order), nreq, npts, _dev_ptr(pts), _dev_ptr(out),
+                                     _stream_ptr(stream))
+    if rc == _lib.FX_ENOTIMPL:
+        return None
+    check(rc)
+    return out
+
+
 def tensor_tabulate_batch(factors, order, pts, out=None, stream=None, grid=False):
     """Tensor-product tabulation of 1..3 LineLagrange factors.
     grid=False: pts (nreq, npts, nf); grid=True: pts (nreq, nf, q) 1-D coordinates."""

@@ -99,6 +99,27 @@ class TensorProductElement:
     def device_factors(self):
         return [f.get_nodal_basis().get_expansion_set().device_line() for f in self._lines]
 
+    def _prism_factors(self):
+        """(device polynomial set of the triangle factor, device 1-D Lagrange factor) of a prism element, or None:
+        A an element on a triangle with a nodal basis over the Dubiner expansion set, B a scalar 1-D Lagrange element
+        or the constant on the interval."""
+        if not hasattr(self, "_prism"):
+            self._prism = None
+            A, B = self.A, self.B
+            simple = not isinstance(A, (TensorProductElement, FlattenedDimensions)) and not isinstance(B, (TensorProductElement, FlattenedDimensions))
+            if simple and A.get_reference_element().get_spatial_dimension() == 2 and A.get_reference_element().is_simplex() \
+                    and B.get_reference_element().get_shape() == LINE and B.value_shape() == () and hasattr(A, "device_polyset"):
+                line = None
+                if _is_line_lagrange(B):
+                    line = B.get_nodal_basis().get_expansion_set().device_line()
+                elif B.space_dimension() == 1 and B.degree() == 0:             # P0: the constant 1 = Lagrange on one node
+                    verts = B.get_reference_element().get_vertices()
+                    line = runtime.LineLagrange([0.5 * (verts[0][0] + verts[1][0])])
+                psA = A.device_polyset() if line is not None else None
+                if psA is not None and isinstance(psA, runtime.SimplexPolySet):
+                    self._prism = (psA, line)
+        return self._prism
+
     def _split(self, entity):
         """(entity of A, entity of B, point columns of A, point columns of B)."""
         if entity is None:
@@ -123,6 +144,12 @@ class TensorProductElement:
         ea, eb, ca, cb = self._split(entity)
         if points.dim() != 3 or points.shape[2] != ca + cb:
             raise ValueError(f"points must have shape (nreq, npts, {ca + cb}), got {tuple(points.shape)}")
+        if whole and order <= 2:                                            # prisms: the fused kernel, where it has an instance
+            prism = self._prism_factors()
+            if prism is not None:
+                res = runtime.prism_tabulate_batch(prism[0], prism[1], order, points, out=out, stream=stream)
+                if res is not None:
+                    return res
         tabs = []
         for factor, ent, cols in ((self.A, ea, points[..., :ca]), (self.B, eb, points[..., ca:ca + cb])):
             tabs.append(factor.tabulate_batch(order, cols.contiguous(), stream=stream, entity=ent))

@@ -154,6 +154,15 @@ int fx_tensor_tabulate_batch(fx_ctx* ctx, int nf, const fx_line_element* const* 
  *   grid device [nreq][nf][q]; points are the q^nf grid (x fastest last, as
  *   make_tensor_product_quadrature, quadrature.py:258-268); same out layout
  *   with npts = q^nf. */
+/* TensorProductElement.tabulate for a prism, fused: `tri` an element on a triangle (scalar- or vector-valued), `line` a 1-D
+ * Lagrange element (FIAT/tensor_product.py:231-317: table alpha = (alpha_A, alpha_B) is the per-point product of the factors'
+ * tables, basis function (a, b) -> a * dim(B) + b, the value component rides on the vector-valued factor).
+ * pts[nreq][npts][3] = (x, y | z), out[nreq][ntab][ndofA * ndofB][vdimA][npts], tables in mis(3, k) order.
+ * Returns FX_ENOTIMPL for shapes without an instance (degree of the triangle factor 1..3, 1..4 nodes, order <= 2 [<= 1 for
+ * degree 3 or 4 nodes], request <= 20 KB): the general route (two factor tabulations + fx_table_outer_batch) serves those. */
+int fx_prism_tabulate_batch(fx_ctx* ctx, const fx_element* tri, const fx_line_element* line, int order, int64_t nreq,
+                            int npts, const double* pts, double* out, void* stream);
+
 int fx_tensor_tabulate_grid_batch(fx_ctx* ctx, int nf, const fx_line_element* const* factors,
                                   int order, int64_t nreq, int q, const double* grid,
                                   double* out, void* stream);

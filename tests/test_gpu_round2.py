@@ -671,3 +671,43 @@ def test_one_rule_many_cells_with_hessians_odd_tables(family, sd, deg, qdeg):
             axes = tuple(range(2, a.ndim))
             err = (np.abs(a - b).max(axis=axes) / np.maximum(1.0, np.abs(b).max(axis=axes))).max()
             assert err <= 1e-10, (family, sd, deg, nreq, order, err)
+
+
+@pytest.mark.parametrize("fa,ka,fb,kb", [("Lagrange", 1, "Lagrange", 1), ("Lagrange", 2, "Lagrange", 1), ("Lagrange", 2, "Lagrange", 2),
+                                         ("Lagrange", 3, "Lagrange", 2), ("DiscontinuousLagrange", 1, "DiscontinuousLagrange", 1),
+                                         ("RaviartThomas", 1, "DiscontinuousLagrange", 0), ("Nedelec", 1, "Lagrange", 1),
+                                         ("BrezziDouglasMarini", 1, "Lagrange", 3), ("Lagrange", 3, "Lagrange", 3)])
+def test_fused_prism_kernel_matches_general_route(fa, ka, fb, kb):
+    """prism_small_kernel (triangle factor x 1-D Lagrange factor in one pass) against the general route (two factor
+    tabulations + fx_table_outer_batch, itself pinned by the reference's prism tables in round2.npz): orders 0-2, ragged
+    batches, scalar and vector-valued triangle factors, the constant on the interval."""
+    import fiat_amd
+    from fiat_amd import runtime
+    ctx = runtime.Context.get()
+    A = getattr(fiat_amd, fa)(fiat_amd.ufc_simplex(2), ka)
+    B = getattr(fiat_amd, fb)(fiat_amd.ufc_simplex(1), kb)
+    el = fiat_amd.TensorProductElement(A, B)
+    prism = el._prism_factors()
+    assert prism is not None
+    rng = np.random.default_rng(17)
+    for order in (0, 1, 2):
+        for nreq, npts in ((1, 1), (3, 6), (50, 18), (1000, 7)):
+            e = rng.exponential(size=(nreq, npts, 3))
+            xy = (e / e.sum(-1, keepdims=True))[..., 1:]
+            pts = np.concatenate([xy, rng.uniform(0, 1, size=(nreq, npts, 1))], axis=-1)
+            fused = runtime.prism_tabulate_batch(prism[0], prism[1], order, pts)
+            a = el.tabulate_batch(order, pts).cpu().numpy()
+            ctx.set_policy("no_small")
+            try:
+                assert runtime.prism_tabulate_batch(prism[0], prism[1], order, pts) is None
+                b = el.tabulate_batch(order, pts).cpu().numpy()
+            finally:
+                ctx.set_policy()
+            assert a.shape == b.shape
+            if fused is not None:
+                assert np.array_equal(fused.cpu().numpy(), a)
+            axes = tuple(range(2, a.ndim))
+            err = (np.abs(a - b).max(axis=axes) / np.maximum(1.0, np.abs(b).max(axis=axes))).max()
+            assert err <= 1e-11, (fa, ka, fb, kb, order, nreq, npts, err)
+    # the registered shapes do run fused
+    assert runtime.prism_tabulate_batch(prism[0], prism[1], 1, np.zeros((4, 6, 3)) + 0.25) is not None or (ka == 3 and kb == 3)
