@@ -711,3 +711,42 @@ def test_fused_prism_kernel_matches_general_route(fa, ka, fb, kb):
             assert err <= 1e-11, (fa, ka, fb, kb, order, nreq, npts, err)
     # the registered shapes do run fused
     assert runtime.prism_tabulate_batch(prism[0], prism[1], 1, np.zeros((4, 6, 3)) + 0.25) is not None or (ka == 3 and kb == 3)
+
+
+def test_launches_capture_into_a_hip_graph():
+    """After one warm-up call per (element, order, shape) the launch path allocates and synchronises nothing: a sequence of
+    tabulations on a side stream captures into a HIP graph (torch.cuda.CUDAGraph) and replays bit-equal (INTEGRATION.md 3;
+    tools/graph_probe.py: 60 small launches 0.68 ms direct, 0.48 ms replayed)."""
+    import torch
+    import fiat_amd
+    rng = np.random.default_rng(3)
+    work = []
+    for fam, sd, deg, npts in (("Lagrange", 3, 3, 23), ("Lagrange", 2, 1, 3), ("Nedelec", 3, 1, 4), ("RaviartThomas", 3, 2, 23),
+                               ("DiscontinuousLagrange", 3, 4, 23)):
+        el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg)
+        e = rng.exponential(size=(300, npts, sd + 1))
+        pts = torch.as_tensor((e / e.sum(-1, keepdims=True))[..., 1:].copy()).cuda()
+        out = torch.empty(el.device_polyset().out_shape(1, 300, npts), dtype=torch.float64, device="cuda")
+        work.append((el, pts, out))
+
+    def run(stream):
+        for el, pts, out in work:
+            el.tabulate_batch(1, pts, out=out, stream=stream)
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run(s)                                             # warm-up: derivative matrices, occupancy queries
+    torch.cuda.synchronize()
+    ref = [o.clone() for _, _, o in work]
+    for _, _, o in work:
+        o.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        run(s)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    for a, (_, _, o) in zip(ref, work):
+        assert torch.equal(a, o)
