@@ -1427,7 +1427,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
         // (fewer stacked rows: the production of the B fragments is no longer amortised over enough row tiles)
         // (measured, tools/coverage_map.py: values-only requests of P3 / P4 tetrahedra, 20 / 35 rows, run at 45 / 30 % of the HBM
         // peak here against 23 / 13 % on the generic kernel; below one row tile nothing is left to amortise)
-        static const long long stacked_min_rows = ab_env("FIAT_AMD_STACKED_MIN_ROWS") ? atoll(ab_env("FIAT_AMD_STACKED_MIN_ROWS")) : 16;
+        // (15 rows: values-only P4 triangles 27-30 % lane-local -> 38-49 % here; 10 rows -- P3 triangles, P2 tetrahedra -- stay
+        // lane-local, 39-43 % against 34-39 %)
+        static const long long stacked_min_rows = ab_env("FIAT_AMD_STACKED_MIN_ROWS") ? atoll(ab_env("FIAT_AMD_STACKED_MIN_ROWS")) : 15;
         const long long R = (long long)ntab * rows;
         const int RT = (int)((R + 15) / 16);
         const bool even = ((R * npts) % 2 == 0) && (((R - 16LL * (RT - 1)) * npts) % 2 == 0);
