@@ -157,15 +157,20 @@ struct LineDesc {
 
 // values phi[i] at x; exact Kronecker delta when x hits a node
 // (barycentric_interpolation.py:35-40: NaN -> 1 after the normalisation).
+// (node data through the constant address space: never written while a kernel runs, so the loads are scalar)
+typedef const __attribute__((address_space(4))) double LineConst;
+
 __device__ __forceinline__ void lagrange_values(const LineDesc& L, double x, double* phi) {
+    LineConst* nodes = (LineConst*)(unsigned long long)L.nodes;
+    LineConst* wts = (LineConst*)(unsigned long long)L.wts;
     double sum = 0.0;
     int hit = -1;
 #pragma unroll
     for (int i = 0; i < NN_MAX; ++i) {
         if (i < L.nn) {
-            double d = x - L.nodes[i];
+            double d = x - nodes[i];
             if (d == 0.0) hit = i;
-            double t = L.wts[i] / d;
+            double t = wts[i] / d;
             phi[i] = t;
             sum += t;
         }
@@ -179,13 +184,14 @@ __device__ __forceinline__ void lagrange_values(const LineDesc& L, double x, dou
 
 // out = dmat . in
 __device__ __forceinline__ void lagrange_diff(const LineDesc& L, const double* in, double* out) {
+    LineConst* dmat = (LineConst*)(unsigned long long)L.dmat;
 #pragma unroll
     for (int i = 0; i < NN_MAX; ++i) {
         if (i < L.nn) {
             double s = 0.0;
 #pragma unroll
             for (int j = 0; j < NN_MAX; ++j)
-                if (j < L.nn) s += L.dmat[i * L.nn + j] * in[j];
+                if (j < L.nn) s += dmat[i * L.nn + j] * in[j];
             out[i] = s;
         }
     }
@@ -193,13 +199,15 @@ __device__ __forceinline__ void lagrange_diff(const LineDesc& L, const double* i
 
 // the same with a compile-time node count: every index is a constant, the node data are uniform loads
 template <int NN> __device__ __forceinline__ void lagrange_values_n(const LineDesc& L, double x, double (&phi)[NN]) {
+    LineConst* nodes = (LineConst*)(unsigned long long)L.nodes;
+    LineConst* wts = (LineConst*)(unsigned long long)L.wts;
     double sum = 0.0;
     int hit = -1;
 #pragma unroll
     for (int i = 0; i < NN; ++i) {
-        const double d = x - L.nodes[i];
+        const double d = x - nodes[i];
         if (d == 0.0) hit = i;
-        const double t = L.wts[i] / d;
+        const double t = wts[i] / d;
         phi[i] = t;
         sum += t;
     }
@@ -209,11 +217,12 @@ template <int NN> __device__ __forceinline__ void lagrange_values_n(const LineDe
 }
 
 template <int NN> __device__ __forceinline__ void lagrange_diff_n(const LineDesc& L, const double (&in)[NN], double (&out)[NN]) {
+    LineConst* dmat = (LineConst*)(unsigned long long)L.dmat;
 #pragma unroll
     for (int i = 0; i < NN; ++i) {
         double s = 0.0;
 #pragma unroll
-        for (int j = 0; j < NN; ++j) s += L.dmat[i * NN + j] * in[j];
+        for (int j = 0; j < NN; ++j) s += dmat[i * NN + j] * in[j];
         out[i] = s;
     }
 }

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64 * NW) void prism_small_kernel(const PrismArgs a)
     const __attribute__((address_space(4))) char* kargs =
         (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
     CDouble* kcoef = (CDouble*)(kargs + __builtin_offsetof(PrismArgs, coef));
+    CDouble* kcmat = (CDouble*)(unsigned long long)a.cmat;  // never written while the kernel runs: scalar loads
 
     for (long long item = (long long)blockIdx.x * NW + wave; item < a.nitems; item += (long long)gridDim.x * NW) {
         const long long r0 = item * a.P;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(64 * NW) void prism_small_kernel(const PrismArgs a)
         double* sp = stage + (size_t)(active ? rl : 0) * reqsize + (active ? pl : 0);
         int dofA = 0, comp = 0;
         for (int row = 0; row < rowsA; ++row) {
-            const double* crow = a.cmat + (size_t)row * NEXP;  // uniform address: scalar loads
+            CDouble* crow = kcmat + (size_t)row * NEXP;
             double acc[NTA];
 #pragma unroll
             for (int t = 0; t < NTA; ++t) acc[t] = 0.0;

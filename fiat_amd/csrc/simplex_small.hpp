@@ -57,6 +57,10 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_small(const SmallArg
     const __attribute__((address_space(4))) char* kargs =
         (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
     CDouble* kcoef = (CDouble*)(kargs + __builtin_offsetof(SmallArgs, coef));
+    // the coefficient matrix is never written while the kernel runs: through the constant address space its rows are SCALAR
+    // loads (as generic global loads the compiler, unable to rule out aliasing with the output stores, issued five vector
+    // loads per row and waited for them row by row -- half of the launch for values-only P3 triangles, tools/small_ablation.py)
+    CDouble* kcmat = (CDouble*)(unsigned long long)a.cmat;
 
     for (long long item = (long long)blockIdx.x * NW + wave; item < a.nitems; item += (long long)gridDim.x * NW) {
         const long long r0 = item * a.P;
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_small(const SmallArg
                 double acc[SD][NTAB];
 #pragma unroll
                 for (int c = 0; c < SD; ++c) {
-                    const double* crow = a.cmat + (size_t)(dof * SD + c) * NEXP;   // uniform address: scalar loads
+                    CDouble* crow = kcmat + (size_t)(dof * SD + c) * NEXP;
 #pragma unroll
                     for (int t = 0; t < NTAB; ++t) acc[c][t] = 0.0;
 #pragma unroll
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_small(const SmallArg
         } else if (!(a.debug & 2)) {
             double* sp = stage + (size_t)(active ? rl : 0) * reqsize + (active ? pl : 0);
             for (int row = 0; row < rows; ++row) {
-                const double* crow = a.cmat + (size_t)row * NEXP;   // uniform address: scalar loads
+                CDouble* crow = kcmat + (size_t)row * NEXP;
                 double acc[NTAB];
 #pragma unroll
                 for (int t = 0; t < NTAB; ++t) acc[t] = 0.0;
