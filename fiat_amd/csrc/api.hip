@@ -866,6 +866,9 @@ int launch_stacked(const Launch& L, hipStream_t s) {
 }
 
 int run_stacked(const Launch& L, hipStream_t s) {
+    // (WPS = 2 variants: instances a few registers above 256 recompiled for two waves per SIMD -- values and gradients have short
+    // row sweeps, the second wave covers a group's production phase: P6 triangles 27-35 -> 32-43 %, P4 tetrahedra at 13-24
+    // points 28-45 -> 32-50 %; with Hessians the sweep is MFMA-bound and one 512-register wave is faster, tools/wps_probe.py)
     switch (L.stacked_id) {  // (same order as kStackedShapes)
         case 0: return launch_stacked<3, 3, 3, 2, 5, 3>(L, s);
         case 1: return launch_stacked<3, 3, 2, 1, 5, 3>(L, s);
@@ -892,7 +895,7 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 22: return launch_stacked<3, 5, 3, 2>(L, s);
         case 23: return launch_stacked<3, 5, 2, 1>(L, s);
         case 24: return launch_stacked<3, 5, 3, 1>(L, s);
-        case 25: return launch_stacked<3, 4, 3, 2>(L, s);
+        case 25: return L.kmix_order <= 1 ? launch_stacked<3, 4, 3, 2, 0, 2>(L, s) : launch_stacked<3, 4, 3, 2>(L, s);
         case 26: return launch_stacked<3, 4, 2, 1>(L, s);
         case 27: return launch_stacked<3, 4, 3, 1>(L, s);
         case 28: return launch_stacked<3, 3, 3, 2>(L, s);
@@ -900,14 +903,14 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 30: return launch_stacked<3, 3, 3, 1>(L, s);
         case 31: return launch_stacked<2, 6, 3, 2>(L, s);
         case 32: return launch_stacked<2, 6, 2, 1>(L, s);
-        case 33: return launch_stacked<2, 6, 3, 1>(L, s);
+        case 33: return L.kmix_order <= 1 ? launch_stacked<2, 6, 3, 1, 0, 2>(L, s) : launch_stacked<2, 6, 3, 1>(L, s);
         case 34: return launch_stacked<2, 5, 3, 2>(L, s);
         case 35: return launch_stacked<2, 5, 2, 1>(L, s);
         case 36: return launch_stacked<2, 5, 3, 1>(L, s);
         case 37: return launch_stacked<3, 6, 3, 3>(L, s);
         case 38: return launch_stacked<3, 5, 3, 3>(L, s);
         case 39: return launch_stacked<3, 5, 4, 1>(L, s);
-        case 40: return launch_stacked<3, 4, 3, 3>(L, s);
+        case 40: return L.kmix_order <= 1 ? launch_stacked<3, 4, 3, 3, 0, 2>(L, s) : launch_stacked<3, 4, 3, 3>(L, s);
         case 41: return launch_stacked<3, 4, 4, 1>(L, s);
         case 42: return launch_stacked<3, 3, 3, 3>(L, s);
         case 43: return launch_stacked<3, 3, 4, 1>(L, s);
@@ -925,7 +928,7 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 55: return launch_stacked<3, 4, 3, 1, 0, 1, true>(L, s);
         case 56: return launch_stacked<3, 3, 3, 1, 0, 1, true>(L, s);
         case 57: return launch_stacked<3, 2, 3, 1, 0, 1, true>(L, s);
-        case 58: return launch_stacked<2, 6, 3, 1, 0, 1, true>(L, s);
+        case 58: return L.kmix_order <= 1 ? launch_stacked<2, 6, 3, 1, 0, 2, true>(L, s) : launch_stacked<2, 6, 3, 1, 0, 1, true>(L, s);
         case 59: return launch_stacked<2, 5, 3, 1, 0, 1, true>(L, s);
         case 60: return launch_stacked<3, 2, 3, 4>(L, s);
         case 61: return launch_stacked<2, 4, 3, 3>(L, s);
