@@ -556,6 +556,7 @@ struct Launch {
     std::vector<double> fucoef;        // [nsteps][12], uniform-cell factor derivatives
     int fgrid = 0, flds_bytes = 0, ncu = 0;
     bool fused_mapping = false;
+    bool kodd = false;  // stacked kernel: requests of an odd number of doubles (8-byte flush instance)
     double* trash = nullptr;
     unsigned long long* queue = nullptr;
     // 0: LDS-image kernel (simplex_fixed.hpp), 1: K-streamed kernel (simplex_stream.hpp),
@@ -787,7 +788,7 @@ const StackedShape kStackedShapes[] = {
 };
 constexpr int STACKED_NW = 4;  // one wave per SIMD
 
-template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0>
+template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0, bool ODD = false>
 int launch_stacked(const Launch& L, hipStream_t s) {
     constexpr int NC = fxk::FixedNC<SD, N>::value;
     fxk::StackedArgs<NC> ka;
@@ -810,7 +811,7 @@ int launch_stacked(const Launch& L, hipStream_t s) {
     ka.lim_afrag = L.khead.lim_afrag;
     if ((int)L.fcoef.size() != NC) return fail(FX_EINVAL, "internal: coefficient table size mismatch");
     memcpy(ka.coef, L.fcoef.data(), NC * sizeof(double));
-    auto kern = fxk::tabulate_simplex_stacked<SD, N, CT, G, RTC, WPS, CHUNK, MIXT>;
+    auto kern = fxk::tabulate_simplex_stacked<SD, N, CT, G, RTC, WPS, CHUNK, MIXT, ODD>;
     // as many workgroups per CU as registers and LDS allow (low degrees need few registers: their short
     // row sweeps rely on other waves to cover the production phase); asked once per kernel
     static thread_local int occ = 0;
@@ -895,17 +896,17 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 22: return launch_stacked<3, 5, 3, 2>(L, s);
         case 23: return launch_stacked<3, 5, 2, 1>(L, s);
         case 24: return launch_stacked<3, 5, 3, 1>(L, s);
-        case 25: return L.kmix_order <= 1 ? launch_stacked<3, 4, 3, 2, 0, 2>(L, s) : launch_stacked<3, 4, 3, 2>(L, s);
+        case 25: return L.kodd ? launch_stacked<3, 4, 3, 2, 0, 1, false, 0, true>(L, s) : L.kmix_order <= 1 ? launch_stacked<3, 4, 3, 2, 0, 2>(L, s) : launch_stacked<3, 4, 3, 2>(L, s);
         case 26: return launch_stacked<3, 4, 2, 1>(L, s);
         case 27: return launch_stacked<3, 4, 3, 1>(L, s);
-        case 28: return launch_stacked<3, 3, 3, 2>(L, s);
+        case 28: return L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 0, true>(L, s) : launch_stacked<3, 3, 3, 2>(L, s);
         case 29: return launch_stacked<3, 3, 2, 1>(L, s);
         case 30: return launch_stacked<3, 3, 3, 1>(L, s);
         case 31: return launch_stacked<2, 6, 3, 2>(L, s);
         case 32: return launch_stacked<2, 6, 2, 1>(L, s);
         case 33: return L.kmix_order <= 1 ? launch_stacked<2, 6, 3, 1, 0, 2>(L, s) : launch_stacked<2, 6, 3, 1>(L, s);
         case 34: return launch_stacked<2, 5, 3, 2>(L, s);
-        case 35: return launch_stacked<2, 5, 2, 1>(L, s);
+        case 35: return L.kodd ? launch_stacked<2, 5, 2, 1, 0, 1, false, 0, true>(L, s) : launch_stacked<2, 5, 2, 1>(L, s);
         case 36: return launch_stacked<2, 5, 3, 1>(L, s);
         case 37: return launch_stacked<3, 6, 3, 3>(L, s);
         case 38: return launch_stacked<3, 5, 3, 3>(L, s);
@@ -918,7 +919,7 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 45: return launch_stacked<2, 6, 4, 1>(L, s);
         case 46: return launch_stacked<2, 5, 3, 3>(L, s);
         case 47: return launch_stacked<2, 5, 4, 1>(L, s);
-        case 48: return launch_stacked<3, 2, 3, 2>(L, s);
+        case 48: return L.kodd ? launch_stacked<3, 2, 3, 2, 0, 1, false, 0, true>(L, s) : launch_stacked<3, 2, 3, 2>(L, s);
         case 49: return launch_stacked<3, 2, 2, 1>(L, s);
         case 50: return launch_stacked<3, 2, 3, 1>(L, s);
         case 51: return launch_stacked<3, 2, 3, 3>(L, s);
@@ -930,7 +931,7 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 57: return launch_stacked<3, 2, 3, 1, 0, 1, true>(L, s);
         case 58: return L.kmix_order <= 1 ? launch_stacked<2, 6, 3, 1, 0, 2, true>(L, s) : launch_stacked<2, 6, 3, 1, 0, 1, true>(L, s);
         case 59: return launch_stacked<2, 5, 3, 1, 0, 1, true>(L, s);
-        case 60: return launch_stacked<3, 2, 3, 4>(L, s);
+        case 60: return L.kodd ? launch_stacked<3, 2, 3, 4, 0, 1, false, 0, true>(L, s) : launch_stacked<3, 2, 3, 4>(L, s);
         case 61: return launch_stacked<2, 4, 3, 3>(L, s);
         case 62: return launch_stacked<2, 4, 3, 2>(L, s);
         case 63: return launch_stacked<2, 4, 2, 1>(L, s);
@@ -1472,7 +1473,10 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 } else if (k.rtc < 0) {  // point-chunked: whatever the whole-request instances above did not take
                     if (npts < 13 || nreq * (long long)((npts + 16 * k.ct - 1) / (16 * k.ct)) > 0x7fffffffLL) continue;
                 } else {
-                    if (!even) continue;  // (16-byte stores of whole request chunks)
+                    // (16-byte stores of whole request chunks; a few instances have an 8-byte twin for odd request sizes)
+                    const bool odd_twin = (k.sd == 3 && k.n == 4 && k.ct == 3 && k.g == 2) || (k.sd == 3 && k.n == 2 && k.ct == 3 && (k.g == 2 || k.g == 4)) ||
+                                          (k.sd == 3 && k.n == 3 && k.ct == 3 && k.g == 2) || (k.sd == 2 && k.n == 5 && k.ct == 2 && k.g == 1);
+                    if (!even && !(odd_twin && !verts)) continue;
                     if (npts > 16 * k.ct / k.g || tighter_instance(k) || !fills_tiles(k)) continue;  // 16 ct / g: points one request may have
                 }
                 bool ok = false;
@@ -1525,6 +1529,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 L.trash = ctx->d_trash;
                 L.queue = ctx->d_queue + (size_t)(ctx->launch_seq++ % FX_QUEUE_SLOTS) * 16;
                 L.kmix_order = order;
+                L.kodd = k.rtc == 0 && !even;
                 L.stacked_id = (int)i;
                 L.small_id = -1;
                 break;

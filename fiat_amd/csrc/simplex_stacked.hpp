@@ -83,7 +83,9 @@ constexpr int stacked_image_doubles(int CT, int KS, int slots = 1) {
 // after the other (each table padded to whole tiles) -- so that a wave holds values and all first derivatives of
 // those dofs at once; their images go to LDS together and the flush applies the chain rule
 // d/dx_d = sum_c K[c][d] d/dX_c while it copies them out.
-template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0>
+// ODD: requests of an odd number of doubles (odd row count x odd point count: P4 / RT2 / N3 tetrahedra, P5 triangles at rules
+// with odd point counts) start on 8-byte boundaries only -- the whole-request flush then moves 8 bytes per lane instead of 16.
+template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0, bool ODD = false>
 __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const StackedArgs<FixedNC<SD, N>::value> a,
                                                                    double* __restrict__ trash,
                                                                    unsigned int* __restrict__ gqueue) {
@@ -91,7 +93,9 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
     constexpr int NEXP = StepTable<SD, N>::NEXP;
     constexpr int KS = (NEXP + 3) / 4;
     constexpr int CPR = 16 * CT / G;                // column budget of one request
-    constexpr int NST = (16 * CPR / 2 + 63) / 64;   // 16-byte stores per lane and request chunk
+    constexpr int NST = ODD ? (16 * CPR + 63) / 64 : (16 * CPR / 2 + 63) / 64;   // 16-byte (ODD: 8-byte) stores per lane and request chunk
+    static_assert(!ODD || (!CHUNK && MIXT == 0 && RTC == 0), "8-byte flush: whole-request groups, streamed fragments");
+    using FlushT = typename std::conditional<ODD, double, v2d>::type;
     constexpr int PCH = 16 * CT;                    // points per chunk (CHUNK)
     static_assert(!CHUNK || (G == 1 && RTC == 0), "point-chunked units: one request per group, streamed fragments");
     constexpr int SLOTS = MIXT > 0 ? MIXT : 1;  // row-tile images per wave
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
             img[ok ? soff + eoff[c] + 4 * jj * estr : DUMP + elane] = acc[c][jj];
         };
         constexpr int NRD = CHUNK ? (16 * PCH + 63) / 64 : G * NST;  // image reads = output stores per row tile
-        v2d fbuf[CHUNK ? 1 : NRD];
+        FlushT fbuf[CHUNK ? 1 : NRD];
         double fbuf1[CHUNK ? NRD : 1];
         const float rpc = 1.0f / (float)pc;
         auto image_get = [&](int r, int nrows, int soff = 0) {  // r-th image read
@@ -330,8 +334,8 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                 fbuf1[r] = img[min(r * 64 + elane, nrows * pc - 1)];
             } else {
                 const int g = r / NST, it = r % NST;
-                const int nch = (nrows * enpts) >> 1;  // 16-byte pieces of a request's chunk (host: even)
-                fbuf[r] = reinterpret_cast<const v2d*>(img + soff + g * echunk)[min(it * 64 + elane, nch - 1)];
+                const int nch = ODD ? nrows * enpts : (nrows * enpts) >> 1;  // pieces of a request's chunk (16-byte: even, host-checked)
+                fbuf[r] = reinterpret_cast<const FlushT*>(img + soff + g * echunk)[min(it * 64 + elane, nch - 1)];
             }
         };
         auto image_out = [&](int r, int rowbase, int nrows) {  // r-th output store of the row tile starting at row `rowbase`
@@ -348,16 +352,18 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                 *dst = fbuf1[r];
             } else {
                 const int g = r / NST, it = r % NST;
-                const int nch = (nrows * enpts) >> 1;
+                const int nch = ODD ? nrows * enpts : (nrows * enpts) >> 1;
 #if FX_DBG & 1024
-                const long long o0 = ((long long)oreq[g] * a.R + (long long)rowbase) * enpts + 2 * min(it * 64 + elane, nch - 1);
-                v2d* g2 = oreq[g] < a.nreq ? reinterpret_cast<v2d*>(a.out + FX_CHK(o0, a.lim_out - 1, 4)) : reinterpret_cast<v2d*>(trash);
-                if (oreq[g] < a.nreq && (o0 < 0 || o0 >= a.lim_out - 1)) g2 = reinterpret_cast<v2d*>(trash);
+                constexpr int EPP = ODD ? 1 : 2;  // doubles per piece
+                const long long o0 = ((long long)oreq[g] * a.R + (long long)rowbase) * enpts + EPP * min(it * 64 + elane, nch - 1);
+                FlushT* g2 = oreq[g] < a.nreq ? reinterpret_cast<FlushT*>(a.out + FX_CHK(o0, a.lim_out - (EPP - 1), 4)) : reinterpret_cast<FlushT*>(trash);
+                if (oreq[g] < a.nreq && (o0 < 0 || o0 >= a.lim_out - (EPP - 1))) g2 = reinterpret_cast<FlushT*>(trash);
                 stream_store(g2, fbuf[r]);
 #else
-                v2d* g2 = oreq[g] < a.nreq ? reinterpret_cast<v2d*>(a.out + ((size_t)oreq[g] * a.R + (size_t)rowbase) * enpts)
-                                           : reinterpret_cast<v2d*>(trash);
-                stream_store(&g2[min(it * 64 + elane, nch - 1)], fbuf[r]);
+                FlushT* g2 = oreq[g] < a.nreq ? reinterpret_cast<FlushT*>(a.out + ((size_t)oreq[g] * a.R + (size_t)rowbase) * enpts)
+                                              : reinterpret_cast<FlushT*>(trash);
+                if constexpr (ODD) g2[min(it * 64 + elane, nch - 1)] = fbuf[r];  // (8-byte pieces, lines shared with the neighbours: plain stores)
+                else stream_store(&g2[min(it * 64 + elane, nch - 1)], fbuf[r]);
 #endif
             }
         };

@@ -750,3 +750,36 @@ def test_launches_capture_into_a_hip_graph():
     torch.cuda.synchronize()
     for a, (_, _, o) in zip(ref, work):
         assert torch.equal(a, o)
+
+
+@pytest.mark.parametrize("family,sd,deg,npts", [("Lagrange", 3, 4, 23), ("Lagrange", 3, 4, 17), ("RaviartThomas", 3, 2, 11),
+                                                 ("RaviartThomas", 3, 2, 23), ("Nedelec", 3, 3, 23), ("Lagrange", 2, 5, 25)])
+def test_odd_request_sizes_on_the_stacked_kernel(family, sd, deg, npts):
+    """Requests of an odd number of doubles (odd rows x odd points) on the 8-byte-flush instances of the stacked-matrix kernel,
+    against the generic kernel (itself checked against the oracle throughout tests/test_gpu_parity.py): orders 0-2, batches of
+    1, 2, 3 (odd requests start on 8-byte boundaries only) and 257 requests."""
+    import fiat_amd
+    from fiat_amd import runtime
+    ctx = runtime.Context.get()
+    el = getattr(fiat_amd, family)(fiat_amd.ufc_simplex(sd), deg)
+    rows = el.space_dimension() * int(np.prod(el.value_shape() or (1,)))
+    assert (rows * npts) % 2 == 1
+    rng = np.random.default_rng(31)
+    ref_cell = np.array(fiat_amd.ufc_simplex(sd).get_vertices(), dtype=float)
+    used = set()
+    for order in (0, 1, 2):
+        for nreq in (1, 2, 3, 257):
+            e = rng.exponential(size=(nreq, npts, sd + 1))
+            pts = np.einsum("rpv,vd->rpd", e / e.sum(-1, keepdims=True), ref_cell)
+            used.add(el.device_polyset().kernel_name(order, nreq, npts))
+            a = el.tabulate_batch(order, pts).cpu().numpy()
+            ctx.set_policy("no_fixed", "no_small", "no_stacked", "no_coop")
+            try:
+                b = el.tabulate_batch(order, pts).cpu().numpy()
+            finally:
+                ctx.set_policy()
+            axes = tuple(range(2, a.ndim))
+            err = (np.abs(a - b).max(axis=axes) / np.maximum(1.0, np.abs(b).max(axis=axes))).max()
+            assert err <= 1e-10, (family, sd, deg, npts, order, nreq, err)
+    assert "fxk::tabulate_simplex_stacked" in used
+    ctx.check()
