@@ -29,7 +29,7 @@ for sd in (2, 3):
             for order in orders:
                 shape1 = ps.out_shape(order, 1, npts)
                 per_req = 8 * (npts * sd + int(np.prod(shape1[1:])))
-                nreq = int(min(2_000_000, 0.8e9 // per_req))
+                nreq = int(min(2_000_000, float(os.environ.get('CAP_GB', '0.8')) * 1e9 // per_req))
                 pts = torch.as_tensor(bench.synth_points(sd, nreq, npts, 1)).cuda()
                 verts = None
                 if "--verts" in sys.argv:
