@@ -557,7 +557,7 @@ def test_flattened_hexahedron_entities(golden):
 
 def test_random_shapes_default_kernels_match_generic():
     """tools/fuzz_policies.py for a few seconds: random elements / orders / point counts / batch sizes / per-request cells,
-    default kernel selection against the generic kernel (a 150 s run covered 7621 cases, worst difference 6e-12)."""
+    default kernel selection against the generic kernel (a 300 s run covered 19 501 simplex and 10 053 tensor / prism cases, worst difference 5e-12)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -52,5 +52,48 @@ while time.time() - t0 < budget:
     n += 1
     if not np.isfinite(a).all() or err > 1e-9:
         print("MISMATCH", key, "order", order, "npts", npts, "nreq", nreq, "verts", verts is not None, kern, err, flush=True)
+# tensor products and prisms: lane-local / fused kernels against the per-request and general routes (policy no_small)
+I = fa.ufc_simplex(1)
+tp_cache = {}
+t1, m = time.time(), 0
+while time.time() - t1 < budget / 4:
+    kind = rng.integers(3)
+    order = int(rng.integers(0, 3))
+    nreq = int(rng.choice([1, 2, 5, 63, 64, 65, 1000, 4097]))
+    if kind < 2:                                   # quadrilateral / hexahedron of equal-degree Lagrange factors
+        dim, k = int(rng.integers(2, 4)), int(rng.integers(1, 5))
+        key = ("q", dim, k)
+        if key not in tp_cache:
+            P = fa.Lagrange(I, k)
+            el = fa.TensorProductElement(P, P)
+            tp_cache[key] = fa.TensorProductElement(el, P) if dim == 3 else el
+        el = tp_cache[key]
+        npts = int(rng.choice([1, 3, 4, 8, 9, 16, 27, 30, 64]))
+        if npts * (k + 1) ** dim * 10 * 8 * nreq > 1e9:
+            nreq = 5
+        pts = rng.uniform(0, 1, size=(nreq, npts, dim))
+        if rng.random() < 0.3:
+            pts[0, 0, 0] = 1.0                     # a coordinate on a node
+    else:                                          # prism
+        fam, ka = [("Lagrange", 1), ("Lagrange", 2), ("Lagrange", 3), ("RaviartThomas", 1), ("Nedelec", 1), ("DiscontinuousLagrange", 1)][rng.integers(6)]
+        kb = int(rng.integers(1, 4))
+        key = ("p", fam, ka, kb)
+        if key not in tp_cache:
+            tp_cache[key] = fa.TensorProductElement(getattr(fa, fam)(fa.ufc_simplex(2), ka), fa.Lagrange(I, kb))
+        el = tp_cache[key]
+        npts = int(rng.choice([1, 2, 6, 7, 12, 18, 33, 64]))
+        e = rng.exponential(size=(nreq, npts, 3))
+        pts = np.concatenate([(e / e.sum(-1, keepdims=True))[..., 1:], rng.uniform(0, 1, size=(nreq, npts, 1))], axis=-1)
+    ctx.set_policy()
+    a = el.tabulate_batch(order, pts).cpu().numpy()
+    ctx.set_policy("no_small")
+    b = el.tabulate_batch(order, pts).cpu().numpy()
+    ctx.set_policy()
+    axes = tuple(range(2, a.ndim))
+    err = float((np.abs(a - b).max(axis=axes) / np.maximum(1.0, np.abs(b).max(axis=axes))).max())
+    worst = max(worst, err)
+    m += 1
+    if not np.isfinite(a).all() or err > 1e-9:
+        print("MISMATCH tensor", key, "order", order, "npts", npts, "nreq", nreq, err, flush=True)
 ctx.check()
-print(f"{n} random cases, worst relative difference {worst:.2e}")
+print(f"{n} random cases + {m} tensor / prism cases, worst relative difference {worst:.2e}")
