@@ -11,10 +11,15 @@
 #include <vector>
 typedef double v2d __attribute__((ext_vector_type(2)));
 
+// NT: 0 plain, 1 non-temporal, 2 sc1, 3 sc0 sc1, 4 sc1 nt, 5 sc0 sc1 nt (cache-policy bits of global_store_dwordx4)
 template <int NT>
 __device__ __forceinline__ void st(v2d* p, v2d v) {
-    if (NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
+    if (NT == 0) *p = v;
+    else if (NT == 1) __builtin_nontemporal_store(v, p);
+    else if (NT == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    else if (NT == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+    else if (NT == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
 }
 
 template <int NT>
@@ -174,7 +179,7 @@ int main(int argc, char** argv) {
     }
     for (int pad : {0}) {
         const int stride = pad ? (bytes + 127) / 128 * 128 : bytes;
-        for (int nt : {0, 1})
+        for (int nt : {0, 1, 2, 3, 4, 5})
             for (int nw : {4, 8})
                 for (int wgs : {1, 2, 4})
                     for (int pattern : pats) {
@@ -182,8 +187,14 @@ int main(int argc, char** argv) {
                         if (quick && (wgs != 1)) continue;
                         const int grid = 256 * wgs;
                         auto fn = [&] {
-                            if (nt) store_blocks<1><<<grid, 64 * nw>>>(out, nblk, bytes / 16, stride / 16, pattern);
-                            else store_blocks<0><<<grid, 64 * nw>>>(out, nblk, bytes / 16, stride / 16, pattern);
+                            switch (nt) {
+                                case 0: store_blocks<0><<<grid, 64 * nw>>>(out, nblk, bytes / 16, stride / 16, pattern); break;
+                                case 1: store_blocks<1><<<grid, 64 * nw>>>(out, nblk, bytes / 16, stride / 16, pattern); break;
+                                case 2: store_blocks<2><<<grid, 64 * nw>>>(out, nblk, bytes / 16, stride / 16, pattern); break;
+                                case 3: store_blocks<3><<<grid, 64 * nw>>>(out, nblk, bytes / 16, stride / 16, pattern); break;
+                                case 4: store_blocks<4><<<grid, 64 * nw>>>(out, nblk, bytes / 16, stride / 16, pattern); break;
+                                default: store_blocks<5><<<grid, 64 * nw>>>(out, nblk, bytes / 16, stride / 16, pattern); break;
+                            }
                         };
                         us = timeit(fn);
                         printf("block %6d B stride %6d nt %d waves/WG %d WG/CU %d pattern %d : %7.1f us %6.0f GB/s\n", bytes, stride, nt, nw, wgs, pattern, us, total / us / 1e3);
