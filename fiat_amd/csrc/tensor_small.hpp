@@ -1,5 +1,5 @@
 // Lane-local tensor-product tabulation for small requests (gfx950): Q1 / Q2 quadrilaterals and hexahedra, Q3 / Q4
-// quadrilaterals -- requests of a few hundred bytes to 8 KB, for which one workgroup per request (tensor_tabulate_kernel,
+// quadrilaterals -- requests of a few hundred bytes to 16 KB, for which one workgroup per request (tensor_tabulate_kernel,
 // aux_kernels.hpp) spends its time in barriers and in the factor tables of 4..27 points: 0.4-6 % of the HBM peak
 // (tools/coverage_map_tensor.py).
 //
