@@ -63,3 +63,23 @@ def test_two_ranks_with_the_staging_ring():
     ag = line["allgather"]
     assert "error" not in ag, ag
     assert line["n_gpus"] == 2 and ag["mode"].startswith("staging ring") and ag["all_finite"] and ag["value_with_allgather"] > 0
+
+
+@pytest.mark.gpu
+def test_driver_style_torchrun_launch_two_ranks():
+    """The driver's launch line for N > 1 -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ... -- rehearsed with two gloo ranks sharing this box's GPU: ONE line from rank 0."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "3000",
+                          "--check", "200"], capture_output=True, text=True, env=_env(FIAT_AMD_BENCH_BACKEND="gloo"), timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["launch"] == "torch.distributed.run" and line["value"] > 0
+    assert line["max_rel_err_vs_oracle"] < 1e-12 and "error" not in line.get("allgather", {})
