@@ -80,6 +80,7 @@ _SIGS = {
     "fx_tabulate_batch_shared": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p]),
     "fx_collapsed_quadrature": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fx_tables_squared_norm": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fx_classify_tables": (c_int, [c_void_p, c_int64, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p]),
     "fx_tables_point_major": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "fx_plan_kernel": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_char_p, c_int]),

@@ -1901,6 +1901,22 @@ int fx_classify_tables(fx_ctx* ctx, int64_t ntables, int rows, int npts, double 
     return FX_OK;
 }
 
+int fx_tables_squared_norm(fx_ctx* ctx, int64_t ntables, int rows, int vdim, int npts, const double* tables, const double* weights,
+                           double* out, void* stream) {
+    if (!ctx) return fail(FX_EINVAL, "null context");
+    if (ntables < 0 || rows < 1 || vdim < 1 || npts < 1)
+        return fail(FX_EINVAL, "bad table shape (%lld, %d, %d, %d)", (long long)ntables, rows, vdim, npts);
+    if ((long long)vdim * npts > 0x7fffffffLL) return fail(FX_EINVAL, "table rows too long");
+    const long long nrows = (long long)ntables * rows;
+    if ((nrows + 3) / 4 > 0x7fffffffLL) return fail(FX_EINVAL, "too many rows for one launch");
+    if (ntables == 0) return FX_OK;
+    if (!tables || !weights || !out) return fail(FX_EINVAL, "null device pointer");
+    fxk::SquaredNormArgs sa{tables, weights, out, rows, vdim, npts};
+    hipLaunchKernelGGL(fxk::squared_norm_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, sa, nrows);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
 int fx_tables_point_major(fx_ctx* ctx, int64_t ntables, int rows, int npts, const double* in, double* out, void* stream) {
     if (!ctx) return fail(FX_EINVAL, "null context");
     if (ntables < 0 || rows < 1 || npts < 1) return fail(FX_EINVAL, "bad table shape (%lld, %d, %d)", (long long)ntables, rows, npts);

@@ -53,6 +53,31 @@ __global__ __launch_bounds__(256) void classify_tables_kernel(const ClassifyArgs
     }
 }
 
+struct SquaredNormArgs {
+    const double* tables;   // [ntables][rows][vdim][npts]
+    const double* weights;  // [npts]
+    double* out;            // [ntables][rows]
+    int rows, vdim, npts;
+};
+
+// FIAT/finite_element.py:250-260 (entity_support_dofs): out[t][r] = sum_p w_p sum_c tables[t][r][c][p]^2 -- the squared
+// L2 norm of every basis function over the entity whose quadrature rule the tables were evaluated at.  One wave per
+// (table, row): lanes stride over the vdim * npts entries of the row (contiguous), wave reduction by DPP shuffles.
+__global__ __launch_bounds__(256) void squared_norm_kernel(const SquaredNormArgs a, long long nrows) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const double* t = a.tables + (size_t)row * a.vdim * a.npts;
+    const int n = a.vdim * a.npts;
+    double acc = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const double x = t[i];
+        acc += a.weights[i % a.npts] * x * x;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) a.out[row] = acc;
+}
+
 struct PointMajorArgs {
     const double* in;  // [ntables][rows][npts]
     double* out;       // [ntables][npts][rows]

@@ -178,3 +178,39 @@ class CiarletElement(FiniteElement):
     @staticmethod
     def is_nodal():
         return True
+
+
+def entity_support_dofs(elem, entity_dim):
+    """{entity id: dofs whose basis functions do not vanish on that entity} for the sub-entities of dimension
+    ``entity_dim`` (FIAT/finite_element.py:222-264; FInAT stands on the same computation,
+    finat/finiteelementbase.py:85-119): the default rule of degree max(2 degree, 1) on the reference sub-entity, mapped
+    onto every entity of that dimension, ONE batched order-0 tabulation of all of them on the device, the squared norm of
+    every basis function against the weights on the device (fx_tables_squared_norm), cut at 1e-8."""
+    import torch
+    from .quadrature import create_quadrature
+    cache = elem.__dict__.setdefault("_entity_support_dofs", {})
+    if entity_dim in cache:
+        return cache[entity_dim]
+    ref_el = elem.get_reference_element()
+    entity_cell = ref_el.construct_subelement(entity_dim)
+    quad = create_quadrature(entity_cell, max(2 * elem.degree(), 1))
+    weights = numpy.asarray(quad.get_weights(), dtype=float)
+    qpts = numpy.asarray(quad.get_points(), dtype=float).reshape(len(weights), -1)
+    ids = list(elem.entity_dofs()[entity_dim].keys())
+    eps = 1.e-8
+    if hasattr(elem, "entity_map"):
+        # simplex elements: every entity is one request of the same batch, the entity transform runs on the device
+        sd = ref_el.get_spatial_dimension()
+        blocks = []
+        for f in ids:
+            emap = elem.entity_map((entity_dim, f))
+            blocks.append(runtime._as_device(qpts, runtime.Context.get()) if emap is None else runtime.map_points(*emap, qpts))
+        pts = torch.stack(blocks).reshape(len(ids), len(weights), sd)
+        tabs = elem.tabulate_batch(0, pts)[:, 0]                        # (nent, ndof, *value_shape, npts)
+    else:
+        # tensor-product elements: the factors' entity transforms differ per entity (tabulate_batch(..., entity=))
+        tabs = torch.cat([elem.tabulate_batch(0, qpts[None], entity=(entity_dim, f))[:, 0] for f in ids])
+    ints = runtime.fetch(runtime.tables_squared_norm(tabs, weights))
+    result = {f: [dof for dof, i in enumerate(ints[k]) if i > eps] for k, f in enumerate(ids)}
+    cache[entity_dim] = result
+    return result

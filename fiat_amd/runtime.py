@@ -354,6 +354,22 @@ def classify_tables(tables, rtol=1e-5, ctx=None, stream=None):
     return stats
 
 
+def tables_squared_norm(tables, weights, ctx=None, stream=None):
+    """``tables[n, rows, *value_shape, npts]`` (order-0 tables at the points of one rule) and the rule's ``weights[npts]``
+    -> device tensor ``[n, rows]`` of squared L2 norms (fx_tables_squared_norm; FIAT/finite_element.py:250-260)."""
+    ctx = ctx or Context.get()
+    tables = _as_device(tables, ctx)
+    weights = _as_device(weights, ctx)
+    if tables.dim() < 3 or weights.dim() != 1 or weights.shape[0] != tables.shape[-1]:
+        raise ValueError("tables must have shape (n, rows, ..., npts) and weights (npts,)")
+    n, rows, npts = int(tables.shape[0]), int(tables.shape[1]), int(tables.shape[-1])
+    vdim = int(np.prod(tables.shape[2:-1], dtype=np.int64)) if tables.dim() > 3 else 1
+    out = torch.empty((n, rows), dtype=torch.float64, device=ctx.device)
+    check(lib.fx_tables_squared_norm(ctx.handle, n, rows, vdim, npts, _dev_ptr(tables), _dev_ptr(weights), _dev_ptr(out),
+                                     _stream_ptr(stream)))
+    return out
+
+
 def tables_point_major(tables, out=None, ctx=None, stream=None):
     """``tables[..., rows, npts]`` -> a new contiguous device tensor ``[..., npts, rows]`` (fx_tables_point_major)."""
     ctx = ctx or Context.get()

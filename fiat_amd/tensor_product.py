@@ -69,7 +69,8 @@ class TensorProductElement:
         return self.formdegree
 
     def degree(self):
-        return self.A.degree() + self.B.degree()
+        """The reference's ``polydegree`` (FIAT/tensor_product.py:215-219): the maximum over the factors."""
+        return max(self.A.degree(), self.B.degree())
 
     def space_dimension(self):
         return self.A.space_dimension() * self.B.space_dimension()

@@ -244,6 +244,13 @@ int fx_collapsed_quadrature(fx_ctx* ctx, int sd, int m, const double* verts, dou
  * numpy's atol).  NaN entries give NaN stats.  tables, stats[ntables][2]: device pointers. */
 int fx_classify_tables(fx_ctx* ctx, int64_t ntables, int rows, int npts, double rtol,
                        const double* tables, double* stats, void* stream);
+/* FIAT/finite_element.py:222-264 (entity_support_dofs; FInAT's twin finat/finiteelementbase.py:85-119): the squared
+ * L2 norm of every basis function over a sub-entity, out[t][r] = sum_p weights[p] sum_c tables[t][r][c][p]^2 for
+ * `ntables` device-resident order-0 tables [rows][vdim][npts] evaluated at the points of ONE quadrature rule
+ * (weights[npts]) mapped onto the entities (fx_map_points + fx_tabulate_batch); a dof belongs to the support of
+ * entity t when out[t][dof] > 1e-8.  tables, weights, out[ntables][rows]: device pointers. */
+int fx_tables_squared_norm(fx_ctx* ctx, int64_t ntables, int rows, int vdim, int npts, const double* tables,
+                           const double* weights, double* out, void* stream);
 /* [ntables][rows][npts] -> [ntables][npts][rows]: the layout FInAT hands tables to generated kernels
  * in (finat/runtime_tabulated.py:79: point extents, then index_shape + value_shape).  in != out. */
 int fx_tables_point_major(fx_ctx* ctx, int64_t ntables, int rows, int npts, const double* in,

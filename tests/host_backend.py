@@ -100,6 +100,19 @@ def _vandermonde_solve_batch(A, B, ctx=None, return_V=False):
     return (X, V) if return_V else X
 
 
+def _map_points(M, b, pts, ctx=None, stream=None):
+    b = np.asarray(b, dtype=float).reshape(-1)
+    M = np.asarray(M, dtype=float).reshape(len(b), -1)
+    pts = np.asarray(pts, dtype=float)
+    return torch.as_tensor(pts @ M.T + b if M.shape[1] else np.broadcast_to(b, pts.shape[:-1] + (len(b),)).copy())
+
+
+def _tables_squared_norm(tables, weights, ctx=None, stream=None):
+    t = np.asarray(tables, dtype=float)
+    t = t.reshape(t.shape[0], t.shape[1], -1, t.shape[-1])
+    return torch.as_tensor(np.einsum("nrcp,nrcp,p->nr", t, t, np.asarray(weights, dtype=float)))
+
+
 @pytest.fixture
 def oracle_backend(monkeypatch):
     from fiat_amd import runtime
@@ -108,4 +121,6 @@ def oracle_backend(monkeypatch):
     monkeypatch.setattr(runtime, "LineLagrange", _LineLagrange)
     monkeypatch.setattr(runtime, "riesz_assemble", _riesz_assemble)
     monkeypatch.setattr(runtime, "vandermonde_solve_batch", _vandermonde_solve_batch)
+    monkeypatch.setattr(runtime, "map_points", _map_points)
+    monkeypatch.setattr(runtime, "tables_squared_norm", _tables_squared_norm)
     return runtime

@@ -1,7 +1,11 @@
 """FInAT-side adapter: the arrays finat/fiat_elements.py:60-123 would wrap in GEM
-literals, the run-time-tabulated arguments (finat/runtime_tabulated.py:68-95) and the factor tables of
-finat/tensor_product.py:103-144, served from device tables.  finat itself is not importable in the build
-container (needs ufl): the expected values restate the cited lines on top of FIAT-parity tabulations."""
+literals, the dual-basis weight tensors (:163-262), the run-time-tabulated arguments (finat/runtime_tabulated.py:68-95),
+the factor tables of finat/tensor_product.py:98-144 and entity_support_dofs (finat/finiteelementbase.py:85-119,
+FIAT/finite_element.py:222-264), served from device tables and compared with tests/golden/finat.npz -- outputs of the
+UNMODIFIED reference modules (tests/golden/make_golden_finat.py imports them under a bare ``finat`` package object, so
+that finat/__init__.py, the only importer of the absent ``ufl`` on this path, never runs; GEM expressions evaluated with
+gem.interpreter.evaluate).  The tests further down that compare the adapter with this package's own ``tabulate`` cover
+the batch forms the reference does not have."""
 import numpy as np
 import pytest
 
@@ -229,3 +233,174 @@ def test_macro_elements_are_not_cellwise_constant(fa, variant):
     for alpha in ((1, 0), (0, 1)):
         assert bres[alpha].kind == ad.POINTWISE
         np.testing.assert_allclose(bres[alpha].array.cpu().numpy()[0], raw[alpha], atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# against the reference (tests/golden/finat.npz)
+KINDS = {0: "pointwise", 1: "cellwise_constant", 2: "zero"}
+BE = [("P2tri", "Lagrange", 2, 2, {}), ("P3tet", "Lagrange", 3, 3, {}), ("P1tet", "Lagrange", 3, 1, {}),
+      ("DG1tet", "DiscontinuousLagrange", 3, 1, {}), ("N2tet", "Nedelec", 3, 2, {}), ("RT2tet", "RaviartThomas", 3, 2, {}),
+      ("RT1tri", "RaviartThomas", 2, 1, {}), ("N2ndtet", "NedelecSecondKind", 3, 1, {}), ("Regge1tri", "Regge", 2, 1, {}),
+      ("P1iso2tri", "Lagrange", 2, 1, {"variant": "equispaced,iso(2)"}),
+      ("P1alfeldtri", "Lagrange", 2, 1, {"variant": "equispaced,alfeld"})]
+
+
+@pytest.mark.parametrize("name,cls,sd,degree,kw", BE, ids=[b[0] for b in BE])
+def test_basis_evaluation_vs_reference(fa, golden, name, cls, sd, degree, kw):
+    """finat/fiat_elements.py:60-123: every table, and which of them the reference stored without a point index
+    (cellwise constant) or as gem.Zero."""
+    fiat_amd, ad = fa
+    g = golden("finat")
+    assert name in g["be_cases"]
+    _, _, order, fdeg, is_simplex = (int(x) for x in g[f"be_{name}_meta"])
+    el = getattr(fiat_amd, cls)(fiat_amd.ufc_simplex(sd), degree, **kw)
+    fe = ad.FiatElement(el)
+    assert fe.degree == fdeg and fe._is_simplex() == bool(is_simplex)
+    assert list(fe.index_shape + tuple(fe.value_shape)) == g[f"be_{name}_shape"].tolist()
+    pts = g[f"be_{name}_pts"]
+    res = fe.basis_evaluation(order, ad.PointSet(pts))
+    alphas = [a for k in range(order + 1) for a in fiat_amd.mis(sd, k)]
+    assert list(res) == alphas
+    for t, alpha in enumerate(alphas):
+        want = g[f"be_{name}_t{t}"]
+        assert res[alpha].kind == KINDS[int(g[f"be_{name}_kinds"][t])], alpha
+        assert res[alpha].shape == want.shape, alpha
+        tol = 1e-12 if sum(alpha) == 0 else 1e-10
+        assert np.abs(res[alpha].array - want).max() <= tol * max(1.0, np.abs(want).max()), alpha
+    # the batch form on the device: request 0 = the reference's point set, request 1 = the same points reversed
+    batch = np.stack([pts, pts[::-1]])
+    bres = fe.basis_evaluation_batch(order, batch)
+    for t, alpha in enumerate(alphas):
+        want = g[f"be_{name}_t{t}"]
+        got = bres[alpha].array.cpu().numpy()
+        assert bres[alpha].kind == KINDS[int(g[f"be_{name}_kinds"][t])]
+        tol = 1e-12 if sum(alpha) == 0 else 1e-10
+        if bres[alpha].kind == "zero":
+            assert got.shape == want.shape and not got.any()
+        else:
+            assert np.abs(got[0] - want).max() <= tol * max(1.0, np.abs(want).max()), alpha
+            if bres[alpha].kind == "pointwise":
+                assert np.abs(got[1] - want[..., ::-1]).max() <= tol * max(1.0, np.abs(want).max()), alpha
+
+
+def test_basis_evaluation_on_a_facet_vs_reference(fa, golden):
+    fiat_amd, ad = fa
+    g = golden("finat")
+    fe = ad.FiatElement(fiat_amd.Lagrange(fiat_amd.ufc_simplex(3), 2))
+    res = fe.basis_evaluation(1, ad.PointSet(g["be_facet_pts"]), entity=(2, 1))
+    for t, alpha in enumerate([a for k in range(2) for a in fiat_amd.mis(3, k)]):
+        np.testing.assert_allclose(res[alpha].array, g[f"be_facet_t{t}"], rtol=0, atol=1e-11)
+
+
+DB = [("P2tri", "Lagrange", 2, 2), ("P3tet", "Lagrange", 3, 3), ("DG2tet", "DiscontinuousLagrange", 3, 2),
+      ("RT2tri", "RaviartThomas", 2, 2), ("N2tet", "Nedelec", 3, 2), ("BDM1tet", "BrezziDouglasMarini", 3, 1),
+      ("Regge1tri", "Regge", 2, 1), ("RT2tet", "RaviartThomas", 3, 2)]
+
+
+@pytest.mark.parametrize("name,cls,sd,degree", DB, ids=[d[0] for d in DB])
+def test_dual_basis_vs_reference(fa, golden, name, cls, sd, degree):
+    """finat/fiat_elements.py:163-262: Q, the unique points and the Kronecker-delta fact, for elements constructed on
+    the device; then Q applied on the device to the reference's own basis tables gives the identity."""
+    fiat_amd, ad = fa
+    g = golden("finat")
+    el = getattr(fiat_amd, cls)(fiat_amd.ufc_simplex(sd), degree)
+    fe = ad.FiatElement(el)
+    Q, ps = fe.dual_basis
+    np.testing.assert_allclose(ps.points, g[f"db_{name}_pts"], rtol=0, atol=1e-14)
+    assert Q.shape == g[f"db_{name}_Q"].shape
+    np.testing.assert_allclose(Q, g[f"db_{name}_Q"], rtol=0, atol=1e-13)
+    assert fe.Q_is_identity == bool(g[f"db_{name}_identity"])
+    phi = el.tabulate(0, ps.points)[(0,) * sd]
+    values = np.moveaxis(phi, -1, 1)                     # (ndof "cells", npts, *value_shape)
+    dofs = fe.dual_evaluation_batch(values).cpu().numpy()
+    np.testing.assert_allclose(dofs, np.eye(el.space_dimension()), rtol=0, atol=1e-11)
+
+
+def test_runtime_tabulated_names_vs_reference(fa, golden):
+    fiat_amd, ad = fa
+    g = golden("finat")
+    cell = fiat_amd.ufc_simplex(1)
+    rt = ad.RuntimeTabulated(cell, 3, variant="equispaced", shift_axes=1, restriction='+', continuous=True)
+    ps = ad.PointSet(np.linspace(0.1, 0.9, 5)[:, None])
+    args = rt.basis_evaluation(2, ps)
+    assert [a.name for a in args.values()] == [str(n) for n in g["rt_names"][:3]]
+    assert [list(a.shape) for a in args.values()] == g["rt_shapes"][:3, :2].tolist()
+    # the device fills arguments of exactly those names and shapes
+    dev = rt.tabulate_arguments(2, ps.points[None, :, 0], fiat_amd.Lagrange(cell, 3))
+    assert sorted(dev) == sorted(str(n) for n in g["rt_names"][:3])
+    assert all(tuple(v.shape[1:]) == tuple(g["rt_shapes"][0, :2]) for v in dev.values())
+
+
+def test_tensor_product_vs_reference(fa, golden):
+    """finat/tensor_product.py:98-144 evaluated by the reference on a tensor point set: the product of the adapter's
+    factor tables under its multi-index split equals the reference's product tables, including the point axis the
+    reference drops for a cellwise-constant factor table."""
+    fiat_amd, ad = fa
+    g = golden("finat")
+    cell = fiat_amd.ufc_simplex(1)
+    fes = [ad.FiatElement(fiat_amd.Lagrange(cell, 2)), ad.FiatElement(fiat_amd.Lagrange(cell, 3)),
+           ad.FiatElement(fiat_amd.DiscontinuousLagrange(cell, 1))]
+    tp = ad.TensorProductElement(fes)
+    pss = [ad.PointSet(g[f"tp_coords{i}"]) for i in range(3)]
+    factor_results, deltas = tp.basis_evaluation(1, pss)
+    assert [list(d) for d in deltas] == g["tp_deltas"].tolist()
+    for t, (Delta, ds) in enumerate(deltas.items()):
+        arrs, present = [], []
+        for fr, d, ps in zip(factor_results, ds, pss):
+            tab = fr[d]
+            present.append(int(tab.kind == ad.POINTWISE))
+            arrs.append(tab.array if tab.kind == ad.POINTWISE else tab.array[..., None])
+        assert present == g[f"tp_present{t}"].tolist()
+        prod = np.einsum("ai,bj,ck->abcijk", *arrs)
+        want = g[f"tp_t{t}"]
+        assert prod.shape == want.shape
+        np.testing.assert_allclose(prod, want, rtol=0, atol=1e-11)
+
+
+ESD = [("P3tet", "Lagrange", 3, 3), ("N2tet", "Nedelec", 3, 2), ("RT2tet", "RaviartThomas", 3, 2),
+       ("DG2tet", "DiscontinuousLagrange", 3, 2), ("P2tri", "Lagrange", 2, 2), ("RT1tri", "RaviartThomas", 2, 1),
+       ("BDM1tet", "BrezziDouglasMarini", 3, 1), ("P1int", "Lagrange", 1, 1)]
+
+
+def _esd_flat(by_dim):
+    out = {}
+    for dim, ents in by_dim.items():
+        tag = "-".join(map(str, dim)) if isinstance(dim, tuple) else str(dim)
+        for f, dofs in ents.items():
+            out[f"{tag}_{f}"] = list(dofs)
+    return out
+
+
+@pytest.mark.parametrize("name,cls,sd,degree", ESD, ids=[e[0] for e in ESD])
+def test_entity_support_dofs_vs_reference(fa, golden, name, cls, sd, degree):
+    """FIAT/finite_element.py:222-264 and finat/finiteelementbase.py:85-119: equal dicts, computed on the device (one
+    batched facet tabulation per entity dimension + fx_tables_squared_norm)."""
+    fiat_amd, ad = fa
+    from fiat_amd.finite_element import entity_support_dofs
+    g = golden("finat")
+    el = getattr(fiat_amd, cls)(fiat_amd.ufc_simplex(sd), degree)
+    want = {str(k): g[f"esd_fiat_{name}_{k}"].tolist() for k in g[f"esd_fiat_{name}_keys"]}
+    assert _esd_flat({dim: entity_support_dofs(el, dim) for dim in range(sd + 1)}) == want
+    want_finat = {str(k): g[f"esd_finat_{name}_{k}"].tolist() for k in g[f"esd_finat_{name}_keys"]}
+    assert _esd_flat(ad.FiatElement(el).entity_support_dofs()) == want_finat
+
+
+def test_entity_support_dofs_of_a_prism_vs_reference(fa, golden):
+    fiat_amd, ad = fa
+    from fiat_amd.finite_element import entity_support_dofs
+    g = golden("finat")
+    prism = fiat_amd.TensorProductElement(fiat_amd.Lagrange(fiat_amd.ufc_simplex(2), 2), fiat_amd.Lagrange(fiat_amd.ufc_simplex(1), 1))
+    assert prism.degree() == int(g["esd_prism_degree"])
+    want = {str(k): g[f"esd_fiat_P2xP1prism_{k}"].tolist() for k in g["esd_fiat_P2xP1prism_keys"]}
+    assert _esd_flat({dim: entity_support_dofs(prism, dim) for dim in sorted(prism.entity_dofs())}) == want
+
+
+def test_squared_norm_kernel(fa):
+    from fiat_amd import runtime
+    rng = np.random.default_rng(4)
+    for shape in [(3, 20, 7), (2, 15, 3, 23), (1, 1, 1), (5, 9, 2, 2, 6), (4, 130, 70)]:
+        x = rng.standard_normal(shape)
+        w = rng.uniform(0.1, 1.0, shape[-1])
+        got = runtime.tables_squared_norm(x, w).cpu().numpy()
+        want = np.einsum("nrcp,p->nr", x.reshape(shape[0], shape[1], -1, shape[-1]) ** 2, w)
+        np.testing.assert_allclose(got, want, rtol=1e-13, atol=0)
