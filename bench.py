@@ -46,7 +46,8 @@ WORKLOADS = {
     "c3": ("Nedelec+RaviartThomas", 3, 2, 1, 23, 50_000),        # configs[2]: 25 000 N2 + 25 000 RT2 per step
     "dg6tet": ("DiscontinuousLagrange", 3, 6, 2, 23, 125_000),   # configs[3]: 1 M over 8 GPUs = 125 000 per GPU
     "dg6tet122": ("DiscontinuousLagrange", 3, 6, 2, 122, 8_000),  # C4 stress variant: 122 points (823 kB per request)
-    "hex": ("P4 x P4 x P4", 3, 4, 1, 125, 200_000 // 8),         # configs[4]: 200 k over 8 GPUs, 5^3 tensor grid
+    "hex": ("P4 x P4 x P4", 3, 4, 1, 125, 200_000),              # configs[4]: batch 200 k (100 GB of tables: fits one GPU), 5^3 tensor grid
+    "hex25k": ("P4 x P4 x P4", 3, 4, 1, 125, 25_000),            # the round-1/2 reading of configs[4] (200 k over 8 GPUs), kept for comparison
     # low-order shapes (not BASELINE configs; for tools/kernel_ab.py)
     "p1tet": ("Lagrange", 3, 1, 1, 4, 2_000_000),
     "p2tet": ("Lagrange", 3, 2, 1, 11, 300_000),
@@ -120,9 +121,9 @@ class SimplexWorkload:
             ntab = ps.out_shape(order, 1, 1)[1]
             part["rows"], part["ntab"] = rows, ntab
             if shared:
-                from oracle import fiat_oracle as fo     # vertices of the UFC cell only (bench is allowed to)
                 rng = np.random.default_rng(1000 + rank + i)
-                part["verts_h"] = fo.UFC_SIMPLEX[sd][None] + rng.uniform(-0.2, 0.2, size=(n, sd + 1, sd))
+                ufc = np.array(fiat_amd.ufc_simplex(sd).get_vertices(), dtype=float)
+                part["verts_h"] = ufc[None] + rng.uniform(-0.2, 0.2, size=(n, sd + 1, sd))
                 ref_h = synth_points(sd, 1, npts, seed=6)[0]
                 bary = np.concatenate([1.0 - ref_h.sum(axis=1, keepdims=True), ref_h], axis=1)
                 part["pts_h"] = np.einsum("pv,rvd->rpd", bary, part["verts_h"])   # the same points, for the check
@@ -311,10 +312,37 @@ def spawn_ranks(args):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stderr=subprocess.PIPE, text=True, bufsize=1))
+
+    def relay(r, pipe):     # every line of a child's stderr carries its rank
+        for text in pipe:
+            sys.stderr.write(f"[rank {r}] {text}")
+            sys.stderr.flush()
+
+    relays = [threading.Thread(target=relay, args=(r, p.stderr), daemon=True) for r, p in enumerate(procs)]
+    for t in relays:
+        t.start()
+    # wait for all; as soon as one rank fails the others are terminated (they would wait in a collective for ever)
+    rc, failed = 0, None
+    live = set(range(args.gpus))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc = max(rc, abs(code))
+                if failed is None:
+                    failed = r
+                    print(f"bench.py: rank {r} exited with status {code}; terminating the other ranks", file=sys.stderr)
+                    for q in live:
+                        procs[q].terminate()
+        if live:
+            time.sleep(0.05)
+    for t in relays:
+        t.join(timeout=2.0)
     return rc
 
 
@@ -349,10 +377,22 @@ def run(args):
         if world > 1:
             dist.barrier()
 
-    cls = HexWorkload if args.workload == "hex" else SimplexWorkload
+    cls = HexWorkload if args.workload.startswith("hex") else SimplexWorkload
     wl = cls(args.workload, args.batch, rank, shared=args.shared_points)
     batch = wl.batch
     stream = torch.cuda.current_stream()
+
+    # the driver's protocol WITHOUT the ramp, for the record: W warm-up + K timed launches from an idle GPU
+    torch.cuda.synchronize()
+    time.sleep(0.5)
+    for _ in range(args.warmup):
+        wl.step()
+    torch.cuda.synchronize()
+    t_cold = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    torch.cuda.synchronize()
+    ms_per_step_cold = (time.perf_counter() - t_cold) / args.steps * 1e3
 
     # clock ramp (disclosed in the line, not part of W): the first launches after idle run ~25 % slower
     t_ramp = time.perf_counter()
@@ -413,6 +453,10 @@ def run(args):
         roofline = dict(roofline, bound="mfma", achieved=tf, peak=F64_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / F64_PEAK_TFLOPS,
                         algorithmic_flops_per_launch=aflops,
                         hbm={"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS})
+    # north_star asks for both: achieved HBM GB/s AND fp64 (MFMA) utilisation against the gfx950 peak
+    tf_alg = aflops / (kernel_ms * 1e-3) / 1e12
+    roofline["mfma"] = {"algorithmic_tflops": tf_alg, "peak_tflops": F64_PEAK_TFLOPS, "frac": tf_alg / F64_PEAK_TFLOPS,
+                        "flop_per_byte": aflops / abytes, "busy_frac_pmc": None}
     prof = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
     if os.path.exists(prof) and not args.shared_points:
         try:
@@ -420,6 +464,9 @@ def run(args):
                 tr = json.load(f)
             if tr.get("workload") == args.workload and tr.get("batch") == batch:
                 roofline["traffic"] = tr["hbm_bytes_per_launch"]
+                if tr.get("mfma_busy_frac") is not None:
+                    # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x kernel cycles) of the profile the traffic comes from
+                    roofline["mfma"]["busy_frac_pmc"] = tr["mfma_busy_frac"]
                 roofline["traffic_source"] = (f"profiles/traffic_{args.workload}.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
                                               "of this command on an earlier box, NOT measured in this run")
         except Exception:
@@ -441,6 +488,7 @@ def run(args):
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_cold": ms_per_step_cold,      # same W + K launches from an idle GPU, before the clock ramp (this rank)
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -461,32 +509,43 @@ def run(args):
             line["cpu_baseline"] = wl.cpu_baseline()
 
     # with-gather leg: after the line is complete, under a watchdog -- a stuck exchange must not cost the
-    # compute-only measurement
-    printed = threading.Event()
+    # compute-only measurement, and it must not look like success either: the line is still printed, the process
+    # then exits with status 3 (never re-exec'ed: it has touched the GPU)
+    lock = threading.Lock()
+    printed = [False]
 
-    def emit():
-        if rank == 0 and not printed.is_set():
-            printed.set()
-            print(json.dumps(line), flush=True)
+    def emit(extra=None):
+        with lock:
+            if extra is not None and line is not None:
+                line["allgather"] = extra
+            if rank == 0 and not printed[0]:
+                printed[0] = True
+                print(json.dumps(line), flush=True)
 
+    failed = False
     if world > 1 and not args.no_allgather and len(wl.parts) == 1 and not args.shared_points:
         def bail():
-            if rank == 0:
-                line["allgather"] = {"error": f"no result within {args.allgather_timeout} s"}
-            emit()
-            os._exit(0)
+            emit({"error": f"no result within {args.allgather_timeout} s"})
+            print(f"bench.py: the all-gather leg did not finish within {args.allgather_timeout} s", file=sys.stderr, flush=True)
+            os._exit(3)
         dog = threading.Timer(args.allgather_timeout, bail)
         dog.daemon = True
         dog.start()
         try:
             res = allgather_leg(wl, world, rank, args, barrier)
-            if rank == 0:
-                line["allgather"] = res
-        except Exception as exc:     # report, keep the compute-only result
-            if rank == 0:
-                line["allgather"] = {"error": f"{type(exc).__name__}: {exc}"}
+        except Exception as exc:     # report, keep the compute-only result, fail the process
+            res = {"error": f"{type(exc).__name__}: {exc}"}
+            failed = True
         dog.cancel()
-    emit()
+        if isinstance(res, dict) and res.get("verify") is not None and not res["verify"].get("ok", False):
+            failed = True
+        emit(res)
+    else:
+        emit()
+    if failed:
+        print("bench.py: the all-gather leg failed (see the line's \"allgather\" field)", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(3)     # peers may be stuck in a collective: no orderly teardown of the process group
     if world > 1:
         dist.destroy_process_group()
 
@@ -504,7 +563,21 @@ def allgather_leg(wl, world, rank, args, barrier):
     reps = max(2, min(10, args.steps // 4))
     res = {"impl": gather.impl, "algo": args.allgather_algo if gather.impl == "rccl" else "torch.distributed",
            "gathered_bytes_per_gpu": world * out.numel() * 8, "reps": reps}
+    if os.environ.get("FIAT_AMD_BENCH_FORCE_GATHER_TIMEOUT") and rank == world - 1:
+        time.sleep(args.allgather_timeout + 30.0)     # test hook (tests/test_bench_launch.py): a rank that never joins
+    # replicated or staged?  Decided COLLECTIVELY: rank 0 keeps an extra buffer in the allocator's cache, so the ranks'
+    # own free-memory readings differ and could choose different (mismatched) collectives.
+    torch.cuda.empty_cache()
     free_bytes, _ = torch.cuda.mem_get_info()
+    fb = torch.tensor([float(free_bytes)], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+    torch.distributed.all_reduce(fb, op=torch.distributed.ReduceOp.MIN)
+    free_bytes = int(fb.item())
+    res["free_bytes_min_over_ranks"] = free_bytes
+    if args.allgather_verify:
+        res["verify"] = verify_gather(wl, gather, world, rank, per, out, tail)
+        if not res["verify"]["ok"]:
+            gather.close()
+            return res
     if args.allgather_mode == "ring" or (args.allgather_mode == "auto" and world * out.numel() * 8 > 0.6 * free_bytes):
         # too large to replicate (C4: 8 x 19 GB, at 122 points 8 x 103 GB): every table still visits every GPU, chunk by chunk,
         # through a ring of staging buffers the consumer drains (here: a reduction that touches every gathered byte)
@@ -571,6 +644,51 @@ def allgather_leg(wl, world, rank, args, barrier):
     return res
 
 
+def verify_gather(wl, gather, world, rank, per, out, tail):
+    """Data check of the exchange on the first N > 1 run: every rank tabulates the SAME requests (rank 0's inputs,
+    broadcast), so after the gather every foreign block must equal the rank's own block bit for bit -- which pins the
+    stride / offset arithmetic of FX_GATHER_DIRECT, one-shot and chunked, rather than just finiteness."""
+    import torch
+    import torch.distributed as dist
+    nv = min(per, 4096)
+    dev = out.device
+    inputs = wl.grid if wl.parts[0] is None else wl.parts[0]["pts"]      # hexahedron: per-request 1-D grids
+    src = inputs[:nv].clone()
+    if dist.get_backend() == "nccl":
+        dist.broadcast(src, src=0)
+    else:
+        h = src.cpu()
+        dist.broadcast(h, src=0)
+        src.copy_(h)
+    saved = inputs[:nv].clone()
+    inputs[:nv].copy_(src)
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    try:
+        full = torch.full((world * nv,) + tail, float("nan"), dtype=torch.float64, device=dev)
+        blocks = full.view(world, nv, *tail)
+        mine = blocks[rank]
+        wl.produce_rows(0, nv, mine)
+        gather.all_gather(mine, world * nv, out=full)
+        sync()
+        one_shot = [bool(torch.equal(blocks[p], mine)) for p in range(world)]
+        full.fill_(float("nan"))
+        chunk = max(1, nv // 5 + 1)                                 # ragged last chunk
+        gather.tabulate_allgather(wl.produce_rows, nv, nv, chunk, full)
+        sync()
+        chunked = [bool(torch.equal(blocks[p], mine)) for p in range(world)]
+    finally:
+        inputs[:nv].copy_(saved)
+    ok = torch.tensor([1.0 if all(one_shot) and all(chunked) else 0.0], dtype=torch.float64,
+                      device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return {"ok": bool(ok.item() == 1.0), "requests": nv, "one_shot_blocks_equal": one_shot, "chunked_blocks_equal": chunked,
+            "rank": rank}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -587,6 +705,9 @@ def main():
     ap.add_argument("--allgather-mode", default="auto", choices=["auto", "replicated", "ring"],
                     help="replicated: every GPU ends with all tables; ring: tables too large to replicate pass through staging buffers")
     ap.add_argument("--allgather-timeout", type=float, default=120.0)
+    ap.add_argument("--allgather-verify", action="store_true",
+                    help="N > 1: before timing the exchange, every rank tabulates the same requests and compares every "
+                         "gathered block with its own (bit for bit); a mismatch fails the run (exit 3)")
     ap.add_argument("--shared-points", action="store_true",
                     help="variant (SURVEY.md 8d): ONE 23-point rule on the reference cell pushed forward to per-request "
                          "physical cells (fx_tabulate_batch_shared) instead of per-request random points")

@@ -98,7 +98,7 @@ _SIGS = {
     "fx_comm_unique_id": (c_int, [c_void_p]),
     "fx_comm_create": (c_int, [c_void_p, c_int, c_int, c_void_p, POINTER(c_void_p)]),
     "fx_comm_destroy": (c_int, [c_void_p]),
-    "fx_allgather_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "fx_allgather_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "fx_ctx_check": (c_int, [c_void_p, c_void_p]),
     "fx_time_tabulate_batch": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, POINTER(c_float)]),

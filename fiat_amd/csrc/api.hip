@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <string>
+#include <numeric>
 #include <vector>
 
 #include "../../include/fiat_amd.h"
@@ -204,7 +205,7 @@ struct fx_line_element {
 extern "C" {
 
 const char* fx_last_error(void) { return g_err.c_str(); }
-int fx_abi_version(void) { return 1; }
+int fx_abi_version(void) { return 2; }  // 2: fx_allgather_tables takes recv_count, fx_tables_squared_norm
 
 int fx_num_tables(int sd, int order) {
     if (sd < 1 || sd > 3 || order < 0) return fail(FX_EINVAL, "fx_num_tables: bad sd/order");
@@ -228,7 +229,12 @@ int fx_ctx_create(int device_id, fx_ctx** out) {
     c->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
     if (c->lds_per_cu <= 0) c->lds_per_cu = 160 * 1024;
     c->name = prop.gcnArchName;
-    if (hipMalloc(&c->d_trash, 64 * 1024) != hipSuccess || hipMalloc(&c->d_queue, FX_QUEUE_SLOTS * 128) != hipSuccess ||
+#if defined(FX_DBG) && (FX_DBG & 512)
+    const size_t trash_bytes = 256 * 1024;  // wave timelines of the ablation build
+#else
+    const size_t trash_bytes = 64 * 1024;
+#endif
+    if (hipMalloc(&c->d_trash, trash_bytes) != hipSuccess || hipMalloc(&c->d_queue, FX_QUEUE_SLOTS * 128) != hipSuccess ||
         hipMemset(c->d_queue, 0, FX_QUEUE_SLOTS * 128) != hipSuccess) {
         if (c->d_trash) (void)hipFree(c->d_trash);
         delete c;
@@ -638,8 +644,39 @@ hipError_t report_wave_lifetimes(const double* trash, int grid, int wg_waves) {
         std::vector<double> v;
         for (int i = 0; i < nw; ++i)
             if (((i / wg_waves) % 8) == x) v.push_back(us[i]);
+        if (v.empty()) continue;
         std::sort(v.begin(), v.end());
         fprintf(stderr, " xcd%d %.0f..%.0f..%.0f", x, v[0], v[v.size() / 2], v.back());
+    }
+    {   // absolute timeline: when did the waves enter the kernel, when did they leave (relative to the first entry)
+        std::vector<double> ab(2 * nw), ini(nw);
+        if (hipMemcpy(ab.data(), trash + 2048 + 6000, ab.size() * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(ini.data(), trash + 2048 + 12000, ini.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            double t0 = 1e300, t1 = 0;
+            for (int i = 0; i < nw; ++i) {
+                t0 = std::min(t0, ab[2 * i]);
+                t1 = std::max(t1, ab[2 * i + 1]);
+            }
+            std::vector<double> st(nw), en(nw);
+            for (int i = 0; i < nw; ++i) {
+                st[i] = (ab[2 * i] - t0) / 100.0;
+                en[i] = (t1 - ab[2 * i + 1]) / 100.0;
+            }
+            std::vector<double> ss = st, se = en, si = ini;
+            std::sort(ss.begin(), ss.end());
+            std::sort(se.begin(), se.end());
+            std::sort(si.begin(), si.end());
+            fprintf(stderr, "\n span %.1f us | entry after first entry: p50 %.1f p90 %.1f max %.1f us | init->first unit: p50 %.1f max %.1f us | idle before the last exit: p10 %.1f p50 %.1f p90 %.1f max %.1f us (mean %.1f)",
+                    (t1 - t0) / 100.0, ss[nw / 2], ss[nw * 9 / 10], ss[nw - 1], si[nw / 2] / 100.0, si[nw - 1] / 100.0, se[nw / 10], se[nw / 2],
+                    se[nw * 9 / 10], se[nw - 1], std::accumulate(se.begin(), se.end(), 0.0) / nw);
+            for (int x = 0; x < 8; ++x) {
+                double ms = 0, me = 0;
+                int n = 0;
+                for (int i = 0; i < nw; ++i)
+                    if (((i / wg_waves) % 8) == x) ms += st[i], me += en[i], ++n;
+                if (n) fprintf(stderr, "%s xcd%d entry +%.1f idle-at-end %.1f", x == 0 ? "\n" : " |", x, ms / n, me / n);
+            }
+        }
     }
     fprintf(stderr, "\n workgroup lifetimes (max over its waves), XCD0:");
     for (int b = 0; b < grid; b += 8) {
@@ -2469,8 +2506,10 @@ int ensure_high_order(fx_ctx* ctx, fx_element* e, int order) {
     static std::mutex build_mutex;
     std::lock_guard<std::mutex> lock(build_mutex);
     if (e->high_state[order] == 1) return FX_OK;
-    if (e->high_state[order] < 0) return fail(FX_ENOTIMPL, "derivative order %d: differentiation matrices could not be built", order);
-    e->high_state[order] = -1;
+    // -1 is recorded for STRUCTURAL failures only (a singular mass matrix: retrying cannot help); transient ones (hipMalloc,
+    // a failed copy) leave the state at 0 so that the next call builds again.  The first order > 2 call per element runs
+    // null-stream launches and synchronous copies in project_derivative_matrices: it synchronises the device once.
+    if (e->high_state[order] < 0) return fail(FX_ENOTIMPL, "derivative order %d: differentiation matrices could not be built (singular mass matrix of the expansion set)", order);
     const int sd = e->sd, nexp = e->nexp;
     const int rows = (int)(e->hC.size() / (size_t)nexp);
     std::vector<double> D1((size_t)sd * nexp * nexp, 0.0);   // D1[d][j][k]
@@ -2478,8 +2517,11 @@ int ensure_high_order(fx_ctx* ctx, fx_element* e, int order) {
         std::vector<double> B;
         bool ok = false;
         int rc = project_derivative_matrices(ctx, e, 1, B, ok);
-        if (rc != FX_OK) return rc;
-        if (!ok) return fail(FX_ENOTIMPL, "derivative order %d: singular mass matrix of the expansion set", order);
+        if (rc != FX_OK) return rc;      // transient (HIP / allocation): state stays 0, the next call retries
+        if (!ok) {
+            e->high_state[order] = -1;
+            return fail(FX_ENOTIMPL, "derivative order %d: singular mass matrix of the expansion set", order);
+        }
         const int nrhs = sd * nexp;
         // members are graded by total degree (Morton order: degree s starts at C(s - 1 + sd, sd)) and differentiation
         // lowers the degree: entries with deg(k) >= deg(j) are structural zeros -- whatever the projection left there
@@ -3054,22 +3096,40 @@ int fx_comm_create(fx_ctx* ctx, int nranks, int rank, const unsigned char* id, f
 }
 
 int fx_comm_destroy(fx_comm* c) {
-    if (c && c->comm) (void)fxcomm::api().CommDestroy(c->comm);
+    if (!c) return FX_OK;
+    int rc = FX_OK;
+    if (c->comm) {
+        // exchanges are enqueued, not waited for: drain the streams they went to before the communicator is destroyed
+        if (hipSetDevice(c->ctx->device) != hipSuccess) rc = FX_EHIP;
+        if (c->used_null_stream) {
+            if (hipDeviceSynchronize() != hipSuccess) rc = FX_EHIP;
+        } else {
+            for (int i = 0; i < c->nused; ++i)
+                if (hipStreamSynchronize(c->used[i]) != hipSuccess) rc = FX_EHIP;
+        }
+        (void)hipGetLastError();
+        if (fxcomm::api().CommDestroy(c->comm) != ncclSuccess) rc = FX_EHIP;
+    }
     delete c;
-    return FX_OK;
+    return rc == FX_OK ? FX_OK : fail(FX_EHIP, "fx_comm_destroy: draining or destroying the communicator failed");
 }
 
 int fx_allgather_tables(fx_comm* c, const double* send, double* recv, int64_t count, int64_t stride, int64_t offset,
-                        int algo, void* stream) {
+                        int64_t recv_count, int algo, void* stream) {
     if (!c || !c->comm) return fail(FX_EINVAL, "fx_allgather_tables: null communicator");
     if (count < 0 || stride < 0 || offset < 0 || offset + count > stride)
         return fail(FX_EINVAL, "fx_allgather_tables: block [%lld, %lld) does not fit the stride %lld", (long long)offset,
                     (long long)(offset + count), (long long)stride);
+    // the receive extent the caller owns: nranks blocks at `stride` must fit it (the last block may end early)
+    if (recv_count < 0 || (c->nranks > 0 && (int64_t)(c->nranks - 1) * stride + offset + count > recv_count))
+        return fail(FX_EINVAL, "fx_allgather_tables: %d blocks at stride %lld (+ offset %lld, count %lld) exceed the receive buffer of %lld doubles",
+                    c->nranks, (long long)stride, (long long)offset, (long long)count, (long long)recv_count);
     if (count == 0) return FX_OK;
     if (!send || !recv) return fail(FX_EINVAL, "fx_allgather_tables: null device pointer");
     const fxcomm::Api& a = fxcomm::api();
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->ctx->device));
+    c->remember(s);
     if (algo == FX_GATHER_RING) {
         if (stride != count || offset != 0)
             return fail(FX_EINVAL, "fx_allgather_tables: FX_GATHER_RING needs blocks that tile the buffer (stride == count, offset == 0)");

@@ -74,4 +74,19 @@ struct fx_comm {
     fx_ctx* ctx = nullptr;
     ncclComm_t comm = nullptr;
     int nranks = 0, rank = 0;
+    // streams an exchange was enqueued on: fx_comm_destroy waits for them before the communicator goes away
+    // (ncclCommDestroy with work in flight is undefined)
+    hipStream_t used[4] = {nullptr, nullptr, nullptr, nullptr};
+    int nused = 0;
+    bool used_null_stream = false;
+    void remember(hipStream_t s) {
+        if (!s) {
+            used_null_stream = true;
+            return;
+        }
+        for (int i = 0; i < nused; ++i)
+            if (used[i] == s) return;
+        if (nused < 4) used[nused++] = s;
+        else used_null_stream = true;  // more streams than slots: fall back to a device-wide wait at destroy time
+    }
 };

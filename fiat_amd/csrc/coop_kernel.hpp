@@ -130,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
     for (int i = tid; i < a.img_doubles; i += 512) img[i] = 0.0;
     __syncthreads();
 
-    const int nrounds = (a.debug & 4) ? 0 : (NTAB + a.TR - 1) / a.TR;
+    const int nrounds = FX_ABL(a, 4) ? 0 : (NTAB + a.TR - 1) / a.TR;
     __shared__ double sM[9];  // Piola matrix of the current request (written by producer 0 before the K loop)
     PiolaSlots pslots;
     if constexpr (PIOLA) {
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
             // one step of an LDS-resident level (0 or 1)
             auto lds_level_step = [&](int level, int& par, int seed, int publish, double* slab, const double* d) {
                 Jet<SD, ORDER> nw, od;
-                if (a.debug & 8) {  // ablation: no LDS chain state (wrong results)
+                if (FX_ABL(a, 8)) {  // ablation: no LDS chain state (wrong results)
                     nw = a2;
                     od = b2;
                     if (level == 0) step(nw, od, 0, d); else step(nw, od, 1, d);
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
                 // readfirstlane: make the control values provably wave uniform (scalar branches,
                 // no exec-mask juggling around every level / parity test)
                 const int e1 = __builtin_amdgcn_readfirstlane(kst[ks + 1]);
-                if (a.debug & 1) e = e1;
+                if (FX_ABL(a, 1)) e = e1;
                 for (; e < e1; ++e) {
                     const int level = __builtin_amdgcn_readfirstlane(nlevel);
                     const int seed = __builtin_amdgcn_readfirstlane(nseed);
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(512, 2) void tabulate_simplex_coop(const CoopArgs a
 #pragma unroll
                     for (int m4 = 0; m4 < M4; ++m4) a4n[m4] = afr[((size_t)(MT16 + m4) * KS + kn) * 64 + lane];
                 }
-                if (!(a.debug & 2))
+                if (!FX_ABL(a, 2))
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) {
 #pragma unroll

@@ -117,11 +117,11 @@ __global__ __launch_bounds__(64 * NW) void tabulate_macro_small(const MacroSmall
                 return s;
             };
             const double tol = dist(kcells) + 1e-12;
-            const int ncell_scan = (a.debug & 1) ? 0 : a.ncell;
+            const int ncell_scan = FX_ABL(a, 1) ? 0 : a.ncell;
             for (int c = 0; c < ncell_scan; ++c)
                 if (dist(kcells + 16 + c * 28 + 12) < tol) cellmask |= 1u << c;
             if (a.unique) cellmask &= ~cellmask + 1u;
-            if (a.debug & 1) cellmask = 1u;
+            if (FX_ABL(a, 1)) cellmask = 1u;
             if (!active) cellmask = 0;
         }
         const int mult = __popc(cellmask);
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_macro_small(const MacroSmall
                 double* sp = stage + (size_t)rla * NTAB * Ls + pla;
                 for (int row0 = 0; row0 < rows; row0 += RC) {
                     const int rc = min(RC, rows - row0);
-                    const int rc_run = (a.debug & 2) ? 0 : rc;
+                    const int rc_run = FX_ABL(a, 2) ? 0 : rc;
                     for (int r = 0; r < rc_run; ++r) {
                         double acc[NTAB];
                         contract(row0 + r, acc);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_macro_small(const MacroSmall
                     // image -> HBM: one run of rc*npts doubles per (request, table)
                     const int L = rc * npts;
                     double* gchunk = gout + (size_t)row0 * npts;
-                    if (a.debug & 4) {
+                    if (FX_ABL(a, 4)) {
                     } else if (a.vec2 && rc == rows && Ls == table) {
                         // one round holds the item's whole requests: the image is contiguous in HBM
                         const int total = (Pcur * NTAB * table) >> 1;

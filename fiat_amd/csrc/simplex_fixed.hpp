@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tabulate_simplex_fixed(const Fixed
                 }
             }
         };
-        if (!(a.debug & 1)) {
+        if (!FX_ABL(a, 1)) {
             // every member lives in a register array with compile-time indices: the
             // compiler keeps only the seeds still needed by later chains alive, and
             // the recurrence never reads LDS back
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tabulate_simplex_fixed(const Fixed
 
         // ---------------- phase 2: contraction ----------------
         double* gout = a.out + (size_t)req * reqsize;
-        if (!(a.debug & 2)) {
+        if (!FX_ABL(a, 2)) {
             double breg[NT][KS];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64 * NW, 2) void tabulate_simplex_fixed(const Fixed
         wave_lds_fence();
 
         // ---------------- phase 3: image -> HBM, 16 B per lane ----------------
-        if (!(a.debug & 4)) {
+        if (!FX_ABL(a, 4)) {
             if ((reqsize & 1) == 0 && !FX_UNROLL_COPY) {
                 const v2d* s2 = reinterpret_cast<const v2d*>(phi);
                 v2d* g2 = reinterpret_cast<v2d*>(gout);

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
             Factors<SD, ORDER> F;
             int fcodim = -1;
             int last_dst = 0;
-            const int nsteps = (a.debug & 1) ? 0 : a.nsteps;
+            const int nsteps = FX_ABL(a, 1) ? 0 : a.nsteps;
             for (int s = 0; s < nsteps; ++s) {
                 // the step table is never written while the kernel runs: read through the constant address space,
                 // so that the (uniform) loads are scalar -- next to the output stores the compiler cannot prove a
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
         const int NT = (ncols + 15) >> 4;
         const bool staged = a.stage_doubles > 0;
         double* gout = a.out + (size_t)r0 * reqsize;
-        const int NTrun = (a.debug & 2) ? 0 : NT;
+        const int NTrun = FX_ABL(a, 2) ? 0 : NT;
         for (int nt = 0; nt < NTrun; ++nt) {
             // decode this lane's output column
             const int c = (nt << 4) + (lane & 15);
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_kernel(const TabArgs
             }
         }
 
-        if (staged && !(a.debug & 4)) {
+        if (staged && !FX_ABL(a, 4)) {
             wave_lds_fence();
             const long long total = (long long)Pcur * reqsize;  // doubles, contiguous in HBM
             if ((reqsize & 1) == 0) {

@@ -54,6 +54,9 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 1 : FX_PAIR_WAVES) void tabulate
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#if FX_DBG & 512
+    const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     // LDS: [A fragments, shared by the workgroup] [per wave: half image of ONE request (the
     // K-step slab of the pair aliases its start) | 64-double dump row for inactive lanes]
     constexpr int NAF = (MT16 + M4) * KS;
@@ -149,7 +152,8 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 1 : FX_PAIR_WAVES) void tabulate
     }
     long long pnext = claim();
 #if FX_DBG & 512
-    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = rt_entry;
+    const unsigned long long rt_first = __builtin_amdgcn_s_memrealtime();   // init + first claim + first point loads issued
 #endif
     // request of this lane's half of the pair (the last pair of an odd batch has no second
     // request: its lanes recompute the first one and the stores are skipped)
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 1 : FX_PAIR_WAVES) void tabulate
             eoff[nt] = ioff[nt];
             asm volatile("" : "+v"(eoff[nt]));
         }
-        if (!(a.debug & 4)) {
+        if (!FX_ABL(a, 4)) {
             wave_lds_fence();
 #pragma unroll
             for (int rq = 0; rq < RPW; ++rq) {
@@ -487,8 +491,12 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 1 : FX_PAIR_WAVES) void tabulate
     if (lane == 0) {  // ablation build: lifetime of every wave (shader cycles, 100 MHz ticks)
         const long long gw = (long long)blockIdx.x * NW + wave;
         if (gw < 3000) {
+            const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
             trash[2048 + 2 * gw] = (double)(__builtin_readcyclecounter() - clk0);
-            trash[2049 + 2 * gw] = (double)(__builtin_amdgcn_s_memrealtime() - rt0);
+            trash[2049 + 2 * gw] = (double)(rt1 - rt0);
+            trash[2048 + 6000 + 2 * gw] = (double)(rt0 & 0xffffffffffffull);   // absolute start / end (100 MHz ticks)
+            trash[2049 + 6000 + 2 * gw] = (double)(rt1 & 0xffffffffffffull);
+            trash[2048 + 12000 + gw] = (double)(rt_first - rt0);
         }
     }
 #endif

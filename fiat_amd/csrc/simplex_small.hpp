@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_small(const SmallArg
         jet_zero(zero);
         jet_zero(mem[0]);
         mem[0].v = a.phi0;
-        if (!(a.debug & 1)) {
+        if (!FX_ABL(a, 1)) {
             Factors<SD, ORDER> F;
             int fcodim = -1;
 #pragma unroll
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_small(const SmallArg
                         }
                 }
             }
-        } else if (!(a.debug & 2)) {
+        } else if (!FX_ABL(a, 2)) {
             double* sp = stage + (size_t)(active ? rl : 0) * reqsize + (active ? pl : 0);
             for (int row = 0; row < rows; ++row) {
                 CDouble* crow = kcmat + (size_t)row * NEXP;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_small(const SmallArg
         wave_lds_fence();
 
         // ---------------- image -> HBM: P whole requests, contiguous ----------------
-        if (!(a.debug & 4)) {
+        if (!FX_ABL(a, 4)) {
             const long long total = (long long)Pcur * reqsize;
             double* gout = a.out + (size_t)r0 * reqsize;
             if ((reqsize & 1) == 0) {

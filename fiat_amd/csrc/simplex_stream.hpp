@@ -303,7 +303,7 @@ __global__ __launch_bounds__(64 * NW, FX_STREAM_WAVES) void tabulate_simplex_str
         }
 
         // ---------------- D tiles -> half images -> HBM ----------------
-        if (!(a.debug & 4)) {
+        if (!FX_ABL(a, 4)) {
             wave_lds_fence();  // the slab (aliasing the image) has been read for the last K-step
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) image_tile(nt, 0);

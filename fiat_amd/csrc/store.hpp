@@ -1,6 +1,7 @@
 // Output stores of the tabulation kernels (gfx950).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "ablation.hpp"
 
 #ifndef FX_NT_STORES
 #define FX_NT_STORES 1

@@ -75,9 +75,11 @@ class TableGather:
         self.impl = "rccl" if self.comm is not None else "torch"
 
     def close(self):
+        """Destroys the communicator.  fx_comm_destroy first waits for the streams exchanges were enqueued on: the
+        gathered tables are complete when this returns."""
         if self.comm is not None:
-            self._lib.lib.fx_comm_destroy(self.comm)
-            self.comm = None
+            comm, self.comm = self.comm, None
+            self._lib.check(self._lib.lib.fx_comm_destroy(comm))
 
     # -- one block per rank into recv[p * stride + offset] ------------------------------------------------
     def _exchange(self, send, full, per, offset, stream=None):
@@ -90,9 +92,11 @@ class TableGather:
             if not (send.is_contiguous() and full.is_contiguous()):
                 raise ValueError("table blocks must be contiguous")
             ring = self.algo == "ring" and m == per and offset == 0
+            if full.shape[0] < self.world * per or (m and int(full[0].numel()) != row):
+                raise ValueError(f"receive buffer of {tuple(full.shape)} cannot hold {self.world} blocks of {per} rows of {row}")
             self._lib.check(self._lib.lib.fx_allgather_tables(
                 self.comm, ctypes.c_void_p(send.data_ptr()), ctypes.c_void_p(full.data_ptr()), m * row, per * row,
-                offset * row, 0 if ring else 1, self._runtime._stream_ptr(stream)))
+                offset * row, int(full.numel()), 0 if ring else 1, self._runtime._stream_ptr(stream)))
             return
         # torch.distributed collectives (gloo: through host memory)
         host = dist.get_backend(self.group) != "nccl"

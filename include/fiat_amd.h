@@ -105,7 +105,8 @@ int fx_num_tables(int sd, int order);
  *         table t of request r is exactly tabulate(order, pts[r])[alpha_t].
  * order <= 2 by the recurrence (FIAT/expansions.py:140-267); orders 3..8 through differentiation matrices
  * (expansions.py:438-446, 577-599), with per-request cells up to order 4.  Derivatives are with respect to the
- * caller's coordinates. */
+ * caller's coordinates.  Stream-asynchronous, with one exception: the FIRST call of an element at an order > 2 builds
+ * its differentiation matrices (null-stream launches, synchronous copies) and thereby synchronises the device once. */
 int fx_tabulate_batch(fx_ctx* ctx, const fx_element* elem, int order,
                       int64_t nreq, int npts, const double* pts,
                       const double* verts, double* out, void* stream);
@@ -331,7 +332,9 @@ int fx_jacobi_batch(fx_ctx* ctx, double a, double b, int n, int order, int64_t n
  * (offset + count <= stride).  send may alias the caller's own block of recv (in place).
  *   FX_GATHER_RING    ncclAllGather (blocks must tile recv);
  *   FX_GATHER_DIRECT  grouped send/recv with every peer: all 7 xGMI links of a GPU at once.
- * Enqueued on `stream`; nothing synchronises. */
+ * recv_count = doubles the caller owns at recv: (nranks-1)*stride + offset + count must not exceed it (FX_EINVAL).
+ * Enqueued on `stream`; the exchange itself does not synchronise.  fx_comm_destroy waits for the streams exchanges
+ * were enqueued on before it destroys the communicator (ABI version 2). */
 typedef struct fx_comm fx_comm;
 #define FX_COMM_ID_BYTES 128
 #define FX_GATHER_RING 0
@@ -341,7 +344,7 @@ int fx_comm_unique_id(unsigned char* id /* host [FX_COMM_ID_BYTES] */);
 int fx_comm_create(fx_ctx* ctx, int nranks, int rank, const unsigned char* id, fx_comm** comm);
 int fx_comm_destroy(fx_comm* comm);
 int fx_allgather_tables(fx_comm* comm, const double* send, double* recv, int64_t count, int64_t stride,
-                        int64_t offset, int algo, void* stream);
+                        int64_t offset, int64_t recv_count, int algo, void* stream);
 
 /* Synchronises `stream` and reports a scheduling failure of the dynamically scheduled kernels (their
  * work queue gives up after ~1 s instead of hanging the GPU; the affected launch's output is then

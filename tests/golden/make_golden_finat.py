@@ -11,7 +11,7 @@ unmodified from /root/reference/finat.  GEM expressions are turned into arrays w
 What is stored (plain numbers and strings):
 * ``be_<case>_*``: ``FiatElement.basis_evaluation(order, PointSet)`` (finat/fiat_elements.py:60-123): the evaluated table
   of every multi-index with the point axis LAST, and ``kind`` = 0 pointwise / 1 cellwise constant (no point index in
-  the expression) / 2 zero (a ``gem.Zero``);
+  the expression) / 2 zero (no point index and the reference's own ``numpy.zeros``);
 * ``db_<case>_*``: ``_dual_basis`` (finat/fiat_elements.py:163-262): dense Q, the unique points, whether the reference
   expressed Q symbolically as a Kronecker delta;
 * ``rt_*``: the ``gem.Variable`` names and shapes ``RuntimeTabulated.basis_evaluation`` asks for
@@ -64,17 +64,6 @@ def dense(expr, point_indices):
     nf = len(fids)
     arr = np.transpose(arr, list(range(nf, arr.ndim)) + order)
     return arr, present
-
-
-def is_zero(expr):
-    node = expr
-    while True:
-        if isinstance(node, gem.Zero):
-            return True
-        if isinstance(node, (gem.ComponentTensor, gem.Indexed)):
-            node = node.children[0]
-            continue
-        return False
 
 
 def variables(expr):
@@ -135,9 +124,9 @@ def main():
         kinds = []
         for t, alpha in enumerate(alphas):
             arr, present = dense(res[alpha], ps.indices)
-            if is_zero(res[alpha]):
-                kind = 2
-                assert not arr.any() and not present[0]
+            if not present[0] and not arr.any():
+                kind = 2              # the reference's own numpy.zeros (:104-108); a gem.Literal like the constant tables
+                assert sum(alpha) > el.degree
             elif not present[0]:
                 kind = 1
             else:

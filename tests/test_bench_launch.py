@@ -32,6 +32,50 @@ def test_world_size_mismatch_is_an_error():
     assert res.returncode != 0 and "WORLD_SIZE=1" in (res.stderr + res.stdout)
 
 
+def test_failing_ranks_fail_the_launcher_with_labelled_stderr():
+    """Self-spawned ranks: a rank that exits non-zero makes the parent exit non-zero, the siblings are terminated instead
+    of being waited for, and every line of a child's stderr carries its rank.  (Without a GPU every rank stops at
+    "bench.py needs an MI355X"; on a GPU box the WORLD_SIZE check of the workload is what fails.)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU: there the ranks would run")
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         env=_env(FIAT_AMD_BENCH_BACKEND="gloo"), timeout=600)
+    assert res.returncode != 0 and not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert "[rank 0] " in res.stderr or "[rank 1] " in res.stderr
+    assert "needs an MI355X" in res.stderr and "terminating the other ranks" in res.stderr
+
+
+@pytest.mark.gpu
+def test_stuck_allgather_leg_is_a_failure_not_a_success():
+    """A rank that never joins the exchange: the watchdog still prints the compute-only line (with the error inside) and
+    the job exits NON-ZERO -- a hung collective must not look like success to the driver."""
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2000", "--check", "50",
+                          "--no-cpu-baseline", "--allgather-timeout", "20"], capture_output=True, text=True,
+                         env=_env(FIAT_AMD_BENCH_BACKEND="gloo", FIAT_AMD_BENCH_FORCE_GATHER_TIMEOUT="1"), timeout=900)
+    assert res.returncode != 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    # rank 0 either runs into its own watchdog or sees the peer (whose watchdog fired first) drop the connection
+    assert line["value"] > 0 and line["allgather"]["error"]
+    assert "[rank " in res.stderr
+
+
+@pytest.mark.gpu
+def test_allgather_verify_two_ranks():
+    """--allgather-verify: both ranks tabulate the same requests and compare every gathered block with their own."""
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "3000", "--check", "50",
+                          "--no-cpu-baseline", "--allgather-verify"], capture_output=True, text=True,
+                         env=_env(FIAT_AMD_BENCH_BACKEND="gloo"), timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    v = line["allgather"]["verify"]
+    assert v["ok"] and v["requests"] == 3000 and all(v["one_shot_blocks_equal"]) and all(v["chunked_blocks_equal"])
+    assert line["allgather"]["free_bytes_min_over_ranks"] > 0 and line["ms_per_step_cold"] > 0
+    assert line["roofline"]["mfma"]["frac"] > 0
+
+
 @pytest.mark.gpu
 def test_bare_two_rank_launch_on_one_gpu():
     """FIAT_AMD_BENCH_BACKEND=gloo lets two ranks share the one GPU of this box: the parent spawns them, both tabulate their

@@ -106,3 +106,67 @@ def test_shard_bounds():
             assert b[0][0] == 0 and b[-1][1] == n
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= -(-n // w)
+
+
+# ---- bench.py --allgather-verify: the data check of the exchange, rehearsed with two gloo ranks on CPU ---------------
+class _FakeWorkload:
+    """What verify_gather needs of a bench workload: per-request inputs and produce_rows (a deterministic function of
+    the inputs standing in for the tabulation)."""
+
+    def __init__(self, rank, nreq):
+        g = torch.Generator().manual_seed(100 + rank)          # ranks draw DIFFERENT inputs, as in the bench
+        self.parts = [{"pts": torch.rand((nreq, 3, 2), dtype=torch.float64, generator=g)}]
+
+    def produce_rows(self, lo, hi, rows):
+        p = self.parts[0]["pts"][lo:hi]
+        rows.copy_(torch.einsum("rpd,rqe->rpqde", p, p).reshape(hi - lo, -1)[:, :12].reshape(hi - lo, 3, 4))
+
+
+def _verify_worker(rank, world, port, sabotage, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from fiat_amd import distributed as D
+    gather = D.TableGather()
+    if sabotage:                       # an exchange that lands foreign blocks one row off: the check must see it
+        good = gather._exchange
+
+        def bad(send, full, per, offset, stream=None):
+            good(send, full, per, offset, stream)
+            view = full.view(world, per, *full.shape[1:])
+            other = 1 - rank
+            view[other, offset:offset + send.shape[0]] = torch.roll(view[other, offset:offset + send.shape[0]], 1, 0)
+        gather._exchange = bad
+    nreq = 37
+    wl = _FakeWorkload(rank, nreq)
+    before = wl.parts[0]["pts"].clone()
+    out = torch.empty((nreq, 3, 4), dtype=torch.float64)
+    res = bench.verify_gather(wl, gather, world, rank, nreq, out, (3, 4))
+    restored = bool(torch.equal(before, wl.parts[0]["pts"]))
+    gather.close()
+    q.put((rank, res, restored))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sabotage", [False, True])
+def test_allgather_verify_world2(sabotage):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_verify_worker, args=(r, 2, port, sabotage, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, r, restored in res:
+        assert restored                                        # the workload's own inputs are put back
+        assert r["requests"] == 37 and r["ok"] == (not sabotage), r
+        if sabotage:
+            assert not r["one_shot_blocks_equal"][1 - rank] and r["one_shot_blocks_equal"][rank]
+        else:
+            assert all(r["one_shot_blocks_equal"]) and all(r["chunked_blocks_equal"])

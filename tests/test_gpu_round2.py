@@ -158,7 +158,19 @@ def test_rccl_gather_through_the_c_abi_world1(algo, tmp_path):
             seen.append(staged[0].clone())
         torch.cuda.synchronize()
         assert torch.equal(torch.cat(seen), local)
+        # the receive extent is validated behind the C ABI: a block that would end past the caller's buffer is refused
+        import ctypes
+        from fiat_amd import _lib, runtime
+        small = torch.empty(5 * 3 * 5, dtype=torch.float64, device="cuda")
+        rc = _lib.lib.fx_allgather_tables(gather.comm, ctypes.c_void_p(local.data_ptr()), ctypes.c_void_p(small.data_ptr()),
+                                          local.numel(), local.numel(), 0, small.numel(), 1, runtime._stream_ptr(None))
+        assert rc != 0 and b"exceed the receive buffer" in _lib.lib.fx_last_error()
+        with pytest.raises(ValueError):
+            gather._exchange(local, small.view(5, 3, 5), 7, 0)
+        # close() drains the stream the last exchange went to before the communicator is destroyed
+        out = gather.all_gather(local, 7)
         gather.close()
+        assert torch.equal(out, local) and gather.comm is None
     finally:
         dist.destroy_process_group()
 

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(_lib.lib, name), f"libfiat_amd.so does not export {name}"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert _lib.lib.fx_abi_version() == 1
+    assert _lib.lib.fx_abi_version() == 2
 
 
 def test_no_gpu_means_loud_failure():
