@@ -15,7 +15,8 @@ from .reference_element import (DefaultLine, DefaultTetrahedron, DefaultTriangle
                                 UFCInterval, UFCTetrahedron, UFCTriangle, default_simplex,
                                 make_affine_mapping, make_lattice, physical_simplex, ufc_simplex)
 from .quadrature import create_quadrature, make_quadrature  # noqa: F401
-from .polynomial_set import ONPolynomialSet, ONSymTensorPolynomialSet, PolynomialSet, mis  # noqa: F401
+from .polynomial_set import (ONPolynomialSet, ONSymTensorPolynomialSet, PolynomialSet,  # noqa: F401
+                             TracelessTensorPolynomialSet, mis)
 from .expansions import ExpansionSet  # noqa: F401
 from .macro import (AlfeldSplit, IsoSplit, PowellSabin12Split, PowellSabinSplit,  # noqa: F401
                     WorseyFarinSplit)
@@ -30,6 +31,7 @@ from .hermite import CubicHermite  # noqa: F401
 from .morley import Morley  # noqa: F401
 from .regge import Regge  # noqa: F401
 from .hellan_herrmann_johnson import HellanHerrmannJohnson  # noqa: F401
+from .gopalakrishnan_lederer_schoberl import GopalakrishnanLedererSchoberlSecondKind  # noqa: F401
 from .tensor_product import FlattenedDimensions, TensorProductElement  # noqa: F401
 from .batch import Request, tabulate_requests  # noqa: F401
 

@@ -1778,7 +1778,7 @@ int fx_tabulate_batch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq,
 
 int fx_tabulate_batch_mapped(fx_ctx* ctx, const fx_element* e, int mapping, int order, int64_t nreq, int npts,
                              const double* pts, const double* verts, double* out, void* stream) {
-    if (mapping < FX_MAP_AFFINE || mapping > FX_MAP_DOUBLE_CONTRAVARIANT_PIOLA) return fail(FX_EINVAL, "unknown mapping %d", mapping);
+    if (mapping < FX_MAP_AFFINE || mapping > FX_MAP_COVARIANT_CONTRAVARIANT_PIOLA) return fail(FX_EINVAL, "unknown mapping %d", mapping);
     if (mapping == FX_MAP_AFFINE) return fx_tabulate_batch(ctx, e, order, nreq, npts, pts, verts, out, stream);
     if (!e) return fail(FX_EINVAL, "null context/element");
     if (mapping >= FX_MAP_DOUBLE_COVARIANT_PIOLA) {
@@ -1799,7 +1799,7 @@ int fx_tabulate_batch_mapped(fx_ctx* ctx, const fx_element* e, int mapping, int 
 int fx_pushforward_batch(fx_ctx* ctx, const fx_element* e, int mapping, int order, int64_t nreq, int npts,
                          const double* verts, double* out, void* stream) {
     if (!ctx || !e) return fail(FX_EINVAL, "null context/element");
-    if (mapping < FX_MAP_AFFINE || mapping > FX_MAP_DOUBLE_CONTRAVARIANT_PIOLA) return fail(FX_EINVAL, "unknown mapping %d", mapping);
+    if (mapping < FX_MAP_AFFINE || mapping > FX_MAP_COVARIANT_CONTRAVARIANT_PIOLA) return fail(FX_EINVAL, "unknown mapping %d", mapping);
     if (order < 0) return fail(FX_EINVAL, "negative derivative order");
     if (order > 2) return fail(FX_ENOTIMPL, "derivative order %d > 2 is not implemented on the device", order);
     if (nreq < 0 || npts < 0) return fail(FX_EINVAL, "negative batch size");

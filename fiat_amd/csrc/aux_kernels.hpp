@@ -467,7 +467,7 @@ struct PiolaArgs {
     const double* verts;  // [nreq][SD+1][SD]
     double* out;          // [nreq][ntab][ndof][SD][npts]
     double G[9];
-    int ntab, ndof, npts, kind;  // kind 1 covariant, 2 contravariant; 3 / 4: the double maps of matrix-valued functions
+    int ntab, ndof, npts, kind;  // kind 1 covariant, 2 contravariant; 3 / 4 / 5: the double maps of matrix-valued functions
     long long nreq;
     int rb;  // requests per workgroup pass (<= PIOLA_RB)
 };
@@ -525,6 +525,7 @@ template <int SD> __global__ __launch_bounds__(256) void piola_apply_kernel(cons
     // elements.  (One workgroup per request left 250 of 256 threads idle on N1 / RT1 requests of 18 elements: 5-9 % of
     // the HBM peak for the whole mapped tabulation, tools/coverage_map.py --verts --pushforward.)
     __shared__ double sM[PIOLA_RB][SD * SD];
+    __shared__ double sR[PIOLA_RB][SD * SD];  // kind 5: the right-hand matrix (J / det J), the left one is J^-T
     const int rb = a.rb;
     const int groups = a.ntab * a.ndof;  // (table, dof) pairs: SD (or SD * SD) rows of npts each
     const int per = groups * a.npts;     // elements per request
@@ -533,11 +534,18 @@ template <int SD> __global__ __launch_bounds__(256) void piola_apply_kernel(cons
         __syncthreads();  // the maps of the previous block are no longer read
         if ((int)threadIdx.x < rb && base + threadIdx.x < a.nreq) {
             double m0[SD][SD];
-            piola_matrix<SD>(a.verts + (size_t)(base + threadIdx.x) * (SD + 1) * SD, a.G, a.kind, m0);
+            piola_matrix<SD>(a.verts + (size_t)(base + threadIdx.x) * (SD + 1) * SD, a.G, a.kind == 5 ? 1 : a.kind, m0);
 #pragma unroll
             for (int r = 0; r < SD; ++r)
 #pragma unroll
                 for (int c = 0; c < SD; ++c) sM[threadIdx.x][r * SD + c] = m0[r][c];
+            if (a.kind == 5) {
+                piola_matrix<SD>(a.verts + (size_t)(base + threadIdx.x) * (SD + 1) * SD, a.G, 2, m0);
+#pragma unroll
+                for (int r = 0; r < SD; ++r)
+#pragma unroll
+                    for (int c = 0; c < SD; ++c) sR[threadIdx.x][r * SD + c] = m0[r][c];
+            }
         }
         __syncthreads();
         const int nb = (int)min((long long)rb, a.nreq - base);
@@ -552,9 +560,14 @@ template <int SD> __global__ __launch_bounds__(256) void piola_apply_kernel(cons
                 for (int c = 0; c < SD; ++c) m[r][c] = sM[rl][r * SD + c];
             double* q = o + ((size_t)rl * groups + g) * rowsper * a.npts + p;
             if (a.kind >= 3) {
-                // matrix-valued functions (value shape (SD, SD), row-major: SD*SD rows per dof): M Phi M^T with the same M
-                // -- double covariant J^-T Phi J^-1, double contravariant J Phi J^T / det^2 (Regge, Hellan-Herrmann-Johnson)
-                double X[SD][SD], T[SD][SD];
+                // matrix-valued functions (value shape (SD, SD), row-major: SD*SD rows per dof): M Phi R^T -- double covariant
+                // J^-T Phi J^-1 and double contravariant J Phi J^T / det^2 with R = M (Regge, Hellan-Herrmann-Johnson), the
+                // mixed map J^-T Phi J^T / det of the GLS elements with M = J^-T, R = J / det
+                double X[SD][SD], T[SD][SD], rm[SD][SD];
+#pragma unroll
+                for (int i = 0; i < SD; ++i)
+#pragma unroll
+                    for (int j = 0; j < SD; ++j) rm[i][j] = a.kind == 5 ? sR[rl][i * SD + j] : m[i][j];
 #pragma unroll
                 for (int i = 0; i < SD; ++i)
 #pragma unroll
@@ -574,7 +587,7 @@ template <int SD> __global__ __launch_bounds__(256) void piola_apply_kernel(cons
                     for (int j = 0; j < SD; ++j) {
                         double t = 0.0;
 #pragma unroll
-                        for (int k = 0; k < SD; ++k) t += T[i][k] * m[j][k];
+                        for (int k = 0; k < SD; ++k) t += T[i][k] * rm[j][k];
                         q[(i * SD + j) * a.npts] = t;
                     }
             } else {

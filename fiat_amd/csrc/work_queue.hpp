@@ -12,6 +12,19 @@
 // so it is paid once per chunk and two chunks ahead), and the 8 units of a chunk to the waves
 // of the workgroup through a counter in LDS (ds_add_rtn, no vmcnt traffic).
 //
+// Round 3 (wave timelines of the FX_DBG=512 build, tools/batch_scaling.py: a launch costs 22-33 us more than its
+// per-request rate explains -- RT2, 25 000 requests: 7 us from kernel entry to the first unit, and at the end the
+// average wave idles 13-17 us, a whole unit, while the last ones finish):
+//   * START: a workgroup's first WQ_AHEAD chunks are STATIC (chunk b, b + G, .. of workgroup b of G): the 768 atomics of
+//     256 workgroups on one address that used to open every launch (two at init, one at the first claim, each waiting
+//     for the previous one's return) are gone; the counter hands out chunk WQ_AHEAD G + n.
+//   * END: when the counter runs dry a workgroup still holds its look-ahead -- with two chunks ahead 16-24 units, two
+//     to three rounds of its 8 waves, which the slow XCDs work off 10-30 % slower than the fast ones.  The finishing
+//     times of the workgroups are spread over one unit by their phase in any case (a chunk is one round of a workgroup);
+//     what the look-ahead adds is (held work) x (speed difference).  One chunk ahead (WQ_AHEAD = 1) halves it; the id is
+//     requested half a unit after the chunk before it was opened and needed a whole unit after (8 claims = one claim of
+//     every wave), so the ~1 us of the atomic stays hidden.
+//
 // The global counter cleans up after itself: the last wave of the last workgroup to finish sets
 // it back to zero (gctr[0] chunk counter, gctr[1] finished workgroups; gctr[2] = protocol-error mark), so a launch costs no
 // extra memset node; the host hands concurrent launches different counters (api.hip).
@@ -20,7 +33,7 @@
 //   ctl[0]            claims of this workgroup so far (k); unit = chunk(k >> 3) * 8 + (k & 7)
 //   ctl[1]            waves of this workgroup that have finished
 //   slot[4] (u64)     ring of chunk ids, slot[j & 3] = (j << 32) | chunk id of the workgroup's
-//                     j-th chunk, written by the wave that claimed the first unit of chunk j-2
+//                     j-th chunk, written by the wave that claimed the first unit of chunk j - WQ_AHEAD
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -28,6 +41,11 @@ namespace fxk {
 
 constexpr int WQ_CTL_DOUBLES = 8;  // control block size in doubles
 constexpr unsigned int WQ_END = 0x7fffffffu;
+#ifndef FX_WQ_AHEAD
+#define FX_WQ_AHEAD 1
+#endif
+constexpr unsigned int WQ_AHEAD = FX_WQ_AHEAD;  // chunks requested ahead of the one being opened (1 or 2; the slot ring holds 4)
+static_assert(WQ_AHEAD == 1 || WQ_AHEAD == 2, "look-ahead of one or two chunks");
 
 struct WorkQueue {
     unsigned int* ctl;            // LDS
@@ -50,12 +68,9 @@ struct WorkQueue {
         if (threadIdx.x == 0) {
             ctl[0] = 0;
             ctl[1] = 0;
-            slot[2] = ~0ULL;
-            slot[3] = ~0ULL;
-            const unsigned int c0 = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned int c1 = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            slot[0] = (0ULL << 32) | (c0 < WQ_END ? c0 : WQ_END);
-            slot[1] = (1ULL << 32) | (c1 < WQ_END ? c1 : WQ_END);
+            // the first WQ_AHEAD chunks of a workgroup are static: no atomic before the first unit
+            for (unsigned int i = 0; i < 4; ++i)
+                slot[i] = i < WQ_AHEAD ? ((unsigned long long)i << 32) | (blockIdx.x + i * gridDim.x) : ~0ULL;
         }
     }
 
@@ -65,11 +80,11 @@ struct WorkQueue {
         if ((threadIdx.x & 63) == 0) r = __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const unsigned int k = __builtin_amdgcn_readfirstlane(r);
         const unsigned int j = k >> 3, off = k & 7;
-        if (off == 0) {  // first unit of chunk j: this wave fetches the id of chunk j+2 (see service())
+        if (off == 0) {  // first unit of chunk j: this wave fetches the id of chunk j + WQ_AHEAD (see service())
             pending = true;
-            pord = j + 2;
+            pord = j + WQ_AHEAD;
         }
-        // the id of chunk j was requested two chunks ago; normally it is there.  The wait is
+        // the id of chunk j was requested WQ_AHEAD chunks ago; normally it is there.  The wait is
         // bounded (~1 s): a protocol error must not hang the GPU, it ends the batch early instead
         // (and the parity tests fail).
         unsigned long long s = 0;
@@ -99,7 +114,7 @@ struct WorkQueue {
         if (!pending) return;
         pending = false;
         if ((threadIdx.x & 63) == 0) {
-            const unsigned int c = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int c = WQ_AHEAD * gridDim.x + __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&slot[pord & 3], ((unsigned long long)pord << 32) | (c < WQ_END ? c : WQ_END), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
         }

@@ -109,6 +109,26 @@ class ONSymTensorPolynomialSet(PolynomialSet):
         super().__init__(ref_el, degree, degree, es, coeffs)
 
 
+class TracelessTensorPolynomialSet(PolynomialSet):
+    """Trace-free matrix-valued polynomials (FIAT/polynomial_set.py:252-282): one copy of the expansion set for every
+    component (i, j) except the last diagonal one; a diagonal copy carries e_i e_i^T - e_n e_n^T, which keeps the trace
+    at zero.  size^2 - 1 blocks of nexp members, blocks in row-major component order -- the space of the GLS elements."""
+
+    def __init__(self, ref_el, degree, size=None, **kwargs):
+        es = expansions.ExpansionSet(ref_el, **kwargs)
+        if size is None:
+            size = ref_el.get_spatial_dimension()
+        nexp = es.get_num_members(degree)
+        blocks = [(i, j) for i in range(size) for j in range(size)][:-1]
+        coeffs = numpy.zeros((len(blocks) * nexp, size, size, nexp))
+        members = numpy.arange(nexp)
+        for b, (i, j) in enumerate(blocks):
+            coeffs[b * nexp + members, i, j, members] = 1.0
+            if i == j:
+                coeffs[b * nexp + members, size - 1, size - 1, members] = -1.0
+        super().__init__(ref_el, degree, degree, es, coeffs)
+
+
 def spanning_basis(A, nullspace=False, rtol=1e-10):
     """Orthonormal basis of the row space (or its complement) of A via SVD."""
     Aflat = A.reshape(A.shape[0], -1)

@@ -149,7 +149,7 @@ class SimplexPolySet:
         return (nreq, num_tables(self.sd, order), self.ndof) + self.value_shape + (npts,)
 
     MAPPINGS = {"affine": 0, "covariant piola": 1, "contravariant piola": 2, "double covariant piola": 3,
-                "double contravariant piola": 4}
+                "double contravariant piola": 4, "covariant contravariant piola": 5}
 
     def tabulate_batch(self, order, pts, verts=None, out=None, stream=None, mapping=None):
         """pts (nreq, npts, sd) -> (nreq, ntab, ndof, *value_shape, npts) on the GPU.

@@ -205,6 +205,9 @@ int fx_plan_coop(int sd, int n, int variant, double scale, int cap, int* KS, int
  *   FX_MAP_DOUBLE_CONTRAVARIANT_PIOLA  phi = J Phi J^T / (det J)^2    (Hellan-Herrmann-Johnson) */
 #define FX_MAP_DOUBLE_COVARIANT_PIOLA 3
 #define FX_MAP_DOUBLE_CONTRAVARIANT_PIOLA 4
+/*   FX_MAP_COVARIANT_CONTRAVARIANT_PIOLA  phi = J^{-T} Phi J^T / det J   (Gopalakrishnan-Lederer-Schoeberl;
+ *   "covariant contravariant piola" of FIAT/gopalakrishnan_lederer_schoberl.py:67) */
+#define FX_MAP_COVARIANT_CONTRAVARIANT_PIOLA 5
 int fx_pushforward_batch(fx_ctx* ctx, const fx_element* elem, int mapping, int order,
                          int64_t nreq, int npts, const double* verts, double* out, void* stream);
 /* fx_tabulate_batch followed by the push-forward `mapping`, in ONE kernel where the shape's kernel

@@ -31,7 +31,7 @@ def _num_tables(sd, order):
 class _SimplexPolySet:
     """runtime.SimplexPolySet with the oracle doing the arithmetic."""
     MAPPINGS = {"affine": 0, "covariant piola": 1, "contravariant piola": 2, "double covariant piola": 3,
-                "double contravariant piola": 4}
+                "double contravariant piola": 4, "covariant contravariant piola": 5}
 
     def __init__(self, sd, n, variant=None, scale=None, verts=None, coeffs=None, ndof=None, value_shape=(), ctx=None):
         self.sd, self.n, self.variant, self.scale = sd, n, variant, scale
