@@ -1050,7 +1050,7 @@ struct SmallShape {
     int sd, n;
 };
 // (measured against the generic kernel: (2,5) and (3,3) are slower lane-local -- 1600+ FMAs per lane -- and stay generic)
-const SmallShape kSmallShapes[] = {{2, 1}, {2, 2}, {2, 3}, {3, 1}, {3, 2}, {2, 4}};
+const SmallShape kSmallShapes[] = {{2, 1}, {2, 2}, {2, 3}, {3, 1}, {3, 2}, {2, 4}, {2, 0}, {3, 0}};  // degree 0 (P0 / DG0: one member, no steps): 6-19 % on the generic kernel
 constexpr int SMALL_NW = 4;
 
 template <int SD, int N>
@@ -1087,6 +1087,8 @@ int run_small(int order, const Launch& L, hipStream_t s) {
         case 3: return launch_small<3, 1>(order, L, s);
         case 4: return launch_small<3, 2>(order, L, s);
         case 5: return launch_small<2, 4>(order, L, s);
+        case 6: return launch_small<2, 0>(order, L, s);
+        case 7: return launch_small<3, 0>(order, L, s);
     }
     return fail(FX_EINVAL, "internal: unknown small kernel %d", L.small_id);
 }
@@ -1099,6 +1101,8 @@ bool small_table_matches(int id, const fx::Program& P) {
         case 3: return table_matches<3, 1>(P);
         case 4: return table_matches<3, 2>(P);
         case 5: return table_matches<2, 4>(P);
+        case 6: return table_matches<2, 0>(P);
+        case 7: return table_matches<3, 0>(P);
     }
     return false;
 }

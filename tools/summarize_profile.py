@@ -47,6 +47,12 @@ if stats:
                    "max_ns": float(r["MaxNs"]), "name": r["Name"]}
             break
 summary = {"source": src, "kernel": dur, "counters": counters}
+# fp64 matrix-pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs, GRBM_GUI_ACTIVE over its
+# 8 XCDs (each counts the cycles the launch was active): busy SIMD-cycles / (SIMDs x kernel cycles)
+mfma_busy = None
+if "SQ_VALU_MFMA_BUSY_CYCLES" in counters and "GRBM_GUI_ACTIVE" in counters and counters["GRBM_GUI_ACTIVE"]["mean_per_launch"] > 0:
+    mfma_busy = counters["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / (1024.0 * counters["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0)
+    summary["mfma_busy_frac"] = {"value": mfma_busy, "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)"}
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     fetch = counters["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2      # gfx950: FETCH_SIZE counts 64 B per 128-B request
     write = counters["WRITE_SIZE"]["mean_per_launch"] * 1024
@@ -55,7 +61,7 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
                               "note": "FETCH_SIZE*1024*2 (gfx950 half-count correction) + WRITE_SIZE*1024"}
     with open(f"profiles/traffic_{workload}.json", "w") as f:
         json.dump({"workload": workload, "batch": batch, "hbm_bytes_per_launch": fetch + write,
-                   "read": fetch, "write": write, "from": f"profiles/{tag}_summary.json"}, f, indent=1)
+                   "read": fetch, "write": write, "mfma_busy_frac": mfma_busy, "from": f"profiles/{tag}_summary.json"}, f, indent=1)
 with open(f"profiles/{tag}_summary.json", "w") as f:
     json.dump(summary, f, indent=1)
 print(json.dumps(summary, indent=1)[:3000])
