@@ -49,6 +49,7 @@ supported_elements = {
     "Gauss-Lobatto-Legendre": GaussLobattoLegendre,
     "Gauss-Legendre": GaussLegendre,
     "Hellan-Herrmann-Johnson": HellanHerrmannJohnson,
+    "Gopalakrishnan-Lederer-Schoberl 2nd kind": GopalakrishnanLedererSchoberlSecondKind,
     "TensorProductElement": TensorProductElement,
     "FlattenedDimensions": FlattenedDimensions,
 }

@@ -46,7 +46,22 @@ if stats:
             dur = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
                    "max_ns": float(r["MaxNs"]), "name": r["Name"]}
             break
-summary = {"source": src, "kernel": dur, "counters": counters}
+# per-phase durations from the kernel trace: bench.py now opens with W + K launches from an idle GPU (ms_per_step_cold), then
+# the clock ramp, then the timed W + K and the K launches of the HIP-event timing -- the all-launch average above mixes them
+phases = None
+traces = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+if traces:
+    rows = []
+    for r in csv.DictReader(open(traces[0])):
+        if kernel_substr in r["Kernel_Name"] and int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) >= 64 * 256:
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    rows.sort()
+    d = [x[1] for x in rows]
+    if len(d) >= 65:
+        phases = {"launches": len(d), "first_25_from_idle_avg_ns": statistics.mean(d[:25]),
+                  "last_40_steady_avg_ns": statistics.mean(d[-40:]), "last_40_steady_median_ns": statistics.median(d[-40:]),
+                  "note": "last 40 = the timed steps + the HIP-event timing launches of bench.py --steps 20"}
+summary = {"source": src, "kernel": dur, "kernel_phases": phases, "counters": counters}
 # fp64 matrix-pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs, GRBM_GUI_ACTIVE over its
 # 8 XCDs (each counts the cycles the launch was active): busy SIMD-cycles / (SIMDs x kernel cycles)
 mfma_busy = None
