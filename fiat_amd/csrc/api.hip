@@ -822,6 +822,11 @@ const StackedShape kStackedShapes[] = {
     // per-request cells, values + gradient, chain rule inside the kernel (as the rtc -2 block above)
     {3, 2, 3, 4, -2}, {3, 2, 3, 3, -2}, {3, 2, 3, 2, -2}, {3, 2, 2, 1, -2},
     {2, 3, 3, 4, -2}, {2, 3, 3, 3, -2}, {2, 3, 3, 2, -2}, {2, 4, 3, 3, -2}, {2, 4, 3, 2, -2}, {2, 4, 2, 1, -2},
+    // round 3: expansion degrees 7 and 8 (were on the generic kernel at 11-30 % of the HBM peak).  Tetrahedra of degree 7 hold
+    // 30 K-steps x 2 column tiles of B fragments (60 doubles per lane, as degree 6 with three tiles); their quadrature rules
+    // have hundreds of points, so the point-chunked instance (32 points a unit) is the one that matters
+    {3, 7, 2, 1, 0}, {3, 7, 2, 1, -1},
+    {2, 7, 3, 1, 0}, {2, 7, 2, 1, 0}, {2, 7, 3, 1, -1}, {2, 8, 4, 1, 0}, {2, 8, 3, 1, -1},
 };
 constexpr int STACKED_NW = 4;  // one wave per SIMD
 
@@ -896,8 +901,13 @@ int launch_stacked(const Launch& L, hipStream_t s) {
         ma.n = L.khead.R / ntab * L.khead.npts;
         ma.order = L.kmix_order;
         ma.slices = std::max(1, std::min(8, (ma.n + 2047) / 2048));
+        ma.nreq = L.khead.nreq;
+        // small requests: blocks of requests per (persistent) workgroup, ~2048 positions a pass
+        ma.rb = ma.n >= 1024 ? 1 : std::max(1, std::min(fxk::MIX_RB, 2048 / std::max(1, ma.n)));
         if (L.khead.nreq * ma.slices > 0x7fffffffLL) return fail(FX_EINVAL, "batch too large for the table-mixing pass");
-        hipLaunchKernelGGL((fxk::table_mix_kernel<SD>), dim3((unsigned)(L.khead.nreq * ma.slices)), dim3(256), 0, s, ma);
+        if ((long long)fxk::MIX_RB * ma.n > 0x3fffffffLL) return fail(FX_EINVAL, "request too large for the table-mixing pass");
+        const long long blocks = ma.rb > 1 ? std::min<long long>((L.khead.nreq + ma.rb - 1) / ma.rb, (long long)L.ncu * 16) : L.khead.nreq * ma.slices;
+        hipLaunchKernelGGL((fxk::table_mix_kernel<SD>), dim3((unsigned)std::max<long long>(1, blocks)), dim3(256), 0, s, ma);
         HIP_TRY(hipGetLastError());
     }
     return FX_OK;
@@ -939,12 +949,12 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 28: return L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 0, true>(L, s) : launch_stacked<3, 3, 3, 2>(L, s);
         case 29: return launch_stacked<3, 3, 2, 1>(L, s);
         case 30: return launch_stacked<3, 3, 3, 1>(L, s);
-        case 31: return launch_stacked<2, 6, 3, 2>(L, s);
-        case 32: return launch_stacked<2, 6, 2, 1>(L, s);
+        case 31: return L.kmix_order <= 1 ? launch_stacked<2, 6, 3, 2, 0, 2>(L, s) : launch_stacked<2, 6, 3, 2>(L, s);
+        case 32: return L.kmix_order <= 1 ? launch_stacked<2, 6, 2, 1, 0, 2>(L, s) : launch_stacked<2, 6, 2, 1>(L, s);
         case 33: return L.kmix_order <= 1 ? launch_stacked<2, 6, 3, 1, 0, 2>(L, s) : launch_stacked<2, 6, 3, 1>(L, s);
-        case 34: return launch_stacked<2, 5, 3, 2>(L, s);
-        case 35: return L.kodd ? launch_stacked<2, 5, 2, 1, 0, 1, false, 0, true>(L, s) : launch_stacked<2, 5, 2, 1>(L, s);
-        case 36: return launch_stacked<2, 5, 3, 1>(L, s);
+        case 34: return L.kmix_order <= 1 ? launch_stacked<2, 5, 3, 2, 0, 2>(L, s) : launch_stacked<2, 5, 3, 2>(L, s);
+        case 35: return L.kodd ? launch_stacked<2, 5, 2, 1, 0, 1, false, 0, true>(L, s) : L.kmix_order <= 1 ? launch_stacked<2, 5, 2, 1, 0, 2>(L, s) : launch_stacked<2, 5, 2, 1>(L, s);
+        case 36: return L.kmix_order <= 1 ? launch_stacked<2, 5, 3, 1, 0, 2>(L, s) : launch_stacked<2, 5, 3, 1>(L, s);
         case 37: return launch_stacked<3, 6, 3, 3>(L, s);
         case 38: return launch_stacked<3, 5, 3, 3>(L, s);
         case 39: return launch_stacked<3, 5, 4, 1>(L, s);
@@ -967,7 +977,7 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 56: return launch_stacked<3, 3, 3, 1, 0, 1, true>(L, s);
         case 57: return launch_stacked<3, 2, 3, 1, 0, 1, true>(L, s);
         case 58: return L.kmix_order <= 1 ? launch_stacked<2, 6, 3, 1, 0, 2, true>(L, s) : launch_stacked<2, 6, 3, 1, 0, 1, true>(L, s);
-        case 59: return launch_stacked<2, 5, 3, 1, 0, 1, true>(L, s);
+        case 59: return L.kmix_order <= 1 ? launch_stacked<2, 5, 3, 1, 0, 2, true>(L, s) : launch_stacked<2, 5, 3, 1, 0, 1, true>(L, s);
         case 60: return L.kodd ? launch_stacked<3, 2, 3, 4, 0, 1, false, 0, true>(L, s) : launch_stacked<3, 2, 3, 4>(L, s);
         case 61: return launch_stacked<2, 4, 3, 3>(L, s);
         case 62: return launch_stacked<2, 4, 3, 2>(L, s);
@@ -996,6 +1006,13 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 85: return launch_stacked<2, 4, 3, 3, 0, 1, false, 3>(L, s);
         case 86: return launch_stacked<2, 4, 3, 2, 0, 1, false, 3>(L, s);
         case 87: return launch_stacked<2, 4, 2, 1, 0, 1, false, 3>(L, s);
+        case 88: return launch_stacked<3, 7, 2, 1>(L, s);
+        case 89: return launch_stacked<3, 7, 2, 1, 0, 1, true>(L, s);
+        case 90: return launch_stacked<2, 7, 3, 1>(L, s);
+        case 91: return launch_stacked<2, 7, 2, 1>(L, s);
+        case 92: return launch_stacked<2, 7, 3, 1, 0, 1, true>(L, s);
+        case 93: return launch_stacked<2, 8, 4, 1>(L, s);
+        case 94: return launch_stacked<2, 8, 3, 1, 0, 1, true>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown stacked kernel %d", L.stacked_id);
 }
@@ -1517,7 +1534,10 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     // (16-byte stores of whole request chunks; a few instances have an 8-byte twin for odd request sizes)
                     const bool odd_twin = (k.sd == 3 && k.n == 4 && k.ct == 3 && k.g == 2) || (k.sd == 3 && k.n == 2 && k.ct == 3 && (k.g == 2 || k.g == 4)) ||
                                           (k.sd == 3 && k.n == 3 && k.ct == 3 && k.g == 2) || (k.sd == 2 && k.n == 5 && k.ct == 2 && k.g == 1);
-                    if (!even && !(odd_twin && !verts)) continue;
+                    // (with per-request cells the 8-byte twin works as it is: the cells only enter the production phase, and the
+                    // chain rule across the tables is the separate mixing pass -- P5 triangles at the 25-point rule with cells ran on
+                    // the point-chunked instance at 17.6 % against 27-37 % on their own cell)
+                    if (!even && !odd_twin) continue;
                     if (npts > 16 * k.ct / k.g || tighter_instance(k) || !fills_tiles(k)) continue;  // 16 ct / g: points one request may have
                 }
                 bool ok = false;
@@ -1530,6 +1550,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 if (e->sd == 3 && e->n == 2) ok = table_matches<3, 2>(e->prog);
                 if (e->sd == 2 && e->n == 4) ok = table_matches<2, 4>(e->prog);
                 if (e->sd == 2 && e->n == 3) ok = table_matches<2, 3>(e->prog);
+                if (e->sd == 3 && e->n == 7) ok = table_matches<3, 7>(e->prog);
+                if (e->sd == 2 && e->n == 7) ok = table_matches<2, 7>(e->prog);
+                if (e->sd == 2 && e->n == 8) ok = table_matches<2, 8>(e->prog);
                 if (!ok) continue;
                 int rc = ensure_stacked(ctx, const_cast<fx_element*>(e), order);
                 if (rc != FX_OK) return rc;
@@ -2466,6 +2489,8 @@ int mix_high_order(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, in
     if (!invert_small(sd, e->A0, ma.A0inv)) return fail(FX_EINVAL, "degenerate cell");
     ma.n = e->ndof * e->vdim * npts;
     ma.slices = std::max(1, std::min(8, (ma.n + 2047) / 2048));
+    ma.nreq = nreq;
+    ma.rb = ma.n >= 1024 ? 1 : std::max(1, std::min(fxk::MIXH_RB, 2048 / std::max(1, ma.n)));   // small requests: blocks per workgroup
     if (nreq * ma.slices > 0x7fffffffLL) return fail(FX_EINVAL, "batch too large for the table-mixing pass");
     // where alpha - e_c sits within the previous order (mis() order inside each order)
     std::vector<std::vector<int>> prev = fx::multi_indices(sd, 0);
@@ -2489,7 +2514,8 @@ int mix_high_order(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, in
         }
         prev = cur;
     }
-    const dim3 grid((unsigned)(nreq * ma.slices));
+    const long long nblk = ma.rb > 1 ? std::min<long long>((nreq + ma.rb - 1) / ma.rb, (long long)ctx->num_cu * 16) : nreq * ma.slices;
+    const dim3 grid((unsigned)std::max<long long>(1, nblk));
     if (sd == 1 && order == 3) hipLaunchKernelGGL((fxk::table_mix_high_kernel<1, 3>), grid, dim3(256), 0, s, ma);
     else if (sd == 1) hipLaunchKernelGGL((fxk::table_mix_high_kernel<1, 4>), grid, dim3(256), 0, s, ma);
     else if (sd == 2 && order == 3) hipLaunchKernelGGL((fxk::table_mix_high_kernel<2, 3>), grid, dim3(256), 0, s, ma);
@@ -2613,7 +2639,8 @@ int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
     static std::mutex build_mutex;
     std::lock_guard<std::mutex> lock(build_mutex);
     if (e->stack_state[order] != 0) return FX_OK;
-    e->stack_state[order] = -1;
+    // -1 ("other kernels serve the element") is recorded for the STRUCTURAL failure only, a singular mass matrix; a transient one
+    // (allocation, copy) returns its error and leaves the state at 0, so that the next call builds again (as ensure_high_order)
     const int sd = e->sd, nexp = e->nexp;
     const int rows = (int)(e->hC.size() / (size_t)nexp);
     const int ntab = fx::binom(sd + order, sd);
@@ -2625,7 +2652,10 @@ int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
         bool ok = false;
         int rc = project_derivative_matrices(ctx, e, order, B, ok);
         if (rc != FX_OK) return rc;
-        if (!ok) return FX_OK;  // (state stays -1: other kernels serve the element)
+        if (!ok) {
+            e->stack_state[order] = -1;
+            return FX_OK;  // other kernels serve the element
+        }
         const int nrhs = (ntab - 1) * nexp;
         // B[k][(t-1) nexp + j] = D_t[j][k];  rows of table t: C D_t
         for (int t = 1; t < ntab; ++t)
@@ -2651,8 +2681,12 @@ int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
                 const int mem = member[4 * ks + (lane >> 4)];
                 if (row < R && mem >= 0) F[((size_t)rt * KS + ks) * 64 + lane] = S[(size_t)row * nexp + mem];
             }
-    HIP_TRY(hipMalloc(&e->d_astack[order], F.size() * sizeof(double)));
-    HIP_TRY(hipMemcpy(e->d_astack[order], F.data(), F.size() * sizeof(double), hipMemcpyHostToDevice));
+    double* d_f = nullptr;
+    HIP_TRY(hipMalloc(&d_f, F.size() * sizeof(double)));
+    if (hipMemcpy(d_f, F.data(), F.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d_f);
+        return fail(FX_EHIP, "ensure_stacked: copy of the stacked matrix failed");
+    }
     if (order == 1) {  // dof-major tiles for the instances that mix the tables in registers (per-request cells)
         const int RTd = (rows + 15) / 16;
         std::vector<double> Fd((size_t)(RTd * ntab + 1) * KS * 64, 0.0);
@@ -2665,9 +2699,16 @@ int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
                         if (r < rows && mem >= 0)
                             Fd[(((size_t)i * ntab + t) * KS + ks) * 64 + lane] = S[((size_t)t * rows + r) * nexp + mem];
                     }
-        HIP_TRY(hipMalloc(&e->d_astack_dm, Fd.size() * sizeof(double)));
-        HIP_TRY(hipMemcpy(e->d_astack_dm, Fd.data(), Fd.size() * sizeof(double), hipMemcpyHostToDevice));
+        double* d_fd = nullptr;
+        if (hipMalloc(&d_fd, Fd.size() * sizeof(double)) != hipSuccess ||
+            hipMemcpy(d_fd, Fd.data(), Fd.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+            if (d_fd) (void)hipFree(d_fd);
+            (void)hipFree(d_f);
+            return fail(FX_EHIP, "ensure_stacked: allocation or copy of the dof-major stacked matrix failed");
+        }
+        e->d_astack_dm = d_fd;
     }
+    e->d_astack[order] = d_f;
     e->stack_state[order] = 1;
     return FX_OK;
 }

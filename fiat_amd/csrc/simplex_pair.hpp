@@ -24,9 +24,6 @@
 #ifndef FX_PAIR_FULLIMG
 #define FX_PAIR_FULLIMG 1  // 1: the LDS image holds a whole request (one write/read-back round per request), 0: half
 #endif
-#ifndef FX_PAIR_STAGGER
-#define FX_PAIR_STAGGER 0
-#endif
 #ifndef FX_PAIR_WAVES
 #define FX_PAIR_WAVES 2  // waves per SIMD requested from the register allocator (2*NT accumulator tiles)
 #endif
@@ -164,15 +161,6 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 1 : FX_PAIR_WAVES) void tabulate
         long long r = RPW * p + sub;
         return r < a.nreq ? r : a.nreq - 1;
     };
-#if FX_PAIR_STAGGER
-    // Staggered start (A/B): the second wave of every SIMD waits ~4 us per FX_PAIR_STAGGER before its first unit.  All
-    // waves of a launch start their first unit together, the two waves of a SIMD share the fp64 pipe for it, and no store
-    // flows until both are done; with the stagger the first wave has the pipe to itself and its stores start earlier.
-    if (NW > 4 && wave >= NW / 2) {
-#pragma unroll
-        for (int i = 0; i < FX_PAIR_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     double xnext[SD];
     {
         const double* pp = a.pts + ((size_t)lane_req(pr) * npts + pl) * SD;

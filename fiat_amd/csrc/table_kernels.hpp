@@ -110,82 +110,123 @@ __global__ __launch_bounds__(256) void point_major_kernel(const PointMajorArgs a
 //   d/dx_d = sum_c K[c][d] d/dX_c,   d2/dx_d dx_e = sum_{c,c'} K[c][d] K[c'][e] d2/dX_c dX_c',   K = A0^-1 A_req
 // (A_req x + b_req and A0 X + b0 are the two maps to the default simplex).  One workgroup per request and
 // slice of positions; every thread owns (row, point) positions and all ntab values at them.
+constexpr int MIX_RB = 32;  // requests a workgroup takes at a time when a request has fewer positions than the workgroup threads
 struct TableMixArgs {
     double* out;          // [nreq][ntab][n]   n = rows * npts
     const double* verts;  // [nreq][SD+1][SD]
     double A0inv[9];
     int n;
     int order;            // 1 or 2
-    int slices;           // workgroups per request
+    int slices;           // workgroups per request (large requests), or
+    int rb;               // requests per workgroup pass (small requests: slices == 1, rb <= MIX_RB); one of the two is 1
+    long long nreq;
 };
 
+// K = A0^-1 A_req of one request (thread-local)
+template <int SD> __device__ __forceinline__ void mix_matrix(const double* verts, const double* A0inv, double* K) {
+    double A[SD][SD], b[SD];
+    cell_map<SD>(verts, A, b);
+    for (int c = 0; c < SD; ++c)
+        for (int d = 0; d < SD; ++d) {
+            double t = 0.0;
+            for (int k = 0; k < SD; ++k) t += A0inv[c * SD + k] * A[k][d];
+            K[c * SD + d] = t;
+        }
+}
+
+template <int SD> __device__ __forceinline__ void mix_position(double* base, int n, int i, int order, const double (&K)[SD][SD]) {
+    constexpr int NH = SD * (SD + 1) / 2;
+    double g[SD], og[SD];
+#pragma unroll
+    for (int c = 0; c < SD; ++c) g[c] = base[(size_t)(1 + c) * n + i];
+#pragma unroll
+    for (int d = 0; d < SD; ++d) {
+        double t = 0.0;
+#pragma unroll
+        for (int c = 0; c < SD; ++c) t += K[c][d] * g[c];
+        og[d] = t;
+    }
+#pragma unroll
+    for (int d = 0; d < SD; ++d) base[(size_t)(1 + d) * n + i] = og[d];
+    if (order >= 2) {
+        // Hessian tables in mis() order: (c, c'), c <= c' -> index c (2 SD - c - 1) / 2 + c'
+        double H[SD][SD];
+#pragma unroll
+        for (int c = 0; c < SD; ++c)
+#pragma unroll
+            for (int e = c; e < SD; ++e) {
+                const double v = base[(size_t)(1 + SD + c * (2 * SD - c - 1) / 2 + e) * n + i];
+                H[c][e] = v;
+                H[e][c] = v;
+            }
+        double T[SD][SD];  // T[c][e] = sum_c' H[c][c'] K[c'][e]
+#pragma unroll
+        for (int c = 0; c < SD; ++c)
+#pragma unroll
+            for (int e = 0; e < SD; ++e) {
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < SD; ++k) t += H[c][k] * K[k][e];
+                T[c][e] = t;
+            }
+#pragma unroll
+        for (int d = 0; d < SD; ++d)
+#pragma unroll
+            for (int e = d; e < SD; ++e) {
+                double t = 0.0;
+#pragma unroll
+                for (int c = 0; c < SD; ++c) t += K[c][d] * T[c][e];
+                base[(size_t)(1 + SD + d * (2 * SD - d - 1) / 2 + e) * n + i] = t;
+            }
+    }
+    (void)NH;
+}
+
+// Large requests: one workgroup per (request, slice of positions).  Small requests (fewer positions than a few
+// workgroups' worth of threads): persistent workgroups over blocks of `rb` requests -- the first rb threads build the
+// blocks' matrices, then all threads walk the block's (request, position) pairs.  One workgroup per request left most
+// of its 256 threads idle on requests of 60-500 positions (P2 / P3 triangles, N1 / RT1 ...), and paid a barrier per request.
 template <int SD>
 __global__ __launch_bounds__(256) void table_mix_kernel(const TableMixArgs a) {
     constexpr int NH = SD * (SD + 1) / 2;
-    __shared__ double sK[SD * SD];
-    const size_t req = blockIdx.x / a.slices;
-    const int slice = blockIdx.x % a.slices;
-    if (threadIdx.x == 0) {
-        double A[SD][SD], b[SD];
-        cell_map<SD>(a.verts + req * (SD + 1) * SD, A, b);
-        for (int c = 0; c < SD; ++c)
-            for (int d = 0; d < SD; ++d) {
-                double t = 0.0;
-                for (int k = 0; k < SD; ++k) t += a.A0inv[c * SD + k] * A[k][d];
-                sK[c * SD + d] = t;
-            }
-    }
-    __syncthreads();
-    double K[SD][SD];
-#pragma unroll
-    for (int c = 0; c < SD; ++c)
-#pragma unroll
-        for (int d = 0; d < SD; ++d) K[c][d] = sK[c * SD + d];
+    __shared__ double sK[MIX_RB][SD * SD];
     const int ntab = a.order >= 2 ? 1 + SD + NH : 1 + SD;
-    double* base = a.out + req * (size_t)ntab * a.n;
-    for (int i = slice * 256 + threadIdx.x; i < a.n; i += a.slices * 256) {
-        double g[SD], og[SD];
+    if (a.rb <= 1) {
+        const size_t req = blockIdx.x / a.slices;
+        const int slice = blockIdx.x % a.slices;
+        if (threadIdx.x == 0) mix_matrix<SD>(a.verts + req * (SD + 1) * SD, a.A0inv, sK[0]);
+        __syncthreads();
+        double K[SD][SD];
 #pragma unroll
-        for (int c = 0; c < SD; ++c) g[c] = base[(size_t)(1 + c) * a.n + i];
+        for (int c = 0; c < SD; ++c)
 #pragma unroll
-        for (int d = 0; d < SD; ++d) {
-            double t = 0.0;
-#pragma unroll
-            for (int c = 0; c < SD; ++c) t += K[c][d] * g[c];
-            og[d] = t;
-        }
-#pragma unroll
-        for (int d = 0; d < SD; ++d) base[(size_t)(1 + d) * a.n + i] = og[d];
-        if (a.order >= 2) {
-            // Hessian tables in mis() order: (c, c'), c <= c' -> index c (2 SD - c - 1) / 2 + c'
-            double H[SD][SD];
+            for (int d = 0; d < SD; ++d) K[c][d] = sK[0][c * SD + d];
+        double* base = a.out + req * (size_t)ntab * a.n;
+        for (int i = slice * 256 + threadIdx.x; i < a.n; i += a.slices * 256) mix_position<SD>(base, a.n, i, a.order, K);
+        return;
+    }
+    const float rinv = 1.0f / (float)a.n;
+    for (long long r0 = (long long)blockIdx.x * a.rb; r0 < a.nreq; r0 += (long long)gridDim.x * a.rb) {
+        __syncthreads();  // the matrices of the previous block are no longer read
+        const int nb = (int)min((long long)a.rb, a.nreq - r0);
+        if ((int)threadIdx.x < nb) mix_matrix<SD>(a.verts + (size_t)(r0 + threadIdx.x) * (SD + 1) * SD, a.A0inv, sK[threadIdx.x]);
+        __syncthreads();
+        for (int e = threadIdx.x; e < nb * a.n; e += 256) {
+            int rl = (int)((float)e * rinv);
+            int i = e - rl * a.n;
+            if (i < 0) {
+                --rl;
+                i += a.n;
+            } else if (i >= a.n) {
+                ++rl;
+                i -= a.n;
+            }
+            double K[SD][SD];
 #pragma unroll
             for (int c = 0; c < SD; ++c)
 #pragma unroll
-                for (int e = c; e < SD; ++e) {
-                    const double v = base[(size_t)(1 + SD + c * (2 * SD - c - 1) / 2 + e) * a.n + i];
-                    H[c][e] = v;
-                    H[e][c] = v;
-                }
-            double T[SD][SD];  // T[c][e] = sum_c' H[c][c'] K[c'][e]
-#pragma unroll
-            for (int c = 0; c < SD; ++c)
-#pragma unroll
-                for (int e = 0; e < SD; ++e) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int k = 0; k < SD; ++k) t += H[c][k] * K[k][e];
-                    T[c][e] = t;
-                }
-#pragma unroll
-            for (int d = 0; d < SD; ++d)
-#pragma unroll
-                for (int e = d; e < SD; ++e) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int c = 0; c < SD; ++c) t += K[c][d] * T[c][e];
-                    base[(size_t)(1 + SD + d * (2 * SD - d - 1) / 2 + e) * a.n + i] = t;
-                }
+                for (int d = 0; d < SD; ++d) K[c][d] = sK[rl][c * SD + d];
+            mix_position<SD>(a.out + (size_t)(r0 + rl) * ntab * a.n, a.n, i, a.order, K);
         }
     }
 }
@@ -204,7 +245,9 @@ struct TableMixHighArgs {
     const double* verts;  // [nreq][SD+1][SD]
     double A0inv[9];
     int n;
-    int slices;
+    int slices;          // workgroups per request (large requests; then rb == 1)
+    int rb;              // requests per workgroup pass (small requests, <= MIXH_RB; then slices == 1)
+    long long nreq;
     signed char down[MIXH_MAXT][3];  // index, within the previous order, of alpha_t - e_c (-1: alpha_t[c] == 0)
     unsigned char lead[MIXH_MAXT];   // first non-zero entry of alpha_t
 };
@@ -231,52 +274,81 @@ __device__ __forceinline__ void mix_one_order(double* base, int n, int i, const 
     }
 }
 
+constexpr int MIXH_RB = 8;  // requests per workgroup pass of the small-request path (their M_1..M_ORDER live in LDS: <= 370 doubles each)
+
 template <int SD, int ORDER>
 __global__ __launch_bounds__(256) void table_mix_high_kernel(const TableMixHighArgs a) {
     static_assert(ORDER == 3 || ORDER == 4, "orders 3 and 4");
     constexpr int C1 = MisCount<SD, 1>::value, C2 = MisCount<SD, 2>::value, C3 = MisCount<SD, 3>::value, C4 = MisCount<SD, 4>::value;
     constexpr int F1 = 1, F2 = F1 + C1, F3 = F2 + C2, F4 = F3 + C3;   // first table of each order
     constexpr int NTAB = ORDER == 3 ? F4 : F4 + C4;
-    __shared__ double sK[SD * SD];
-    __shared__ double M1[C1 * C1], M2[C2 * C2], M3[C3 * C3], M4[ORDER >= 4 ? C4 * C4 : 1];
-    const size_t req = blockIdx.x / a.slices;
-    const int slice = blockIdx.x % a.slices;
-    if (threadIdx.x == 0) {
-        double A[SD][SD], b[SD];
-        cell_map<SD>(a.verts + req * (SD + 1) * SD, A, b);
-        for (int c = 0; c < SD; ++c)
-            for (int d = 0; d < SD; ++d) {
-                double t = 0.0;
-                for (int k = 0; k < SD; ++k) t += a.A0inv[c * SD + k] * A[k][d];
-                sK[c * SD + d] = t;
-            }
-    }
-    __syncthreads();
-    // M_k[t][s] from M_{k-1}; tables of order k are first..first+cnt-1
-    auto build = [&](double* Mk, const double* Mp, int first, int cnt, int pcnt) {
-        for (int e = threadIdx.x; e < cnt * cnt; e += 256) {
-            const int t = e / cnt, s2 = e - t * cnt;
-            const int d = a.lead[first + t];
-            const int tp = a.down[first + t][d];
-            double acc = 0.0;
-            for (int c = 0; c < SD; ++c) {
-                const int sp = a.down[first + s2][c];
-                if (sp >= 0) acc += sK[c * SD + d] * (Mp ? Mp[tp * pcnt + sp] : 1.0);
-            }
-            Mk[e] = acc;
+    constexpr int O1 = 0, O2 = O1 + C1 * C1, O3 = O2 + C2 * C2, O4 = O3 + C3 * C3, MTOT = O4 + (ORDER >= 4 ? C4 * C4 : 0);
+    __shared__ double sK[MIXH_RB][SD * SD];
+    __shared__ double sM[MIXH_RB][MTOT];
+    // Large requests (rb == 1): one workgroup per (request, slice of positions).  Small requests: persistent workgroups over
+    // blocks of rb requests, as table_mix_kernel / piola_apply_kernel -- one workgroup per request spent four barriers and a
+    // serial K on requests of a few hundred positions.
+    const bool blocked = a.rb > 1;
+    const float rinv = 1.0f / (float)a.n;
+    const long long nblocks = blocked ? (a.nreq + a.rb - 1) / a.rb : 0;
+    for (long long blk = blockIdx.x; blocked ? blk < nblocks : blk == (long long)blockIdx.x; blk += gridDim.x) {
+        const long long r0 = blocked ? blk * a.rb : (long long)(blockIdx.x / a.slices);
+        const int slice = blocked ? 0 : (int)(blockIdx.x % a.slices);
+        const int nb = blocked ? (int)min((long long)a.rb, a.nreq - r0) : 1;
+        __syncthreads();  // the matrices of the previous block are no longer read
+        if ((int)threadIdx.x < nb) {
+            double A[SD][SD], b[SD];
+            cell_map<SD>(a.verts + (size_t)(r0 + threadIdx.x) * (SD + 1) * SD, A, b);
+            for (int c = 0; c < SD; ++c)
+                for (int d = 0; d < SD; ++d) {
+                    double t = 0.0;
+                    for (int k = 0; k < SD; ++k) t += a.A0inv[c * SD + k] * A[k][d];
+                    sK[threadIdx.x][c * SD + d] = t;
+                }
         }
         __syncthreads();
-    };
-    build(M1, nullptr, F1, C1, 1);
-    build(M2, M1, F2, C2, C1);
-    build(M3, M2, F3, C3, C2);
-    if constexpr (ORDER >= 4) build(M4, M3, F4, C4, C3);
-    double* base = a.out + req * (size_t)NTAB * a.n;
-    for (int i = slice * 256 + threadIdx.x; i < a.n; i += a.slices * 256) {
-        mix_one_order<SD, ORDER, 1>(base, a.n, i, M1, F1);
-        mix_one_order<SD, ORDER, 2>(base, a.n, i, M2, F2);
-        mix_one_order<SD, ORDER, 3>(base, a.n, i, M3, F3);
-        if constexpr (ORDER >= 4) mix_one_order<SD, ORDER, 4>(base, a.n, i, M4, F4);
+        // M_k[t][s] from M_{k-1}; tables of order k are first..first+cnt-1
+        auto build = [&](int ok, int op, bool has_prev, int first, int cnt, int pcnt) {
+            for (int idx = threadIdx.x; idx < nb * cnt * cnt; idx += 256) {
+                const int rl = idx / (cnt * cnt), e = idx - rl * cnt * cnt;
+                const int t = e / cnt, s2 = e - t * cnt;
+                const int d = a.lead[first + t];
+                const int tp = a.down[first + t][d];
+                double acc = 0.0;
+                for (int c = 0; c < SD; ++c) {
+                    const int sp = a.down[first + s2][c];
+                    if (sp >= 0) acc += sK[rl][c * SD + d] * (has_prev ? sM[rl][op + tp * pcnt + sp] : 1.0);
+                }
+                sM[rl][ok + e] = acc;
+            }
+            __syncthreads();
+        };
+        build(O1, 0, false, F1, C1, 1);
+        build(O2, O1, true, F2, C2, C1);
+        build(O3, O2, true, F3, C3, C2);
+        if constexpr (ORDER >= 4) build(O4, O3, true, F4, C4, C3);
+        const int total = nb * a.n;
+        for (int e = slice * 256 + threadIdx.x; e < total; e += a.slices * 256) {
+            int rl = 0, i = e;
+            if (blocked) {
+                rl = (int)((float)e * rinv);
+                i = e - rl * a.n;
+                if (i < 0) {
+                    --rl;
+                    i += a.n;
+                } else if (i >= a.n) {
+                    ++rl;
+                    i -= a.n;
+                }
+            }
+            double* base = a.out + (size_t)(r0 + rl) * NTAB * a.n;
+            const double* M = sM[rl];
+            mix_one_order<SD, ORDER, 1>(base, a.n, i, M + O1, F1);
+            mix_one_order<SD, ORDER, 2>(base, a.n, i, M + O2, F2);
+            mix_one_order<SD, ORDER, 3>(base, a.n, i, M + O3, F3);
+            if constexpr (ORDER >= 4) mix_one_order<SD, ORDER, 4>(base, a.n, i, M + O4, F4);
+        }
+        if (!blocked) break;
     }
 }
 

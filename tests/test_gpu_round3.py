@@ -159,3 +159,54 @@ def test_gls_against_the_reference(golden, sd, k):
     vals_m, vals_p = mapped[0].reshape(mapped.shape[1], -1), phys[0].reshape(phys.shape[1], -1)
     scale = np.einsum("ij,ij->i", vals_m, vals_p) / np.einsum("ij,ij->i", vals_m, vals_m)
     assert np.abs(vals_m * scale[:, None] - vals_p).max() <= 1e-9 * max(1.0, np.abs(vals_p).max())
+
+
+@pytest.mark.parametrize("family,sd,degree,npts", [("Lagrange", 2, 5, 25), ("RaviartThomas", 3, 2, 11), ("Lagrange", 3, 4, 23),
+                                                   ("DiscontinuousLagrange", 2, 5, 25)])
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_odd_request_sizes_with_per_request_cells(family, sd, degree, npts, order, kernel_policy):
+    """Requests of an odd number of doubles (odd rows x odd points) with per-request cells now take the stacked kernel's
+    8-byte flush twin (+ the table-mixing pass) instead of the point-chunked instance: equal to the generic kernel."""
+    import fiat_amd as fa
+    el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
+    rng = np.random.default_rng(77 + order)
+    nreq = 301
+    ref = np.array(fa.ufc_simplex(sd).get_vertices(), dtype=float)
+    A = np.eye(sd) + 0.15 * rng.standard_normal((nreq, sd, sd))
+    A[::7, :, 0] *= -1.0
+    verts = np.einsum("vd,red->rve", ref, A) + rng.standard_normal((nreq, 1, sd))
+    e = rng.exponential(size=(nreq, npts, sd + 1))
+    pts = np.einsum("rpv,rvd->rpd", e / e.sum(-1, keepdims=True), verts)
+    got = el.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    name = el.device_polyset().kernel_name(order, nreq, npts, has_verts=True)
+    kernel_policy("no_stacked", "no_small", "no_fixed", "no_coop")
+    want = el.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    assert el.device_polyset().kernel_name(order, nreq, npts, has_verts=True).endswith("tabulate_simplex_kernel")
+    assert got.shape == want.shape
+    for t in range(got.shape[1]):
+        assert rel(got[:, t], want[:, t]) <= (1e-12 if t == 0 else 1e-10), (name, t, rel(got[:, t], want[:, t]))
+
+
+@pytest.mark.parametrize("family,sd,degree,npts", [("Lagrange", 3, 7, 30), ("DiscontinuousLagrange", 3, 7, 101), ("Lagrange", 2, 7, 42),
+                                                   ("DiscontinuousLagrange", 2, 7, 24), ("Lagrange", 2, 8, 55), ("Lagrange", 2, 8, 130),
+                                                   ("Lagrange", 2, 7, 97)])
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_expansion_degrees_7_and_8_on_the_stacked_kernel(family, sd, degree, npts, order, kernel_policy):
+    """Round 3 registered expansion degrees 7 (tetrahedra, triangles) and 8 (triangles) with the stacked-matrix kernel
+    (whole-request and point-chunked instances): equal to the generic kernel, which the reference goldens pin
+    (test_expansion_degrees_7_to_10, nodality of P7 in test_gpu_facade)."""
+    import fiat_amd as fa
+    el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
+    rng = np.random.default_rng(5 + order)
+    nreq = 37
+    e = rng.exponential(size=(nreq, npts, sd + 1))
+    pts = (e / e.sum(-1, keepdims=True))[..., 1:].copy()
+    ps = el.device_polyset()
+    name = ps.kernel_name(order, nreq, npts)
+    assert name.endswith("tabulate_simplex_stacked"), name
+    got = el.tabulate_batch(order, pts).cpu().numpy()
+    kernel_policy("no_stacked", "no_small", "no_fixed", "no_coop")
+    assert ps.kernel_name(order, nreq, npts).endswith("tabulate_simplex_kernel")
+    want = el.tabulate_batch(order, pts).cpu().numpy()
+    for t in range(got.shape[1]):
+        assert rel(got[:, t], want[:, t]) <= (1e-12 if t == 0 else 1e-10), (t, rel(got[:, t], want[:, t]))

@@ -63,3 +63,7 @@ for sd in (2, 3):
 print("\n-- slowest 25 --")
 for frac, line in sorted(rows)[:25]:
     print(line)
+fr = np.array(sorted(r[0] for r in rows))
+if len(fr):
+    print(f"\n{len(fr)} shapes: geometric mean {np.exp(np.mean(np.log(fr))):.1f} % of the HBM peak, median {np.median(fr):.1f}, "
+          f"quartiles {np.percentile(fr, 25):.1f} / {np.percentile(fr, 75):.1f}, min {fr[0]:.1f}, max {fr[-1]:.1f}")
