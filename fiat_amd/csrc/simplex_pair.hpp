@@ -24,6 +24,9 @@
 #ifndef FX_PAIR_FULLIMG
 #define FX_PAIR_FULLIMG 1  // 1: the LDS image holds a whole request (one write/read-back round per request), 0: half
 #endif
+#ifndef FX_PAIR_PLAIN_EDGES
+#define FX_PAIR_PLAIN_EDGES 0
+#endif
 #ifndef FX_PAIR_WAVES
 #define FX_PAIR_WAVES 2  // waves per SIMD requested from the register allocator (2*NT accumulator tiles)
 #endif
@@ -339,6 +342,7 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 1 : FX_PAIR_WAVES) void tabulate
                 }
             }
         };
+        v2d carry = v2d{0.0, 0.0};  // (CARRY instances) trailing partial line of half 0, one 16-byte chunk per lane
         auto flush_half = [&](long long req, int half) {
             const int ntab_h = half == 0 ? TH : NTAB - TH;
             const int nch = (ntab_h * ROWS * enpts) >> 1;
@@ -356,17 +360,45 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 1 : FX_PAIR_WAVES) void tabulate
             constexpr int NFLS = SHIFT ? NFL + 1 : NFL;
             int shift = 0;
             if constexpr (SHIFT) shift = (int)((reinterpret_cast<unsigned long long>(g2) >> 4) & 7ull);
+            // Two half images per request (RT2, P4): the boundary between them falls inside a line as well, and that line
+            // used to be written twice, partially, a few microseconds apart.  Half 0 now leaves its trailing partial
+            // line (tl chunks) out and keeps it in a register per lane (`carry`); half 1's first store instruction
+            // starts tl chunks earlier -- the two halves are adjacent in memory -- and writes carry + its own first
+            // chunks as ONE whole line: two partial lines per request instead of four (tools/ubench6.hip: two
+            // shifted half blocks cost 2.6-4.5 % more than one shifted block of the same bytes).
+            constexpr bool CARRY = SHIFT && !FULLIMG && NTAB > TH;
+            int tl = 0, lo = 0;
+            if constexpr (CARRY) {
+                if (half == 0) tl = (shift + nch) & 7;
+                else lo = -shift;
+            }
+            const int last = nch - 1 - tl;
 #pragma unroll
             for (int b0 = 0; b0 < NFLS; b0 += FB) {
                 v2d buf[FB];
 #pragma unroll
                 for (int it = b0; it < NFLS && it < b0 + FB; ++it) {
-                    const int i = SHIFT ? max(0, min(it * 64 + elane - shift, nch - 1)) : min(it * 64 + elane, nch - 1);
+                    const int i = SHIFT ? max(0, min(it * 64 + elane - shift, last)) : min(it * 64 + elane, nch - 1);
                     buf[it - b0] = s2[i];
+                    if constexpr (CARRY) {
+                        if (it == 0 && half == 1 && elane < shift) buf[0] = carry;
+                    }
+                }
+                if constexpr (CARRY) {
+                    // (read before the image is overwritten by the next half's tiles: lane e < tl holds chunk nch - tl + e)
+                    if (b0 == 0 && half == 0) carry = s2[min(nch - tl + elane, nch - 1)];
                 }
 #pragma unroll
                 for (int it = b0; it < NFLS && it < b0 + FB; ++it) {
-                    const int i = SHIFT ? max(0, min(it * 64 + elane - shift, nch - 1)) : min(it * 64 + elane, nch - 1);
+                    const int i = SHIFT ? max(lo, min(it * 64 + elane - shift, last)) : min(it * 64 + elane, nch - 1);
+#if FX_PAIR_PLAIN_EDGES
+                    // The instruction that holds the request's first (last) partial line is a PLAIN store: the line is shared
+                    // with the neighbouring request, which another wave writes at another time; a non-temporal partial write
+                    // leaves the L2 at once and the two halves of the line reach memory separately, a plain one stays in the L2
+                    // until its other half has arrived
+                    if (SHIFT && ((it == 0 && (!CARRY || half == 0)) || (it == NFLS - 1 && (!CARRY || half == 1)))) g2[i] = buf[it - b0];
+                    else
+#endif
                     stream_store(&g2[i], buf[it - b0]);
                 }
             }

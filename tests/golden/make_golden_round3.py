@@ -118,10 +118,11 @@ def main():
         base = make(FIAT.ufc_simplex(sd))
         for order in (3, 4):
             for r in range(ncell):
-                tab = base.tabulate(order, ref_pts[r]) if hasattr(base, "dual_basis") else base.tabulate(ref_pts[r], order)
-                out[f"pc_{name}_o{order}_ref{r}"] = stack(tab, sd, order)
                 if rebuild:
                     out[f"pc_{name}_o{order}_phys{r}"] = stack(make(physical(sd, verts[r])).tabulate(order, pts[r]), sd, order)
+                else:
+                    tab = base.tabulate(order, ref_pts[r]) if hasattr(base, "dual_basis") else base.tabulate(ref_pts[r], order)
+                    out[f"pc_{name}_o{order}_ref{r}"] = stack(tab, sd, order)
     # ---- traceless tensors and GLS -----------------------------------------------------------------------
     for sd, k in ((2, 0), (2, 1), (2, 2), (3, 0), (3, 1)):
         cell = FIAT.ufc_simplex(sd)
