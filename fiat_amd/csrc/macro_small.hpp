@@ -217,8 +217,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_macro_small(const MacroSmall
                         const int total = (Pcur * NTAB * table) >> 1;
                         const v2d* s2 = reinterpret_cast<const v2d*>(stage);
                         v2d* g2 = reinterpret_cast<v2d*>(gout);
-#pragma unroll 4
-                        for (int j = lane; j < total; j += 64) stream_store(&g2[j], s2[j]);
+                        flush_block(g2, s2, total, lane);  // whole-line non-temporal body, plain partial edges (store.hpp)
                     } else if (a.vec2) {
                         const int hp = L >> 1;
                         const int total = runs * hp;

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * NW) void prism_small_kernel(const PrismArgs a)
             if ((reqsize & 1) == 0) {
                 const v2d* s2 = reinterpret_cast<const v2d*>(stage);
                 v2d* g2 = reinterpret_cast<v2d*>(gout);
-                for (long long i = lane; i < (total >> 1); i += 64) stream_store(&g2[i], s2[i]);
+                flush_block(g2, s2, (int)(total >> 1), lane);  // whole-line non-temporal body, plain partial edges (store.hpp)
             } else {
                 for (long long i = lane; i < total; i += 64) gout[i] = stage[i];
             }

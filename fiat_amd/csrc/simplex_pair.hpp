@@ -25,7 +25,7 @@
 #define FX_PAIR_FULLIMG 1  // 1: the LDS image holds a whole request (one write/read-back round per request), 0: half
 #endif
 #ifndef FX_PAIR_PLAIN_EDGES
-#define FX_PAIR_PLAIN_EDGES 0
+#define FX_PAIR_PLAIN_EDGES 1  // plain (write-back) stores for the two store instructions of a request that hold lines shared with its neighbours
 #endif
 #ifndef FX_PAIR_WAVES
 #define FX_PAIR_WAVES 2  // waves per SIMD requested from the register allocator (2*NT accumulator tiles)
@@ -391,15 +391,14 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 1 : FX_PAIR_WAVES) void tabulate
 #pragma unroll
                 for (int it = b0; it < NFLS && it < b0 + FB; ++it) {
                     const int i = SHIFT ? max(lo, min(it * 64 + elane - shift, last)) : min(it * 64 + elane, nch - 1);
-#if FX_PAIR_PLAIN_EDGES
-                    // The instruction that holds the request's first (last) partial line is a PLAIN store: the line is shared
-                    // with the neighbouring request, which another wave writes at another time; a non-temporal partial write
-                    // leaves the L2 at once and the two halves of the line reach memory separately, a plain one stays in the L2
-                    // until its other half has arrived
-                    if (SHIFT && ((it == 0 && (!CARRY || half == 0)) || (it == NFLS - 1 && (!CARRY || half == 1)))) g2[i] = buf[it - b0];
-                    else
-#endif
-                    stream_store(&g2[i], buf[it - b0]);
+                    // The store instruction that holds the request's first (last) line is a PLAIN store when requests are not line
+                    // multiples: that line is shared with the neighbouring request, which another wave writes at another time.  A
+                    // non-temporal partial write leaves the L2 at once and the two parts of the line reach memory as separate
+                    // masked writes; a plain one stays in the L2 until the other part has arrived (RT2, 25 000 requests:
+                    // 167 -> 152.5 us, 100 000: 615 -> 581 us; P4: neutral).  N2 / P3 requests are line multiples: all non-temporal.
+                    constexpr bool EDGES = FX_PAIR_PLAIN_EDGES && SHIFT && (NTAB * ROWS * 8) % 128 != 0;
+                    if (EDGES && ((it == 0 && (!CARRY || half == 0)) || (it == NFLS - 1 && (!CARRY || half == 1)))) g2[i] = buf[it - b0];
+                    else stream_store(&g2[i], buf[it - b0]);
                 }
             }
         };

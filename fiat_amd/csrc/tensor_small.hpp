@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void tensor_small_kernel(const TensorArgs a, c
         if ((total & 1) == 0) {
             const v2d_t* s2 = reinterpret_cast<const v2d_t*>(img);
             v2d_t* d2 = reinterpret_cast<v2d_t*>(dst);
-            for (int c = lane; c < (n >> 1); c += 64) d2[c] = s2[c];
+            flush_block(d2, s2, n >> 1, lane);  // whole-line non-temporal body, plain partial edges (store.hpp)
         } else {
             for (int c = lane; c < n; c += 64) dst[c] = img[c];
         }
