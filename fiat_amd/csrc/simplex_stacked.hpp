@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                 FlushT* g2 = oreq[g] < a.nreq ? reinterpret_cast<FlushT*>(a.out + ((size_t)oreq[g] * a.R + (size_t)rowbase) * enpts)
                                               : reinterpret_cast<FlushT*>(trash);
                 if constexpr (ODD) g2[min(it * 64 + elane, nch - 1)] = fbuf[r];  // (8-byte pieces, lines shared with the neighbours: plain stores)
-                else stream_store(&g2[min(it * 64 + elane, nch - 1)], fbuf[r]);
+                else stream_store(&g2[min(it * 64 + elane, nch - 1)], fbuf[r]);  // (all-plain here: 30 shapes, geometric mean 1.05 x the time, 0.85 ... 1.64)
 #endif
             }
         };
