@@ -20,12 +20,17 @@ workload = sys.argv[4] if len(sys.argv) > 4 else "p3tet"
 batch = int(sys.argv[5]) if len(sys.argv) > 5 else 100000
 os.makedirs("profiles", exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+def newest(pattern):
+    """gpurun MERGES output directories: a re-run leaves the previous run's files (other PIDs) beside the new ones."""
+    return sorted(glob.glob(pattern), key=os.path.getmtime, reverse=True)
+
+
+stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], f"profiles/{tag}_kernel_stats.csv")
 counters = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(d, "*", "*_counter_collection.csv"))[:1]:
         agg = collections.defaultdict(list)
         meta = {}
         for r in csv.DictReader(open(f)):
@@ -49,7 +54,7 @@ if stats:
 # per-phase durations from the kernel trace: bench.py now opens with W + K launches from an idle GPU (ms_per_step_cold), then
 # the clock ramp, then the timed W + K and the K launches of the HIP-event timing -- the all-launch average above mixes them
 phases = None
-traces = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+traces = newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
 if traces:
     rows = []
     for r in csv.DictReader(open(traces[0])):
