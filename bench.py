@@ -705,9 +705,10 @@ def main():
     ap.add_argument("--allgather-mode", default="auto", choices=["auto", "replicated", "ring"],
                     help="replicated: every GPU ends with all tables; ring: tables too large to replicate pass through staging buffers")
     ap.add_argument("--allgather-timeout", type=float, default=120.0)
-    ap.add_argument("--allgather-verify", action="store_true",
-                    help="N > 1: before timing the exchange, every rank tabulates the same requests and compares every "
+    ap.add_argument("--allgather-verify", dest="allgather_verify", action="store_true", default=True,
+                    help="N > 1 (default): before timing the exchange, every rank tabulates the same requests and compares every "
                          "gathered block with its own (bit for bit); a mismatch fails the run (exit 3)")
+    ap.add_argument("--no-allgather-verify", dest="allgather_verify", action="store_false")
     ap.add_argument("--shared-points", action="store_true",
                     help="variant (SURVEY.md 8d): ONE 23-point rule on the reference cell pushed forward to per-request "
                          "physical cells (fx_tabulate_batch_shared) instead of per-request random points")
