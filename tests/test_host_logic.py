@@ -173,3 +173,21 @@ def test_lagrange_node_placement_matches_oracle():
             b = BrokenLagrangeDualSet(cell, deg)
             assert b.get_entity_ids()[sd][0] == list(range(len(ref_nodes)))
             assert all(v == [] for dim in range(sd) for v in b.get_entity_ids()[dim].values())
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The drop-in boundary is a C ABI: include/fiat_amd.h must compile as C (no C++ types, no torch types) and a C program
+    must link against the library by its declarations alone."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    src = tmp_path / "abi_check.c"
+    src.write_text('#include "fiat_amd.h"\nint main(void) { return fx_abi_version() == 2 && fx_num_tables(3, 1) == 4 ? 0 : 1; }\n')
+    inc = os.path.join(ROOT, "include")
+    lib = os.path.join(ROOT, "fiat_amd", "csrc")
+    exe = tmp_path / "abi_check"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{inc}", str(src), f"-L{lib}", "-lfiat_amd",
+                    f"-Wl,-rpath,{lib}", "-o", str(exe)], check=True, capture_output=True)
+    assert subprocess.run([str(exe)], capture_output=True).returncode == 0
