@@ -404,3 +404,38 @@ def test_squared_norm_kernel(fa):
         got = runtime.tables_squared_norm(x, w).cpu().numpy()
         want = np.einsum("nrcp,p->nr", x.reshape(shape[0], shape[1], -1, shape[-1]) ** 2, w)
         np.testing.assert_allclose(got, want, rtol=1e-13, atol=0)
+
+
+# The reference's own known answers for entity_support_dofs (test/FIAT/unit/test_facet_support_dofs.py:25-46, 79-100):
+# tensor products of Lagrange / DG factors on the quadrilateral and the prism, horizontal and vertical facets.
+QUAD = [(("DiscontinuousLagrange", 0), ("DiscontinuousLagrange", 0), {0: [0], 1: [0]}, {0: [0], 1: [0]}),
+        (("DiscontinuousLagrange", 1), ("DiscontinuousLagrange", 1), {0: [0, 2], 1: [1, 3]}, {0: [0, 1], 1: [2, 3]}),
+        (("Lagrange", 1), ("Lagrange", 1), {0: [0, 2], 1: [1, 3]}, {0: [0, 1], 1: [2, 3]}),
+        (("DiscontinuousLagrange", 0), ("Lagrange", 1), {0: [0], 1: [1]}, {0: [0, 1], 1: [0, 1]}),
+        (("Lagrange", 1), ("DiscontinuousLagrange", 0), {0: [0, 1], 1: [0, 1]}, {0: [0], 1: [1]})]
+PRISM = [(("DiscontinuousLagrange", 0), ("DiscontinuousLagrange", 0), {0: [0], 1: [0]}, {0: [0], 1: [0], 2: [0]}),
+         (("DiscontinuousLagrange", 1), ("DiscontinuousLagrange", 1), {0: [0, 2, 4], 1: [1, 3, 5]},
+          {0: [2, 3, 4, 5], 1: [0, 1, 4, 5], 2: [0, 1, 2, 3]}),
+         (("Lagrange", 1), ("Lagrange", 1), {0: [0, 2, 4], 1: [1, 3, 5]}, {0: [2, 3, 4, 5], 1: [0, 1, 4, 5], 2: [0, 1, 2, 3]}),
+         (("DiscontinuousLagrange", 0), ("Lagrange", 1), {0: [0], 1: [1]}, {0: [0, 1], 1: [0, 1], 2: [0, 1]}),
+         (("Lagrange", 1), ("DiscontinuousLagrange", 0), {0: [0, 1, 2], 1: [0, 1, 2]}, {0: [1, 2], 1: [0, 2], 2: [0, 1]})]
+
+
+@pytest.mark.parametrize("base,extr,horiz,vert", QUAD)
+def test_facet_support_dofs_quadrilateral_known_answers(fa, base, extr, horiz, vert):
+    fiat_amd, _ = fa
+    from fiat_amd.finite_element import entity_support_dofs
+    I = fiat_amd.ufc_simplex(1)
+    elem = fiat_amd.TensorProductElement(getattr(fiat_amd, base[0])(I, base[1]), getattr(fiat_amd, extr[0])(I, extr[1]))
+    assert entity_support_dofs(elem, (1, 0)) == horiz
+    assert entity_support_dofs(elem, (0, 1)) == vert
+
+
+@pytest.mark.parametrize("base,extr,horiz,vert", PRISM)
+def test_facet_support_dofs_prism_known_answers(fa, base, extr, horiz, vert):
+    fiat_amd, _ = fa
+    from fiat_amd.finite_element import entity_support_dofs
+    elem = fiat_amd.TensorProductElement(getattr(fiat_amd, base[0])(fiat_amd.ufc_simplex(2), base[1]),
+                                         getattr(fiat_amd, extr[0])(fiat_amd.ufc_simplex(1), extr[1]))
+    assert entity_support_dofs(elem, (2, 0)) == horiz
+    assert entity_support_dofs(elem, (1, 1)) == vert
