@@ -186,7 +186,7 @@ struct fx_element {
     // [C; C D^alpha ...] per derivative order (built at first use, ensure_stacked)
     std::vector<double> hC;
     double* d_astack[3] = {nullptr, nullptr, nullptr};
-    double* d_astack_dm = nullptr;   // order 1, dof-major tiles (tables of 16 dofs consecutive, each table padded): MIXT instances
+    double* d_astack_dm[3] = {nullptr, nullptr, nullptr};   // orders 1 and 2, dof-major tiles (the tables of 16 dofs one after the other, each padded to a tile): MIXT instances
     int stack_state[3] = {0, 0, 0};  // 0 not built, 1 built, -1 failed
     bool raw_expansion = false;      // internal helper element (identity coefficients): never takes the stacked path
     // derivative orders 3..FX_MAX_ORDER (ensure_high_order): an internal element whose rows are the stacked matrix
@@ -365,8 +365,10 @@ static int upload_coeffs(fx_element* e, int ndof, int vdim, const double* coeffs
         e->d_astack[o] = nullptr;
         e->stack_state[o] = 0;
     }
-    if (e->d_astack_dm) (void)hipFree(e->d_astack_dm);
-    e->d_astack_dm = nullptr;
+    for (int o = 0; o < 3; ++o) {
+        if (e->d_astack_dm[o]) (void)hipFree(e->d_astack_dm[o]);
+        e->d_astack_dm[o] = nullptr;
+    }
     for (int o = 0; o <= FX_MAX_ORDER; ++o) {
         if (e->high[o]) fx_element_destroy(e->high[o]);
         e->high[o] = nullptr;
@@ -524,7 +526,8 @@ int fx_element_destroy(fx_element* e) {
     if (e->d_afrag_coop) (void)hipFree(e->d_afrag_coop);
     for (int o = 0; o < 3; ++o)
         if (e->d_astack[o]) (void)hipFree(e->d_astack[o]);
-    if (e->d_astack_dm) (void)hipFree(e->d_astack_dm);
+    for (int o = 0; o < 3; ++o)
+        if (e->d_astack_dm[o]) (void)hipFree(e->d_astack_dm[o]);
     for (int o = 0; o <= FX_MAX_ORDER; ++o)
         if (e->high[o]) fx_element_destroy(e->high[o]);
     delete e;
@@ -771,6 +774,8 @@ struct StackedShape {
     int sd, n, ct, g;
     int rtc;  // > 0: instance for exactly rtc row tiles with register-resident A fragments (small shapes); 0: any
               // -2: per-request cells, order 1 on tetrahedra: dof-major tiles, chain rule across the tables in registers
+              // -3: per-request cells, order 2: the same with the Hessian tables (accumulator-side mixing, simplex_stacked.hpp MIXR)
+              // -4 / -5: point-chunked units with the order-1 / order-2 chain rule inside the kernel
               // -1: point-chunked instance (a unit = 16 ct points of one request): any number of points >= 13, odd
               //      table sizes too -- taken when no whole-request instance applies
 };
@@ -827,10 +832,39 @@ const StackedShape kStackedShapes[] = {
     // have hundreds of points, so the point-chunked instance (32 points a unit) is the one that matters
     {3, 7, 2, 1, 0}, {3, 7, 2, 1, -1},
     {2, 7, 3, 1, 0}, {2, 7, 2, 1, 0}, {2, 7, 3, 1, -1}, {2, 8, 4, 1, 0}, {2, 8, 3, 1, -1},
+    // round 3: per-request cells with Hessians, chain rule on the accumulators (rtc -3; were two passes: kernel + table_mix_kernel)
+    {3, 2, 3, 4, -3}, {3, 2, 3, 3, -3}, {3, 2, 3, 2, -3}, {3, 2, 2, 1, -3},
+    {3, 3, 3, 2, -3}, {3, 3, 2, 1, -3}, {3, 3, 3, 1, -3},
+    {3, 4, 3, 2, -3}, {3, 4, 2, 1, -3}, {3, 4, 3, 1, -3},
+    {3, 5, 2, 1, -3}, {3, 6, 2, 1, -3},
+    {2, 3, 3, 4, -3}, {2, 3, 3, 3, -3}, {2, 3, 3, 2, -3},
+    {2, 4, 3, 3, -3}, {2, 4, 3, 2, -3}, {2, 4, 2, 1, -3},
+    {2, 5, 3, 2, -3}, {2, 5, 2, 1, -3}, {2, 5, 3, 1, -3},
+    {2, 6, 3, 2, -3}, {2, 6, 2, 1, -3}, {2, 6, 3, 1, -3},
+    // degree-6 tetrahedra with three column tiles, order 1 with cells: accumulator-side mixing needs ~150 registers fewer than
+    // the flush-side version that could not be registered (see the rtc -2 block above): 0 scratch
+    {3, 6, 3, 2, -2}, {3, 6, 3, 1, -2},
+    // point-chunked units with the chain rule inside the kernel: order 1 (rtc -4), order 2 (rtc -5) -- rules of more points than a
+    // whole-request instance holds (the 74- and 122-point rules of P5 / P6 tetrahedra ...), any table size
+    {3, 6, 3, 1, -4}, {3, 5, 3, 1, -4}, {3, 4, 3, 1, -4}, {3, 3, 3, 1, -4}, {3, 2, 3, 1, -4}, {2, 6, 3, 1, -4}, {2, 5, 3, 1, -4},
+    {3, 6, 2, 1, -5}, {3, 5, 2, 1, -5}, {3, 4, 2, 1, -5}, {3, 3, 3, 1, -5}, {3, 2, 3, 1, -5}, {2, 6, 3, 1, -5}, {2, 5, 3, 1, -5},
 };
 constexpr int STACKED_NW = 4;  // one wave per SIMD
-
-template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0, bool ODD = false>
+// Order-1 in-kernel chain rule (rtc -2): on the accumulators (MIXR) or in the flush.  tools/mixr_ab.sh, all 26 instances, ABAB:
+// accumulator-side 0.84-1.00 of the flush-side launch time except on four single-request triangle instances (1.01-1.05); of
+// those, the degree-5 and -6 ones gain from a second wave per SIMD (below), which only the accumulator-side version has the
+// registers for -- the flush-side version stays on <2, 4, 2, 1>.
+#ifndef FX_MIXR1
+#define FX_MIXR1 1  // 0: flush-side everywhere, 2: accumulator-side everywhere (A/B switch)
+#endif
+constexpr bool mixr1(int sd, int n, int ct, int g) {
+    return FX_MIXR1 == 2 || (FX_MIXR1 != 0 && !(sd == 2 && g == 1 && n == 4 && ct == 2));
+}
+// Waves per SIMD of the instances with accumulator-side mixing: triangles of degree 5 and 6 need < 256 registers and run two
+// (ABAB, orders 1 and 2: 0.83-0.94 of the one-wave launch time on the three-tile instances, 0.98-1.00 on the two-tile ones;
+// degrees 3 and 4: 0.97-1.06, left at one)
+constexpr int mixr_wps(int sd, int n) { return sd == 2 && n >= 5 ? 2 : 1; }
+template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0, bool ODD = false, bool MIXR = false>
 int launch_stacked(const Launch& L, hipStream_t s) {
     constexpr int NC = fxk::FixedNC<SD, N>::value;
     fxk::StackedArgs<NC> ka;
@@ -853,7 +887,7 @@ int launch_stacked(const Launch& L, hipStream_t s) {
     ka.lim_afrag = L.khead.lim_afrag;
     if ((int)L.fcoef.size() != NC) return fail(FX_EINVAL, "internal: coefficient table size mismatch");
     memcpy(ka.coef, L.fcoef.data(), NC * sizeof(double));
-    auto kern = fxk::tabulate_simplex_stacked<SD, N, CT, G, RTC, WPS, CHUNK, MIXT, ODD>;
+    auto kern = fxk::tabulate_simplex_stacked<SD, N, CT, G, RTC, WPS, CHUNK, MIXT, ODD, MIXR>;
     // as many workgroups per CU as registers and LDS allow (low degrees need few registers: their short
     // row sweeps rely on other waves to cover the production phase); asked once per kernel
     static thread_local int occ = 0;
@@ -921,22 +955,22 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 0: return launch_stacked<3, 3, 3, 2, 5, 3>(L, s);
         case 1: return launch_stacked<3, 3, 2, 1, 5, 3>(L, s);
         case 2: return launch_stacked<3, 3, 3, 1, 5, 3>(L, s);
-        case 3: return launch_stacked<3, 6, 2, 1, 0, 1, false, 4>(L, s);
-        case 4: return launch_stacked<3, 5, 3, 2, 0, 1, false, 4>(L, s);
-        case 5: return launch_stacked<3, 5, 2, 1, 0, 1, false, 4>(L, s);
-        case 6: return launch_stacked<3, 5, 3, 1, 0, 1, false, 4>(L, s);
-        case 7: return launch_stacked<2, 6, 3, 2, 0, 1, false, 3>(L, s);
-        case 8: return launch_stacked<2, 6, 2, 1, 0, 1, false, 3>(L, s);
-        case 9: return launch_stacked<2, 6, 3, 1, 0, 1, false, 3>(L, s);
-        case 10: return launch_stacked<2, 5, 3, 2, 0, 1, false, 3>(L, s);
-        case 11: return launch_stacked<2, 5, 2, 1, 0, 1, false, 3>(L, s);
-        case 12: return launch_stacked<2, 5, 3, 1, 0, 1, false, 3>(L, s);
-        case 13: return launch_stacked<3, 4, 3, 2, 0, 1, false, 4>(L, s);
-        case 14: return launch_stacked<3, 4, 2, 1, 0, 1, false, 4>(L, s);
-        case 15: return launch_stacked<3, 4, 3, 1, 0, 1, false, 4>(L, s);
-        case 16: return launch_stacked<3, 3, 3, 2, 0, 1, false, 4>(L, s);
-        case 17: return launch_stacked<3, 3, 2, 1, 0, 1, false, 4>(L, s);
-        case 18: return launch_stacked<3, 3, 3, 1, 0, 1, false, 4>(L, s);
+        case 3: return launch_stacked<3, 6, 2, 1, 0, 1, false, 4, false, mixr1(3, 6, 2, 1)>(L, s);
+        case 4: return launch_stacked<3, 5, 3, 2, 0, 1, false, 4, false, mixr1(3, 5, 3, 2)>(L, s);
+        case 5: return launch_stacked<3, 5, 2, 1, 0, 1, false, 4, false, mixr1(3, 5, 2, 1)>(L, s);
+        case 6: return launch_stacked<3, 5, 3, 1, 0, 1, false, 4, false, mixr1(3, 5, 3, 1)>(L, s);
+        case 7: return launch_stacked<2, 6, 3, 2, 0, mixr_wps(2, 6), false, 3, false, mixr1(2, 6, 3, 2)>(L, s);
+        case 8: return launch_stacked<2, 6, 2, 1, 0, mixr_wps(2, 6), false, 3, false, mixr1(2, 6, 2, 1)>(L, s);
+        case 9: return launch_stacked<2, 6, 3, 1, 0, mixr_wps(2, 6), false, 3, false, mixr1(2, 6, 3, 1)>(L, s);
+        case 10: return launch_stacked<2, 5, 3, 2, 0, mixr_wps(2, 5), false, 3, false, mixr1(2, 5, 3, 2)>(L, s);
+        case 11: return L.kodd ? launch_stacked<2, 5, 2, 1, 0, 1, false, 3, true, true>(L, s) : launch_stacked<2, 5, 2, 1, 0, mixr_wps(2, 5), false, 3, false, mixr1(2, 5, 2, 1)>(L, s);
+        case 12: return launch_stacked<2, 5, 3, 1, 0, mixr_wps(2, 5), false, 3, false, mixr1(2, 5, 3, 1)>(L, s);
+        case 13: return launch_stacked<3, 4, 3, 2, 0, 1, false, 4, false, mixr1(3, 4, 3, 2)>(L, s);
+        case 14: return launch_stacked<3, 4, 2, 1, 0, 1, false, 4, false, mixr1(3, 4, 2, 1)>(L, s);
+        case 15: return launch_stacked<3, 4, 3, 1, 0, 1, false, 4, false, mixr1(3, 4, 3, 1)>(L, s);
+        case 16: return L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 4, true, true>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 4, false, mixr1(3, 3, 3, 2)>(L, s);
+        case 17: return launch_stacked<3, 3, 2, 1, 0, 1, false, 4, false, mixr1(3, 3, 2, 1)>(L, s);
+        case 18: return launch_stacked<3, 3, 3, 1, 0, 1, false, 4, false, mixr1(3, 3, 3, 1)>(L, s);
         case 19: return launch_stacked<3, 6, 3, 2>(L, s);
         case 20: return launch_stacked<3, 6, 2, 1>(L, s);
         case 21: return launch_stacked<3, 6, 3, 1>(L, s);
@@ -996,16 +1030,16 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 75: return launch_stacked<2, 4, 3, 6>(L, s);
         case 76: return launch_stacked<2, 4, 3, 1, 0, 1, true>(L, s);
         case 77: return launch_stacked<2, 3, 3, 1, 0, 1, true>(L, s);
-        case 78: return launch_stacked<3, 2, 3, 4, 0, 1, false, 4>(L, s);
-        case 79: return launch_stacked<3, 2, 3, 3, 0, 1, false, 4>(L, s);
-        case 80: return launch_stacked<3, 2, 3, 2, 0, 1, false, 4>(L, s);
-        case 81: return launch_stacked<3, 2, 2, 1, 0, 1, false, 4>(L, s);
-        case 82: return launch_stacked<2, 3, 3, 4, 0, 1, false, 3>(L, s);
-        case 83: return launch_stacked<2, 3, 3, 3, 0, 1, false, 3>(L, s);
-        case 84: return launch_stacked<2, 3, 3, 2, 0, 1, false, 3>(L, s);
-        case 85: return launch_stacked<2, 4, 3, 3, 0, 1, false, 3>(L, s);
-        case 86: return launch_stacked<2, 4, 3, 2, 0, 1, false, 3>(L, s);
-        case 87: return launch_stacked<2, 4, 2, 1, 0, 1, false, 3>(L, s);
+        case 78: return launch_stacked<3, 2, 3, 4, 0, 1, false, 4, false, mixr1(3, 2, 3, 4)>(L, s);
+        case 79: return launch_stacked<3, 2, 3, 3, 0, 1, false, 4, false, mixr1(3, 2, 3, 3)>(L, s);
+        case 80: return launch_stacked<3, 2, 3, 2, 0, 1, false, 4, false, mixr1(3, 2, 3, 2)>(L, s);
+        case 81: return launch_stacked<3, 2, 2, 1, 0, 1, false, 4, false, mixr1(3, 2, 2, 1)>(L, s);
+        case 82: return launch_stacked<2, 3, 3, 4, 0, mixr_wps(2, 3), false, 3, false, mixr1(2, 3, 3, 4)>(L, s);
+        case 83: return launch_stacked<2, 3, 3, 3, 0, mixr_wps(2, 3), false, 3, false, mixr1(2, 3, 3, 3)>(L, s);
+        case 84: return launch_stacked<2, 3, 3, 2, 0, mixr_wps(2, 3), false, 3, false, mixr1(2, 3, 3, 2)>(L, s);
+        case 85: return launch_stacked<2, 4, 3, 3, 0, mixr_wps(2, 4), false, 3, false, mixr1(2, 4, 3, 3)>(L, s);
+        case 86: return launch_stacked<2, 4, 3, 2, 0, mixr_wps(2, 4), false, 3, false, mixr1(2, 4, 3, 2)>(L, s);
+        case 87: return launch_stacked<2, 4, 2, 1, 0, mixr_wps(2, 4), false, 3, false, mixr1(2, 4, 2, 1)>(L, s);
         case 88: return launch_stacked<3, 7, 2, 1>(L, s);
         case 89: return launch_stacked<3, 7, 2, 1, 0, 1, true>(L, s);
         case 90: return launch_stacked<2, 7, 3, 1>(L, s);
@@ -1013,6 +1047,46 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 92: return launch_stacked<2, 7, 3, 1, 0, 1, true>(L, s);
         case 93: return launch_stacked<2, 8, 4, 1>(L, s);
         case 94: return launch_stacked<2, 8, 3, 1, 0, 1, true>(L, s);
+        case 95: return L.kodd ? launch_stacked<3, 2, 3, 4, 0, 1, false, 10, true, true>(L, s) : launch_stacked<3, 2, 3, 4, 0, 1, false, 10, false, true>(L, s);
+        case 96: return launch_stacked<3, 2, 3, 3, 0, 1, false, 10, false, true>(L, s);
+        case 97: return launch_stacked<3, 2, 3, 2, 0, 1, false, 10, false, true>(L, s);
+        case 98: return launch_stacked<3, 2, 2, 1, 0, 1, false, 10, false, true>(L, s);
+        case 99: return L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 10, true, true>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 10, false, true>(L, s);
+        case 100: return launch_stacked<3, 3, 2, 1, 0, 1, false, 10, false, true>(L, s);
+        case 101: return launch_stacked<3, 3, 3, 1, 0, 1, false, 10, false, true>(L, s);
+        case 102: return launch_stacked<3, 4, 3, 2, 0, 1, false, 10, false, true>(L, s);
+        case 103: return launch_stacked<3, 4, 2, 1, 0, 1, false, 10, false, true>(L, s);
+        case 104: return launch_stacked<3, 4, 3, 1, 0, 1, false, 10, false, true>(L, s);
+        case 105: return launch_stacked<3, 5, 2, 1, 0, 1, false, 10, false, true>(L, s);
+        case 106: return launch_stacked<3, 6, 2, 1, 0, 1, false, 10, false, true>(L, s);
+        case 107: return launch_stacked<2, 3, 3, 4, 0, mixr_wps(2, 3), false, 6, false, true>(L, s);
+        case 108: return launch_stacked<2, 3, 3, 3, 0, mixr_wps(2, 3), false, 6, false, true>(L, s);
+        case 109: return launch_stacked<2, 3, 3, 2, 0, mixr_wps(2, 3), false, 6, false, true>(L, s);
+        case 110: return launch_stacked<2, 4, 3, 3, 0, mixr_wps(2, 4), false, 6, false, true>(L, s);
+        case 111: return launch_stacked<2, 4, 3, 2, 0, mixr_wps(2, 4), false, 6, false, true>(L, s);
+        case 112: return launch_stacked<2, 4, 2, 1, 0, mixr_wps(2, 4), false, 6, false, true>(L, s);
+        case 113: return launch_stacked<2, 5, 3, 2, 0, mixr_wps(2, 5), false, 6, false, true>(L, s);
+        case 114: return L.kodd ? launch_stacked<2, 5, 2, 1, 0, 1, false, 6, true, true>(L, s) : launch_stacked<2, 5, 2, 1, 0, mixr_wps(2, 5), false, 6, false, true>(L, s);
+        case 115: return launch_stacked<2, 5, 3, 1, 0, mixr_wps(2, 5), false, 6, false, true>(L, s);
+        case 116: return launch_stacked<2, 6, 3, 2, 0, mixr_wps(2, 6), false, 6, false, true>(L, s);
+        case 117: return launch_stacked<2, 6, 2, 1, 0, mixr_wps(2, 6), false, 6, false, true>(L, s);
+        case 118: return launch_stacked<2, 6, 3, 1, 0, mixr_wps(2, 6), false, 6, false, true>(L, s);
+        case 119: return launch_stacked<3, 6, 3, 2, 0, 1, false, 4, false, true>(L, s);
+        case 120: return launch_stacked<3, 6, 3, 1, 0, 1, false, 4, false, true>(L, s);
+        case 121: return launch_stacked<3, 6, 3, 1, 0, 1, true, 4, false, true>(L, s);
+        case 122: return launch_stacked<3, 5, 3, 1, 0, 1, true, 4, false, true>(L, s);
+        case 123: return launch_stacked<3, 4, 3, 1, 0, 1, true, 4, false, true>(L, s);
+        case 124: return launch_stacked<3, 3, 3, 1, 0, 1, true, 4, false, true>(L, s);
+        case 125: return launch_stacked<3, 2, 3, 1, 0, 1, true, 4, false, true>(L, s);
+        case 126: return launch_stacked<2, 6, 3, 1, 0, 1, true, 3, false, true>(L, s);  // (two waves per SIMD: 116-364 B of scratch)
+        case 127: return launch_stacked<2, 5, 3, 1, 0, 1, true, 3, false, true>(L, s);  // (two waves per SIMD: 116-364 B of scratch)
+        case 128: return launch_stacked<3, 6, 2, 1, 0, 1, true, 10, false, true>(L, s);
+        case 129: return launch_stacked<3, 5, 2, 1, 0, 1, true, 10, false, true>(L, s);
+        case 130: return launch_stacked<3, 4, 2, 1, 0, 1, true, 10, false, true>(L, s);
+        case 131: return launch_stacked<3, 3, 3, 1, 0, 1, true, 10, false, true>(L, s);
+        case 132: return launch_stacked<3, 2, 3, 1, 0, 1, true, 10, false, true>(L, s);
+        case 133: return launch_stacked<2, 6, 3, 1, 0, 1, true, 6, false, true>(L, s);  // (two waves per SIMD: 116-364 B of scratch)
+        case 134: return launch_stacked<2, 5, 3, 1, 0, 1, true, 6, false, true>(L, s);  // (two waves per SIMD: 116-364 B of scratch)
     }
     return fail(FX_EINVAL, "internal: unknown stacked kernel %d", L.stacked_id);
 }
@@ -1501,7 +1575,11 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
         // (the lane-local kernel keeps the shapes no stacked instance takes -- degrees 1 and 2 on triangles, degree 1 on
         // tetrahedra, fewer than 16 stacked rows -- and per-request cells, where it applies the chain rule itself; elsewhere
         // the MFMA contraction wins: tools/coverage_map.py, P3 / P4 triangles and P2 tetrahedra with derivatives 26-52 % -> 50-69 %)
-        if (!nostacked && L.fixed_id < 0 && (L.small_id < 0 || !verts) && !L.fused_mapping && !e->raw_expansion && order <= 2) {
+        // (order 2 with per-request cells: the rtc -3 instances beat the lane-local kernel on P4 triangles and P2 tetrahedra,
+        // 21 -> 58 % and 19 -> 38 % of the HBM peak, tools/coverage_map.py --verts --order 2 [--policy no_small])
+        const bool small_keeps = L.small_id >= 0 && verts;
+        const bool over_small = order == 2 && ((e->sd == 2 && e->n >= 4) || (e->sd == 3 && e->n >= 2));
+        if (!nostacked && L.fixed_id < 0 && (!small_keeps || over_small) && !L.fused_mapping && !e->raw_expansion && order <= 2) {
             // among the instances of one kind that hold the request, the one with the fewest padding columns
             auto tighter_instance = [&](const StackedShape& k) {
                 for (const StackedShape& o : kStackedShapes)
@@ -1513,8 +1591,15 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             // ... and only when the group's points fill more than two thirds of its column tiles (measured: at 16 of 48
             // columns the in-kernel chain-rule instance runs at 18 % where the generic kernel reaches 43 %)
             auto fills_tiles = [&](const StackedShape& k) { return 3LL * k.g * npts > 2LL * 16 * k.ct; };
-            for (size_t i = 0; i < sizeof(kStackedShapes) / sizeof(kStackedShapes[0]); ++i) {
+            // (first the instances that apply the chain rule themselves, then the rest, each in table order)
+            for (size_t i2 = 0; i2 < 2 * (sizeof(kStackedShapes) / sizeof(kStackedShapes[0])) && L.stacked_id < 0; ++i2) {
+                const size_t i = i2 % (sizeof(kStackedShapes) / sizeof(kStackedShapes[0]));
                 const StackedShape& k = kStackedShapes[i];
+                bool mix_odd = false;
+                const bool inmix = k.rtc == -2 || k.rtc == -3 || k.rtc == -4 || k.rtc == -5;  // chain rule inside the kernel
+                const bool chunked = k.rtc == -1 || k.rtc == -4 || k.rtc == -5;
+                if (inmix != (i2 == i)) continue;
+                if (small_keeps && k.rtc != -3) continue;
                 if (k.sd != e->sd || k.n != e->n) continue;
                 // small shapes with register-resident fragments: A/B partner of the paired kernel only (measured
                 // equal on C2, 302 vs 303 us -- both sit on the store-path plateau -- and the paired kernel's
@@ -1522,14 +1607,24 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 if (k.rtc > 0 ? (RT != k.rtc || verts || !stacked_small) : R < stacked_min_rows) continue;
                 // (per-request cells with derivatives on the low-degree shapes: the second pass over the tables costs more
                 // than the generic kernel's in-kernel chain rule -- tools/small_vs_stacked.py --verts, 18-29 % against 25-48 %)
-                if (k.rtc != -2 && verts && order >= 1 && (k.n <= 2 || (k.sd == 2 && k.n <= 4))) continue;
-                if (k.rtc == -2) {  // per-request cells, order 1: tables mixed in registers (dof-major tiles)
+                if (!inmix && verts && order >= 1 && (k.n <= 2 || (k.sd == 2 && k.n <= 4))) continue;
+                if (k.rtc == -2 || k.rtc == -3) {  // per-request cells, order 1 / 2: chain rule across the tables inside the kernel (dof-major tiles)
                     const bool nomix = (ctx->policy & FX_POLICY_NO_STACKED_MIX) != 0;
-                    if (nomix || !verts || order != 1 || ((long long)rows * npts) % 2 || ((long long)(rows - 16 * ((rows + 15) / 16 - 1)) * npts) % 2)
+                    if (nomix || !verts || order != (k.rtc == -2 ? 1 : 2)) continue;
+                    // (16-byte pieces of whole tables; three shapes have an 8-byte twin for odd table sizes: P5 triangles at the
+                    // 25-point rule, N3 and RT2 tetrahedra at the 23- and 11-point rules)
+                    mix_odd = ((long long)rows * npts) % 2 || ((long long)(rows - 16 * ((rows + 15) / 16 - 1)) * npts) % 2;
+                    // (RT2 at order 1 stays on the generic kernel: 44.7 % of the HBM peak there, 39.2 % on the twin)
+                    if (mix_odd && !((k.sd == 2 && k.n == 5 && k.ct == 2 && k.g == 1) || (k.sd == 3 && k.n == 3 && k.ct == 3 && k.g == 2) ||
+                                     (k.rtc == -3 && k.sd == 3 && k.n == 2 && k.ct == 3 && k.g == 4)))
                         continue;
                     if (npts > 16 * k.ct / k.g || tighter_instance(k) || !fills_tiles(k)) continue;
-                } else if (k.rtc < 0) {  // point-chunked: whatever the whole-request instances above did not take
+                } else if (chunked) {  // point-chunked: whatever the whole-request instances above did not take
                     if (npts < 13 || nreq * (long long)((npts + 16 * k.ct - 1) / (16 * k.ct)) > 0x7fffffffLL) continue;
+                    if (inmix) {  // ... with the chain rule inside: rules of more than one chunk
+                        const bool nomix = (ctx->policy & FX_POLICY_NO_STACKED_MIX) != 0;
+                        if (nomix || !verts || order != (k.rtc == -4 ? 1 : 2) || npts <= 16 * k.ct) continue;
+                    }
                 } else {
                     // (16-byte stores of whole request chunks; a few instances have an 8-byte twin for odd request sizes)
                     const bool odd_twin = (k.sd == 3 && k.n == 4 && k.ct == 3 && k.g == 2) || (k.sd == 3 && k.n == 2 && k.ct == 3 && (k.g == 2 || k.g == 4)) ||
@@ -1568,8 +1663,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 ka.pts = pts;
                 ka.verts = verts;
                 ka.out = out;
-                ka.afrag = k.rtc == -2 ? e->d_astack_dm : e->d_astack[order];
-                if (k.rtc == -2 && !invert_small(e->sd, e->A0, ka.A0inv)) continue;
+                const bool dofmajor = inmix;
+                ka.afrag = dofmajor ? e->d_astack_dm[order] : e->d_astack[order];
+                if (dofmajor && !invert_small(e->sd, e->A0, ka.A0inv)) continue;
                 ka.phi0 = e->prog.phi0;
                 memcpy(ka.A0, e->A0, sizeof ka.A0);
                 memcpy(ka.b0, e->b0, sizeof ka.b0);
@@ -1581,10 +1677,12 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 ka.lim_pts = (long long)nreq * npts * e->sd;
                 ka.lim_verts = verts ? (long long)nreq * (e->sd + 1) * e->sd : 0;
                 ka.lim_out = (long long)nreq * R * npts;
-                ka.lim_afrag = (k.rtc == -2 ? ((long long)((rows + 15) / 16) * ntab + 1) : (long long)(RT + 1)) * ((e->nexp + 3) / 4) * 64;
-                L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * fxk::stacked_image_doubles(k.ct, (e->nexp + 3) / 4, k.rtc == -2 ? e->sd + 1 : 1)) * 8;
+                ka.lim_afrag = (dofmajor ? ((long long)((rows + 15) / 16) * ntab + 1) : (long long)(RT + 1)) * ((e->nexp + 3) / 4) * 64;
+                const bool mixr = k.rtc == -3 || k.rtc == -4 || k.rtc == -5 || (k.rtc == -2 && (mix_odd || mixr1(k.sd, k.n, k.ct, k.g) || (k.sd == 3 && k.n == 6 && k.ct == 3)));
+                const int slots = fxk::stacked_mix_slots(e->sd, dofmajor ? ntab : 0, mixr);
+                L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * (fxk::stacked_image_doubles(k.ct, (e->nexp + 3) / 4, slots) + (mixr ? fxk::STACKED_KBUF : 0))) * 8;
                 if (L.klds_bytes > ctx->lds_per_cu) continue;
-                const long long groups = k.rtc == -1 ? nreq * ((npts + 16 * k.ct - 1) / (16 * k.ct)) : (nreq + k.g - 1) / k.g;
+                const long long groups = chunked ? nreq * ((npts + 16 * k.ct - 1) / (16 * k.ct)) : (nreq + k.g - 1) / k.g;
                 // one workgroup per CU = one wave per SIMD (measured: a second wave per SIMD at half the registers
                 // spills in the production phase and gains nothing, 1.45 -> 1.48 ms: the kernel is bound by the
                 // shared fp64 MFMA/VALU pipe, not by latencies)
@@ -1593,7 +1691,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 L.trash = ctx->d_trash;
                 L.queue = ctx->d_queue + (size_t)(ctx->launch_seq++ % FX_QUEUE_SLOTS) * 16;
                 L.kmix_order = order;
-                L.kodd = k.rtc == 0 && !even;
+                L.kodd = (k.rtc == 0 && !even) || mix_odd;
                 L.stacked_id = (int)i;
                 L.small_id = -1;
                 break;
@@ -2000,8 +2098,13 @@ int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, in
     Launch L;
     // plan_launch only records the pointers; a non-null dummy stands for "per-request cells given"
     static double dummy;
-    int rc = plan_launch(ctx, e, order, nreq, npts, &dummy, has_verts ? &dummy : nullptr, &dummy, L);
+    int rc = plan_launch(ctx, e, order, nreq, npts, &dummy, (has_verts & 1) ? &dummy : nullptr, &dummy, L);
     if (rc != FX_OK) return rc;
+    if ((has_verts & 2) && L.stacked_id >= 0 && L.fixed_id < 0) {  // with the instance of the stacked-matrix registry
+        const StackedShape& k = kStackedShapes[L.stacked_id];
+        snprintf(name, (size_t)name_len, "fxk::tabulate_simplex_stacked<%d,%d,%d,%d,%d>", k.sd, k.n, k.ct, k.g, k.rtc);
+        return FX_OK;
+    }
     const char* k = "fxk::tabulate_simplex_kernel";
     if (L.fixed_id >= 0)
         k = L.fkind == 0   ? "fxk::tabulate_simplex_fixed"
@@ -2687,7 +2790,7 @@ int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
         (void)hipFree(d_f);
         return fail(FX_EHIP, "ensure_stacked: copy of the stacked matrix failed");
     }
-    if (order == 1) {  // dof-major tiles for the instances that mix the tables in registers (per-request cells)
+    if (order >= 1) {  // dof-major tiles for the instances that apply the chain rule across the tables themselves (per-request cells)
         const int RTd = (rows + 15) / 16;
         std::vector<double> Fd((size_t)(RTd * ntab + 1) * KS * 64, 0.0);
         for (int i = 0; i < RTd; ++i)
@@ -2706,7 +2809,7 @@ int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
             (void)hipFree(d_f);
             return fail(FX_EHIP, "ensure_stacked: allocation or copy of the dof-major stacked matrix failed");
         }
-        e->d_astack_dm = d_fd;
+        e->d_astack_dm[order] = d_fd;
     }
     e->d_astack[order] = d_f;
     e->stack_state[order] = 1;

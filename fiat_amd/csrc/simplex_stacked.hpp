@@ -78,14 +78,32 @@ constexpr int stacked_image_doubles(int CT, int KS, int slots = 1) {
 // WPS: waves per SIMD the register allocation aims for (short sweeps need other waves to cover the
 // production phase of a group).
 // CHUNK: a unit is one request's next 16 CT points (any number of points per request, odd table sizes too):
-// the image of a row tile is [row][points of the chunk] and leaves row by row as 8-byte stores.
+// the image of a row tile is [row][points of the chunk] and leaves row by row as 8-byte stores.  (With MIXR: the same
+// units on dof-major tiles, chain rule on the accumulators.)
 // MIXT > 0 (= 1 + SD, per-request cells, order 1): the row tiles come dof-major -- the MIXT tables of 16 dofs one
 // after the other (each table padded to whole tiles) -- so that a wave holds values and all first derivatives of
 // those dofs at once; their images go to LDS together and the flush applies the chain rule
 // d/dx_d = sum_c K[c][d] d/dX_c while it copies them out.
+// MIXR (with MIXT = 1 + SD: order 1, or MIXT = 1 + SD + SD (SD + 1) / 2: order 2): the chain rule is applied to the ACCUMULATORS
+// instead -- in the MFMA result layout a lane holds the same (row, column) entry of every table, so the mix across tables is
+// lane-local: per column tile the lane reads K of its column's request from LDS (9 doubles, transient) and rewrites its
+// accumulators; the images then hold final values and the flush is a plain copy (the flush-side mix reads every image SD
+// times, and its wave-uniform K of all G requests lives in up to 72 scalar registers).  A dof tile is worked off in "halves":
+// values + gradient (1 + SD tables), then the Hessian tables (SD (SD + 1) / 2; they mix among themselves only -- the map is
+// affine), each half flushing the images of the half before it under its MFMAs.
 // ODD: requests of an odd number of doubles (odd row count x odd point count: P4 / RT2 / N3 tetrahedra, P5 triangles at rules
 // with odd point counts) start on 8-byte boundaries only -- the whole-request flush then moves 8 bytes per lane instead of 16.
-template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0, bool ODD = false>
+template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int CNT, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, CNT>{}, f); }
+
+constexpr int stacked_mix_slots(int sd, int mixt, bool mixr) {  // row-tile images per wave
+    return mixt == 0 ? 1 : (mixr && mixt > 1 + sd && sd * (sd + 1) / 2 > 1 + sd) ? sd * (sd + 1) / 2 : 1 + sd;
+}
+constexpr int STACKED_KBUF = 48;  // doubles per wave behind the images (MIXR): K of the group's (<= 4) requests
+
+template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0, bool ODD = false, bool MIXR = false>
 __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const StackedArgs<FixedNC<SD, N>::value> a,
                                                                    double* __restrict__ trash,
                                                                    unsigned int* __restrict__ gqueue) {
@@ -94,13 +112,17 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
     constexpr int KS = (NEXP + 3) / 4;
     constexpr int CPR = 16 * CT / G;                // column budget of one request
     constexpr int NST = ODD ? (16 * CPR + 63) / 64 : (16 * CPR / 2 + 63) / 64;   // 16-byte (ODD: 8-byte) stores per lane and request chunk
-    static_assert(!ODD || (!CHUNK && MIXT == 0 && RTC == 0), "8-byte flush: whole-request groups, streamed fragments");
+    static_assert(!ODD || (!CHUNK && (MIXT == 0 || MIXR) && RTC == 0), "8-byte flush: whole-request groups, streamed fragments");
     using FlushT = typename std::conditional<ODD, double, v2d>::type;
     constexpr int PCH = 16 * CT;                    // points per chunk (CHUNK)
     static_assert(!CHUNK || (G == 1 && RTC == 0), "point-chunked units: one request per group, streamed fragments");
-    constexpr int SLOTS = MIXT > 0 ? MIXT : 1;  // row-tile images per wave
-    constexpr int IMG = stacked_image_doubles(CT, KS, SLOTS);
-    static_assert(MIXT == 0 || (MIXT == 1 + SD && !CHUNK && RTC == 0), "table mixing: order 1, whole-request groups");
+    constexpr int NTA = 1 + SD, NTB = SD * (SD + 1) / 2;           // tables of orders <= 1, of order 2
+    constexpr int MORD = MIXT == 0 ? 0 : MIXT == NTA ? 1 : 2;      // derivative order of a table-mixing instance
+    constexpr int SLOTS = stacked_mix_slots(SD, MIXT, MIXR);
+    constexpr int IMG = stacked_image_doubles(CT, KS, SLOTS) + (MIXR ? STACKED_KBUF : 0);
+    static_assert(MIXT == 0 || ((MIXT == NTA || (MIXR && MIXT == NTA + NTB)) && (!CHUNK || MIXR) && RTC == 0 && (!ODD || MIXR)),
+                  "table mixing: orders 1 and 2, whole-request groups");
+    static_assert(!MIXR || (MIXT > 0 && G * SD * SD <= STACKED_KBUF && KS >= 3), "accumulator-side mixing");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -125,6 +147,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
     // a valid point and drop their results in the dump row
     const int kk = lane >> 4;
     int ioff[CT];
+    int kofs[MIXR ? CT : 1];  // MIXR: where K of the column's request sits in the wave's K buffer
     {
         const float rinv = 1.0f / (float)npts;
 #pragma unroll
@@ -133,6 +156,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
             const int g = idiv_small(j, rinv);
             const bool valid = g < G;
             ioff[c] = valid ? g * chunk + kk * npts + (j - g * npts) : -1;
+            if constexpr (MIXR) kofs[c] = valid ? g * SD * SD : 0;
         }
     }
 
@@ -290,7 +314,12 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
         }
         long long oreq[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) oreq[g] = CHUNK ? grp / nchunk : grp * G + g;
+        for (int g = 0; g < G; ++g) {
+            oreq[g] = CHUNK ? grp / nchunk : grp * G + g;
+            // (MIXR: the padding requests of the last group ARE its last request -- same points, same cell, same values to the
+            // same place -- so the stores need no second destination)
+            if constexpr (MIXR) oreq[g] = oreq[g] < a.nreq ? oreq[g] : a.nreq - 1;
+        }
         const int p0 = CHUNK ? (int)(grp - oreq[0] * nchunk) * PCH : 0;  // first point of the chunk
         const int pc = CHUNK ? min(PCH, npts - p0) : npts;             // points of the chunk = row stride of the image
         const int RTn = RTC > 0 ? RTC : a.RT;
@@ -331,7 +360,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
         const float rpc = 1.0f / (float)pc;
         auto image_get = [&](int r, int nrows, int soff = 0) {  // r-th image read
             if constexpr (CHUNK) {
-                fbuf1[r] = img[min(r * 64 + elane, nrows * pc - 1)];
+                fbuf1[r] = img[soff + min(r * 64 + elane, nrows * pc - 1)];
             } else {
                 const int g = r / NST, it = r % NST;
                 const int nch = ODD ? nrows * enpts : (nrows * enpts) >> 1;  // pieces of a request's chunk (16-byte: even, host-checked)
@@ -360,8 +389,8 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                 if (oreq[g] < a.nreq && (o0 < 0 || o0 >= a.lim_out - (EPP - 1))) g2 = reinterpret_cast<FlushT*>(trash);
                 stream_store(g2, fbuf[r]);
 #else
-                FlushT* g2 = oreq[g] < a.nreq ? reinterpret_cast<FlushT*>(a.out + ((size_t)oreq[g] * a.R + (size_t)rowbase) * enpts)
-                                              : reinterpret_cast<FlushT*>(trash);
+                FlushT* g2 = (MIXR || oreq[g] < a.nreq) ? reinterpret_cast<FlushT*>(a.out + ((size_t)oreq[g] * a.R + (size_t)rowbase) * enpts)
+                                                        : reinterpret_cast<FlushT*>(trash);
                 if constexpr (ODD) g2[min(it * 64 + elane, nch - 1)] = fbuf[r];  // (8-byte pieces, lines shared with the neighbours: plain stores)
                 else stream_store(&g2[min(it * 64 + elane, nch - 1)], fbuf[r]);  // (all-plain here: 30 shapes, geometric mean 1.05 x the time, 0.85 ... 1.64)
 #endif
@@ -437,8 +466,185 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
             for (int r = 0; r < NRD; ++r) image_out(r, 16 * (RTn - 1), last_rows);
             wave_lds_fence();
         };
-        if constexpr (MIXT > 0) {
-            // ---- dof-major tiles with the chain rule across the tables applied in registers ----
+        if constexpr (MIXT > 0 && MIXR) {
+            // ---- dof-major tiles, chain rule applied to the accumulators (lane-local), plain-copy flush ----
+            const int rows = a.R / MIXT;                      // rows per table
+            const int RTd = (rows + 15) / 16;                 // dof tiles; tile (i, t) = table t, rows [16 i, 16 i + 16)
+            const int rows_last = rows - 16 * (RTd - 1);
+            constexpr int SLOT = 16 * 16 * CT;
+            double* kbuf = img + (IMG - STACKED_KBUF);        // [G][SD][SD]: K = A0^-1 A_req of the group's requests
+            if (lane < G) {
+                long long req = CHUNK ? grp / nchunk : grp * G + lane;
+                req = req < a.nreq ? req : a.nreq - 1;
+                double J[SD][SD], bb[SD];
+                cell_map<SD>(a.verts + FX_CHK((size_t)req * (SD + 1) * SD, a.lim_verts - (SD + 1) * SD + 1, 2), J, bb);
+#pragma unroll
+                for (int i = 0; i < SD; ++i)
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int k = 0; k < SD; ++k) t += a.A0inv[i * SD + k] * J[k][d];
+                        kbuf[lane * SD * SD + i * SD + d] = t;
+                    }
+            }
+            wave_lds_fence();
+            v4d acc[SLOTS][CT];
+            // Hessian tables in mis() order: (c, c'), c <= c' -> c (2 SD - c - 1) / 2 + c'
+            auto hidx = [](int c, int e) { return c <= e ? c * (2 * SD - c - 1) / 2 + e : e * (2 * SD - e - 1) / 2 + c; };
+            // chain rule on the accumulators of one half: d/dx_d = sum_c K[c][d] d/dX_c; d2/dx_d dx_e = sum K[c][d] K[c'][e] d2/dX_c dX_c'
+            auto mix_acc = [&](auto phase_c) {
+                constexpr int PHS = decltype(phase_c)::value;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    double Kl[SD][SD];
+#pragma unroll
+                    for (int i = 0; i < SD; ++i)
+#pragma unroll
+                        for (int d = 0; d < SD; ++d) Kl[i][d] = kbuf[kofs[c] + i * SD + d];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        if constexpr (PHS == 0) {
+                            double gr[SD];
+#pragma unroll
+                            for (int i = 0; i < SD; ++i) gr[i] = acc[1 + i][c][jj];
+#pragma unroll
+                            for (int d = 0; d < SD; ++d) {
+                                double t = 0.0;
+#pragma unroll
+                                for (int i = 0; i < SD; ++i) t += Kl[i][d] * gr[i];
+                                acc[1 + d][c][jj] = t;
+                            }
+                        } else {
+                            double T[SD][SD];  // T[i][e] = sum_k H[i][k] K[k][e]
+#pragma unroll
+                            for (int i = 0; i < SD; ++i)
+#pragma unroll
+                                for (int e = 0; e < SD; ++e) {
+                                    double t = 0.0;
+#pragma unroll
+                                    for (int k = 0; k < SD; ++k) t += acc[hidx(i, k)][c][jj] * Kl[k][e];
+                                    T[i][e] = t;
+                                }
+#pragma unroll
+                            for (int d = 0; d < SD; ++d)
+#pragma unroll
+                                for (int e = d; e < SD; ++e) {
+                                    double t = 0.0;
+#pragma unroll
+                                    for (int i = 0; i < SD; ++i) t += Kl[i][d] * T[i][e];
+                                    acc[hidx(d, e)][c][jj] = t;
+                                }
+                        }
+                    }
+                }
+            };
+            // One tile: MFMAs of tile q into `cur`, fragments of tile q + 1 into `an` (all in the first third of the K-steps:
+            // older than every output store of the stage), and NF images of the previous half -- slots slot0 .., output rows
+            // rowbase0 + f rows .. -- copied out in the remaining K-steps, image after image (reads, then stores)
+            constexpr int LPK3 = (KS + T3 - 1) / T3;
+            auto rstage = [&](v4d (&cur)[CT], int q, const double (&af)[KS], double (&an)[KS], auto nf_c, int slot0, int rowbase0, int pn) {
+                constexpr int NF = decltype(nf_c)::value;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) cur[c] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    mfma_steps(cur, af, ks, ks + 1);
+                    if (ks < T3) {
+#pragma unroll
+                        for (int l = ks * LPK3; l < (ks + 1) * LPK3 && l < KS; ++l)
+                            an[l] = a.afrag[FX_CHK((size_t)(q + 1) * KS * 64 + l * 64 + elane, a.lim_afrag, 3)];
+                    }
+#pragma unroll
+                    for (int f = 0; f < (NF > 0 ? NF : 0); ++f) {
+                        constexpr int NFD = NF > 0 ? NF : 1;
+                        const int w0 = T3 + (KS - T3) * f / NFD, w1 = T3 + (KS - T3) * (f + 1) / NFD;  // K-steps of image f
+                        const int wm = w1 - w0 >= 2 ? w0 + (w1 - w0) / 2 : w0;                        // reads [w0, wm), stores [wm, w1)
+                        if (w1 - w0 < 2) {
+                            if (ks == w0) {
+#pragma unroll
+                                for (int r = 0; r < NRD; ++r) image_get(r, pn, (slot0 + f) * SLOT);
+#pragma unroll
+                                for (int r = 0; r < NRD; ++r) image_out(r, rowbase0 + f * rows, pn);
+                            }
+                        } else if (ks >= w0 && ks < wm) {
+                            const int per = (NRD + (wm - w0) - 1) / (wm - w0);
+#pragma unroll
+                            for (int r = (ks - w0) * per; r < (ks - w0 + 1) * per && r < NRD; ++r) image_get(r, pn, (slot0 + f) * SLOT);
+                        } else if (ks >= wm && ks < w1) {
+                            const int per = (NRD + (w1 - wm) - 1) / (w1 - wm);
+#pragma unroll
+                            for (int r = (ks - wm) * per; r < (ks - wm + 1) * per && r < NRD; ++r) image_out(r, rowbase0 + f * rows, pn);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(an[ks]));
+            };
+            // One half of dof tile i: PHS 0 = tables [0, NTA), 1 = tables [NTA, MIXT).  FL: the images hold the half before it
+            // (dof tile i - 1 for PHS 0 of an order-1 instance and for PHS 0 after PHS 1, dof tile i for PHS 1), which leaves
+            // under this half's MFMAs.  IODD: tile i MIXT is odd (odd table counts: the fragment buffers alternate per tile).
+            auto half_tile = [&](int i, auto phase_c, auto flush_c, auto iodd_c) {
+                constexpr int PHS = decltype(phase_c)::value;
+                constexpr bool FL = decltype(flush_c)::value;
+                constexpr int NCUR = PHS == 0 ? NTA : NTB, T0 = PHS == 0 ? 0 : NTA;
+                constexpr int NPREV = !FL ? 0 : MORD == 1 ? NTA : PHS == 0 ? NTB : NTA;
+                constexpr int TP0 = (MORD == 2 && PHS == 0) ? NTA : 0;            // first table of the half before
+                asm volatile("" : "+s"(i));  // (opaque per half: no induction variables for the ~40 output bases of a dof tile)
+                const int iprev = (MORD == 2 && PHS == 1) ? i : i - 1;
+                const int pn = iprev == RTd - 1 ? rows_last : 16;
+                static_for<NCUR>([&](auto s_c) {
+                    constexpr int s = decltype(s_c)::value;
+                    constexpr int F0 = s * NPREV / NCUR, F1 = (s + 1) * NPREV / NCUR;
+                    const int q = i * MIXT + T0 + s;
+                    if constexpr (((T0 + s + (decltype(iodd_c)::value ? 1 : 0)) & 1) == 0)
+                        rstage(acc[s], q, fa0, fa1, std::integral_constant<int, F1 - F0>{}, F0, (TP0 + F0) * rows + 16 * iprev, pn);
+                    else
+                        rstage(acc[s], q, fa1, fa0, std::integral_constant<int, F1 - F0>{}, F0, (TP0 + F0) * rows + 16 * iprev, pn);
+                });
+                mix_acc(phase_c);
+                wave_lds_fence();  // (the images of the half before have been read)
+                const int nrows = i == RTd - 1 ? rows_last : 16;
+                static_for<NCUR>([&](auto s_c) {
+                    constexpr int s = decltype(s_c)::value;
+#pragma unroll
+                    for (int w = 0; w < NWR; ++w) image_put(acc[s], w, nrows, s * SLOT);
+                });
+                wave_lds_fence();
+            };
+            using IC0 = std::integral_constant<int, 0>;
+            using IC1 = std::integral_constant<int, 1>;
+            half_tile(0, IC0{}, std::false_type{}, std::false_type{});
+            if constexpr (MORD == 2) {
+                static_assert(MIXT % 2 == 0, "even table count: the fragment buffer of a tile depends on its table only");
+                half_tile(0, IC1{}, std::true_type{}, std::false_type{});
+                for (int i = 1; i < RTd; ++i) {
+                    half_tile(i, IC0{}, std::true_type{}, std::false_type{});
+                    half_tile(i, IC1{}, std::true_type{}, std::false_type{});
+                }
+            } else if constexpr (MIXT % 2 == 0) {
+                for (int i = 1; i < RTd; ++i) half_tile(i, IC0{}, std::true_type{}, std::false_type{});
+            } else {
+                int i = 1;
+                for (; i + 1 < RTd; i += 2) {
+                    half_tile(i, IC0{}, std::true_type{}, std::true_type{});
+                    half_tile(i + 1, IC0{}, std::true_type{}, std::false_type{});
+                }
+                if (i < RTd) half_tile(i, IC0{}, std::true_type{}, std::true_type{});
+            }
+            // the images of the last half
+            constexpr int NLAST = MORD == 2 ? NTB : NTA, TL0 = MORD == 2 ? NTA : 0;
+#pragma unroll
+            for (int t = 0; t < NLAST; ++t) {
+#pragma unroll
+                for (int r = 0; r < NRD; ++r) image_get(r, rows_last, t * SLOT);
+#pragma unroll
+                for (int r = 0; r < NRD; ++r) image_out(r, (TL0 + t) * rows + 16 * (RTd - 1), rows_last);
+            }
+            wave_lds_fence();
+        } else if constexpr (MIXT > 0) {
+            // ---- dof-major tiles with the chain rule across the tables applied in the flush ----
             const int rows = a.R / MIXT;                      // rows per table
             const int RTd = (rows + 15) / 16;                 // dof tiles; tile (i, t) = table t, rows [16 i, 16 i + 16)
             const int rows_last = rows - 16 * (RTd - 1);

@@ -218,11 +218,12 @@ class SimplexPolySet:
                                            _dev_ptr(ref_pts), _dev_ptr(verts), _dev_ptr(out), _stream_ptr(stream)))
         return out
 
-    def kernel_name(self, order, nreq, npts, has_verts=False):
-        """Device kernel ``tabulate_batch`` launches for this request shape (fx_plan_kernel)."""
+    def kernel_name(self, order, nreq, npts, has_verts=False, instance=False):
+        """Device kernel ``tabulate_batch`` launches for this request shape (fx_plan_kernel); ``instance``: with the
+        registry instance of the stacked-matrix kernel."""
         buf = ctypes.create_string_buffer(96)
-        check(lib.fx_plan_kernel(self.ctx.handle, self.handle, int(order), int(nreq), int(npts), int(bool(has_verts)),
-                                 buf, 96))
+        check(lib.fx_plan_kernel(self.ctx.handle, self.handle, int(order), int(nreq), int(npts),
+                                 int(bool(has_verts)) | (2 if instance else 0), buf, 96))
         return buf.value.decode()
 
     def time_tabulate_batch(self, order, pts, verts, out, reps, stream=None):

@@ -210,3 +210,57 @@ def test_expansion_degrees_7_and_8_on_the_stacked_kernel(family, sd, degree, npt
     want = el.tabulate_batch(order, pts).cpu().numpy()
     for t in range(got.shape[1]):
         assert rel(got[:, t], want[:, t]) <= (1e-12 if t == 0 else 1e-10), (t, rel(got[:, t], want[:, t]))
+
+
+# (family, sd, degree, points, order) -> the registry instance <sd, n, column tiles, requests per group, kind> that must take it;
+# kinds: -2 / -3 whole requests with the order-1 / order-2 chain rule inside the kernel, -4 / -5 the same on point chunks
+MIXR = [("Lagrange", 3, 2, 11, 2, "3,2,3,4,-3"), ("Lagrange", 3, 2, 14, 2, "3,2,3,3,-3"), ("Lagrange", 3, 2, 22, 2, "3,2,3,2,-3"),
+        ("Lagrange", 3, 2, 30, 2, "3,2,2,1,-3"), ("Lagrange", 3, 3, 23, 2, "3,3,3,2,-3"), ("Lagrange", 3, 3, 30, 2, "3,3,2,1,-3"),
+        ("Lagrange", 3, 3, 44, 2, "3,3,3,1,-3"), ("Lagrange", 3, 4, 24, 2, "3,4,3,2,-3"), ("Lagrange", 3, 4, 30, 2, "3,4,2,1,-3"),
+        ("Lagrange", 3, 4, 44, 2, "3,4,3,1,-3"), ("Lagrange", 3, 5, 30, 2, "3,5,2,1,-3"), ("Lagrange", 3, 6, 30, 2, "3,6,2,1,-3"),
+        ("Lagrange", 2, 3, 12, 2, "2,3,3,4,-3"), ("Lagrange", 2, 3, 16, 2, "2,3,3,3,-3"), ("Lagrange", 2, 3, 22, 2, "2,3,3,2,-3"),
+        ("Lagrange", 2, 4, 16, 2, "2,4,3,3,-3"), ("Lagrange", 2, 4, 22, 2, "2,4,3,2,-3"), ("Lagrange", 2, 4, 30, 2, "2,4,2,1,-3"),
+        ("Lagrange", 2, 5, 24, 2, "2,5,3,2,-3"), ("Lagrange", 2, 5, 30, 2, "2,5,2,1,-3"), ("Lagrange", 2, 5, 44, 2, "2,5,3,1,-3"),
+        ("Lagrange", 2, 6, 23, 2, "2,6,3,2,-3"), ("Lagrange", 2, 6, 30, 2, "2,6,2,1,-3"), ("Lagrange", 2, 6, 44, 2, "2,6,3,1,-3"),
+        # odd table sizes: the 8-byte twins
+        ("Lagrange", 2, 5, 25, 2, "2,5,2,1,-3"), ("Lagrange", 2, 5, 25, 1, "2,5,2,1,-2"), ("Nedelec", 3, 3, 23, 2, "3,3,3,2,-3"),
+        ("Nedelec", 3, 3, 23, 1, "3,3,3,2,-2"), ("RaviartThomas", 3, 2, 11, 2, "3,2,3,4,-3"),
+        # order 1 on the accumulators (every instance also runs in test_gpu_parity's per-request-cell cases)
+        ("Lagrange", 3, 6, 23, 1, "3,6,3,2,-2"), ("Lagrange", 3, 6, 44, 1, "3,6,3,1,-2"), ("Nedelec", 3, 2, 11, 1, "3,2,3,4,-2"),
+        ("Lagrange", 3, 5, 24, 1, "3,5,3,2,-2"), ("Nedelec", 2, 3, 12, 1, "2,3,3,4,-2"), ("Lagrange", 2, 6, 30, 1, "2,6,2,1,-2"),
+        # point chunks
+        ("Lagrange", 3, 6, 122, 1, "3,6,3,1,-4"), ("Lagrange", 3, 5, 74, 1, "3,5,3,1,-4"), ("Lagrange", 3, 4, 50, 1, "3,4,3,1,-4"),
+        ("Lagrange", 3, 3, 97, 1, "3,3,3,1,-4"), ("Nedelec", 3, 2, 49, 1, "3,2,3,1,-4"), ("Lagrange", 2, 6, 73, 1, "2,6,3,1,-4"),
+        ("Lagrange", 2, 5, 55, 1, "2,5,3,1,-4"),
+        ("Lagrange", 3, 6, 122, 2, "3,6,2,1,-5"), ("Lagrange", 3, 5, 74, 2, "3,5,2,1,-5"), ("Lagrange", 3, 4, 45, 2, "3,4,2,1,-5"),
+        ("Lagrange", 3, 3, 97, 2, "3,3,3,1,-5"), ("Nedelec", 3, 2, 49, 2, "3,2,3,1,-5"), ("Lagrange", 2, 6, 73, 2, "2,6,3,1,-5"),
+        ("Lagrange", 2, 5, 55, 2, "2,5,3,1,-5")]
+
+
+@pytest.mark.parametrize("family,sd,degree,npts,order,instance", MIXR, ids=[f"{m[0][:2]}{m[2]}-{m[3]}pt-o{m[4]}-{m[5]}" for m in MIXR])
+@pytest.mark.parametrize("nreq", [5, 1033])
+def test_chain_rule_on_the_accumulators_of_the_stacked_kernel(family, sd, degree, npts, order, instance, nreq, kernel_policy):
+    """Per-request cells with derivatives: the stacked-matrix kernel applies the chain rule across the gradient and the
+    Hessian tables to its accumulators (simplex_stacked.hpp MIXR) instead of leaving it to a second pass over the tables.
+    Every order-2 instance, the 8-byte twins for odd table sizes, the point-chunked units and a sample of the order-1
+    instances; a batch smaller than one group and one of several groups per wave, cells of both orientations, against the
+    C oracle's recurrence ON the physical cells (the oracle the reference goldens pin)."""
+    import fiat_amd as fa
+    from oracle import c_oracle
+    from oracle import fiat_oracle as fo
+    el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
+    ps = el.device_polyset()
+    kernel_policy("no_small", "no_fixed")       # (the lane-local and the paired kernels keep some of these shapes by default)
+    assert ps.kernel_name(order, nreq, npts, has_verts=True, instance=True) == f"fxk::tabulate_simplex_stacked<{instance}>"
+    rng = np.random.default_rng(97 * degree + npts + sd)
+    A = np.eye(sd) + 0.15 * rng.standard_normal((nreq, sd, sd))
+    A[::3, :, 0] *= -1.0
+    verts = np.einsum("vd,red->rve", fo.UFC_SIMPLEX[sd], A) + rng.standard_normal((nreq, 1, sd))
+    e = rng.exponential(size=(nreq, npts, sd + 1))
+    pts = np.einsum("rpv,rvd->rpd", e / e.sum(axis=-1, keepdims=True), verts)
+    out = ps.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    n = el.get_nodal_basis().get_embedded_degree()
+    ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[sd], n, el.get_coeffs(), order, pts, verts=verts, scale=el._expansion_scale,
+                                  variant=el._expansion_variant).reshape(out.shape)
+    for t in range(out.shape[1]):
+        assert rel(out[:, t], ref[:, t]) <= (1e-12 if t == 0 else 1e-10), (instance, t, rel(out[:, t], ref[:, t]))
