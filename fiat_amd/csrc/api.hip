@@ -187,6 +187,7 @@ struct fx_element {
     std::vector<double> hC;
     double* d_astack[3] = {nullptr, nullptr, nullptr};
     double* d_astack_dm[3] = {nullptr, nullptr, nullptr};   // orders 1 and 2, dof-major tiles (the tables of 16 dofs one after the other, each padded to a tile): MIXT instances
+    double* d_astack_dmp[3] = {nullptr, nullptr, nullptr};  // orders 0-2, vector-valued elements: dof-major tiles with the components of a dof in one MFMA lane (PIO instances)
     int stack_state[3] = {0, 0, 0};  // 0 not built, 1 built, -1 failed
     bool raw_expansion = false;      // internal helper element (identity coefficients): never takes the stacked path
     // derivative orders 3..FX_MAX_ORDER (ensure_high_order): an internal element whose rows are the stacked matrix
@@ -368,6 +369,8 @@ static int upload_coeffs(fx_element* e, int ndof, int vdim, const double* coeffs
     for (int o = 0; o < 3; ++o) {
         if (e->d_astack_dm[o]) (void)hipFree(e->d_astack_dm[o]);
         e->d_astack_dm[o] = nullptr;
+        if (e->d_astack_dmp[o]) (void)hipFree(e->d_astack_dmp[o]);
+        e->d_astack_dmp[o] = nullptr;
     }
     for (int o = 0; o <= FX_MAX_ORDER; ++o) {
         if (e->high[o]) fx_element_destroy(e->high[o]);
@@ -526,8 +529,10 @@ int fx_element_destroy(fx_element* e) {
     if (e->d_afrag_coop) (void)hipFree(e->d_afrag_coop);
     for (int o = 0; o < 3; ++o)
         if (e->d_astack[o]) (void)hipFree(e->d_astack[o]);
-    for (int o = 0; o < 3; ++o)
+    for (int o = 0; o < 3; ++o) {
         if (e->d_astack_dm[o]) (void)hipFree(e->d_astack_dm[o]);
+        if (e->d_astack_dmp[o]) (void)hipFree(e->d_astack_dmp[o]);
+    }
     for (int o = 0; o <= FX_MAX_ORDER; ++o)
         if (e->high[o]) fx_element_destroy(e->high[o]);
     delete e;
@@ -566,6 +571,7 @@ struct Launch {
     int fgrid = 0, flds_bytes = 0, ncu = 0;
     bool fused_mapping = false;
     bool kodd = false;  // stacked kernel: requests of an odd number of doubles (8-byte flush instance)
+    int kpiola = 0;     // stacked kernel: Piola map applied to the accumulators (PIO instance), FX_MAP_*
     double* trash = nullptr;
     unsigned long long* queue = nullptr;
     // 0: LDS-image kernel (simplex_fixed.hpp), 1: K-streamed kernel (simplex_stream.hpp),
@@ -776,6 +782,7 @@ struct StackedShape {
               // -2: per-request cells, order 1 on tetrahedra: dof-major tiles, chain rule across the tables in registers
               // -3: per-request cells, order 2: the same with the Hessian tables (accumulator-side mixing, simplex_stacked.hpp MIXR)
               // -4 / -5: point-chunked units with the order-1 / order-2 chain rule inside the kernel
+              // -6: per-request cells, order 0, Piola map of a vector-valued element applied in the kernel
               // -1: point-chunked instance (a unit = 16 ct points of one request): any number of points >= 13, odd
               //      table sizes too -- taken when no whole-request instance applies
 };
@@ -848,7 +855,13 @@ const StackedShape kStackedShapes[] = {
     // whole-request instance holds (the 74- and 122-point rules of P5 / P6 tetrahedra ...), any table size
     {3, 6, 3, 1, -4}, {3, 5, 3, 1, -4}, {3, 4, 3, 1, -4}, {3, 3, 3, 1, -4}, {3, 2, 3, 1, -4}, {2, 6, 3, 1, -4}, {2, 5, 3, 1, -4},
     {3, 6, 2, 1, -5}, {3, 5, 2, 1, -5}, {3, 4, 2, 1, -5}, {3, 3, 3, 1, -5}, {3, 2, 3, 1, -5}, {2, 6, 3, 1, -5}, {2, 5, 3, 1, -5},
+    // vector-valued elements on per-request cells with their Piola map, values only (rtc -6): the map is applied to the
+    // accumulators (simplex_stacked.hpp PIO; with derivatives: the PIO twins of the rtc -2 / -3 instances of these shapes)
+    {3, 2, 3, 4, -6}, {3, 2, 3, 3, -6}, {3, 2, 3, 2, -6}, {3, 2, 2, 1, -6}, {3, 3, 3, 2, -6}, {3, 3, 2, 1, -6}, {3, 3, 3, 1, -6},
+    {2, 3, 3, 4, -6}, {2, 3, 3, 3, -6}, {2, 3, 3, 2, -6}, {2, 4, 3, 3, -6}, {2, 4, 3, 2, -6}, {2, 4, 2, 1, -6},
 };
+// shapes whose in-kernel chain-rule instances (rtc -2 / -3 / -6) have a twin that applies the Piola map too
+constexpr bool stacked_has_pio(int sd, int n) { return (sd == 3 && (n == 2 || n == 3)) || (sd == 2 && (n == 3 || n == 4)); }
 constexpr int STACKED_NW = 4;  // one wave per SIMD
 // Order-1 in-kernel chain rule (rtc -2): on the accumulators (MIXR) or in the flush.  tools/mixr_ab.sh, all 26 instances, ABAB:
 // accumulator-side 0.84-1.00 of the flush-side launch time except on four single-request triangle instances (1.01-1.05); of
@@ -864,7 +877,7 @@ constexpr bool mixr1(int sd, int n, int ct, int g) {
 // (ABAB, orders 1 and 2: 0.83-0.94 of the one-wave launch time on the three-tile instances, 0.98-1.00 on the two-tile ones;
 // degrees 3 and 4: 0.97-1.06, left at one)
 constexpr int mixr_wps(int sd, int n) { return sd == 2 && n >= 5 ? 2 : 1; }
-template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0, bool ODD = false, bool MIXR = false>
+template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0, bool ODD = false, bool MIXR = false, int PIO = 0>
 int launch_stacked(const Launch& L, hipStream_t s) {
     constexpr int NC = fxk::FixedNC<SD, N>::value;
     fxk::StackedArgs<NC> ka;
@@ -876,6 +889,8 @@ int launch_stacked(const Launch& L, hipStream_t s) {
     memcpy(ka.A0, L.khead.A0, sizeof ka.A0);
     memcpy(ka.b0, L.khead.b0, sizeof ka.b0);
     memcpy(ka.A0inv, L.khead.A0inv, sizeof ka.A0inv);
+    memcpy(ka.G, L.khead.G, sizeof ka.G);
+    ka.piola = L.khead.piola;
     ka.nreq = L.khead.nreq;
     ka.npts = L.khead.npts;
     ka.R = L.khead.R;
@@ -887,7 +902,7 @@ int launch_stacked(const Launch& L, hipStream_t s) {
     ka.lim_afrag = L.khead.lim_afrag;
     if ((int)L.fcoef.size() != NC) return fail(FX_EINVAL, "internal: coefficient table size mismatch");
     memcpy(ka.coef, L.fcoef.data(), NC * sizeof(double));
-    auto kern = fxk::tabulate_simplex_stacked<SD, N, CT, G, RTC, WPS, CHUNK, MIXT, ODD, MIXR>;
+    auto kern = fxk::tabulate_simplex_stacked<SD, N, CT, G, RTC, WPS, CHUNK, MIXT, ODD, MIXR, PIO>;
     // as many workgroups per CU as registers and LDS allow (low degrees need few registers: their short
     // row sweeps rely on other waves to cover the production phase); asked once per kernel
     static thread_local int occ = 0;
@@ -926,7 +941,7 @@ int launch_stacked(const Launch& L, hipStream_t s) {
         if (ab_env("FIAT_AMD_VERBOSE")) fprintf(stderr, "[fiat_amd] range check done <%d,%d,%d,%d,mixt %d>\n", SD, N, CT, G, MIXT);
     }
 #endif
-    if (L.khead.verts && L.kmix_order >= 1 && MIXT == 0) {  // chain rule across the derivative tables, in place
+    if (L.khead.verts && L.kmix_order >= 1 && MIXT == 0 && PIO == 0) {  // chain rule across the derivative tables, in place
         fxk::TableMixArgs ma;
         ma.out = L.khead.out;
         ma.verts = L.khead.verts;
@@ -968,9 +983,9 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 13: return launch_stacked<3, 4, 3, 2, 0, 1, false, 4, false, mixr1(3, 4, 3, 2)>(L, s);
         case 14: return launch_stacked<3, 4, 2, 1, 0, 1, false, 4, false, mixr1(3, 4, 2, 1)>(L, s);
         case 15: return launch_stacked<3, 4, 3, 1, 0, 1, false, 4, false, mixr1(3, 4, 3, 1)>(L, s);
-        case 16: return L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 4, true, true>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 4, false, mixr1(3, 3, 3, 2)>(L, s);
-        case 17: return launch_stacked<3, 3, 2, 1, 0, 1, false, 4, false, mixr1(3, 3, 2, 1)>(L, s);
-        case 18: return launch_stacked<3, 3, 3, 1, 0, 1, false, 4, false, mixr1(3, 3, 3, 1)>(L, s);
+        case 16: return L.kpiola ? launch_stacked<3, 3, 3, 2, 0, 1, false, 4, false, true, 1>(L, s) : L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 4, true, true>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 4, false, mixr1(3, 3, 3, 2)>(L, s);
+        case 17: return L.kpiola ? launch_stacked<3, 3, 2, 1, 0, 1, false, 4, false, true, 1>(L, s) : launch_stacked<3, 3, 2, 1, 0, 1, false, 4, false, mixr1(3, 3, 2, 1)>(L, s);
+        case 18: return L.kpiola ? launch_stacked<3, 3, 3, 1, 0, 1, false, 4, false, true, 1>(L, s) : launch_stacked<3, 3, 3, 1, 0, 1, false, 4, false, mixr1(3, 3, 3, 1)>(L, s);
         case 19: return launch_stacked<3, 6, 3, 2>(L, s);
         case 20: return launch_stacked<3, 6, 2, 1>(L, s);
         case 21: return launch_stacked<3, 6, 3, 1>(L, s);
@@ -1030,16 +1045,16 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 75: return launch_stacked<2, 4, 3, 6>(L, s);
         case 76: return launch_stacked<2, 4, 3, 1, 0, 1, true>(L, s);
         case 77: return launch_stacked<2, 3, 3, 1, 0, 1, true>(L, s);
-        case 78: return launch_stacked<3, 2, 3, 4, 0, 1, false, 4, false, mixr1(3, 2, 3, 4)>(L, s);
-        case 79: return launch_stacked<3, 2, 3, 3, 0, 1, false, 4, false, mixr1(3, 2, 3, 3)>(L, s);
-        case 80: return launch_stacked<3, 2, 3, 2, 0, 1, false, 4, false, mixr1(3, 2, 3, 2)>(L, s);
-        case 81: return launch_stacked<3, 2, 2, 1, 0, 1, false, 4, false, mixr1(3, 2, 2, 1)>(L, s);
-        case 82: return launch_stacked<2, 3, 3, 4, 0, mixr_wps(2, 3), false, 3, false, mixr1(2, 3, 3, 4)>(L, s);
-        case 83: return launch_stacked<2, 3, 3, 3, 0, mixr_wps(2, 3), false, 3, false, mixr1(2, 3, 3, 3)>(L, s);
-        case 84: return launch_stacked<2, 3, 3, 2, 0, mixr_wps(2, 3), false, 3, false, mixr1(2, 3, 3, 2)>(L, s);
-        case 85: return launch_stacked<2, 4, 3, 3, 0, mixr_wps(2, 4), false, 3, false, mixr1(2, 4, 3, 3)>(L, s);
-        case 86: return launch_stacked<2, 4, 3, 2, 0, mixr_wps(2, 4), false, 3, false, mixr1(2, 4, 3, 2)>(L, s);
-        case 87: return launch_stacked<2, 4, 2, 1, 0, mixr_wps(2, 4), false, 3, false, mixr1(2, 4, 2, 1)>(L, s);
+        case 78: return L.kpiola ? launch_stacked<3, 2, 3, 4, 0, 1, false, 4, false, true, 1>(L, s) : launch_stacked<3, 2, 3, 4, 0, 1, false, 4, false, mixr1(3, 2, 3, 4)>(L, s);
+        case 79: return L.kpiola ? launch_stacked<3, 2, 3, 3, 0, 1, false, 4, false, true, 1>(L, s) : launch_stacked<3, 2, 3, 3, 0, 1, false, 4, false, mixr1(3, 2, 3, 3)>(L, s);
+        case 80: return L.kpiola ? launch_stacked<3, 2, 3, 2, 0, 1, false, 4, false, true, 1>(L, s) : launch_stacked<3, 2, 3, 2, 0, 1, false, 4, false, mixr1(3, 2, 3, 2)>(L, s);
+        case 81: return L.kpiola ? launch_stacked<3, 2, 2, 1, 0, 1, false, 4, false, true, 1>(L, s) : launch_stacked<3, 2, 2, 1, 0, 1, false, 4, false, mixr1(3, 2, 2, 1)>(L, s);
+        case 82: return L.kpiola ? launch_stacked<2, 3, 3, 4, 0, 1, false, 3, false, true, 1>(L, s) : launch_stacked<2, 3, 3, 4, 0, mixr_wps(2, 3), false, 3, false, mixr1(2, 3, 3, 4)>(L, s);
+        case 83: return L.kpiola ? launch_stacked<2, 3, 3, 3, 0, 1, false, 3, false, true, 1>(L, s) : launch_stacked<2, 3, 3, 3, 0, mixr_wps(2, 3), false, 3, false, mixr1(2, 3, 3, 3)>(L, s);
+        case 84: return L.kpiola ? launch_stacked<2, 3, 3, 2, 0, 1, false, 3, false, true, 1>(L, s) : launch_stacked<2, 3, 3, 2, 0, mixr_wps(2, 3), false, 3, false, mixr1(2, 3, 3, 2)>(L, s);
+        case 85: return L.kpiola ? launch_stacked<2, 4, 3, 3, 0, 1, false, 3, false, true, 1>(L, s) : launch_stacked<2, 4, 3, 3, 0, mixr_wps(2, 4), false, 3, false, mixr1(2, 4, 3, 3)>(L, s);
+        case 86: return L.kpiola ? launch_stacked<2, 4, 3, 2, 0, 1, false, 3, false, true, 1>(L, s) : launch_stacked<2, 4, 3, 2, 0, mixr_wps(2, 4), false, 3, false, mixr1(2, 4, 3, 2)>(L, s);
+        case 87: return L.kpiola ? launch_stacked<2, 4, 2, 1, 0, 1, false, 3, false, true, 1>(L, s) : launch_stacked<2, 4, 2, 1, 0, mixr_wps(2, 4), false, 3, false, mixr1(2, 4, 2, 1)>(L, s);
         case 88: return launch_stacked<3, 7, 2, 1>(L, s);
         case 89: return launch_stacked<3, 7, 2, 1, 0, 1, true>(L, s);
         case 90: return launch_stacked<2, 7, 3, 1>(L, s);
@@ -1047,24 +1062,24 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 92: return launch_stacked<2, 7, 3, 1, 0, 1, true>(L, s);
         case 93: return launch_stacked<2, 8, 4, 1>(L, s);
         case 94: return launch_stacked<2, 8, 3, 1, 0, 1, true>(L, s);
-        case 95: return L.kodd ? launch_stacked<3, 2, 3, 4, 0, 1, false, 10, true, true>(L, s) : launch_stacked<3, 2, 3, 4, 0, 1, false, 10, false, true>(L, s);
-        case 96: return launch_stacked<3, 2, 3, 3, 0, 1, false, 10, false, true>(L, s);
-        case 97: return launch_stacked<3, 2, 3, 2, 0, 1, false, 10, false, true>(L, s);
-        case 98: return launch_stacked<3, 2, 2, 1, 0, 1, false, 10, false, true>(L, s);
-        case 99: return L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 10, true, true>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 10, false, true>(L, s);
-        case 100: return launch_stacked<3, 3, 2, 1, 0, 1, false, 10, false, true>(L, s);
-        case 101: return launch_stacked<3, 3, 3, 1, 0, 1, false, 10, false, true>(L, s);
+        case 95: return L.kpiola ? launch_stacked<3, 2, 3, 4, 0, 1, false, 10, false, true, 1>(L, s) : L.kodd ? launch_stacked<3, 2, 3, 4, 0, 1, false, 10, true, true>(L, s) : launch_stacked<3, 2, 3, 4, 0, 1, false, 10, false, true>(L, s);
+        case 96: return L.kpiola ? launch_stacked<3, 2, 3, 3, 0, 1, false, 10, false, true, 1>(L, s) : launch_stacked<3, 2, 3, 3, 0, 1, false, 10, false, true>(L, s);
+        case 97: return L.kpiola ? launch_stacked<3, 2, 3, 2, 0, 1, false, 10, false, true, 1>(L, s) : launch_stacked<3, 2, 3, 2, 0, 1, false, 10, false, true>(L, s);
+        case 98: return L.kpiola ? launch_stacked<3, 2, 2, 1, 0, 1, false, 10, false, true, 1>(L, s) : launch_stacked<3, 2, 2, 1, 0, 1, false, 10, false, true>(L, s);
+        case 99: return L.kpiola ? launch_stacked<3, 3, 3, 2, 0, 1, false, 10, false, true, 1>(L, s) : L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 10, true, true>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 10, false, true>(L, s);
+        case 100: return L.kpiola ? launch_stacked<3, 3, 2, 1, 0, 1, false, 10, false, true, 1>(L, s) : launch_stacked<3, 3, 2, 1, 0, 1, false, 10, false, true>(L, s);
+        case 101: return L.kpiola ? launch_stacked<3, 3, 3, 1, 0, 1, false, 10, false, true, 1>(L, s) : launch_stacked<3, 3, 3, 1, 0, 1, false, 10, false, true>(L, s);
         case 102: return launch_stacked<3, 4, 3, 2, 0, 1, false, 10, false, true>(L, s);
         case 103: return launch_stacked<3, 4, 2, 1, 0, 1, false, 10, false, true>(L, s);
         case 104: return launch_stacked<3, 4, 3, 1, 0, 1, false, 10, false, true>(L, s);
         case 105: return launch_stacked<3, 5, 2, 1, 0, 1, false, 10, false, true>(L, s);
         case 106: return launch_stacked<3, 6, 2, 1, 0, 1, false, 10, false, true>(L, s);
-        case 107: return launch_stacked<2, 3, 3, 4, 0, mixr_wps(2, 3), false, 6, false, true>(L, s);
-        case 108: return launch_stacked<2, 3, 3, 3, 0, mixr_wps(2, 3), false, 6, false, true>(L, s);
-        case 109: return launch_stacked<2, 3, 3, 2, 0, mixr_wps(2, 3), false, 6, false, true>(L, s);
-        case 110: return launch_stacked<2, 4, 3, 3, 0, mixr_wps(2, 4), false, 6, false, true>(L, s);
-        case 111: return launch_stacked<2, 4, 3, 2, 0, mixr_wps(2, 4), false, 6, false, true>(L, s);
-        case 112: return launch_stacked<2, 4, 2, 1, 0, mixr_wps(2, 4), false, 6, false, true>(L, s);
+        case 107: return L.kpiola ? launch_stacked<2, 3, 3, 4, 0, 1, false, 6, false, true, 1>(L, s) : launch_stacked<2, 3, 3, 4, 0, mixr_wps(2, 3), false, 6, false, true>(L, s);
+        case 108: return L.kpiola ? launch_stacked<2, 3, 3, 3, 0, 1, false, 6, false, true, 1>(L, s) : launch_stacked<2, 3, 3, 3, 0, mixr_wps(2, 3), false, 6, false, true>(L, s);
+        case 109: return L.kpiola ? launch_stacked<2, 3, 3, 2, 0, 1, false, 6, false, true, 1>(L, s) : launch_stacked<2, 3, 3, 2, 0, mixr_wps(2, 3), false, 6, false, true>(L, s);
+        case 110: return L.kpiola ? launch_stacked<2, 4, 3, 3, 0, 1, false, 6, false, true, 1>(L, s) : launch_stacked<2, 4, 3, 3, 0, mixr_wps(2, 4), false, 6, false, true>(L, s);
+        case 111: return L.kpiola ? launch_stacked<2, 4, 3, 2, 0, 1, false, 6, false, true, 1>(L, s) : launch_stacked<2, 4, 3, 2, 0, mixr_wps(2, 4), false, 6, false, true>(L, s);
+        case 112: return L.kpiola ? launch_stacked<2, 4, 2, 1, 0, 1, false, 6, false, true, 1>(L, s) : launch_stacked<2, 4, 2, 1, 0, mixr_wps(2, 4), false, 6, false, true>(L, s);
         case 113: return launch_stacked<2, 5, 3, 2, 0, mixr_wps(2, 5), false, 6, false, true>(L, s);
         case 114: return L.kodd ? launch_stacked<2, 5, 2, 1, 0, 1, false, 6, true, true>(L, s) : launch_stacked<2, 5, 2, 1, 0, mixr_wps(2, 5), false, 6, false, true>(L, s);
         case 115: return launch_stacked<2, 5, 3, 1, 0, mixr_wps(2, 5), false, 6, false, true>(L, s);
@@ -1087,6 +1102,19 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 132: return launch_stacked<3, 2, 3, 1, 0, 1, true, 10, false, true>(L, s);
         case 133: return launch_stacked<2, 6, 3, 1, 0, 1, true, 6, false, true>(L, s);  // (two waves per SIMD: 116-364 B of scratch)
         case 134: return launch_stacked<2, 5, 3, 1, 0, 1, true, 6, false, true>(L, s);  // (two waves per SIMD: 116-364 B of scratch)
+        case 135: return launch_stacked<3, 2, 3, 4, 0, 1, false, 1, false, true, 1>(L, s);
+        case 136: return launch_stacked<3, 2, 3, 3, 0, 1, false, 1, false, true, 1>(L, s);
+        case 137: return launch_stacked<3, 2, 3, 2, 0, 1, false, 1, false, true, 1>(L, s);
+        case 138: return launch_stacked<3, 2, 2, 1, 0, 1, false, 1, false, true, 1>(L, s);
+        case 139: return launch_stacked<3, 3, 3, 2, 0, 1, false, 1, false, true, 1>(L, s);
+        case 140: return launch_stacked<3, 3, 2, 1, 0, 1, false, 1, false, true, 1>(L, s);
+        case 141: return launch_stacked<3, 3, 3, 1, 0, 1, false, 1, false, true, 1>(L, s);
+        case 142: return launch_stacked<2, 3, 3, 4, 0, 1, false, 1, false, true, 1>(L, s);
+        case 143: return launch_stacked<2, 3, 3, 3, 0, 1, false, 1, false, true, 1>(L, s);
+        case 144: return launch_stacked<2, 3, 3, 2, 0, 1, false, 1, false, true, 1>(L, s);
+        case 145: return launch_stacked<2, 4, 3, 3, 0, 1, false, 1, false, true, 1>(L, s);
+        case 146: return launch_stacked<2, 4, 3, 2, 0, 1, false, 1, false, true, 1>(L, s);
+        case 147: return launch_stacked<2, 4, 2, 1, 0, 1, false, 1, false, true, 1>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown stacked kernel %d", L.stacked_id);
 }
@@ -1258,6 +1286,15 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     if ((nreq > 0 && npts > 0) && (!pts || !out)) return fail(FX_EINVAL, "null device pointer");
     const int ntab = fx::binom(e->sd + order, e->sd);
     const int rows = e->ndof * e->vdim;
+    // the element's Piola map asked for with the tabulation, and can the stacked kernel apply it to its accumulators (PIO
+    // instances: whole requests of <= 48 points, even table sizes)?  Then the cooperative and the lane-local kernel leave
+    // their fused variants of these shapes to it (coverage map with the map: N2 tetrahedra at 11 points, gradients,
+    // 14 % of the HBM peak on the cooperative kernel against 37 %; N3 triangles 29 % lane-local against 50 %)
+    const bool want_piola = (mapping == FX_MAP_COVARIANT_PIOLA || mapping == FX_MAP_CONTRAVARIANT_PIOLA) && verts && e->vdim == e->sd && e->sd >= 2;
+    const int TRp = fxk::stacked_tile_rows(e->sd, 1);
+    const bool stacked_pio_ok = want_piola && !(ctx->policy & (FX_POLICY_NO_STACKED | FX_POLICY_NO_STACKED_MIX)) && !e->raw_expansion &&
+                                stacked_has_pio(e->sd, e->n) && npts <= 48 && !(((long long)rows * npts) % 2) &&
+                                !(((long long)(rows - TRp * ((rows + TRp - 1) / TRp - 1)) * npts) % 2) && (long long)ntab * rows >= 15;
     fxk::TabArgs& a = L.args;
     memset(&a, 0, sizeof a);
     a.pts = pts;
@@ -1327,6 +1364,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 if (c.sd != e->sd || c.order != order || c.mt16 != mt16 || c.m4 != m4 || nt_need > 4 * c.tpw) continue;
                 const bool piola = c.can_piola && (mapping == FX_MAP_COVARIANT_PIOLA || mapping == FX_MAP_CONTRAVARIANT_PIOLA) && verts && e->vdim == e->sd;
                 if (c.piola_only && !piola) continue;
+                if (piola && stacked_pio_ok) continue;
                 const int table = rows * npts;
                 // tables per output round: as many as LDS holds next to the A fragments and the chain
                 // state while two workgroups still fit a CU (fewer rounds = fewer workgroup barriers per
@@ -1520,6 +1558,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 const bool fuse_small = (mapping == FX_MAP_COVARIANT_PIOLA || mapping == FX_MAP_CONTRAVARIANT_PIOLA) && verts &&
                                         e->vdim == e->sd && rows % e->sd == 0 && L.fixed_id < 0 && L.coop_id < 0 && !L.fused_mapping &&
                                         !(e->sd == 3 && e->n == 2 && order == 2);  // (that instance spills 39 registers)
+                if (fuse_small && rows > 24 && order >= 1 && stacked_pio_ok) break;
                 if (fuse_small ? rows > 36 : (rows > 24 || (rows > 16 && P == 1))) break;
                 fxk::SmallArgs& sa = L.sargs;
                 memset(&sa, 0, sizeof sa);
@@ -1595,8 +1634,8 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             for (size_t i2 = 0; i2 < 2 * (sizeof(kStackedShapes) / sizeof(kStackedShapes[0])) && L.stacked_id < 0; ++i2) {
                 const size_t i = i2 % (sizeof(kStackedShapes) / sizeof(kStackedShapes[0]));
                 const StackedShape& k = kStackedShapes[i];
-                bool mix_odd = false;
-                const bool inmix = k.rtc == -2 || k.rtc == -3 || k.rtc == -4 || k.rtc == -5;  // chain rule inside the kernel
+                bool mix_odd = false, pio = false;
+                const bool inmix = k.rtc == -2 || k.rtc == -3 || k.rtc == -4 || k.rtc == -5 || k.rtc == -6;  // chain rule / Piola map inside the kernel
                 const bool chunked = k.rtc == -1 || k.rtc == -4 || k.rtc == -5;
                 if (inmix != (i2 == i)) continue;
                 if (small_keeps && k.rtc != -3) continue;
@@ -1608,13 +1647,19 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 // (per-request cells with derivatives on the low-degree shapes: the second pass over the tables costs more
                 // than the generic kernel's in-kernel chain rule -- tools/small_vs_stacked.py --verts, 18-29 % against 25-48 %)
                 if (!inmix && verts && order >= 1 && (k.n <= 2 || (k.sd == 2 && k.n <= 4))) continue;
-                if (k.rtc == -2 || k.rtc == -3) {  // per-request cells, order 1 / 2: chain rule across the tables inside the kernel (dof-major tiles)
+                if (k.rtc == -2 || k.rtc == -3 || k.rtc == -6) {  // per-request cells, order 1 / 2: chain rule across the tables inside the kernel (dof-major tiles)
                     const bool nomix = (ctx->policy & FX_POLICY_NO_STACKED_MIX) != 0;
-                    if (nomix || !verts || order != (k.rtc == -2 ? 1 : 2)) continue;
+                    if (nomix || !verts || order != (k.rtc == -2 ? 1 : k.rtc == -3 ? 2 : 0)) continue;
+                    // the element's Piola map too (vector-valued elements: the twin with the components of a dof in one lane,
+                    // 12 rows per tile in 3-D); values only: nothing else to mix, so only with the map
+                    pio = want_piola && stacked_has_pio(k.sd, k.n) && !(((long long)rows * npts) % 2) &&
+                          !(((long long)(rows - TRp * ((rows + TRp - 1) / TRp - 1)) * npts) % 2);
+                    if (k.rtc == -6 && !pio) continue;
                     // (16-byte pieces of whole tables; three shapes have an 8-byte twin for odd table sizes: P5 triangles at the
                     // 25-point rule, N3 and RT2 tetrahedra at the 23- and 11-point rules)
                     mix_odd = ((long long)rows * npts) % 2 || ((long long)(rows - 16 * ((rows + 15) / 16 - 1)) * npts) % 2;
                     // (RT2 at order 1 stays on the generic kernel: 44.7 % of the HBM peak there, 39.2 % on the twin)
+                    if (pio) mix_odd = false;
                     if (mix_odd && !((k.sd == 2 && k.n == 5 && k.ct == 2 && k.g == 1) || (k.sd == 3 && k.n == 3 && k.ct == 3 && k.g == 2) ||
                                      (k.rtc == -3 && k.sd == 3 && k.n == 2 && k.ct == 3 && k.g == 4)))
                         continue;
@@ -1664,7 +1709,12 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 ka.verts = verts;
                 ka.out = out;
                 const bool dofmajor = inmix;
-                ka.afrag = dofmajor ? e->d_astack_dm[order] : e->d_astack[order];
+                ka.afrag = pio ? e->d_astack_dmp[order] : dofmajor ? e->d_astack_dm[order] : e->d_astack[order];
+                if (!ka.afrag) continue;
+                if (pio) {
+                    for (int q = 0; q < 9; ++q) ka.G[q] = 0.5 * e->A0[q];
+                    ka.piola = mapping;
+                }
                 if (dofmajor && !invert_small(e->sd, e->A0, ka.A0inv)) continue;
                 ka.phi0 = e->prog.phi0;
                 memcpy(ka.A0, e->A0, sizeof ka.A0);
@@ -1677,8 +1727,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 ka.lim_pts = (long long)nreq * npts * e->sd;
                 ka.lim_verts = verts ? (long long)nreq * (e->sd + 1) * e->sd : 0;
                 ka.lim_out = (long long)nreq * R * npts;
-                ka.lim_afrag = (dofmajor ? ((long long)((rows + 15) / 16) * ntab + 1) : (long long)(RT + 1)) * ((e->nexp + 3) / 4) * 64;
-                const bool mixr = k.rtc == -3 || k.rtc == -4 || k.rtc == -5 || (k.rtc == -2 && (mix_odd || mixr1(k.sd, k.n, k.ct, k.g) || (k.sd == 3 && k.n == 6 && k.ct == 3)));
+                const int TRk = fxk::stacked_tile_rows(e->sd, pio ? 1 : 0);
+                ka.lim_afrag = (dofmajor ? ((long long)((rows + TRk - 1) / TRk) * ntab + 1) : (long long)(RT + 1)) * ((e->nexp + 3) / 4) * 64;
+                const bool mixr = pio || k.rtc == -3 || k.rtc == -4 || k.rtc == -5 || (k.rtc == -2 && (mix_odd || mixr1(k.sd, k.n, k.ct, k.g) || (k.sd == 3 && k.n == 6 && k.ct == 3)));
                 const int slots = fxk::stacked_mix_slots(e->sd, dofmajor ? ntab : 0, mixr);
                 L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * (fxk::stacked_image_doubles(k.ct, (e->nexp + 3) / 4, slots) + (mixr ? fxk::STACKED_KBUF : 0))) * 8;
                 if (L.klds_bytes > ctx->lds_per_cu) continue;
@@ -1692,6 +1743,8 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 L.queue = ctx->d_queue + (size_t)(ctx->launch_seq++ % FX_QUEUE_SLOTS) * 16;
                 L.kmix_order = order;
                 L.kodd = (k.rtc == 0 && !even) || mix_odd;
+                L.kpiola = pio ? mapping : 0;
+                if (pio) L.fused_mapping = true;
                 L.stacked_id = (int)i;
                 L.small_id = -1;
                 break;
@@ -2098,11 +2151,12 @@ int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, in
     Launch L;
     // plan_launch only records the pointers; a non-null dummy stands for "per-request cells given"
     static double dummy;
-    int rc = plan_launch(ctx, e, order, nreq, npts, &dummy, (has_verts & 1) ? &dummy : nullptr, &dummy, L);
+    int rc = plan_launch(ctx, e, order, nreq, npts, &dummy, (has_verts & 1) ? &dummy : nullptr, &dummy, L, (has_verts >> 2) & 3);
     if (rc != FX_OK) return rc;
     if ((has_verts & 2) && L.stacked_id >= 0 && L.fixed_id < 0) {  // with the instance of the stacked-matrix registry
         const StackedShape& k = kStackedShapes[L.stacked_id];
-        snprintf(name, (size_t)name_len, "fxk::tabulate_simplex_stacked<%d,%d,%d,%d,%d>", k.sd, k.n, k.ct, k.g, k.rtc);
+        snprintf(name, (size_t)name_len, "fxk::tabulate_simplex_stacked<%d,%d,%d,%d,%d>%s", k.sd, k.n, k.ct, k.g, k.rtc,
+                 L.kpiola ? "+piola" : "");
         return FX_OK;
     }
     const char* k = "fxk::tabulate_simplex_kernel";
@@ -2810,6 +2864,31 @@ int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
             return fail(FX_EHIP, "ensure_stacked: allocation or copy of the dof-major stacked matrix failed");
         }
         e->d_astack_dm[order] = d_fd;
+    }
+    if (e->vdim == sd && sd >= 2) {  // vector-valued: dof-major tiles with the components of a dof in one lane (fused Piola map)
+        const int TR = fxk::stacked_tile_rows(sd, 1);
+        const int RTd = (rows + TR - 1) / TR;
+        std::vector<double> Fp((size_t)(RTd * ntab + 1) * KS * 64, 0.0);
+        for (int i = 0; i < RTd; ++i)
+            for (int t = 0; t < ntab; ++t)
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int pos = lane & 15;  // tile position 4 jj + kk
+                        const int tr = fxk::stacked_pio_row(sd, pos >> 2, pos & 3);
+                        const int mem = member[4 * ks + (lane >> 4)];
+                        if (tr >= 0 && TR * i + tr < rows && mem >= 0)
+                            Fp[(((size_t)i * ntab + t) * KS + ks) * 64 + lane] = S[((size_t)t * rows + TR * i + tr) * nexp + mem];
+                    }
+        double* d_fp = nullptr;
+        if (hipMalloc(&d_fp, Fp.size() * sizeof(double)) != hipSuccess ||
+            hipMemcpy(d_fp, Fp.data(), Fp.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+            if (d_fp) (void)hipFree(d_fp);
+            if (e->d_astack_dm[order]) (void)hipFree(e->d_astack_dm[order]);
+            e->d_astack_dm[order] = nullptr;
+            (void)hipFree(d_f);
+            return fail(FX_EHIP, "ensure_stacked: allocation or copy of the component-major stacked matrix failed");
+        }
+        e->d_astack_dmp[order] = d_fp;
     }
     e->d_astack[order] = d_f;
     e->stack_state[order] = 1;

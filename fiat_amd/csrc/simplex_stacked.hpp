@@ -36,6 +36,8 @@ template <int NC> struct StackedArgs {
     double A0[9];
     double b0[3];
     double A0inv[9];  // (MIXT instances: K = A0^-1 A_req of the chain rule)
+    double G[9];      // (PIO instances: A0 / 2, the reference part of the Piola Jacobian J = E_req G)
+    int piola;        // (PIO instances: 1 covariant, 2 contravariant)
     long long nreq;
     int npts;
     int R;   // stacked rows = ntab * rows
@@ -99,11 +101,18 @@ template <int... I, class F> __device__ __forceinline__ void static_for_impl(std
 template <int CNT, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, CNT>{}, f); }
 
 constexpr int stacked_mix_slots(int sd, int mixt, bool mixr) {  // row-tile images per wave
-    return mixt == 0 ? 1 : (mixr && mixt > 1 + sd && sd * (sd + 1) / 2 > 1 + sd) ? sd * (sd + 1) / 2 : 1 + sd;
+    return mixt <= 1 ? 1 : (mixr && mixt > 1 + sd && sd * (sd + 1) / 2 > 1 + sd) ? sd * (sd + 1) / 2 : 1 + sd;
 }
-constexpr int STACKED_KBUF = 48;  // doubles per wave behind the images (MIXR): K of the group's (<= 4) requests
+constexpr int STACKED_KBUF = 80;  // doubles per wave behind the images (MIXR): K, and the Piola matrices, of the group's (<= 4) requests
+// PIO (vector-valued elements, value shape (SD,), rows = (dof, component)): rows per dof tile and where the tile position
+// 4 jj + kk (element jj of lane kk of an MFMA result column) sits among them -- the SD components of a dof in ONE lane:
+//   SD 3: lane kk holds dof kk of the tile, jj = component (jj 3 unused: 12 rows per tile);  SD 2: two dofs per lane, 16 rows
+constexpr int stacked_tile_rows(int sd, int pio) { return pio && sd == 3 ? 12 : 16; }
+__host__ __device__ constexpr int stacked_pio_row(int sd, int jj, int kk) {
+    return sd == 3 ? (jj < 3 ? 3 * kk + jj : -1) : 8 * (jj >> 1) + 2 * kk + (jj & 1);
+}
 
-template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0, bool ODD = false, bool MIXR = false>
+template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0, bool ODD = false, bool MIXR = false, int PIO = 0>
 __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const StackedArgs<FixedNC<SD, N>::value> a,
                                                                    double* __restrict__ trash,
                                                                    unsigned int* __restrict__ gqueue) {
@@ -111,13 +120,16 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
     constexpr int NEXP = StepTable<SD, N>::NEXP;
     constexpr int KS = (NEXP + 3) / 4;
     constexpr int CPR = 16 * CT / G;                // column budget of one request
-    constexpr int NST = ODD ? (16 * CPR + 63) / 64 : (16 * CPR / 2 + 63) / 64;   // 16-byte (ODD: 8-byte) stores per lane and request chunk
+    constexpr int TR = stacked_tile_rows(SD, PIO);  // rows of a row tile (16; 12 with three components per lane)
+    constexpr int NST = ODD ? (TR * CPR + 63) / 64 : (TR * CPR / 2 + 63) / 64;   // 16-byte (ODD: 8-byte) stores per lane and request chunk
     static_assert(!ODD || (!CHUNK && (MIXT == 0 || MIXR) && RTC == 0), "8-byte flush: whole-request groups, streamed fragments");
     using FlushT = typename std::conditional<ODD, double, v2d>::type;
     constexpr int PCH = 16 * CT;                    // points per chunk (CHUNK)
     static_assert(!CHUNK || (G == 1 && RTC == 0), "point-chunked units: one request per group, streamed fragments");
-    constexpr int NTA = 1 + SD, NTB = SD * (SD + 1) / 2;           // tables of orders <= 1, of order 2
-    constexpr int MORD = MIXT == 0 ? 0 : MIXT == NTA ? 1 : 2;      // derivative order of a table-mixing instance
+    constexpr int NTA = MIXT == 1 ? 1 : 1 + SD, NTB = SD * (SD + 1) / 2;   // tables of orders <= 1, of order 2
+    constexpr int MORD = MIXT <= 1 ? 0 : MIXT == NTA ? 1 : 2;              // derivative order of a table-mixing instance
+    static_assert(PIO == 0 || (MIXR && !CHUNK && !ODD && SD >= 2), "fused Piola map: accumulator-side mixing, whole requests");
+    static_assert(MIXT != 1 || PIO != 0, "one table: only the Piola map is left to mix");
     constexpr int SLOTS = stacked_mix_slots(SD, MIXT, MIXR);
     constexpr int IMG = stacked_image_doubles(CT, KS, SLOTS) + (MIXR ? STACKED_KBUF : 0);
     static_assert(MIXT == 0 || ((MIXT == NTA || (MIXR && MIXT == NTA + NTB)) && (!CHUNK || MIXR) && RTC == 0 && (!ODD || MIXR)),
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
     CDouble* kcoef = (CDouble*)(kargs + __builtin_offsetof(ArgsT, coef));
 
     const int npts = a.npts;
-    const int chunk = 16 * npts;  // doubles one request contributes to a row tile
+    const int chunk = TR * npts;  // doubles one request contributes to a row tile
     const int nchunk = CHUNK ? (npts + PCH - 1) / PCH : 1;
     const long long ngroups = CHUNK ? a.nreq * nchunk : (a.nreq + G - 1) / G;
     WorkQueue wqueue;
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
             const int j = 16 * c + (lane & 15);
             const int g = idiv_small(j, rinv);
             const bool valid = g < G;
-            ioff[c] = valid ? g * chunk + kk * npts + (j - g * npts) : -1;
+            ioff[c] = valid ? g * chunk + (PIO ? (SD == 3 ? 3 : 2) : 1) * kk * npts + (j - g * npts) : -1;
             if constexpr (MIXR) kofs[c] = valid ? g * SD * SD : 0;
         }
     }
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
 #pragma unroll
             for (int c = 0; c < CT; ++c) asm volatile("" : "+v"(eoff[c]));
         }
-        const int echunk = 16 * enpts;
+        const int echunk = TR * enpts;
         const int last_rows = a.R - 16 * (RTn - 1);
 
         // D tile: element jj of lane (kk, col) is row 4 jj + kk -> image [request][row][point]
@@ -351,8 +363,15 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
         const int estr = CHUNK ? pc : enpts;  // row stride of the image
         auto image_put = [&](const v4d (&acc)[CT], int w, int nrows, int soff = 0) {  // w-th of the 4 CT image stores
             const int c = w >> 2, jj = w & 3;
-            const bool ok = eoff[c] >= 0 && 4 * jj + ekk < nrows;
-            img[ok ? soff + eoff[c] + 4 * jj * estr : DUMP + elane] = acc[c][jj];
+            if constexpr (PIO != 0) {  // (rows of the tile: stacked_pio_row)
+                if (SD == 3 && jj == 3) return;
+                const int jrow = SD == 3 ? jj : 8 * (jj >> 1) + (jj & 1);
+                const bool ok = eoff[c] >= 0 && jrow + (SD == 3 ? 3 : 2) * ekk < nrows;
+                img[ok ? soff + eoff[c] + jrow * estr : DUMP + elane] = acc[c][jj];
+            } else {
+                const bool ok = eoff[c] >= 0 && 4 * jj + ekk < nrows;
+                img[ok ? soff + eoff[c] + 4 * jj * estr : DUMP + elane] = acc[c][jj];
+            }
         };
         constexpr int NRD = CHUNK ? (16 * PCH + 63) / 64 : G * NST;  // image reads = output stores per row tile
         FlushT fbuf[CHUNK ? 1 : NRD];
@@ -469,11 +488,24 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
         if constexpr (MIXT > 0 && MIXR) {
             // ---- dof-major tiles, chain rule applied to the accumulators (lane-local), plain-copy flush ----
             const int rows = a.R / MIXT;                      // rows per table
-            const int RTd = (rows + 15) / 16;                 // dof tiles; tile (i, t) = table t, rows [16 i, 16 i + 16)
-            const int rows_last = rows - 16 * (RTd - 1);
+            const int RTd = (rows + TR - 1) / TR;             // dof tiles; tile (i, t) = table t, rows [TR i, TR i + TR)
+            const int rows_last = rows - TR * (RTd - 1);
             constexpr int SLOT = 16 * 16 * CT;
             double* kbuf = img + (IMG - STACKED_KBUF);        // [G][SD][SD]: K = A0^-1 A_req of the group's requests
-            if (lane < G) {
+            double* pbuf = kbuf + STACKED_KBUF / 2;           // [G][SD][SD]: the Piola matrices (PIO)
+            if constexpr (PIO != 0) {
+                if (lane < G) {
+                    long long req = grp * G + lane;
+                    req = req < a.nreq ? req : a.nreq - 1;
+                    double M[SD][SD];
+                    piola_matrix<SD>(a.verts + FX_CHK((size_t)req * (SD + 1) * SD, a.lim_verts - (SD + 1) * SD + 1, 2), a.G, a.piola, M);
+#pragma unroll
+                    for (int i = 0; i < SD; ++i)
+#pragma unroll
+                        for (int d = 0; d < SD; ++d) pbuf[lane * SD * SD + i * SD + d] = M[i][d];
+                }
+            }
+            if (MORD > 0 && lane < G) {
                 long long req = CHUNK ? grp / nchunk : grp * G + lane;
                 req = req < a.nreq ? req : a.nreq - 1;
                 double J[SD][SD], bb[SD];
@@ -495,6 +527,33 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
             // chain rule on the accumulators of one half: d/dx_d = sum_c K[c][d] d/dX_c; d2/dx_d dx_e = sum K[c][d] K[c'][e] d2/dX_c dX_c'
             auto mix_acc = [&](auto phase_c) {
                 constexpr int PHS = decltype(phase_c)::value;
+                if constexpr (PIO != 0) {  // phi = M Phi on every table of the half: the components of a dof sit in one lane
+                    constexpr int NCUR = PHS == 0 ? NTA : NTB;
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        double Ml[SD][SD];
+#pragma unroll
+                        for (int i = 0; i < SD; ++i)
+#pragma unroll
+                            for (int d = 0; d < SD; ++d) Ml[i][d] = pbuf[kofs[c] + i * SD + d];
+#pragma unroll
+                        for (int t = 0; t < NCUR; ++t)
+#pragma unroll
+                            for (int h = 0; h < (SD == 2 ? 2 : 1); ++h) {  // (two dofs per lane in 2-D)
+                                double v[SD];
+#pragma unroll
+                                for (int i = 0; i < SD; ++i) v[i] = acc[t][c][SD * h + i];
+#pragma unroll
+                                for (int i = 0; i < SD; ++i) {
+                                    double w = 0.0;
+#pragma unroll
+                                    for (int d = 0; d < SD; ++d) w += Ml[i][d] * v[d];
+                                    acc[t][c][SD * h + i] = w;
+                                }
+                            }
+                    }
+                }
+                if constexpr (MORD > 0) {
 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
                     double Kl[SD][SD];
@@ -537,6 +596,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                                 }
                         }
                     }
+                }
                 }
             };
             // One tile: MFMAs of tile q into `cur`, fragments of tile q + 1 into `an` (all in the first third of the K-steps:
@@ -589,23 +649,23 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                 constexpr int PHS = decltype(phase_c)::value;
                 constexpr bool FL = decltype(flush_c)::value;
                 constexpr int NCUR = PHS == 0 ? NTA : NTB, T0 = PHS == 0 ? 0 : NTA;
-                constexpr int NPREV = !FL ? 0 : MORD == 1 ? NTA : PHS == 0 ? NTB : NTA;
+                constexpr int NPREV = !FL ? 0 : MORD <= 1 ? NTA : PHS == 0 ? NTB : NTA;
                 constexpr int TP0 = (MORD == 2 && PHS == 0) ? NTA : 0;            // first table of the half before
                 asm volatile("" : "+s"(i));  // (opaque per half: no induction variables for the ~40 output bases of a dof tile)
                 const int iprev = (MORD == 2 && PHS == 1) ? i : i - 1;
-                const int pn = iprev == RTd - 1 ? rows_last : 16;
+                const int pn = iprev == RTd - 1 ? rows_last : TR;
                 static_for<NCUR>([&](auto s_c) {
                     constexpr int s = decltype(s_c)::value;
                     constexpr int F0 = s * NPREV / NCUR, F1 = (s + 1) * NPREV / NCUR;
                     const int q = i * MIXT + T0 + s;
                     if constexpr (((T0 + s + (decltype(iodd_c)::value ? 1 : 0)) & 1) == 0)
-                        rstage(acc[s], q, fa0, fa1, std::integral_constant<int, F1 - F0>{}, F0, (TP0 + F0) * rows + 16 * iprev, pn);
+                        rstage(acc[s], q, fa0, fa1, std::integral_constant<int, F1 - F0>{}, F0, (TP0 + F0) * rows + TR * iprev, pn);
                     else
-                        rstage(acc[s], q, fa1, fa0, std::integral_constant<int, F1 - F0>{}, F0, (TP0 + F0) * rows + 16 * iprev, pn);
+                        rstage(acc[s], q, fa1, fa0, std::integral_constant<int, F1 - F0>{}, F0, (TP0 + F0) * rows + TR * iprev, pn);
                 });
                 mix_acc(phase_c);
                 wave_lds_fence();  // (the images of the half before have been read)
-                const int nrows = i == RTd - 1 ? rows_last : 16;
+                const int nrows = i == RTd - 1 ? rows_last : TR;
                 static_for<NCUR>([&](auto s_c) {
                     constexpr int s = decltype(s_c)::value;
 #pragma unroll
@@ -640,7 +700,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
 #pragma unroll
                 for (int r = 0; r < NRD; ++r) image_get(r, rows_last, t * SLOT);
 #pragma unroll
-                for (int r = 0; r < NRD; ++r) image_out(r, (TL0 + t) * rows + 16 * (RTd - 1), rows_last);
+                for (int r = 0; r < NRD; ++r) image_out(r, (TL0 + t) * rows + TR * (RTd - 1), rows_last);
             }
             wave_lds_fence();
         } else if constexpr (MIXT > 0) {

@@ -218,12 +218,13 @@ class SimplexPolySet:
                                            _dev_ptr(ref_pts), _dev_ptr(verts), _dev_ptr(out), _stream_ptr(stream)))
         return out
 
-    def kernel_name(self, order, nreq, npts, has_verts=False, instance=False):
+    def kernel_name(self, order, nreq, npts, has_verts=False, instance=False, mapping=None):
         """Device kernel ``tabulate_batch`` launches for this request shape (fx_plan_kernel); ``instance``: with the
-        registry instance of the stacked-matrix kernel."""
+        registry instance of the stacked-matrix kernel; ``mapping``: the Piola map asked for with the tabulation."""
         buf = ctypes.create_string_buffer(96)
-        check(lib.fx_plan_kernel(self.ctx.handle, self.handle, int(order), int(nreq), int(npts),
-                                 int(bool(has_verts)) | (2 if instance else 0), buf, 96))
+        code = self.MAPPINGS[mapping] if mapping else 0
+        flags = int(bool(has_verts)) | (2 if instance else 0) | ((code << 2) if code in (1, 2) else 0)
+        check(lib.fx_plan_kernel(self.ctx.handle, self.handle, int(order), int(nreq), int(npts), flags, buf, 96))
         return buf.value.decode()
 
     def time_tabulate_batch(self, order, pts, verts, out, reps, stream=None):

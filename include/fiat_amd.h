@@ -263,7 +263,8 @@ int fx_tables_point_major(fx_ctx* ctx, int64_t ntables, int rows, int npts, cons
 /* Name of the device kernel fx_tabulate_batch would launch for this element and request shape
  * ("fxk::tabulate_simplex_stream", "..._fixed", "..._coop" or the generic "..._kernel"); has_verts != 0
  * stands for per-request cell geometry (bit 0; bit 1: append the registry instance of the stacked-matrix kernel,
- * "...stacked<sd,n,column tiles,requests per group,kind>").  Lets benchmarks and tests name the kernel they measured
+ * "...stacked<sd,n,column tiles,requests per group,kind>", "+piola" when the instance applies the map of bits 2-3 --
+ * FX_MAP_COVARIANT_PIOLA / FX_MAP_CONTRAVARIANT_PIOLA << 2 -- itself).  Lets benchmarks and tests name the kernel they measured
  * (no reference counterpart: FIAT has a single NumPy path, FIAT/expansions.py:449-490). */
 int fx_plan_kernel(fx_ctx* ctx, const fx_element* elem, int order, int64_t nreq, int npts, int has_verts, char* name,
                    int name_len);

@@ -264,3 +264,57 @@ def test_chain_rule_on_the_accumulators_of_the_stacked_kernel(family, sd, degree
                                   variant=el._expansion_variant).reshape(out.shape)
     for t in range(out.shape[1]):
         assert rel(out[:, t], ref[:, t]) <= (1e-12 if t == 0 else 1e-10), (instance, t, rel(out[:, t], ref[:, t]))
+
+
+# (family, sd, degree, points) of vector-valued elements -> the stacked instance <sd, n, column tiles, requests per group>
+PIOLA = [("Nedelec", 3, 2, 11, "3,2,3,4"), ("BrezziDouglasMarini", 3, 2, 14, "3,2,3,3"), ("NedelecSecondKind", 3, 2, 22, "3,2,3,2"),
+         ("Nedelec", 3, 2, 30, "3,2,2,1"), ("RaviartThomas", 3, 3, 24, "3,3,3,2"), ("Nedelec", 3, 3, 30, "3,3,2,1"),
+         ("BrezziDouglasMarini", 3, 3, 44, "3,3,3,1"), ("Nedelec", 2, 3, 12, "2,3,3,4"), ("RaviartThomas", 2, 3, 16, "2,3,3,3"),
+         ("BrezziDouglasMarini", 2, 3, 22, "2,3,3,2"), ("Nedelec", 2, 4, 16, "2,4,3,3"), ("RaviartThomas", 2, 4, 22, "2,4,3,2"),
+         ("NedelecSecondKind", 2, 3, 12, "2,3,3,4"), ("RaviartThomas", 2, 4, 30, "2,4,2,1")]
+
+
+@pytest.mark.parametrize("family,sd,degree,npts,instance", PIOLA, ids=[f"{m[0][:3]}{m[2]}-sd{m[1]}-{m[3]}pt" for m in PIOLA])
+@pytest.mark.parametrize("order", [0, 1, 2])
+@pytest.mark.parametrize("nreq", [3, 1033])
+def test_piola_map_on_the_accumulators_of_the_stacked_kernel(family, sd, degree, npts, instance, order, nreq, kernel_policy):
+    """Vector-valued elements on per-request cells with their Piola map (FIAT/finite_element.py:84-88, formulas of
+    finat/hdivcurl.py:95-191): the stacked-matrix kernel keeps the components of a dof in one MFMA lane and applies
+    phi = M Phi to its accumulators, together with the chain rule across the derivative tables -- one pass instead of
+    tabulation + a read-modify-write of every table.  Against the separate passes (policy no_stacked_mix: kernel, table
+    mixing pass, push-forward pass -- the route the reference goldens of tests/test_gpu_pushforward.py pin) and against the
+    formula evaluated on the C oracle's tables of a few cells."""
+    import fiat_amd as fa
+    from oracle import c_oracle
+    from oracle import fiat_oracle as fo
+    el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
+    ps = el.device_polyset()
+    mapping = el.mapping()[0]
+    kernel_policy("no_small", "no_fixed", "no_coop")
+    kind = {0: -6, 1: -2, 2: -3}[order]
+    assert ps.kernel_name(order, nreq, npts, has_verts=True, instance=True, mapping=mapping) == \
+        f"fxk::tabulate_simplex_stacked<{instance},{kind}>+piola"
+    rng = np.random.default_rng(13 * degree + npts + sd + order)
+    A = np.eye(sd) + 0.15 * rng.standard_normal((nreq, sd, sd))
+    A[::3, :, 0] *= -1.0
+    verts = np.einsum("vd,red->rve", fo.UFC_SIMPLEX[sd], A) + rng.standard_normal((nreq, 1, sd))
+    e = rng.exponential(size=(nreq, npts, sd + 1))
+    pts = np.einsum("rpv,rvd->rpd", e / e.sum(axis=-1, keepdims=True), verts)
+    fused = ps.tabulate_batch(order, pts, verts=verts, mapping=mapping).cpu().numpy()
+    kernel_policy("no_small", "no_fixed", "no_coop", "no_stacked_mix")
+    assert not ps.kernel_name(order, nreq, npts, has_verts=True, instance=True, mapping=mapping).endswith("+piola")
+    two = ps.pushforward_batch(order, ps.tabulate_batch(order, pts, verts=verts), verts, mapping).cpu().numpy()
+    assert fused.shape == two.shape
+    for t in range(fused.shape[1]):
+        assert rel(fused[:, t], two[:, t]) <= (1e-12 if t == 0 else 1e-10), (instance, t, rel(fused[:, t], two[:, t]))
+    n = el.get_nodal_basis().get_embedded_degree()
+    sel = sorted({0, nreq // 2, nreq - 1})
+    raw = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[sd], n, el.get_coeffs(), order, pts[sel], verts=verts[sel], scale=el._expansion_scale,
+                                  variant=el._expansion_variant).reshape(fused[sel].shape)
+    ref = fo.UFC_SIMPLEX[sd]
+    for j, i in enumerate(sel):
+        J = (verts[i][1:] - verts[i][0]).T @ np.linalg.inv((ref[1:] - ref[0]).T)
+        M = np.linalg.inv(J).T if mapping.startswith("cov") else J / np.linalg.det(J)
+        want = np.einsum("ce,tdep->tdcp", M, raw[j].reshape(raw.shape[1], -1, sd, npts)).reshape(fused[i].shape)
+        for t in range(want.shape[0]):
+            assert rel(fused[i, t], want[t]) <= (1e-12 if t == 0 else 1e-10), (instance, "oracle", i, t)
