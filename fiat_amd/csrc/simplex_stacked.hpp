@@ -651,6 +651,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
                 constexpr int NCUR = PHS == 0 ? NTA : NTB, T0 = PHS == 0 ? 0 : NTA;
                 constexpr int NPREV = !FL ? 0 : MORD <= 1 ? NTA : PHS == 0 ? NTB : NTA;
                 constexpr int TP0 = (MORD == 2 && PHS == 0) ? NTA : 0;            // first table of the half before
+                i = __builtin_amdgcn_readfirstlane(i);
                 asm volatile("" : "+s"(i));  // (opaque per half: no induction variables for the ~40 output bases of a dof tile)
                 const int iprev = (MORD == 2 && PHS == 1) ? i : i - 1;
                 const int pn = iprev == RTd - 1 ? rows_last : TR;
