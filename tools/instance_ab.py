@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-request-cell launches of chosen shapes, one line each: registry instance, launch time, fraction of the HBM peak
-(measurement tooling).  python tools/instance_ab.py "Lagrange,3,4,44,1;RaviartThomas,3,3,23,2" [--policy no_small]
+(measurement tooling).  python tools/instance_ab.py "Lagrange,3,4,44,1;RaviartThomas,3,3,23,2" [--policy no_small] [--pushforward]
 (family, sd, degree, points, derivative order).  A/B between libraries: run it under FIAT_AMD_LIB=... alternately
 (tools/tool_ab.sh)."""
 import os, sys
@@ -30,7 +30,22 @@ for spec in sys.argv[1].split(";"):
         pts = (torch.einsum("rpd,red->rpe", pts, A) + b).contiguous()
     out = torch.empty(ps.out_shape(order, nreq, npts), dtype=torch.float64, device="cuda")
     name = ps.kernel_name(order, nreq, npts, has_verts=cells, instance=True)
-    for _ in range(3):
-        ps.time_tabulate_batch(order, pts, verts, out, 5)
-    t = min(ps.time_tabulate_batch(order, pts, verts, out, 10) for _ in range(5))
+    if "--pushforward" in sys.argv and cells and el.mapping()[0] != "affine":   # the element's Piola map with the tabulation
+        m = el.mapping()[0]
+        name = ps.kernel_name(order, nreq, npts, has_verts=True, instance=True, mapping=m)
+
+        def timed(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ps.tabulate_batch(order, pts, verts=verts, out=out, mapping=m)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        timed(5)
+        t = min(timed(10) for _ in range(5))
+    else:
+        for _ in range(3):
+            ps.time_tabulate_batch(order, pts, verts, out, 5)
+        t = min(ps.time_tabulate_batch(order, pts, verts, out, 10) for _ in range(5))
     print(f"{spec:34s} {t * 1e3:8.1f} us  {nreq * per_req / t / 1e6 / 8000 * 100:5.1f} % HBM  {name.replace('fxk::tabulate_simplex_', '')}", flush=True)
