@@ -151,3 +151,81 @@ def test_singular_vandermonde_raises(fa):
         finite_element.CiarletElement(polynomial_set.ONPolynomialSet(T, 1), dual_set.DualSet(nodes, T, ids), 1)
     with pytest.raises(ValueError):
         finite_element.CiarletElement(polynomial_set.ONPolynomialSet(T, 2), dual_set.DualSet(nodes, T, ids), 1)
+
+
+def test_basis_derivatives_scaling_known_answers():
+    """The reference's regression test of derivative scaling (test/FIAT/unit/test_fiat.py:76-117, "issue #9"), on the device:
+    Lagrange P1 on 26 random intervals [a, b] of length up to 1000, nodal basis tabulated with two derivatives at a, the
+    midpoint and b -- values (1, 1/2, 0) / (0, 1/2, 1), first derivatives -+ 1 / (b - a), second derivatives 0; same seed,
+    same draws, numpy.isclose as there."""
+    import random
+    import fiat_amd
+    from fiat_amd.reference_element import physical_simplex
+    random.seed(42)
+    for _ in range(26):
+        a = 1000.0 * (random.random() - 0.5)
+        b = 1000.0 * (random.random() - 0.5)
+        a, b = min(a, b), max(a, b)
+        element = fiat_amd.Lagrange(physical_simplex([[a], [b]]), 1)
+        points = [(a,), (0.5 * (a + b),), (b,)]
+        tab = element.get_nodal_basis().tabulate(points, 2)
+        assert np.allclose(tab[(0,)][0], [1.0, 0.5, 0.0]) and np.allclose(tab[(0,)][1], [0.0, 0.5, 1.0])
+        D = 1.0 / (b - a)
+        for p in range(3):
+            assert np.isclose(tab[(1,)][0][p], -D) and np.isclose(tab[(1,)][1][p], +D)
+            assert np.isclose(tab[(2,)][0][p], 0.0) and np.isclose(tab[(2,)][1][p], 0.0)
+
+
+def _outer_rows(*cols):
+    """Row a nB + b of a product element = outer product of the factors' columns, last factor fastest."""
+    out = cols[0]
+    for c in cols[1:]:
+        out = np.multiply.outer(out, c).reshape(-1)
+    return out
+
+
+def test_tensor_product_tables_are_products_of_the_factor_tables(fa):
+    """The reference's product-rule tests of TensorProductElement.tabulate (test/FIAT/unit/test_tensor_product.py:35-52 DG1 x P2
+    on the quadrilateral, :102-123 DG1(triangle) x P2 on the prism, :126-146 (P1 x DG1) x P1 on the hexahedron), at the
+    points used there, every multi-index of order <= 1: table[da + db][a nB + b] = A[da][a] B[db][b], numpy.isclose as there."""
+    I, S = fa.UFCInterval(), fa.UFCTriangle()
+    # 1-D x 1-D
+    A, B = fa.DiscontinuousLagrange(I, 1), fa.Lagrange(I, 2)
+    elt = fa.TensorProductElement(A, B)
+    assert elt.value_shape() == ()
+    tab, tA, tB = elt.tabulate(1, [(0.1, 0.2)]), A.tabulate(1, [(0.1,)]), B.tabulate(1, [(0.2,)])
+    for da, db in [[(0,), (0,)], [(1,), (0,)], [(0,), (1,)]]:
+        assert np.allclose(tab[da + db][:, 0], _outer_rows(tA[da][:, 0], tB[db][:, 0]), rtol=1e-5, atol=1e-8)
+    # triangle x interval
+    A = fa.DiscontinuousLagrange(S, 1)
+    elt = fa.TensorProductElement(A, B)
+    assert elt.value_shape() == ()
+    tab, tA, tB = elt.tabulate(1, [(0.1, 0.2, 0.3)]), A.tabulate(1, [(0.1, 0.2)]), B.tabulate(1, [(0.3,)])
+    for da, db in [[(0, 0), (0,)], [(1, 0), (0,)], [(0, 1), (0,)], [(0, 0), (1,)]]:
+        assert np.allclose(tab[da + db][:, 0], _outer_rows(tA[da][:, 0], tB[db][:, 0]), rtol=1e-5, atol=1e-8)
+    # (interval x interval) x interval
+    P1, D1 = fa.Lagrange(I, 1), fa.DiscontinuousLagrange(I, 1)
+    elt = fa.TensorProductElement(fa.TensorProductElement(P1, D1), P1)
+    assert elt.value_shape() == ()
+    tab = elt.tabulate(1, [(0.1, 0.2, 0.3)])
+    tA, tB, tC = P1.tabulate(1, [(0.1,)]), D1.tabulate(1, [(0.2,)]), P1.tabulate(1, [(0.3,)])
+    for da, db, dc in [[(0,), (0,), (0,)], [(1,), (0,), (0,)], [(0,), (1,), (0,)], [(0,), (0,), (1,)]]:
+        assert np.allclose(tab[da + db + dc][:, 0], _outer_rows(tA[da][:, 0], tB[db][:, 0], tC[dc][:, 0]), rtol=1e-5, atol=1e-8)
+
+
+def test_flattened_dimensions_equal_the_product_element(fa):
+    """test/FIAT/unit/test_tensor_product.py:523-565: FlattenedDimensions of the P1 x P1 quadrilateral and of the
+    (P1 x P1) x P1 hexahedron tabulate what the product elements tabulate, keyed by flat multi-indices."""
+    I = fa.UFCInterval()
+    P1 = fa.Lagrange(I, 1)
+    quad = fa.TensorProductElement(P1, P1)
+    flat_quad = fa.FlattenedDimensions(quad)
+    assert quad.value_shape() == ()
+    t, f = quad.tabulate(1, [(0.1, 0.2)]), flat_quad.tabulate(1, [(0.1, 0.2)])
+    for dc in [(0, 0), (1, 0), (0, 1)]:
+        assert np.allclose(t[dc], f[dc], rtol=1e-5, atol=1e-8) and t[dc].shape[0] == 4
+    hexa = fa.TensorProductElement(quad, P1)
+    flat_hex = fa.FlattenedDimensions(fa.TensorProductElement(flat_quad, P1))
+    t, f = hexa.tabulate(1, [(0.1, 0.2, 0.3)]), flat_hex.tabulate(1, [(0.1, 0.2, 0.3)])
+    for dd in [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)]:
+        assert np.allclose(t[dd], f[dd], rtol=1e-5, atol=1e-8) and t[dd].shape[0] == 8
