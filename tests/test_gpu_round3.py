@@ -318,3 +318,19 @@ def test_piola_map_on_the_accumulators_of_the_stacked_kernel(family, sd, degree,
         want = np.einsum("ce,tdep->tdcp", M, raw[j].reshape(raw.shape[1], -1, sd, npts)).reshape(fused[i].shape)
         for t in range(want.shape[0]):
             assert rel(fused[i, t], want[t]) <= (1e-12 if t == 0 else 1e-10), (instance, "oracle", i, t)
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_expansion_orthonormality_degree_10_on_the_device(dim):
+    """test/FIAT/unit/test_polynomial.py:112-120 on the device: the degree-10 expansion set of the default simplex tabulated at
+    the default quadrature rule of degree 20 is L2-orthonormal (numpy.allclose, as there); the rule is the one
+    ``create_quadrature`` serves (reference tables up to degree 18 on the tetrahedron, the collapsed Gauss-Jacobi rule beyond)."""
+    import fiat_amd as fa
+    cell = fa.default_simplex(dim)
+    U = fa.ExpansionSet(cell)
+    rule = fa.create_quadrature(cell, 20)
+    phi = U.tabulate(10, rule.get_points())
+    results = np.dot(np.multiply(phi, rule.get_weights()), phi.T)
+    assert np.allclose(results, np.diag(np.diag(results)))
+    assert np.allclose(np.diag(results), 1.0)
+    print(f"dim {dim}: {phi.shape[0]} members x {phi.shape[1]} points, max |G - I| = {np.abs(results - np.eye(len(results))).max():.2e}")
