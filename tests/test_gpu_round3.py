@@ -334,3 +334,41 @@ def test_expansion_orthonormality_degree_10_on_the_device(dim):
     assert np.allclose(results, np.diag(np.diag(results)))
     assert np.allclose(np.diag(results), 1.0)
     print(f"dim {dim}: {phi.shape[0]} members x {phi.shape[1]} points, max |G - I| = {np.abs(results - np.eye(len(results))).max():.2e}")
+
+
+@pytest.mark.parametrize("sd", [2, 3])
+@pytest.mark.parametrize("degree", [1, 2, 3])
+def test_gls_second_kind_bubbles_as_in_the_reference_test(sd, degree):
+    """The reference's own test of the GLS element, second kind (test/FIAT/unit/test_gopalakrishnan_lederer_schoberl.py:19-79
+    with kind = 2), tabulating on the device: dimension of the space and of the interior bubbles, the normal-tangential
+    components of every basis function on every facet are polynomials of degree <= degree (moments against the degree + 1
+    part of an orthonormal facet basis vanish), and the normal-tangential components of the bubbles vanish on the facets."""
+    import fiat_amd as fa
+    from fiat_amd.expansions import polynomial_dimension
+    from fiat_amd.polynomial_set import ONPolynomialSet
+    from fiat_amd.quadrature import FacetQuadratureRule
+    cell = fa.ufc_simplex(sd)
+    fe = fa.GopalakrishnanLedererSchoberlSecondKind(cell, degree)
+    facet_el = cell.construct_subelement(sd - 1)
+    poly_set = fe.get_nodal_basis()
+    assert poly_set.get_num_members() == (sd ** 2 - 1) * polynomial_dimension(cell, degree)
+    bubbles = poly_set.take(fe.entity_dofs()[sd][0])
+    assert bubbles.get_num_members() == (sd ** 2 - 1) * polynomial_dimension(cell, degree - 1)
+    Qref = fa.create_quadrature(facet_el, 2 * degree + 1)
+    Pk = ONPolynomialSet(facet_el, degree + 1)
+    PkH = Pk.take(list(range(polynomial_dimension(facet_el, degree), polynomial_dimension(facet_el, degree + 1))))
+    PkH_at_qpts = PkH.tabulate(Qref.get_points())[(0,) * (sd - 1)]
+    weights = np.transpose(np.multiply(PkH_at_qpts, Qref.get_weights()))
+    for facet in cell.get_topology()[sd - 1]:
+        n = cell.compute_scaled_normal(facet)
+        rts = cell.compute_tangents(sd - 1, facet)
+        Q = FacetQuadratureRule(cell, sd - 1, facet, Qref)
+        qpts, qwts = Q.get_points(), Q.get_weights()
+        phi_at_pts = fe.tabulate(0, qpts)[(0,) * sd]
+        for t in rts:
+            phi_nt = np.tensordot(np.outer(t, n), phi_at_pts, axes=((0, 1), (1, 2)))
+            assert np.allclose(np.dot(phi_nt, weights), 0)
+        phi_at_pts = bubbles.tabulate(qpts)[(0,) * sd]
+        for t in rts:
+            phi_nt = np.tensordot(np.outer(t, n), phi_at_pts, axes=((0, 1), (1, 2)))
+            assert np.allclose(np.dot(phi_nt ** 2, qwts), 0)
