@@ -1322,7 +1322,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
 
     // ---- choose the work-item shape under a per-wave LDS budget ----
     const long long budget = 32 * 1024;  // bytes per wave: >= 5 resident waves per CU
-    const long long hard = 64 * 1024;
+    // (hard limit: one wave's tile may take what a CU has -- the kernel runs one wave per workgroup; reached by expansion
+    // degrees beyond 12 on tetrahedra, one column tile of 16 x nexp doubles: degree 16, 969 members, 124 KB)
+    const long long hard = std::max<long long>(64 * 1024, (long long)ctx->lds_per_cu - 4096);
     auto phi_bytes = [&](long long cols) { return ((cols + 15) / 16) * (long long)e->KS * 64 * 8; };
     const long long reqbytes = (long long)ntab * rows * npts * 8;
     int P = 1, pc = npts, nchunk = 1;
@@ -2289,7 +2291,8 @@ int fx_vandermonde_solve_batch(fx_ctx* ctx, int64_t nsys, int ndof, int m, const
 // ---------------------------------------------------------------------------------
 int fx_line_element_create(fx_ctx* ctx, int nn, const double* nodes, fx_line_element** out) {
     if (!ctx || !nodes || !out) return fail(FX_EINVAL, "fx_line_element_create: null argument");
-    if (nn < 1 || nn > fxk::NN_MAX) return fail(FX_ENOTIMPL, "1-D Lagrange with %d nodes (max %d)", nn, fxk::NN_MAX);
+    // (up to NN_MAX nodes: register-resident kernels, tensor products, prisms; beyond: fx_line_tabulate_batch only)
+    if (nn < 1 || nn > fxk::NN_BIG_MAX) return fail(FX_ENOTIMPL, "1-D Lagrange with %d nodes (max %d)", nn, fxk::NN_BIG_MAX);
     HIP_TRY(hipSetDevice(ctx->device));
     fx_line_element* e = new fx_line_element;
     e->ctx = ctx;
@@ -2352,8 +2355,12 @@ int fx_line_tabulate_batch(fx_ctx* ctx, const fx_line_element* e, int order, int
     long long total = (long long)nreq * npts;
     if (total == 0) return FX_OK;
     int grid = (int)((total + 127) / 128);
-    hipLaunchKernelGGL(fxk::line_tabulate_kernel, dim3(grid), dim3(128), 0, (hipStream_t)stream, line_desc(e), order,
-                       (long long)nreq, npts, pts, out);
+    if (e->nn > fxk::NN_MAX)
+        hipLaunchKernelGGL(fxk::line_tabulate_big_kernel, dim3(grid), dim3(128), 0, (hipStream_t)stream, line_desc(e), order,
+                           (long long)nreq, npts, pts, out);
+    else
+        hipLaunchKernelGGL(fxk::line_tabulate_kernel, dim3(grid), dim3(128), 0, (hipStream_t)stream, line_desc(e), order,
+                           (long long)nreq, npts, pts, out);
     HIP_TRY(hipGetLastError());
     return FX_OK;
 }
@@ -2397,6 +2404,8 @@ static int tensor_launch(fx_ctx* ctx, int nf, const fx_line_element* const* fact
     const int w = grid_mode ? q : npts;
     for (int f = 0; f < nf; ++f) {
         if (!factors[f]) return fail(FX_EINVAL, "null factor");
+        if (factors[f]->nn > fxk::NN_MAX)
+            return fail(FX_ENOTIMPL, "tensor products of 1-D Lagrange factors with %d nodes (max %d)", factors[f]->nn, fxk::NN_MAX);
         a.L[f] = line_desc(factors[f]);
         lds += (size_t)(order + 1) * factors[f]->nn * w * 8;
     }
@@ -2453,6 +2462,7 @@ int fx_prism_tabulate_batch(fx_ctx* ctx, const fx_element* tri, const fx_line_el
     if (!ctx || !tri || !line) return fail(FX_EINVAL, "fx_prism_tabulate_batch: null context/element");
     if (order < 0 || nreq < 0 || npts < 0) return fail(FX_EINVAL, "fx_prism_tabulate_batch: bad argument");
     if (tri->sd != 2) return fail(FX_EINVAL, "fx_prism_tabulate_batch: the first factor must live on a triangle");
+    if (line->nn > fxk::NN_MAX) return fail(FX_ENOTIMPL, "prisms with a 1-D Lagrange factor of %d nodes (max %d)", line->nn, fxk::NN_MAX);
     if (nreq == 0 || npts == 0) return FX_OK;
     if (!pts || !out) return fail(FX_EINVAL, "fx_prism_tabulate_batch: null device pointer");
     const int rows = (int)(tri->hC.size() / (size_t)tri->nexp);

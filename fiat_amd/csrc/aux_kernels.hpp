@@ -249,6 +249,40 @@ __global__ void line_tabulate_kernel(LineDesc L, int order, long long nreq, int 
     }
 }
 
+// More than NN_MAX nodes (1-D spectral elements of degree 16 ... 255: construction and interpolation studies, not a
+// throughput path): one thread per (r, p) again, but nothing is kept in registers -- the values go straight to `out`
+// (two passes over the nodes: sum and node hit, then the normalised terms), derivative order k is dmat times the thread's
+// own order k - 1 column of `out`, read back from memory.
+constexpr int NN_BIG_MAX = 256;
+__global__ void line_tabulate_big_kernel(LineDesc L, int order, long long nreq, int npts,
+                                         const double* __restrict__ pts, double* out) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nreq * npts) return;
+    long long r = idx / npts;
+    int p = (int)(idx - r * npts);
+    const double x = pts[idx];
+    const int nn = L.nn;
+    double sum = 0.0;
+    int hit = -1;
+    for (int i = 0; i < nn; ++i) {
+        const double d = x - L.nodes[i];
+        if (d == 0.0) hit = i;
+        sum += L.wts[i] / d;
+    }
+    double* o = out + (size_t)r * (order + 1) * nn * npts + p;
+    const double inv = 1.0 / sum;
+    for (int i = 0; i < nn; ++i) o[(size_t)i * npts] = hit >= 0 ? (i == hit ? 1.0 : 0.0) : (L.wts[i] / (x - L.nodes[i])) * inv;
+    for (int k = 1; k <= order; ++k) {
+        const double* prev = o + (size_t)(k - 1) * nn * npts;
+        double* cur = o + (size_t)k * nn * npts;
+        for (int i = 0; i < nn; ++i) {
+            double s = 0.0;
+            for (int j = 0; j < nn; ++j) s += L.dmat[(size_t)i * nn + j] * prev[(size_t)j * npts];
+            cur[(size_t)i * npts] = s;
+        }
+    }
+}
+
 // Tensor-product expansion (tensor_product.py:231-292, scalar factors, nested
 // left to right).  One workgroup per request:
 //   phase 1: factor tables T[f][k][i][p] -> LDS (threads <-> (f, p))

@@ -78,6 +78,21 @@ class GaussLegendreQuadratureLineRule(GaussJacobiQuadratureLineRule):
         super().__init__(ref_el, m)
 
 
+class GaussLobattoLegendreQuadratureLineRule(QuadratureRule):
+    """m-point Gauss-Lobatto-Legendre rule on the interval, exact to degree 2m - 3 (FIAT/quadrature.py:113-125): the end
+    points and the roots of P'_{m-1} (Jacobi(1, 1) of degree m - 2), weights 2 / (m (m - 1) P_{m-1}(x)^2)."""
+
+    def __init__(self, ref_el, m):
+        if m < 2:
+            raise ValueError("Gauss-Labotto-Legendre quadrature invalid for fewer than 2 points")
+        from scipy.special import eval_legendre
+        inner = roots_jacobi(m - 2, 1, 1)[0] if m > 2 else numpy.zeros(0)
+        x = numpy.concatenate([[-1.0], inner, [1.0]])
+        w = 2.0 / (m * (m - 1) * eval_legendre(m - 1, x) ** 2)
+        pts, wts = map_quadrature(x.reshape(-1, 1), w, reference_element.default_simplex(1), ref_el)
+        super().__init__(ref_el, pts, wts)
+
+
 def _collapsed_rule(dim, m):
     """Product of Gauss-Jacobi(j, 0) rules on the cube mapped by the Duffy
     transformation onto the (-1,1)^dim simplex (Karniadakis & Sherwin)."""

@@ -392,6 +392,25 @@ def default_simplex(spatial_dim):
                           _DEFAULT_TOPOLOGY[spatial_dim])
 
 
+class SymmetricSimplex(Simplex):
+    def construct_subelement(self, dimension):
+        return symmetric_simplex(dimension)
+
+
+def symmetric_simplex(spatial_dim):
+    """The regular simplex of edge length 2 centred at the origin, UFC topology (FIAT/reference_element.py:966-974,
+    1718-1727): vertex 0 = (-1, -1/sqrt 3, -1/sqrt 6), vertex 1 = its mirror image in x, vertex 2 above the first edge's
+    midpoint, vertex 3 on the third axis -- truncated to the first ``spatial_dim`` coordinates."""
+    if spatial_dim == 0:
+        return Point()
+    if spatial_dim not in (1, 2, 3):
+        raise RuntimeError(f"Can't create symmetric simplex of dimension {spatial_dim}.")
+    r3, r6 = math.sqrt(3.0), math.sqrt(6.0)
+    full = [(-1.0, -1.0 / r3, -1.0 / r6), (1.0, -1.0 / r3, -1.0 / r6), (0.0, 2.0 / r3, -1.0 / r6), (0.0, 0.0, 3.0 / r6)]
+    verts = [v[:spatial_dim] for v in full[:spatial_dim + 1]]
+    return SymmetricSimplex(_SHAPES[spatial_dim], verts, _UFC_TOPOLOGY[spatial_dim])
+
+
 def UFCInterval():
     return ufc_simplex(1)
 

@@ -136,7 +136,8 @@ class TensorProductElement:
         Lagrange factors): per-request 1-D coordinates (nreq, nf, q) of a tensor grid instead of explicit points.
         ``entity=((dA, dB), id)``: points in the coordinates of that reference sub-entity."""
         whole = entity is None or tuple(entity[0]) == tuple(self.ref_el.get_dimension())
-        if self._lines is not None and whole and (order <= 2 or grid):     # (the fused kernel serves orders <= 2)
+        fused = self._lines is not None and max(f.space_dimension() for f in self._lines) <= 16   # (its node-count bound)
+        if fused and whole and (order <= 2 or grid):                        # (the fused kernel serves orders <= 2)
             return runtime.tensor_tabulate_batch(self.device_factors(), order, points, out=out, stream=stream, grid=grid)
         if grid:
             raise NotImplementedError("grid input is served for products of 1-D Lagrange factors only")

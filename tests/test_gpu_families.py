@@ -181,3 +181,16 @@ def test_double_piola_pushforward(golden, name, cls, sd):
         rt.tabulate_batch(0, pts, verts=verts, mapping="double covariant piola")
     with pytest.raises(ValueError):
         el.device_polyset().tabulate_batch(0, pts, verts=verts, mapping="covariant piola")
+
+
+def test_rotated_regge_is_hhj_on_the_device():
+    """test/FIAT/unit/test_regge_hhj.py:7-19: on the triangle, the lowest-order Regge basis function r_i is S(h_i) of the
+    Hellan-Herrmann-Johnson function h_i, S(u) = tr(u) I - u; single-point tabulation on the device, numpy.isclose as there."""
+    import fiat_amd
+    triangle = fiat_amd.UFCTriangle()
+    R = fiat_amd.Regge(triangle, 0)
+    H = fiat_amd.HellanHerrmannJohnson(triangle, 0)
+    rt, ht = R.tabulate(0, (0.2, 0.2))[(0, 0)], H.tabulate(0, (0.2, 0.2))[(0, 0)]
+    assert rt.shape == ht.shape == (3, 2, 2)
+    for r, h in zip(rt, ht):
+        assert np.all(np.isclose(r, np.eye(2) * np.trace(h) - h))

@@ -191,3 +191,30 @@ def test_header_is_plain_c99(tmp_path):
     subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{inc}", str(src), f"-L{lib}", "-lfiat_amd",
                     f"-Wl,-rpath,{lib}", "-o", str(exe)], check=True, capture_output=True)
     assert subprocess.run([str(exe)], capture_output=True).returncode == 0
+
+
+def test_symmetric_simplex_and_gll_line_rule():
+    """FIAT/reference_element.py:966-974,1718-1727: the symmetric simplex is regular (edge length 2), centred at the origin,
+    with the UFC topology, and its sub-elements are symmetric simplices; FIAT/quadrature.py:113-125: the m-point
+    Gauss-Lobatto-Legendre rule contains the end points and integrates degree 2m - 3 exactly."""
+    from fiat_amd import quadrature, reference_element
+    for sd in (1, 2, 3):
+        s = reference_element.symmetric_simplex(sd)
+        v = np.array(s.get_vertices())
+        assert np.allclose(v.sum(axis=0), 0.0)
+        for i in range(sd + 1):
+            for j in range(i):
+                assert np.isclose(np.linalg.norm(v[i] - v[j]), 2.0)
+        assert s.get_topology() == reference_element.ufc_simplex(sd).get_topology()
+        if sd > 1:
+            assert isinstance(s.construct_subelement(sd - 1), reference_element.SymmetricSimplex)
+    line = reference_element.ufc_simplex(1)
+    for m in (2, 3, 5, 9):
+        r = quadrature.GaussLobattoLegendreQuadratureLineRule(line, m)
+        x, w = r.get_points().ravel(), r.get_weights()
+        assert np.isclose(x[0], 0.0) and np.isclose(x[-1], 1.0) and len(x) == m
+        for k in range(2 * m - 2):
+            assert np.isclose(np.dot(w, x ** k), 1.0 / (k + 1)), (m, k)
+        assert abs(np.dot(w, x ** (2 * m - 2)) - 1.0 / (2 * m - 1)) > 1e-11      # ... and not one degree more
+    with pytest.raises(ValueError):
+        quadrature.GaussLobattoLegendreQuadratureLineRule(line, 1)
