@@ -84,6 +84,10 @@ class TensorProductElement:
     def get_coeffs(self):
         raise NotImplementedError("get_coeffs not implemented")
 
+    def is_nodal(self):
+        """Nodal iff both factors are (FIAT/tensor_product.py:357-360)."""
+        return all([self.A.is_nodal(), self.B.is_nodal()])
+
     def entity_dofs(self):
         """{(dA, dB): {entity: dofs}}: dofs of entity (eA, eB) are i * dim(B) + j over the factors' entity dofs,
         entities numbered row-major (FIAT/tensor_product.py:52-68)."""
@@ -224,6 +228,23 @@ class FlattenedDimensions:
 
     def mapping(self):
         return self.element.mapping()
+
+    # the rest of the FiniteElement interface the reference's class inherits or forwards (FIAT/tensor_product.py:370-434):
+    # the dual nodes are the product element's, order / form degree / nodality too
+    def dual_basis(self):
+        return self.element.dual_basis()
+
+    def get_order(self):
+        return self.element.get_order()
+
+    def get_formdegree(self):
+        return self.element.get_formdegree()
+
+    def is_nodal(self):
+        return self.element.is_nodal()
+
+    def get_coeffs(self):
+        return self.element.get_coeffs()
 
     def entity_dofs(self):
         """{flat dimension: {flat number: dofs}} of the product element's entity dofs."""

@@ -229,3 +229,41 @@ def test_flattened_dimensions_equal_the_product_element(fa):
     t, f = hexa.tabulate(1, [(0.1, 0.2, 0.3)]), flat_hex.tabulate(1, [(0.1, 0.2, 0.3)])
     for dd in [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)]:
         assert np.allclose(t[dd], f[dd], rtol=1e-5, atol=1e-8) and t[dd].shape[0] == 8
+
+
+TP_NODAL = ["TensorProductElement(Lagrange(I, 1), Lagrange(I, 1))",
+            "TensorProductElement(Lagrange(I, 2), Lagrange(I, 2))",
+            "TensorProductElement(TensorProductElement(Lagrange(I, 1), Lagrange(I, 1)), Lagrange(I, 1))",
+            "TensorProductElement(TensorProductElement(Lagrange(I, 2), Lagrange(I, 2)), Lagrange(I, 2))",
+            "FlattenedDimensions(TensorProductElement(Lagrange(I, 1), Lagrange(I, 1)))",
+            "FlattenedDimensions(TensorProductElement(Lagrange(I, 2), Lagrange(I, 2)))",
+            "FlattenedDimensions(TensorProductElement(FlattenedDimensions(TensorProductElement(Lagrange(I, 1), Lagrange(I, 1))), Lagrange(I, 1)))",
+            "FlattenedDimensions(TensorProductElement(FlattenedDimensions(TensorProductElement(Lagrange(I, 2), Lagrange(I, 2))), Lagrange(I, 2)))"]
+
+
+@pytest.mark.parametrize("element", TP_NODAL)
+def test_nodality_tabulate_of_tensor_product_elements(fa, element):
+    """test/FIAT/unit/test_fiat.py:549-581: the eight tensor-product / flattened elements listed there are nodal -- every
+    dual node is a point evaluation, and tabulating at node j gives the j-th unit vector (numpy.isclose as there)."""
+    from fiat_amd import FlattenedDimensions, Lagrange, TensorProductElement  # noqa: F401  (names of the parametrisation)
+    I = fa.UFCInterval()  # noqa: F841
+    element = eval(element)
+    nodes_coords = []
+    for node in element.dual_basis():
+        (coords, weights), = node.get_point_dict().items()
+        assert weights == [(1.0, ())]
+        nodes_coords.append(coords)
+    for j, x in enumerate(nodes_coords):
+        basis, = element.tabulate(0, (x,)).values()
+        for i in range(len(basis)):
+            assert np.isclose(basis[i], 1.0 if i == j else 0.0)
+
+
+def test_constructor_errors_as_in_the_reference(fa):
+    """test/FIAT/unit/test_fiat.py:626-650: integral variants with a negative quadrature degree ("integral(-1)") and
+    discontinuous elements of degree 1 on a point are ValueErrors."""
+    S, P = fa.ufc_simplex(3), fa.ufc_simplex(0)
+    for make in (lambda: fa.Nedelec(S, 3, variant="integral(-1)"), lambda: fa.NedelecSecondKind(S, 3, variant="integral(-1)"),
+                 lambda: fa.DiscontinuousLagrange(P, 1), lambda: fa.GaussLegendre(P, 1)):
+        with pytest.raises(ValueError):
+            make()
