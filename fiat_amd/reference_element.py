@@ -209,6 +209,32 @@ class Simplex(Cell):
             return 1.0
         return abs(numpy.linalg.det(v[1:] - v[0])) / math.factorial(sd)
 
+    def compute_barycentric_coordinates(self, points, rescale=False):
+        """Barycentric coordinates of points (npts, sd) with respect to the cell's vertices, (npts, sd + 1); ``rescale``:
+        each coordinate times the height of its vertex over the opposite facet, so that it measures a distance
+        (FIAT/reference_element.py:616-644, the single-cell case)."""
+        points = numpy.asarray(points, dtype=float)
+        if points.size == 0:
+            return points
+        v = numpy.asarray(self.vertices, dtype=float)
+        sd = self.get_spatial_dimension()
+        # lambda = G [x; 1] with G the inverse of the matrix of homogeneous vertex coordinates
+        G = numpy.linalg.inv(numpy.vstack([v.T, numpy.ones(sd + 1)]))
+        lam = points.reshape(-1, sd) @ G[:, :sd].T + G[:, sd]
+        if rescale:
+            lam = lam / numpy.linalg.norm(G[:, :sd], axis=1)
+        return lam.reshape(points.shape[:-1] + (sd + 1,))
+
+    def distance_to_point_l1(self, points, rescale=False):
+        """0 inside the cell, otherwise minus the sum of the negative barycentric coordinates
+        (FIAT/reference_element.py:651-780: the binning criterion of macro elements, here on the host)."""
+        lam = self.compute_barycentric_coordinates(points, rescale=rescale)
+        return numpy.maximum(-lam, 0.0).sum(axis=-1)
+
+    def contains_point(self, point, epsilon=0.0):
+        """FIAT/reference_element.py:782-801."""
+        return bool(self.distance_to_point_l1(point) <= epsilon)
+
     def make_points(self, dim, entity_id, order, variant=None, interior=1):
         """Lattice points in the interior of a sub-entity."""
         if dim == 0:
@@ -486,6 +512,24 @@ class TensorProductCell(Cell):
 
     def construct_subelement(self, dimension):
         return TensorProductCell(*[c.construct_subelement(d) for c, d in zip(self.cells, dimension)])
+
+    def volume(self):
+        """Product of the factors' volumes (FIAT/reference_element.py:1247-1249)."""
+        return float(numpy.prod([c.volume() for c in self.cells]))
+
+    def distance_to_point_l1(self, point, rescale=False):
+        """Sum of the factors' distances to their slices of the point (FIAT/reference_element.py:1291-1301)."""
+        point = numpy.asarray(point, dtype=float)
+        total, start = 0.0, 0
+        for c in self.cells:
+            n = c.get_spatial_dimension()
+            total = total + c.distance_to_point_l1(point[..., start:start + n], rescale=rescale)
+            start += n
+        return total
+
+    def contains_point(self, point, epsilon=0.0):
+        """FIAT/reference_element.py:1266-1289."""
+        return bool(self.distance_to_point_l1(point) <= epsilon)
 
     def flat_cells(self):
         """The simplex factors, left to right, with nesting removed."""

@@ -218,3 +218,86 @@ def test_symmetric_simplex_and_gll_line_rule():
         assert abs(np.dot(w, x ** (2 * m - 2)) - 1.0 / (2 * m - 1)) > 1e-11      # ... and not one degree more
     with pytest.raises(ValueError):
         quadrature.GaussLobattoLegendreQuadratureLineRule(line, 1)
+
+
+def _cells():
+    from fiat_amd import reference_element as re
+    I, T, S = re.ufc_simplex(1), re.ufc_simplex(2), re.ufc_simplex(3)
+    return {"interval": I, "triangle": T, "tetrahedron": S, "interval_x_interval": re.TensorProductCell(I, I),
+            "triangle_x_interval": re.TensorProductCell(T, I),
+            "quadrilateral_x_interval": re.TensorProductCell(re.TensorProductCell(I, I), I)}
+
+
+# (cell, point, epsilon, expected) and (cell, point, distance): the reference's own known answers
+# (test/FIAT/unit/test_reference_element.py:160-293 and :296-405; the rows of cells this facade has)
+def _contains_cases():
+    e = 1e-12
+    out = []
+    out += [("interval", [0.5], 0.0, True), ("interval", [0.0], 1e-14, True), ("interval", [1.0], 1e-14, True),
+            ("interval", [-e], 1e-11, True), ("interval", [1 + e], 1e-11, True), ("interval", [-e], 1e-13, False),
+            ("interval", [1 + e], 1e-13, False)]
+    out += [("triangle", [0.25, 0.25], 0.0, True), ("triangle", [0.0, 0.0], 1e-14, True), ("triangle", [1.0, 0.0], 1e-14, True),
+            ("triangle", [0.0, 1.0], 1e-14, True), ("triangle", [0.5, 0.5], 1e-14, True)]
+    for p in ([-e, 0.0], [1 + e, 0.0], [0.0, -e], [0.0, 1 + e]):
+        out += [("triangle", p, 1e-11, True), ("triangle", p, 1e-13, False)]
+    out += [("triangle", [0.5 + e, 0.5], 1e-13, False), ("triangle", [0.5, 0.5 + e], 1e-13, False)]
+    out += [("tetrahedron", [0.25, 0.25, 0.25], 0.0, True), ("tetrahedron", [1 / 3, 1 / 3, 1 / 3], 1e-14, True)]
+    for p in ([0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [0.0, 0.5, 0.5], [0.5, 0.0, 0.5], [0.5, 0.5, 0.0]):
+        out += [("tetrahedron", p, 1e-14, True)]
+    for p in ([-e, 0.0, 0.0], [1 + e, 0.0, 0.0], [0.0, -e, 0.0], [0.0, 1 + e, 0.0], [0.0, 0.0, -e], [0.0, 0.0, 1 + e]):
+        out += [("tetrahedron", p, 1e-11, True), ("tetrahedron", p, 1e-13, False)]
+    out += [("tetrahedron", [0.5 + e, 0.5, 0.5], 1e-13, False), ("tetrahedron", [0.5, 0.5 + e, 0.5], 1e-13, False),
+            ("tetrahedron", [0.5, 0.5, 0.5 + e], 1e-13, False)]
+    out += [("interval_x_interval", [0.5, 0.5], 0.0, True)]
+    for p in ([0.0, 0.0], [1.0, 0.0], [0.0, 1.0], [1.0, 1.0]):
+        out += [("interval_x_interval", p, 1e-14, True)]
+    for p in ([-e, 0.5], [1 + e, 0.5], [0.5, -e], [0.5, 1 + e]):
+        out += [("interval_x_interval", p, 1e-11, True), ("interval_x_interval", p, 1e-13, False)]
+    out += [("triangle_x_interval", [0.25, 0.25, 0.5], 0.0, True), ("triangle_x_interval", [0.5, 0.5, 0.5], 1e-14, True)]
+    for p in ([0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]):
+        out += [("triangle_x_interval", p, 1e-14, True), ("quadrilateral_x_interval", p, 1e-14, True)]
+    for p in ([-e, 0.0, 0.5], [1 + e, 0.0, 0.5], [0.0, -e, 0.5], [0.0, 1 + e, 0.5], [0.0, 0.0, -e], [0.0, 0.0, 1 + e]):
+        out += [("triangle_x_interval", p, 1e-11, True), ("triangle_x_interval", p, 1e-13, False)]
+    out += [("triangle_x_interval", [0.5 + e, 0.5, 0.5], 1e-13, False), ("triangle_x_interval", [0.5, 0.5 + e, 0.5], 1e-13, False)]
+    out += [("quadrilateral_x_interval", [0.5, 0.5, 0.5], 0.0, True)]
+    for p in ([-e, 0.0, 0.0], [1 + e, 0.0, 0.0], [0.0, -e, 0.0], [0.0, 1 + e, 0.0], [0.0, 0.0, -e], [0.0, 0.0, 1 + e]):
+        out += [("quadrilateral_x_interval", p, 1e-11, True), ("quadrilateral_x_interval", p, 1e-13, False)]
+    return out
+
+
+def test_contains_point_and_l1_distance_known_answers():
+    cells = _cells()
+    for name, point, eps, expected in _contains_cases():
+        assert cells[name].contains_point(point, eps) == expected, (name, point, eps)
+    e = 1e-12
+    third = 1 / 3
+    dist = [("interval", [0.5], 0.0), ("interval", [0.0], 0.0), ("interval", [1.0], 0.0), ("interval", [-e], e), ("interval", [1 + e], e),
+            ("triangle", [0.25, 0.25], 0.0), ("triangle", [0.5, 0.5], 0.0), ("triangle", [-e, 0.0], e), ("triangle", [1 + e, 0.0], e),
+            ("triangle", [0.0, -e], e), ("triangle", [0.0, 1 + e], e), ("triangle", [0.5 + e, 0.5], e), ("triangle", [0.5, 0.5 + e], e),
+            ("tetrahedron", [0.25, 0.25, 0.25], 0.0), ("tetrahedron", [third, third, third], 0.0), ("tetrahedron", [0.0, 0.5, 0.5], 0.0),
+            ("tetrahedron", [-e, 0.0, 0.0], e), ("tetrahedron", [1 + e, 0.0, 0.0], e), ("tetrahedron", [0.0, 0.0, 1 + e], e),
+            ("tetrahedron", [third + e, third, third], e), ("tetrahedron", [third, third, third + e], e),
+            ("interval_x_interval", [0.5, 0.5], 0.0), ("interval_x_interval", [-e, 0.5], e), ("interval_x_interval", [0.5, 1 + e], e),
+            ("triangle_x_interval", [0.25, 0.25, 0.5], 0.0), ("triangle_x_interval", [0.5 + e, 0.5, 0.5], e),
+            ("triangle_x_interval", [0.0, 0.0, 1 + e], e), ("quadrilateral_x_interval", [0.5, 0.5, 0.5], 0.0),
+            ("quadrilateral_x_interval", [0.0, 1 + e, 0.0], e)]
+    for name, point, expected in dist:
+        assert np.isclose(cells[name].distance_to_point_l1(point), expected, rtol=1e-3), (name, point)
+
+
+def test_volumes_and_reference_normals_known_answers():
+    """test/FIAT/unit/test_reference_element.py:88-131 for the cells of this facade: volumes 1, 1/2, 1/6 and their products;
+    facet normals of the UFC interval / triangle / tetrahedron as listed there."""
+    from fiat_amd import reference_element as re
+    cells = _cells()
+    for name, vol in (("interval", 1), ("triangle", 1 / 2), ("tetrahedron", 1 / 6), ("interval_x_interval", 1),
+                      ("triangle_x_interval", 1 / 2), ("quadrilateral_x_interval", 1)):
+        assert np.allclose(vol, cells[name].volume()), name
+    assert np.allclose(1, re.Point().volume())
+    normals = {"interval": [[-1], [1]], "triangle": [[1, 1], [-1, 0], [0, -1]],
+               "tetrahedron": [[1, 1, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1]]}
+    for name, ns in normals.items():
+        cell = cells[name]
+        facet_dim = cell.get_spatial_dimension() - 1
+        for facet_number in range(len(cell.get_topology()[facet_dim])):
+            assert np.allclose(ns[facet_number], cell.compute_reference_normal(facet_dim, facet_number)), (name, facet_number)
