@@ -92,3 +92,24 @@ def test_composite_rules_on_split_cells(golden):
     from fiat_amd.macro import MacroQuadratureRule
     same(MacroQuadratureRule(fiat_amd.IsoSplit(fiat_amd.ufc_simplex(2)), fiat_amd.create_quadrature(fiat_amd.ufc_simplex(1), 2),
                              parent_facets=[0, 2]), "mq_iso_tri_facets")
+
+
+def test_line_rules_and_argument_errors_as_in_the_reference_tests():
+    """test/FIAT/unit/test_quadrature.py:104-108 (points / weights mismatch is a ValueError), :166-168 (negative degree is a
+    ValueError), :187-196 and :211-220: the m-point Gauss-Lobatto-Legendre / Gauss-Legendre rules on the UFC interval integrate
+    x^d exactly for d < 2m - 2 / d < 2m, m = 2..9 (numpy.round(error, 14) == 0 as there)."""
+    import fiat_amd
+    from fiat_amd import quadrature
+    interval = fiat_amd.ufc_simplex(1)
+    with pytest.raises(ValueError):
+        quadrature.QuadratureRule(interval, [[0.5, 0.5]], [0.5, 0.5, 0.5])
+    for cell in (interval, fiat_amd.ufc_simplex(2), fiat_amd.ufc_simplex(3)):
+        with pytest.raises(ValueError):
+            fiat_amd.create_quadrature(cell, -1)
+    for points in range(2, 10):
+        gll = quadrature.GaussLobattoLegendreQuadratureLineRule(interval, points)
+        for degree in range(2 * points - 2):
+            assert np.round(gll.integrate(lambda x: x[0] ** degree) - 1. / (degree + 1), 14) == 0.
+        gl = quadrature.GaussLegendreQuadratureLineRule(interval, points)
+        for degree in range(2 * points):
+            assert np.round(gl.integrate(lambda x: x[0] ** degree) - 1. / (degree + 1), 14) == 0.
