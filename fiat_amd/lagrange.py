@@ -32,9 +32,10 @@ class Lagrange(finite_element.CiarletElement):
         splitting, lattice_family = parse_lagrange_variant(variant)
         if splitting is not None:       # macro element: nodes and C0 expansion set live on the split cell
             ref_el = splitting(ref_el)
-        on_line = ref_el.get_shape() == LINE
-        if on_line and ref_el.is_macrocell():
-            raise NotImplementedError("macro Lagrange elements on intervals")
+        # (on a split interval the reference keeps the primal 1-D basis piecewise, FIAT/lagrange.py:80-84, to save one basis
+        # change's round-off; here the C0 hierarchy of the split interval serves it, as on split triangles and tetrahedra --
+        # the same space and nodal basis, coefficients with respect to the other expansion set)
+        on_line = ref_el.get_shape() == LINE and not ref_el.is_macrocell()
         dual = LagrangeDualSet(ref_el, degree, lattice_family, sort_entities)
         if on_line:
             space = LagrangePolynomialSet(ref_el, get_lagrange_points(dual))

@@ -234,17 +234,36 @@ class PowellSabinSplit(SplitSimplicialComplex):
         return PowellSabinSplit(sub, dimension=self.split_dimension)
 
 
+def _cached_split(cls, ref_el):
+    """One split object of a kind per cell OBJECT (FIAT/macro.py:311-316, 327-332: the variant parser and user code that ask
+    for the same split of the same cell share it, so that ``element.ref_complex is AlfeldSplit(cell)``)."""
+    cache = ref_el.__dict__.setdefault("_split_cache", {})
+    if cls not in cache:
+        cache[cls] = object.__new__(cls)
+    return cache[cls]
+
+
 class AlfeldSplit(PowellSabinSplit):
     """Barycentric refinement: every vertex joined to the cell barycentre."""
 
+    def __new__(cls, ref_el):
+        return _cached_split(cls, ref_el)
+
     def __init__(self, ref_el):
+        if "_parent_complex" in self.__dict__:   # (the cached object: built already)
+            return
         super().__init__(ref_el, dimension=ref_el.get_spatial_dimension())
 
 
 class WorseyFarinSplit(PowellSabinSplit):
     """Cell and facet barycentres (Powell-Sabin on a triangle, Alfeld on an interval)."""
 
+    def __new__(cls, ref_el):
+        return _cached_split(cls, ref_el)
+
     def __init__(self, ref_el):
+        if "_parent_complex" in self.__dict__:
+            return
         super().__init__(ref_el, dimension=max(1, ref_el.get_spatial_dimension() - 1))
 
 

@@ -300,7 +300,7 @@ class Simplex(Cell):
     def get_entity_transform(self, dim, entity):
         """Map from the reference sub-entity's coordinates into this cell."""
         sd = self.get_spatial_dimension()
-        if dim == sd:
+        if dim == sd and len(self.topology[sd]) == 1:   # (a single cell: the identity; the cells of a complex: affine maps below)
             if entity != 0:
                 raise ValueError("a simplex has a single cell")
             return lambda x: x

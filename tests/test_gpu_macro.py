@@ -210,3 +210,107 @@ def test_macro_facet_entity_and_single_point():
     many = e.tabulate(1, np.array([[0.2, 0.3]]))
     for alpha in one:
         assert one[alpha].shape == (10,) and np.array_equal(one[alpha], many[alpha][:, 0])
+
+
+# ---- the reference's own macro-element tests (test/FIAT/unit/test_macro.py), tabulating on the device ----
+
+@pytest.mark.parametrize("sd", [1, 2, 3])
+@pytest.mark.parametrize("split", ["AlfeldSplit", "IsoSplit"])
+def test_split_geometry_as_in_the_reference_tests(sd, split):
+    """test_macro.py:22-29 (splits are cached per cell and shared with the elements' complexes), :32-45 (entity transforms map
+    the sub-element's barycentre to the entity's), :48-59 (entity lattices are the mapped sub-element lattices, degree 4,
+    gll and equispaced), :62-86 (Iso split: the points of a child entity lie among its parent entity's points)."""
+    import fiat_amd
+    from fiat_amd import macro
+    cell = fiat_amd.ufc_simplex(sd)
+    split_cls = getattr(macro, split)
+    split_cell = split_cls(cell)
+    if split == "AlfeldSplit":
+        assert split_cls(cell) is split_cell
+        assert fiat_amd.Lagrange(cell, 1, variant="alfeld").ref_complex is split_cell
+    top = split_cell.get_topology()
+    for dim in range(1, sd + 1):
+        ref_el = split_cell.construct_subelement(dim)
+        b = np.average(ref_el.get_vertices(), axis=0)
+        for entity in top[dim]:
+            mapped = split_cell.get_entity_transform(dim, entity)(b)
+            assert np.allclose(mapped, np.average(split_cell.get_vertices_of_subcomplex(top[dim][entity]), axis=0))
+        for variant in ("gll", "equispaced"):
+            pts_ref = ref_el.make_points(dim, 0, 4, variant=variant)
+            for entity in top[dim]:
+                assert np.allclose(split_cell.get_entity_transform(dim, entity)(pts_ref), split_cell.make_points(dim, entity, 4, variant=variant))
+    if split == "IsoSplit":
+        degree = 2 if sd == 3 else 4
+        ptop = cell.get_topology()
+        parent_pts = {d: {e: cell.make_points(d, e, 2 * degree) for e in ptop[d]} for d in ptop}
+        child_to_parent = split_cell.get_child_to_parent()
+        for d in top:
+            for e in top[d]:
+                pd, pe = child_to_parent[d][e]
+                child = {tuple(np.round(p, 12)) for p in split_cell.make_points(d, e, degree)}
+                assert child <= {tuple(np.round(p, 12)) for p in parent_pts[pd][pe]}
+
+
+@pytest.mark.parametrize("degree", range(1, 5))
+@pytest.mark.parametrize("variant", ("equispaced", "gll"))
+@pytest.mark.parametrize("split", ("AlfeldSplit", "IsoSplit"))
+@pytest.mark.parametrize("sd", [1, 2, 3])
+def test_macro_lagrange_as_in_the_reference_test(variant, degree, split, sd):
+    """test_macro.py:132-168: Lagrange on a split cell -- the polynomial set lives on the split, the element on the parent, the
+    parent's entities are the ones exposed, tabulating at the lattice points of the children gives the identity, and the
+    expansion set tabulated there is the element's Vandermonde matrix."""
+    import fiat_amd
+    from fiat_amd import macro
+    cell = fiat_amd.ufc_simplex(sd)
+    ref_el = getattr(macro, split)(cell)
+    fe = fiat_amd.Lagrange(ref_el, degree, variant=variant)
+    poly_set = fe.get_nodal_basis()
+    assert poly_set.get_reference_element() is ref_el
+    assert fe.get_reference_element() is cell
+    entity_ids = fe.entity_dofs()
+    parent_top = ref_el.get_parent().get_topology()
+    for dim in parent_top:
+        assert len(entity_ids[dim]) == len(parent_top[dim])
+    parent_to_children = ref_el.get_parent_to_children()
+    pts = []
+    for dim in sorted(parent_to_children):
+        for entity in sorted(parent_to_children[dim]):
+            for cdim, centity in parent_to_children[dim][entity]:
+                pts.extend(ref_el.make_points(cdim, centity, degree, variant=variant))
+    phis = fe.tabulate(2, pts)
+    assert np.allclose(phis[(0,) * sd], np.eye(fe.space_dimension()))
+    U = poly_set.get_expansion_set()
+    V = U.tabulate(degree, pts).T
+    assert np.allclose(fe.V, V)
+
+
+@pytest.mark.parametrize("degree", (1, 4))
+@pytest.mark.parametrize("variant", (None, "bubble"))
+@pytest.mark.parametrize("split", ("AlfeldSplit", "IsoSplit"))
+@pytest.mark.parametrize("sd", [1, 2, 3])
+def test_macro_expansion_as_in_the_reference_test(sd, split, variant, degree):
+    """test_macro.py:336-375: the orthonormal set on a split cell, tabulated with two derivatives at interior lattice points of
+    every sub-cell, restricted to the sub-cell's members and points equals the orthonormal set of that sub-cell alone."""
+    import fiat_amd
+    from fiat_amd import macro
+    from fiat_amd.expansions import polynomial_cell_node_map
+    from fiat_amd.polynomial_set import ONPolynomialSet
+    from fiat_amd.reference_element import physical_simplex
+    ref_complex = getattr(macro, split)(fiat_amd.ufc_simplex(sd))
+    top = ref_complex.get_topology()
+    P = ONPolynomialSet(ref_complex, degree, variant=variant, scale=1)
+    npoints = degree + sd + 1
+    cell_point_map, pts = [], []
+    for cell in top[sd]:
+        cur = len(pts)
+        pts.extend(ref_complex.make_points(sd, cell, npoints))
+        cell_point_map.append(list(range(cur, len(pts))))
+    values = P.tabulate(pts, 2)
+    cell_node_map = polynomial_cell_node_map(ref_complex, degree, continuity=P.expansion_set.continuity)
+    for cell in top[sd]:
+        sub_el = physical_simplex(ref_complex.get_vertices_of_subcomplex(top[sd][cell]))
+        Pcell = ONPolynomialSet(sub_el, degree, variant=variant, scale=1)
+        cell_values = Pcell.tabulate(sub_el.make_points(sd, 0, npoints), 2)
+        indices = np.ix_(cell_node_map[cell], cell_point_map[cell])
+        for alpha in values:
+            assert np.allclose(cell_values[alpha], values[alpha][indices])
