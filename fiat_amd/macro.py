@@ -160,8 +160,7 @@ class SplitSimplicialComplex(SimplicialComplex):
     def get_parent_complex(self):
         return self._parent_complex
 
-    def __eq__(self, other):
-        return (type(self) is type(other) and self.vertices == other.vertices and self.topology == other.topology)
+    __eq__ = SimplicialComplex.__eq__     # (geometric equality, reference_element.Cell)
 
     def __hash__(self):
         return hash((type(self).__name__, self.vertices))

@@ -190,9 +190,48 @@ class Cell:
         """True for a single simplex only; complexes and product cells say False (FIAT/reference_element.py:327,914)."""
         return False
 
+    def get_parent_complex(self):
+        return None
+
+    def is_parent(self, other, strict=False):
+        """Is this cell ``other`` or one of the complexes / the simplex it was split from (FIAT/reference_element.py:345-354)?"""
+        parent = other.get_parent_complex() if strict else other
+        while parent is not None:
+            if self == parent:
+                return True
+            parent = parent.get_parent_complex()
+        return False
+
     def __eq__(self, other):
-        return (type(self) is type(other) and self.shape == other.shape
-                and self.vertices == other.vertices and self.topology == other.topology)
+        """Geometric equality: the same vertex positions and, per dimension, the same entities as vertex tuples -- whatever the
+        class (Powell-Sabin with the cell's own split dimension IS the Alfeld split; FIAT/reference_element.py:356-367)."""
+        if self is other:
+            return True
+        if not isinstance(other, Cell) or isinstance(other, TensorProductCell) != isinstance(self, TensorProductCell):
+            return False
+        A, B = self.get_vertices(), other.get_vertices()
+        if len(A) != len(B) or (len(A) and len(A[0]) != len(B[0])) or not numpy.allclose(A, B):
+            return False
+        atop, btop = self.get_topology(), other.get_topology()
+        if set(atop) != set(btop):
+            return False
+        return all(set(atop[dim].values()) == set(btop[dim].values()) for dim in atop)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    # refinement order: A > B when A was obtained by splitting B (FIAT/reference_element.py:372-382)
+    def __gt__(self, other):
+        return other.is_parent(self, strict=True)
+
+    def __lt__(self, other):
+        return self.is_parent(other, strict=True)
+
+    def __ge__(self, other):
+        return other.is_parent(self, strict=False)
+
+    def __le__(self, other):
+        return self.is_parent(other, strict=False)
 
     def __hash__(self):
         return hash((type(self).__name__, self.shape, self.vertices))

@@ -314,3 +314,98 @@ def test_macro_expansion_as_in_the_reference_test(sd, split, variant, degree):
         indices = np.ix_(cell_node_map[cell], cell_point_map[cell])
         for alpha in values:
             assert np.allclose(cell_values[alpha], values[alpha][indices])
+
+
+def _mass_matrix(fa, fe):
+    sd = fe.ref_el.get_spatial_dimension()
+    Q = fa.create_quadrature(fe.ref_complex, 2 * fe.degree())
+    phi = fe.tabulate(0, Q.get_points())[(0,) * sd]
+    return np.dot(np.multiply(phi, Q.get_weights()), phi.T)
+
+
+@pytest.mark.parametrize("sd", [1, 2, 3])
+def test_powell_sabin_ordering_as_in_the_reference_test(sd):
+    """test_macro.py:171-183: Alfeld refines the cell, Powell-Sabin with the cell's own dimension IS Alfeld, lower split
+    dimensions refine Alfeld and have (d + 1)! / split_dim! cells."""
+    import math
+    import fiat_amd
+    from fiat_amd.macro import AlfeldSplit, PowellSabinSplit
+    cell = fiat_amd.ufc_simplex(sd)
+    A = AlfeldSplit(cell)
+    assert A > cell
+    assert PowellSabinSplit(cell, sd) == A
+    for split_dim in range(1, sd):
+        PS = PowellSabinSplit(cell, split_dim)
+        assert PS > A and PS > cell
+        assert len(PS.get_topology()[sd]) == math.factorial(sd + 1) // math.factorial(split_dim)
+
+
+@pytest.mark.parametrize("degree", (1, 2, 4))
+@pytest.mark.parametrize("variant", ("equispaced", "gll"))
+@pytest.mark.parametrize("sd", [1, 2, 3])
+def test_lagrange_alfeld_duals_as_in_the_reference_test(sd, degree, variant):
+    """test_macro.py:195-213: the facet nodes of Lagrange on the Alfeld split are those of P_k, and the Galerkin projection of
+    the macro mass matrix through P_k tabulated at the macro nodes is P_k's mass matrix (P_k is a subspace)."""
+    import fiat_amd
+    from fiat_amd.barycentric_interpolation import get_lagrange_points
+    from fiat_amd.macro import AlfeldSplit
+    cell = fiat_amd.ufc_simplex(sd)
+    Pk = fiat_amd.Lagrange(cell, degree, variant=variant)
+    alfeld = fiat_amd.Lagrange(AlfeldSplit(cell), degree, variant=variant)
+    Pk_pts = np.asarray(get_lagrange_points(Pk.dual_basis()))
+    alfeld_pts = np.asarray(get_lagrange_points(alfeld.dual_basis()))
+    ids = alfeld.entity_dofs()
+    facet_dim = sum(len(ids[dim][entity]) for dim in range(sd) for entity in ids[dim])
+    assert np.allclose(alfeld_pts[:facet_dim], Pk_pts[:facet_dim])
+    phi = Pk.tabulate(0, alfeld_pts)[(0,) * sd]
+    assert np.allclose(_mass_matrix(fiat_amd, Pk), np.dot(np.dot(phi, _mass_matrix(fiat_amd, alfeld)), phi.T))
+
+
+@pytest.mark.parametrize("degree", (1, 2, 4))
+@pytest.mark.parametrize("sd", [1, 2, 3])
+def test_lagrange_iso_duals_as_in_the_reference_test(sd, degree):
+    """test_macro.py:216-235: the nodes of P_k on the iso split are those of P_2k on the cell up to the entity ordering, and the
+    reordered macro basis is dual to P_2k's point evaluations."""
+    import fiat_amd
+    from fiat_amd.barycentric_interpolation import get_lagrange_points
+    from fiat_amd.macro import IsoSplit
+    cell = fiat_amd.ufc_simplex(sd)
+    Pk = fiat_amd.Lagrange(cell, 2 * degree, variant="equispaced")
+    Piso = fiat_amd.Lagrange(IsoSplit(cell), degree, variant="equispaced")
+    Pk_pts = np.asarray(get_lagrange_points(Pk.dual_basis()))
+    Piso_pts = np.asarray(get_lagrange_points(Piso.dual_basis()))
+    ids = Piso.entity_dofs()
+    reorder = []
+    for dim in ids:
+        for entity in ids[dim]:
+            reorder.extend(ids[dim][entity])
+    assert np.allclose(Piso_pts[reorder], Pk_pts)
+    poly_set = Piso.get_nodal_basis().take(reorder)
+    assert np.allclose(np.eye(Piso.space_dimension()), np.dot(Pk.get_dual_set().to_riesz(poly_set), poly_set.get_coeffs().T))
+
+
+@pytest.mark.parametrize("variant", ("gll", "Alfeld,equispaced", "gll,iso"))
+def test_is_macro_lagrange_as_in_the_reference_test(variant):
+    """test_macro.py:238-246."""
+    import fiat_amd
+    is_macro = "alfeld" in variant.lower() or "iso" in variant.lower()
+    fe = fiat_amd.Lagrange(fiat_amd.ufc_simplex(2), 2, variant)
+    assert not fe.get_reference_element().is_macrocell()
+    assert fe.is_macroelement() == is_macro
+    assert fe.get_reference_complex().is_macrocell() == is_macro
+    assert fe.get_nodal_basis().get_reference_element().is_macrocell() == is_macro
+
+
+@pytest.mark.parametrize("variant", ("gl", "Alfeld,equispaced_interior", "chebyshev,iso"))
+@pytest.mark.parametrize("degree", (0, 2))
+def test_is_macro_discontinuous_lagrange_as_in_the_reference_test(degree, variant):
+    """test_macro.py:249-261."""
+    import fiat_amd
+    is_macro = "alfeld" in variant.lower() or "iso" in variant.lower()
+    fe = fiat_amd.DiscontinuousLagrange(fiat_amd.ufc_simplex(2), degree, variant)
+    if degree == 0 and not is_macro:
+        assert isinstance(fe, fiat_amd.P0)
+    assert not fe.get_reference_element().is_macrocell()
+    assert fe.is_macroelement() == is_macro
+    assert fe.get_reference_complex().is_macrocell() == is_macro
+    assert fe.get_nodal_basis().get_reference_element().is_macrocell() == is_macro
