@@ -983,7 +983,7 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 13: return launch_stacked<3, 4, 3, 2, 0, 1, false, 4, false, mixr1(3, 4, 3, 2)>(L, s);
         case 14: return launch_stacked<3, 4, 2, 1, 0, 1, false, 4, false, mixr1(3, 4, 2, 1)>(L, s);
         case 15: return launch_stacked<3, 4, 3, 1, 0, 1, false, 4, false, mixr1(3, 4, 3, 1)>(L, s);
-        case 16: return L.kpiola ? launch_stacked<3, 3, 3, 2, 0, 1, false, 4, false, true, 1>(L, s) : L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 4, true, true>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 4, false, mixr1(3, 3, 3, 2)>(L, s);
+        case 16: return L.kpiola ? (L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 4, true, true, 1>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 4, false, true, 1>(L, s)) : L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 4, true, true>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 4, false, mixr1(3, 3, 3, 2)>(L, s);
         case 17: return L.kpiola ? launch_stacked<3, 3, 2, 1, 0, 1, false, 4, false, true, 1>(L, s) : launch_stacked<3, 3, 2, 1, 0, 1, false, 4, false, mixr1(3, 3, 2, 1)>(L, s);
         case 18: return L.kpiola ? launch_stacked<3, 3, 3, 1, 0, 1, false, 4, false, true, 1>(L, s) : launch_stacked<3, 3, 3, 1, 0, 1, false, 4, false, mixr1(3, 3, 3, 1)>(L, s);
         case 19: return launch_stacked<3, 6, 3, 2>(L, s);
@@ -1045,7 +1045,7 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 75: return launch_stacked<2, 4, 3, 6>(L, s);
         case 76: return launch_stacked<2, 4, 3, 1, 0, 1, true>(L, s);
         case 77: return launch_stacked<2, 3, 3, 1, 0, 1, true>(L, s);
-        case 78: return L.kpiola ? launch_stacked<3, 2, 3, 4, 0, 1, false, 4, false, true, 1>(L, s) : launch_stacked<3, 2, 3, 4, 0, 1, false, 4, false, mixr1(3, 2, 3, 4)>(L, s);
+        case 78: return L.kpiola ? (L.kodd ? launch_stacked<3, 2, 3, 4, 0, 1, false, 4, true, true, 1>(L, s) : launch_stacked<3, 2, 3, 4, 0, 1, false, 4, false, true, 1>(L, s)) : launch_stacked<3, 2, 3, 4, 0, 1, false, 4, false, mixr1(3, 2, 3, 4)>(L, s);
         case 79: return L.kpiola ? launch_stacked<3, 2, 3, 3, 0, 1, false, 4, false, true, 1>(L, s) : launch_stacked<3, 2, 3, 3, 0, 1, false, 4, false, mixr1(3, 2, 3, 3)>(L, s);
         case 80: return L.kpiola ? launch_stacked<3, 2, 3, 2, 0, 1, false, 4, false, true, 1>(L, s) : launch_stacked<3, 2, 3, 2, 0, 1, false, 4, false, mixr1(3, 2, 3, 2)>(L, s);
         case 81: return L.kpiola ? launch_stacked<3, 2, 2, 1, 0, 1, false, 4, false, true, 1>(L, s) : launch_stacked<3, 2, 2, 1, 0, 1, false, 4, false, mixr1(3, 2, 2, 1)>(L, s);
@@ -1062,11 +1062,11 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 92: return launch_stacked<2, 7, 3, 1, 0, 1, true>(L, s);
         case 93: return launch_stacked<2, 8, 4, 1>(L, s);
         case 94: return launch_stacked<2, 8, 3, 1, 0, 1, true>(L, s);
-        case 95: return L.kpiola ? launch_stacked<3, 2, 3, 4, 0, 1, false, 10, false, true, 1>(L, s) : L.kodd ? launch_stacked<3, 2, 3, 4, 0, 1, false, 10, true, true>(L, s) : launch_stacked<3, 2, 3, 4, 0, 1, false, 10, false, true>(L, s);
+        case 95: return L.kpiola ? (L.kodd ? launch_stacked<3, 2, 3, 4, 0, 1, false, 10, true, true, 1>(L, s) : launch_stacked<3, 2, 3, 4, 0, 1, false, 10, false, true, 1>(L, s)) : L.kodd ? launch_stacked<3, 2, 3, 4, 0, 1, false, 10, true, true>(L, s) : launch_stacked<3, 2, 3, 4, 0, 1, false, 10, false, true>(L, s);
         case 96: return L.kpiola ? launch_stacked<3, 2, 3, 3, 0, 1, false, 10, false, true, 1>(L, s) : launch_stacked<3, 2, 3, 3, 0, 1, false, 10, false, true>(L, s);
         case 97: return L.kpiola ? launch_stacked<3, 2, 3, 2, 0, 1, false, 10, false, true, 1>(L, s) : launch_stacked<3, 2, 3, 2, 0, 1, false, 10, false, true>(L, s);
         case 98: return L.kpiola ? launch_stacked<3, 2, 2, 1, 0, 1, false, 10, false, true, 1>(L, s) : launch_stacked<3, 2, 2, 1, 0, 1, false, 10, false, true>(L, s);
-        case 99: return L.kpiola ? launch_stacked<3, 3, 3, 2, 0, 1, false, 10, false, true, 1>(L, s) : L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 10, true, true>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 10, false, true>(L, s);
+        case 99: return L.kpiola ? (L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 10, true, true, 1>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 10, false, true, 1>(L, s)) : L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 10, true, true>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 10, false, true>(L, s);
         case 100: return L.kpiola ? launch_stacked<3, 3, 2, 1, 0, 1, false, 10, false, true, 1>(L, s) : launch_stacked<3, 3, 2, 1, 0, 1, false, 10, false, true>(L, s);
         case 101: return L.kpiola ? launch_stacked<3, 3, 3, 1, 0, 1, false, 10, false, true, 1>(L, s) : launch_stacked<3, 3, 3, 1, 0, 1, false, 10, false, true>(L, s);
         case 102: return launch_stacked<3, 4, 3, 2, 0, 1, false, 10, false, true>(L, s);
@@ -1102,11 +1102,11 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 132: return launch_stacked<3, 2, 3, 1, 0, 1, true, 10, false, true>(L, s);
         case 133: return launch_stacked<2, 6, 3, 1, 0, 1, true, 6, false, true>(L, s);  // (two waves per SIMD: 116-364 B of scratch)
         case 134: return launch_stacked<2, 5, 3, 1, 0, 1, true, 6, false, true>(L, s);  // (two waves per SIMD: 116-364 B of scratch)
-        case 135: return launch_stacked<3, 2, 3, 4, 0, 1, false, 1, false, true, 1>(L, s);
+        case 135: return L.kodd ? launch_stacked<3, 2, 3, 4, 0, 1, false, 1, true, true, 1>(L, s) : launch_stacked<3, 2, 3, 4, 0, 1, false, 1, false, true, 1>(L, s);
         case 136: return launch_stacked<3, 2, 3, 3, 0, 1, false, 1, false, true, 1>(L, s);
         case 137: return launch_stacked<3, 2, 3, 2, 0, 1, false, 1, false, true, 1>(L, s);
         case 138: return launch_stacked<3, 2, 2, 1, 0, 1, false, 1, false, true, 1>(L, s);
-        case 139: return launch_stacked<3, 3, 3, 2, 0, 1, false, 1, false, true, 1>(L, s);
+        case 139: return L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 1, true, true, 1>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 1, false, true, 1>(L, s);
         case 140: return launch_stacked<3, 3, 2, 1, 0, 1, false, 1, false, true, 1>(L, s);
         case 141: return launch_stacked<3, 3, 3, 1, 0, 1, false, 1, false, true, 1>(L, s);
         case 142: return launch_stacked<2, 3, 3, 4, 0, 1, false, 1, false, true, 1>(L, s);
@@ -1292,9 +1292,11 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     // 14 % of the HBM peak on the cooperative kernel against 37 %; N3 triangles 29 % lane-local against 50 %)
     const bool want_piola = (mapping == FX_MAP_COVARIANT_PIOLA || mapping == FX_MAP_CONTRAVARIANT_PIOLA) && verts && e->vdim == e->sd && e->sd >= 2;
     const int TRp = fxk::stacked_tile_rows(e->sd, 1);
+    const bool pio_even = !(((long long)rows * npts) % 2) && !(((long long)(rows - TRp * ((rows + TRp - 1) / TRp - 1)) * npts) % 2);
+    // (odd table sizes: 8-byte twins of the two instances RT2 / N3 tetrahedra meet at their 11- / 23-point rules)
+    const bool pio_odd_twin = e->sd == 3 && ((e->n == 2 && npts > 8 && npts <= 12) || (e->n == 3 && npts > 16 && npts <= 24));
     const bool stacked_pio_ok = want_piola && !(ctx->policy & (FX_POLICY_NO_STACKED | FX_POLICY_NO_STACKED_MIX)) && !e->raw_expansion &&
-                                stacked_has_pio(e->sd, e->n) && npts <= 48 && !(((long long)rows * npts) % 2) &&
-                                !(((long long)(rows - TRp * ((rows + TRp - 1) / TRp - 1)) * npts) % 2) && (long long)ntab * rows >= 15;
+                                stacked_has_pio(e->sd, e->n) && npts <= 48 && (pio_even || pio_odd_twin) && (long long)ntab * rows >= 15;
     fxk::TabArgs& a = L.args;
     memset(&a, 0, sizeof a);
     a.pts = pts;
@@ -1654,16 +1656,16 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     if (nomix || !verts || order != (k.rtc == -2 ? 1 : k.rtc == -3 ? 2 : 0)) continue;
                     // the element's Piola map too (vector-valued elements: the twin with the components of a dof in one lane,
                     // 12 rows per tile in 3-D); values only: nothing else to mix, so only with the map
-                    pio = want_piola && stacked_has_pio(k.sd, k.n) && !(((long long)rows * npts) % 2) &&
-                          !(((long long)(rows - TRp * ((rows + TRp - 1) / TRp - 1)) * npts) % 2);
+                    const bool odd_pio_instance = k.sd == 3 && k.ct == 3 && ((k.n == 2 && k.g == 4) || (k.n == 3 && k.g == 2));
+                    pio = want_piola && stacked_has_pio(k.sd, k.n) && (pio_even || (pio_odd_twin && odd_pio_instance));
                     if (k.rtc == -6 && !pio) continue;
                     // (16-byte pieces of whole tables; three shapes have an 8-byte twin for odd table sizes: P5 triangles at the
                     // 25-point rule, N3 and RT2 tetrahedra at the 23- and 11-point rules)
                     mix_odd = ((long long)rows * npts) % 2 || ((long long)(rows - 16 * ((rows + 15) / 16 - 1)) * npts) % 2;
                     // (RT2 at order 1 stays on the generic kernel: 44.7 % of the HBM peak there, 39.2 % on the twin)
-                    if (pio) mix_odd = false;
-                    if (mix_odd && !((k.sd == 2 && k.n == 5 && k.ct == 2 && k.g == 1) || (k.sd == 3 && k.n == 3 && k.ct == 3 && k.g == 2) ||
-                                     (k.rtc == -3 && k.sd == 3 && k.n == 2 && k.ct == 3 && k.g == 4)))
+                    if (pio) mix_odd = !pio_even;
+                    if (mix_odd && !pio && !((k.sd == 2 && k.n == 5 && k.ct == 2 && k.g == 1) || (k.sd == 3 && k.n == 3 && k.ct == 3 && k.g == 2) ||
+                                             (k.rtc == -3 && k.sd == 3 && k.n == 2 && k.ct == 3 && k.g == 4)))
                         continue;
                     if (npts > 16 * k.ct / k.g || tighter_instance(k) || !fills_tiles(k)) continue;
                 } else if (chunked) {  // point-chunked: whatever the whole-request instances above did not take

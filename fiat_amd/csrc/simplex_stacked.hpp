@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
     static_assert(!CHUNK || (G == 1 && RTC == 0), "point-chunked units: one request per group, streamed fragments");
     constexpr int NTA = MIXT == 1 ? 1 : 1 + SD, NTB = SD * (SD + 1) / 2;   // tables of orders <= 1, of order 2
     constexpr int MORD = MIXT <= 1 ? 0 : MIXT == NTA ? 1 : 2;              // derivative order of a table-mixing instance
-    static_assert(PIO == 0 || (MIXR && !CHUNK && !ODD && SD >= 2), "fused Piola map: accumulator-side mixing, whole requests");
+    static_assert(PIO == 0 || (MIXR && !CHUNK && SD >= 2), "fused Piola map: accumulator-side mixing, whole requests");
     static_assert(MIXT != 1 || PIO != 0, "one table: only the Piola map is left to mix");
     constexpr int SLOTS = stacked_mix_slots(SD, MIXT, MIXR);
     constexpr int IMG = stacked_image_doubles(CT, KS, SLOTS) + (MIXR ? STACKED_KBUF : 0);

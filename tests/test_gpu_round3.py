@@ -271,7 +271,9 @@ PIOLA = [("Nedelec", 3, 2, 11, "3,2,3,4"), ("BrezziDouglasMarini", 3, 2, 14, "3,
          ("Nedelec", 3, 2, 30, "3,2,2,1"), ("RaviartThomas", 3, 3, 24, "3,3,3,2"), ("Nedelec", 3, 3, 30, "3,3,2,1"),
          ("BrezziDouglasMarini", 3, 3, 44, "3,3,3,1"), ("Nedelec", 2, 3, 12, "2,3,3,4"), ("RaviartThomas", 2, 3, 16, "2,3,3,3"),
          ("BrezziDouglasMarini", 2, 3, 22, "2,3,3,2"), ("Nedelec", 2, 4, 16, "2,4,3,3"), ("RaviartThomas", 2, 4, 22, "2,4,3,2"),
-         ("NedelecSecondKind", 2, 3, 12, "2,3,3,4"), ("RaviartThomas", 2, 4, 30, "2,4,2,1")]
+         ("NedelecSecondKind", 2, 3, 12, "2,3,3,4"), ("RaviartThomas", 2, 4, 30, "2,4,2,1"),
+         # odd table sizes (45 x 11, 135 x 23 doubles): the 8-byte twins
+         ("RaviartThomas", 3, 2, 11, "3,2,3,4"), ("Nedelec", 3, 3, 23, "3,3,3,2")]
 
 
 @pytest.mark.parametrize("family,sd,degree,npts,instance", PIOLA, ids=[f"{m[0][:3]}{m[2]}-sd{m[1]}-{m[3]}pt" for m in PIOLA])
