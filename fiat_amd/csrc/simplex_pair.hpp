@@ -104,7 +104,10 @@ __global__ __launch_bounds__(64 * NW, NW <= 4 ? 1 : FX_PAIR_WAVES) void tabulate
     for (int i = lane; i < a.lds_doubles; i += 64) img[i] = 0.0;
     for (int i = threadIdx.x; i < NAF * 64; i += 64 * NW) afr[i] = a.afrag[i];
     const long long npairs = (a.nreq + RPW - 1) / RPW;  // units (pairs or single requests)
-    WorkQueue wqueue;
+#ifndef FX_WQ_TAIL
+#define FX_WQ_TAIL 0  // 1: no look-ahead in the last two rounds (work_queue.hpp TAIL; measured: mean idle at the end 12.0 -> 10.5-11.5 us, launch times within noise)
+#endif
+    WorkQueueT<(FX_WQ_TAIL != 0)> wqueue;
     wqueue.init(lds, gqueue, npairs);  // pairs are handed out dynamically, see work_queue.hpp
     __syncthreads();
 

@@ -32,6 +32,7 @@
 // LDS control block (64 bytes at the start of dynamic LDS):
 //   ctl[0]            claims of this workgroup so far (k); unit = chunk(k >> 3) * 8 + (k & 7)
 //   ctl[1]            waves of this workgroup that have finished
+//   ctl[10]           (TAIL) newest chunk id the workgroup holds (byte 40, behind the slot ring)
 //   slot[4] (u64)     ring of chunk ids, slot[j & 3] = (j << 32) | chunk id of the workgroup's
 //                     j-th chunk, written by the wave that claimed the first unit of chunk j - WQ_AHEAD
 #pragma once
@@ -47,7 +48,22 @@ constexpr unsigned int WQ_END = 0x7fffffffu;
 constexpr unsigned int WQ_AHEAD = FX_WQ_AHEAD;  // chunks requested ahead of the one being opened (1 or 2; the slot ring holds 4)
 static_assert(WQ_AHEAD == 1 || WQ_AHEAD == 2, "look-ahead of one or two chunks");
 
-struct WorkQueue {
+constexpr int WQ_NEWEST = 10;                   // index into ctl (32-bit words) of the newest chunk id, behind the slot ring
+constexpr unsigned int WQ_DEFER = 0x7ffffffeu;  // slot value: "fetch this chunk's id when you open it" (TAIL)
+
+// TAIL: near the end of the batch the look-ahead is switched off.  When the counter runs dry a workgroup still holds its
+// look-ahead chunk -- a whole round of its waves that nobody else can take, while workgroups that found the counter empty
+// sit idle for up to two unit times (wave timelines: the average wave idles 13-17 us before the last one exits, a unit of the
+// benchmark kernels takes 11).  So a workgroup whose newest chunk id is within two rounds of the end (ids advance by about
+// gridDim.x per round) no longer asks ahead: it marks the slot WQ_DEFER, and the wave that opens that chunk fetches the id
+// then (its ~1 us is exposed, but only in the last round or two); every chunk not yet started stays in the counter for
+// whoever is free first.
+// MEASURED (round 3, FX_DBG=512 timelines + tools/queue_ab.sh, RT2 25 000 / P3 100 000 requests): mean idle before the last
+// exit 12.0 -> 10.5-11.5 us, p90 17 -> 15, launch times 151.3 vs 152.4 us (RT2), 205.8 vs 206.6 (N2), 270.3 vs 268.5 (P3):
+// within noise, so it is OFF (FX_WQ_TAIL=0 in simplex_pair.hpp).  The exits still spread over two unit times: the last
+// chunk of a workgroup is 8 units for its 8 waves, but the waves free up over a whole unit time, so an early wave takes two
+// of them while idle workgroups cannot help -- the granularity at the end is a workgroup's chunk, not a unit.
+template <bool TAIL> struct WorkQueueT {
     unsigned int* ctl;            // LDS
     unsigned long long* slot;     // LDS, 4 entries
     unsigned int* gctr;           // global chunk counter (zeroed before the launch)
@@ -68,6 +84,7 @@ struct WorkQueue {
         if (threadIdx.x == 0) {
             ctl[0] = 0;
             ctl[1] = 0;
+            ctl[WQ_NEWEST] = blockIdx.x + (WQ_AHEAD - 1) * gridDim.x;   // (TAIL) newest chunk id this workgroup holds
             // the first WQ_AHEAD chunks of a workgroup are static: no atomic before the first unit
             for (unsigned int i = 0; i < 4; ++i)
                 slot[i] = i < WQ_AHEAD ? ((unsigned long long)i << 32) | (blockIdx.x + i * gridDim.x) : ~0ULL;
@@ -101,7 +118,36 @@ struct WorkQueue {
             if ((threadIdx.x & 63) == 0) __hip_atomic_store(gctr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return nunits;
         }
-        const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)s);
+        unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)s);
+        if constexpr (TAIL) {
+            if (lo == WQ_DEFER) {  // (wave-uniform) the id was not asked for ahead of time
+                if (off == 0) {    // this wave opens the chunk: fetch the id now and publish it
+                    unsigned int c = 0;
+                    if ((threadIdx.x & 63) == 0) {
+                        c = WQ_AHEAD * gridDim.x + __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        c = c < WQ_END ? c : WQ_END;
+                        __hip_atomic_store(&slot[j & 3], ((unsigned long long)j << 32) | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(ctl + WQ_NEWEST, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    lo = __builtin_amdgcn_readfirstlane(c);
+                } else {           // the others wait for it (bounded, as above)
+                    ok = false;
+                    for (int spin = 0; spin < (1 << 22); ++spin) {
+                        s = __hip_atomic_load(&slot[j & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if ((unsigned int)(s >> 32) == j && (unsigned int)s != WQ_DEFER) {
+                            ok = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (!ok) {
+                        if ((threadIdx.x & 63) == 0) __hip_atomic_store(gctr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        return nunits;
+                    }
+                    lo = __builtin_amdgcn_readfirstlane((unsigned int)s);
+                }
+            }
+        }
         if (lo >= nchunks) return nunits;
         const long long u = (long long)lo * 8 + off;
         return u < nunits ? u : nunits;
@@ -114,9 +160,18 @@ struct WorkQueue {
         if (!pending) return;
         pending = false;
         if ((threadIdx.x & 63) == 0) {
+            if constexpr (TAIL) {
+                const unsigned int last = __hip_atomic_load(ctl + WQ_NEWEST, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((unsigned long long)last + 2ull * gridDim.x >= nchunks) {  // within two rounds of the end: no look-ahead
+                    __hip_atomic_store(&slot[pord & 3], ((unsigned long long)pord << 32) | WQ_DEFER, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                    return;
+                }
+            }
             const unsigned int c = WQ_AHEAD * gridDim.x + __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&slot[pord & 3], ((unsigned long long)pord << 32) | (c < WQ_END ? c : WQ_END), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (TAIL) __hip_atomic_store(ctl + WQ_NEWEST, c < WQ_END ? c : WQ_END, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 
@@ -134,5 +189,7 @@ struct WorkQueue {
         }
     }
 };
+
+using WorkQueue = WorkQueueT<false>;
 
 }  // namespace fxk
