@@ -188,8 +188,9 @@ class ExpansionSet:
         return {a: out[t] for t, a in enumerate(keys)}
 
     def get_dmats(self, degree, cell=0):
-        """dmats[d][j, i]: d/dx_d phi_j = sum_i dmats[d][j, i] phi_i on one sub-cell (FIAT/expansions.py:576-600,
-        transposed), from a device tabulation of values and gradients at a unisolvent interior lattice."""
+        """dmats[d][i, j]: d/dx_d phi_j = sum_i dmats[d][i, j] phi_i on one sub-cell -- the array FIAT/expansions.py:576-600
+        returns (solve(V^T, dV^T); the regression suite's reference-polynomials data pin this orientation) -- from a device
+        tabulation of values and gradients at a unisolvent interior lattice."""
         key = ("dmats", degree, cell)
         if key not in self._dev:
             sd = self.ref_el.get_spatial_dimension()
@@ -199,7 +200,7 @@ class ExpansionSet:
                 else [tuple(numpy.mean(numpy.asarray(verts), axis=0))]
             tab = self._tabulate_on_cell(degree, numpy.array(lattice), 1, cell=cell)
             V = tab[(0,) * sd]
-            self._dev[key] = [numpy.linalg.solve(V.T, tab[alpha].T).T for alpha in mis(sd, 1)]
+            self._dev[key] = [numpy.linalg.solve(V.T, tab[alpha].T) for alpha in mis(sd, 1)]
         return self._dev[key]
 
     def _tabulate(self, n, pts, order=0):

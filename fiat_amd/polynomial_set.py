@@ -49,6 +49,10 @@ class PolynomialSet:
     def get_expansion_set(self):
         return self.expansion_set
 
+    def get_dmats(self, cell=0):
+        """Differentiation matrices of the expansion set at this set's degree (FIAT/polynomial_set.py:91-92)."""
+        return self.expansion_set.get_dmats(self.degree, cell=cell)
+
     def get_coeffs(self):
         return self.coeffs
 

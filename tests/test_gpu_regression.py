@@ -1,0 +1,85 @@
+"""The reference's regression suite (test/FIAT/regression/test_regression.py) on the device.  Its expected values live in JSON
+files of a separate repository that cannot be fetched; tests/golden/make_golden_regression.py runs the suite's own
+``create_data`` recipes on the unmodified reference instead (the suite's fallback when the files are absent) and
+tests/golden/regression.npz holds the numbers.  Tolerance of the suite: 1e-8 absolute; here 1e-10 relative-to-max for the
+element tables (north star) and the suite's 1e-8 for the differentiation matrices (they are projections through a
+lattice of points on both sides)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = ([("Lagrange", d, k) for d in (1, 2, 3) for k in (1, 2, 3)] + [("Discontinuous Lagrange", d, k) for d in (1, 2, 3) for k in (0, 1, 2)]
+         + [(f, d, k) for f in ("Brezzi-Douglas-Marini", "Raviart-Thomas", "Nedelec 1st kind H(curl)", "Nedelec 2nd kind H(curl)")
+            for d in (2, 3) for k in (1, 2, 3)]
+         + [("Regge", d, k) for d in (2, 3) for k in (0, 1, 2)] + [("Hellan-Herrmann-Johnson", 2, k) for k in (0, 1, 2)])
+
+
+def test_polynomials_dmats(golden):
+    """:81-114: differentiation matrices of the orthonormal sets of degree 3 on the default tetrahedron and line."""
+    from fiat_amd import polynomial_set, reference_element
+    g = golden("regression")
+    for name, cell in (("dmats_tet3", reference_element.DefaultTetrahedron()), ("dmats_line3", reference_element.DefaultLine())):
+        dmats = polynomial_set.ONPolynomialSet(ref_el=cell, degree=3).get_dmats()
+        assert len(dmats) == len(g[name])
+        for dmat, ref in zip(dmats, g[name]):
+            assert (abs(np.asarray(dmat) - ref) < 1e-8).all()
+
+
+def test_expansions(golden):
+    """:117-146: Dubiner values and (value, gradient) pairs of degree 3 at the lattice of the default triangle."""
+    from fiat_amd import expansions, reference_element
+    g = golden("regression")
+    E = reference_element.DefaultTriangle()
+    pts = reference_element.make_lattice(E.get_vertices(), 3)
+    assert np.allclose(np.array(pts), g["exp_tri3_pts"])
+    Phis = expansions.ExpansionSet(E)
+    assert (abs(np.array(Phis.tabulate(3, pts)) - g["exp_tri3_phi"]) < 1e-12).all()
+    d = Phis.tabulate_derivatives(3, pts)
+    value = np.array([[p[0] for p in row] for row in d])
+    grad = np.array([[p[1] for p in row] for row in d])
+    assert (abs(value - g["exp_tri3_dphi_value"]) < 1e-12).all() and (abs(grad - g["exp_tri3_dphi_grad"]) < 1e-10).all()
+
+
+def test_expansions_jet(golden):
+    """:149-166: tabulate_jet(1, lattice 2, order 2) on the default tetrahedron."""
+    from fiat_amd import expansions, reference_element
+    g = golden("regression")
+    T = reference_element.DefaultTetrahedron()
+    pts = reference_element.make_lattice(T.get_vertices(), 2)
+    jet = expansions.ExpansionSet(T).tabulate_jet(1, pts, 2)
+    assert len(jet) == 3
+    for r, datum in enumerate(jet):
+        assert np.array(datum).shape == g[f"jet_tet_{r}"].shape
+        assert (abs(np.array(datum) - g[f"jet_tet_{r}"]) < 1e-10).all()
+
+
+@pytest.mark.parametrize("family,dim,degree", CASES, ids=[f"{f.replace(' ', '_')}-{d}-{k}" for f, d, k in CASES])
+def test_quadrature(golden, family, dim, degree):
+    """:200-323: element.tabulate(3, points of make_quadrature(simplex, 3)) for the in-scope rows of the suite's 72 (family,
+    dimension, degree) cases -- every multi-index up to order 3 present, same shapes, same numbers."""
+    import fiat_amd
+    g = golden("regression")
+    key = f"quad_{family.replace(' ', '_')}_{dim}_{degree}"
+    kwargs = {"variant": "point"} if family in {"Regge", "Hellan-Herrmann-Johnson"} else {}
+    domain = fiat_amd.ufc_simplex(dim)
+    if family == "Hellan-Herrmann-Johnson":
+        with pytest.raises(NotImplementedError):   # (the refused rows: the 2-D point variant, fiat_amd/hellan_herrmann_johnson.py)
+            fiat_amd.supported_elements[family](domain, degree, **kwargs)
+        return
+    element = fiat_amd.supported_elements[family](domain, degree, **kwargs)
+    points = fiat_amd.make_quadrature(domain, 3).get_points()
+    assert np.allclose(points, g[key + "_pts"], atol=1e-14)
+    table = element.tabulate(3, points)
+    names = [n for n in g.files if n.startswith(key + "_") and not n.endswith("_pts")]
+    assert len(names) == len(table)
+    worst = 0.0
+    for n in names:
+        alpha = tuple(int(c) for c in n[len(key) + 1:])
+        assert alpha in table
+        ref = g[n]
+        assert table[alpha].shape == ref.shape
+        err = np.abs(table[alpha] - ref).max() / max(1.0, np.abs(ref).max())
+        worst = max(worst, err)
+        assert (abs(table[alpha] - ref) < 1e-8).all()           # the suite's own criterion
+    assert worst <= 1e-10, worst
