@@ -67,12 +67,15 @@ class ComponentPointEvaluation(Functional):
     """f -> f_comp(x) for f of value shape shp."""
 
     def __init__(self, ref_el, comp, shp, x):
-        if len(shp) != 1:
-            raise ValueError("Illegal shape")
-        if comp < 0 or comp >= shp[0]:
+        # (vector- and tensor-valued functions: comp is an index or a tuple of indices, FIAT/functional.py:173-186)
+        if not isinstance(comp, tuple):
+            comp = (comp,)
+        if len(shp) != len(comp):
+            raise ValueError("Component and shape are incompatible")
+        if any(i < 0 or i >= n for i, n in zip(comp, shp)):
             raise ValueError("Illegal component")
-        self.comp = comp
-        super().__init__(ref_el, shp, {tuple(x): [(1.0, (comp,))]}, {}, "ComponentPointEval")
+        self.comp = comp if len(comp) > 1 else comp[0]
+        super().__init__(ref_el, shp, {tuple(x): [(1.0, comp)]}, {}, "ComponentPointEval")
 
 
 class IntegralMoment(Functional):

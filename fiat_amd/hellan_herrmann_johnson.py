@@ -2,7 +2,7 @@
 
 Facets: n^T u n against an orthonormal basis of P_k of the facet.  Cell: n_f^T u n_f for every facet normal
 against P_{k-1}, and the mixed products n_a^T u n_b of consecutive facet normals against P_k.  "point"
-variant (tetrahedra): the same bilinear forms at lattice points.  Behaviour as
+variant: the same bilinear forms at lattice points (on triangles the interior dofs are the Cartesian upper-triangle components).  Behaviour as
 FIAT/hellan_herrmann_johnson.py:11-120; written as dof blocks over fiat_amd/dof_layout.py."""
 import numpy
 
@@ -20,13 +20,14 @@ def hhj_dofs(cell, k, variant, moment_degree, scheme):
     n = {f: numpy.asarray(cell.compute_scaled_normal(f), dtype=float) for f in facets}
     mixed = [(facets[i + 1], facets[i + 2]) for i in range((sd - 1) * (sd - 2))]   # off-diagonal pairs (3-D only)
     if variant == "point":
-        if sd == 2:
-            raise NotImplementedError("the 2-D point variant of HHJ keeps Cartesian interior dofs whose Riesz rows "
-                                      "rely on NumPy fancy indexing in the reference; use the integral variant")
         at = functional.PointwiseInnerProductEvaluation
         lay.lattice(sd - 1, k + sd, lambda f, pts: [at(cell, n[f], n[f], x) for x in pts])
-        lay.lattice(sd, k + sd, lambda _, pts: [at(cell, n[f], n[f], x) for x in pts for f in facets])
-        lay.lattice(sd, k + sd + 1, lambda _, pts: [at(cell, n[a], n[b], x) for x in pts for a, b in mixed])
+        if sd == 2:   # triangles keep Cartesian interior dofs: the upper-triangle components at the interior lattice (:38-46)
+            comp = functional.ComponentPointEvaluation
+            lay.lattice(sd, k + sd, lambda _, pts: [comp(cell, (i, j), (sd, sd), x) for i in range(sd) for j in range(i, sd) for x in pts])
+        else:
+            lay.lattice(sd, k + sd, lambda _, pts: [at(cell, n[f], n[f], x) for x in pts for f in facets])
+            lay.lattice(sd, k + sd + 1, lambda _, pts: [at(cell, n[a], n[b], x) for x in pts for a, b in mixed])
     else:
         q = moment_degree + k
         lay.moments(sd - 1, k, q, lambda f: [numpy.outer(n[f], n[f])], scheme=scheme, tag=_TAG)

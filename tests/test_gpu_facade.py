@@ -338,17 +338,15 @@ NODAL = [
 
 def _not_served(element):
     """Rows of the list this facade refuses, loudly: expansion sets on a POINT cell (DG on a point; Raviart-Thomas on the
-    interval, whose facets are points) and the 2-D point variant of HHJ (its interior dofs rely on NumPy fancy indexing in the
-    reference, fiat_amd/hellan_herrmann_johnson.py)."""
-    return (element.startswith("RaviartThomas(I,") and "point" not in element) or element == "DiscontinuousLagrange(P, 0)" or \
-        element == "HellanHerrmannJohnson(T, 1, variant='point')"
+    interval, whose facets are points)."""
+    return (element.startswith("RaviartThomas(I,") and "point" not in element) or element == "DiscontinuousLagrange(P, 0)"
 
 
 @pytest.mark.parametrize("element", NODAL)
 def test_nodality_of_every_in_scope_element_of_the_reference_test(fa, element):
     """test/FIAT/unit/test_fiat.py:446-470 on the device: the element's dual basis applied to its nodal basis (Riesz
     representations against expansion coefficients) is the identity, and the nodal basis lives on a cell at least as fine as
-    the dual set's.  175 of the 183 in-scope rows; the other 8 must fail with ValueError / NotImplementedError (_not_served)."""
+    the dual set's.  176 of the 183 in-scope rows; the other 7 must fail with ValueError / NotImplementedError (_not_served)."""
     from fiat_amd import (BrezziDouglasMarini, CubicHermite, DiscontinuousLagrange, GaussLegendre, GaussLobattoLegendre,  # noqa: F401
                           GopalakrishnanLedererSchoberlSecondKind, HellanHerrmannJohnson, Lagrange, Morley, Nedelec,
                           NedelecSecondKind, P0, RaviartThomas, Regge)

@@ -63,10 +63,6 @@ def test_quadrature(golden, family, dim, degree):
     key = f"quad_{family.replace(' ', '_')}_{dim}_{degree}"
     kwargs = {"variant": "point"} if family in {"Regge", "Hellan-Herrmann-Johnson"} else {}
     domain = fiat_amd.ufc_simplex(dim)
-    if family == "Hellan-Herrmann-Johnson":
-        with pytest.raises(NotImplementedError):   # (the refused rows: the 2-D point variant, fiat_amd/hellan_herrmann_johnson.py)
-            fiat_amd.supported_elements[family](domain, degree, **kwargs)
-        return
     element = fiat_amd.supported_elements[family](domain, degree, **kwargs)
     points = fiat_amd.make_quadrature(domain, 3).get_points()
     assert np.allclose(points, g[key + "_pts"], atol=1e-14)
