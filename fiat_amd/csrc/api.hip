@@ -698,6 +698,9 @@ hipError_t report_wave_lifetimes(const double* trash, int grid, int wg_waves) {
 }
 #endif
 
+#ifndef FX_PAIR_BALANCE
+#define FX_PAIR_BALANCE 0  // 1: grid of the paired kernel chosen for whole rounds (measured within noise: RT2 152.0 vs 152.1 us, N2 205.0 vs 205.9, C2 265.1 vs 261.9)
+#endif
 // PAIR_ONLY: only the paired kernel is instantiated for this shape (the A/B partners
 // `stream` and `image` exist for the benchmark shape)
 template <int SD, int N, int ORDER, int ROWS, int NT, bool PAIR_ONLY = false, int RPW = 2, bool FULLIMG = true, int PAIR_NW = 8,
@@ -744,8 +747,24 @@ int launch_fixed(const Launch& L, hipStream_t s) {
             cached_occ = q;
         }
         const int occ = cached_occ;
-        const long long nwg = ((L.fhead.nreq + RPW - 1) / RPW + PAIR_NW - 1) / PAIR_NW;
-        const int grid = (int)std::max<long long>(1, std::min<long long>(nwg, (long long)L.ncu * std::max(1, occ)));
+        const long long nwg = ((L.fhead.nreq + RPW - 1) / RPW + PAIR_NW - 1) / PAIR_NW;   // = chunks of the work queue
+        int grid = (int)std::max<long long>(1, std::min<long long>(nwg, (long long)L.ncu * std::max(1, occ)));
+#if FX_PAIR_BALANCE
+        // Whole rounds: with nwg chunks over `grid` workgroups the last round keeps only nwg mod grid of them busy (RT2 / N2 at
+        // 25 000 requests: 1563 chunks over 256 workgroups = 6.1 rounds -- nine tenths of the chip idle through the last one).
+        // The kernel is bound by the write path, not by the number of CUs in use: take the grid within 1/8 of the maximum
+        // that wastes the fewest workgroup-rounds (224 x 7 = 1568 for RT2, 250 x 25 = 6250 for the 100 000 requests of C2).
+        if (nwg > grid) {
+            long long best = (nwg + grid - 1) / grid * grid - nwg;
+            for (int g = grid - 1; g >= grid - grid / 8 && best > 0; --g) {
+                const long long waste = (nwg + g - 1) / g * g - nwg;
+                if (waste < best) {
+                    best = waste;
+                    grid = g;
+                }
+            }
+        }
+#endif
         static const bool verbose = ab_env("FIAT_AMD_VERBOSE") != nullptr;
         if (verbose) fprintf(stderr, "[fiat_amd] pair kernel: occupancy %d WG/CU, grid %d, lds %d B\n", occ, grid, lds_bytes);
         hipLaunchKernelGGL(kp, dim3(grid), dim3(64 * PAIR_NW), lds_bytes, s, fa, L.trash, reinterpret_cast<unsigned int*>(L.queue));
