@@ -113,3 +113,25 @@ def test_line_rules_and_argument_errors_as_in_the_reference_tests():
         gl = quadrature.GaussLegendreQuadratureLineRule(interval, points)
         for degree in range(2 * points):
             assert np.round(gl.integrate(lambda x: x[0] ** degree) - 1. / (degree + 1), 14) == 0.
+
+
+def test_quadrature_on_product_cells_as_in_the_reference_tests():
+    """test/FIAT/unit/test_quadrature.py:128-141, :171-184: create_quadrature on interval x interval and triangle x interval
+    with a degree per factor integrates x^a y^b / (x + y)^a z^b exactly for a < 5, b < 4; negative degrees are ValueErrors;
+    the rule of a product is the product of the factors' rules (point counts)."""
+    import fiat_amd
+    from fiat_amd import reference_element as re
+    I, T = re.ufc_simplex(1), re.ufc_simplex(2)
+    extr_interval, extr_triangle = re.TensorProductCell(I, I), re.TensorProductCell(T, I)
+    for basedeg in range(5):
+        for extrdeg in range(4):
+            q = fiat_amd.create_quadrature(extr_interval, (basedeg, extrdeg))
+            assert np.allclose(q.integrate(lambda x: x[0] ** basedeg * x[1] ** extrdeg), 1 / (basedeg + 1) * 1 / (extrdeg + 1))
+            q = fiat_amd.create_quadrature(extr_triangle, (basedeg, extrdeg))
+            assert np.allclose(q.integrate(lambda x: (x[0] + x[1]) ** basedeg * x[2] ** extrdeg), 1 / (basedeg + 2) * 1 / (extrdeg + 1))
+    for cell in (extr_interval, extr_triangle):
+        with pytest.raises(ValueError):
+            fiat_amd.create_quadrature(cell, (-1, -1))
+    qa, qb = fiat_amd.create_quadrature(T, 4), fiat_amd.create_quadrature(I, 4)
+    q = fiat_amd.create_quadrature(extr_triangle, (4, 4))
+    assert len(q.get_points()) == len(qa.get_points()) * len(qb.get_points())
