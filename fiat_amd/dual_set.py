@@ -141,6 +141,8 @@ class DualSet:
 
     def _expansion_tables(self, es, ed, pts, order):
         """Device tensor (ntab, nexp, npts): the expansion set and its derivatives <= order at pts."""
+        if es.ref_el.get_spatial_dimension() == 0:     # the constant 1 on a point cell (expansions.ExpansionSet._tabulate)
+            return torch.ones((1, 1, len(pts)), dtype=torch.float64, device=runtime.Context.get().device)
         if hasattr(es, "_device_set"):
             return es._device_set(ed).tabulate_batch(order, pts[None])[0]
         return es.device_line().tabulate_batch(order, pts.reshape(1, -1))[0]  # 1-D Lagrange expansion set

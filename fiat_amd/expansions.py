@@ -110,14 +110,14 @@ class ExpansionSet:
         if variant not in (None, "bubble", "dual"):
             raise ValueError(f"Invalid variant {variant}")
         sd = ref_el.get_spatial_dimension()
-        if ref_el.get_shape() not in (reference_element.LINE, reference_element.TRIANGLE,
+        if ref_el.get_shape() not in (reference_element.POINT, reference_element.LINE, reference_element.TRIANGLE,
                                       reference_element.TETRAHEDRON):
             raise ValueError("Invalid reference element type.")
         self.ref_el = ref_el
         self.variant = variant
         self.num_cells = len(ref_el.get_topology()[sd])
         if scale is None:
-            scale = math.sqrt(1.0 / reference_element.default_simplex(sd).volume())
+            scale = 1.0 if sd == 0 else math.sqrt(1.0 / reference_element.default_simplex(sd).volume())
         elif isinstance(scale, str):
             if scale.lower() not in ("orthonormal", "l2 piola"):
                 raise ValueError(f"Invalid scale {scale}")
@@ -205,8 +205,12 @@ class ExpansionSet:
 
     def _tabulate(self, n, pts, order=0):
         """{alpha: table[i, j] = D^alpha phi_i(pts[j])}; a single point drops the last axis."""
-        pts = numpy.asarray(pts, dtype=float)
         sd = self.ref_el.get_spatial_dimension()
+        if sd == 0:     # the one constant on a point (FIAT/expansions.py:638-649): host arithmetic, nothing to launch
+            if n != 0 or order != 0:
+                raise ValueError("Only degree zero polynomials and no derivatives on point elements.")
+            return {(): numpy.ones((1, len(pts)))}
+        pts = numpy.asarray(pts, dtype=float)
         single = pts.ndim == 1
         P = pts.reshape(1, -1, sd)
         out = runtime.fetch(self._device_set(n).tabulate_batch(order, P))[0]

@@ -32,8 +32,11 @@ class PolynomialSet:
 
     def tabulate(self, pts, jet_order=0):
         """{alpha: (num_members, *value_shape, npts)} for all |alpha| <= jet_order."""
-        pts = numpy.asarray(pts, dtype=float)
         sd = self.ref_el.get_spatial_dimension()
+        if sd == 0:     # point cell: coefficients times the constant 1 (host arithmetic, FIAT/expansions.py:638-649)
+            base = self.expansion_set._tabulate(self.embedded_degree, pts, jet_order)[()]
+            return {(): numpy.dot(self.coeffs, base)}
+        pts = numpy.asarray(pts, dtype=float)
         single = pts.ndim == 1
         out = runtime.fetch(self.device_polyset().tabulate_batch(jet_order, pts.reshape(1, -1, sd)))[0]
         keys = [a for k in range(jet_order + 1) for a in mis(sd, k)]

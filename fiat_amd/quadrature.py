@@ -131,8 +131,13 @@ class FacetQuadratureRule(QuadratureRule):
         verts = ref_el.get_vertices_of_subcomplex(ref_el.get_topology()[entity_dim][entity_id])
         facet = reference_element.UFCSimplex(facet.get_shape(), verts, facet.get_topology()) \
             if entity_dim > 0 else facet
-        pts, wts, J = map_quadrature(Q_ref.get_points(), Q_ref.get_weights(), Q_ref.ref_el, facet,
-                                     jacobian=True, avg=avg)
+        if entity_dim == 0:     # a vertex: the one-point rule sits at the vertex's coordinates in the cell (no Jacobian to speak of)
+            wts = tuple(float(w) for w in Q_ref.get_weights())
+            pts = (tuple(float(c) for c in verts[0]),) * len(wts)
+            J = numpy.zeros((len(verts[0]), 0))
+        else:
+            pts, wts, J = map_quadrature(Q_ref.get_points(), Q_ref.get_weights(), Q_ref.ref_el, facet,
+                                         jacobian=True, avg=avg)
         super().__init__(facet, pts, wts)
         self._J = J
         self._reference_rule = Q_ref

@@ -9,7 +9,9 @@ recipes.  This script runs those recipes on the *unmodified reference* in the bu
 * ``jet_tet``: TetrahedronExpansionSet.tabulate_jet(1, lattice 2, order 2)                               (:149-166)
 * ``quad_<family>_<dim>_<degree>_<alpha>``: element.tabulate(3, make_quadrature(simplex, 3) points) for the (family, dim,
   degree) rows of the parametrisation (:200-272) whose family is in scope; "point" variant for Regge / HHJ
-  as there (:283-284).
+  as there (:283-284);
+* ``ptcell_*`` (not from the regression suite): Raviart-Thomas on the interval (degrees 1-3, three variants) with first
+  derivatives, and DG of degree 0 on a point -- the elements of test_fiat.py's nodality list that need polynomials on a POINT cell.
 Plain numbers only."""
 import os
 
@@ -52,6 +54,18 @@ def main():
         out[key + "_pts"] = np.array(points)
         for alpha, v in table.items():
             out[key + "_" + "".join(map(str, alpha))] = np.asarray(v)
+    # (not part of the regression suite: the elements over POINT cells of test_fiat.py's nodality list, tabulated)
+    import FIAT
+    I = ufc_simplex(1)
+    ipts = np.array([[0.0], [0.3], [0.5], [0.77], [1.0]])
+    out["ptcell_pts"] = ipts
+    for k in (1, 2, 3):
+        for variant in ("integral", "integral(1)", "point"):
+            el = FIAT.RaviartThomas(I, k, variant=variant)
+            tab = el.tabulate(1, ipts)
+            out[f"ptcell_rt{k}_{variant}_0"], out[f"ptcell_rt{k}_{variant}_1"] = np.asarray(tab[(0,)]), np.asarray(tab[(1,)])
+    dg = FIAT.DiscontinuousLagrange(ufc_simplex(0), 0)
+    out["ptcell_dg0"] = np.asarray(dg.tabulate(0, [()])[()])
     path = os.path.join(HERE, "regression.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path)} bytes")

@@ -336,25 +336,15 @@ NODAL = [
     ]
 
 
-def _not_served(element):
-    """Rows of the list this facade refuses, loudly: expansion sets on a POINT cell (DG on a point; Raviart-Thomas on the
-    interval, whose facets are points)."""
-    return (element.startswith("RaviartThomas(I,") and "point" not in element) or element == "DiscontinuousLagrange(P, 0)"
-
-
 @pytest.mark.parametrize("element", NODAL)
 def test_nodality_of_every_in_scope_element_of_the_reference_test(fa, element):
     """test/FIAT/unit/test_fiat.py:446-470 on the device: the element's dual basis applied to its nodal basis (Riesz
     representations against expansion coefficients) is the identity, and the nodal basis lives on a cell at least as fine as
-    the dual set's.  176 of the 183 in-scope rows; the other 7 must fail with ValueError / NotImplementedError (_not_served)."""
+    the dual set's.  All 183 in-scope rows, incl. DG on a point and Raviart-Thomas on the interval (polynomials on POINT cells are host arithmetic)."""
     from fiat_amd import (BrezziDouglasMarini, CubicHermite, DiscontinuousLagrange, GaussLegendre, GaussLobattoLegendre,  # noqa: F401
                           GopalakrishnanLedererSchoberlSecondKind, HellanHerrmannJohnson, Lagrange, Morley, Nedelec,
                           NedelecSecondKind, P0, RaviartThomas, Regge)
     P, I, T, S = fa.ufc_simplex(0), fa.UFCInterval(), fa.UFCTriangle(), fa.UFCTetrahedron()  # noqa: F841
-    if _not_served(element):
-        with pytest.raises((ValueError, NotImplementedError)):
-            eval(element)
-        return
     element = eval(element)
     poly_set = element.get_nodal_basis()
     dual_set = element.get_dual_set()

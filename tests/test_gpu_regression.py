@@ -79,3 +79,22 @@ def test_quadrature(golden, family, dim, degree):
         worst = max(worst, err)
         assert (abs(table[alpha] - ref) < 1e-8).all()           # the suite's own criterion
     assert worst <= 1e-10, worst
+
+
+def test_elements_over_point_cells(golden):
+    """Raviart-Thomas on the interval (its facets are points: FIAT/expansions.py:638-649 serves the constant on a POINT cell)
+    and DG of degree 0 on a point, the rows of test_fiat.py's nodality list that need them: values and first derivatives
+    equal the reference's."""
+    import fiat_amd
+    g = golden("regression")
+    I = fiat_amd.ufc_simplex(1)
+    for k in (1, 2, 3):
+        for variant in ("integral", "integral(1)", "point"):
+            el = fiat_amd.RaviartThomas(I, k, variant=variant)
+            tab = el.tabulate(1, g["ptcell_pts"])
+            for a, key in (((0,), "0"), ((1,), "1")):
+                ref = g[f"ptcell_rt{k}_{variant}_{key}"]
+                assert tab[a].shape == ref.shape
+                assert np.abs(tab[a] - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), (k, variant, a)
+    dg = fiat_amd.DiscontinuousLagrange(fiat_amd.ufc_simplex(0), 0)
+    assert np.allclose(dg.tabulate(0, [()])[()], g["ptcell_dg0"])
