@@ -439,3 +439,22 @@ def test_facet_support_dofs_prism_known_answers(fa, base, extr, horiz, vert):
                                          getattr(fiat_amd, extr[0])(fiat_amd.ufc_simplex(1), extr[1]))
     assert entity_support_dofs(elem, (2, 0)) == horiz
     assert entity_support_dofs(elem, (1, 1)) == vert
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+@pytest.mark.parametrize("degree", [1, 2])
+def test_cellwise_constant_as_in_the_reference_test(fa, dim, degree):
+    """test/finat/test_point_evaluation.py:15-27: for Lagrange of degree 1 and 2 on the interval, triangle and tetrahedron,
+    derivative tables of order < degree depend on the point (there: carry the point's free index), those of order >= degree
+    do not (no free index: stored once per cell, or zero) -- at 17 points, orders up to 2, on the device."""
+    fiat_amd, adapter = fa
+    element = adapter.FiatElement(fiat_amd.Lagrange(fiat_amd.ufc_simplex(dim), degree))
+    rng = np.random.default_rng(dim + degree)
+    e = rng.exponential(size=(17, dim + 1))
+    ps = adapter.PointSet((e / e.sum(axis=1, keepdims=True))[:, 1:])
+    for alpha, table in element.basis_evaluation(2, ps).items():
+        if sum(alpha) < degree:
+            assert table.kind == adapter.POINTWISE and table.array.shape[-1] == 17
+        else:
+            assert table.kind in (adapter.CELLWISE_CONSTANT, adapter.ZERO)
+            assert table.array.shape == (element.space_dimension(),)
