@@ -1817,9 +1817,32 @@ bool launch_shared_reg_sliced(int units, const fxk::SharedArgs& sa, int grid, hi
     return false;
 }
 
+#ifndef FX_SHARED_FLAT_MAX
+#define FX_SHARED_FLAT_MAX 12   // doubles of tables per request up to which the flat small-request kernel takes the launch (odd tables: 32)
+#endif
+static inline bool noflat_shared(unsigned policy) { return (policy & FX_POLICY_NO_SHARED_REG) != 0 && (policy & FX_POLICY_NO_SHARED_WAVE) != 0; }
+
 template <int SD>
 int launch_shared(int order, const fxk::SharedArgs& sa, int grid, hipStream_t s, unsigned policy) {
     const int table = sa.rows * sa.npts;
+    // tiny requests (<= FX_SHARED_FLAT_MAX doubles of tables): a wave per 64 requests, flat contiguous output
+    {
+        const long long total = (long long)fx::binom(SD + order, SD) * table;
+        // (tools/coverage_map_cells.py, flat kernel for <= 64 doubles against the kernels below: P0 / DG0 with derivatives 4-15 ->
+        // 20-64 % of the HBM peak, P1 triangles at 3 points 30-32 -> 36-57 %; but P1 tetrahedra at 4 points 50-55 -> 30-43 % and
+        // P2 triangles 52 -> 41 %: those keep the wave / register-resident kernels)
+        if (!noflat_shared(policy) && (total <= FX_SHARED_FLAT_MAX || ((table & 1) && total <= 32)) && (sa.kind == 0 || sa.vdim == SD)) {
+            const long long teams = (sa.nreq + 63) / 64;
+            const int fgrid = (int)std::max<long long>(1, std::min<long long>((teams + 3) / 4, (long long)grid));
+            switch (order) {
+                case 0: hipLaunchKernelGGL((fxk::shared_points_flat_kernel<SD, 0>), dim3(fgrid), dim3(256), 0, s, sa); break;
+                case 1: hipLaunchKernelGGL((fxk::shared_points_flat_kernel<SD, 1>), dim3(fgrid), dim3(256), 0, s, sa); break;
+                default: hipLaunchKernelGGL((fxk::shared_points_flat_kernel<SD, 2>), dim3(fgrid), dim3(256), 0, s, sa); break;
+            }
+            HIP_TRY(hipGetLastError());
+            return FX_OK;
+        }
+    }
     // small affine requests, order <= 1: one wave per request, line-aligned 1 KB stores
     const bool nowave = (policy & FX_POLICY_NO_SHARED_WAVE) != 0;
     if (!nowave && sa.kind == 0 && order == 1 && (table & 1) == 0) {

@@ -107,6 +107,117 @@ template <int SD, int ORDER> __global__ __launch_bounds__(256) void shared_point
     }
 }
 
+// Tiny requests (a few doubles to ~2 KB of tables per request: P0 / P1 / DG1, N1 / RT1 at their small rules): the kernels below
+// spend a workgroup pass (or a wave) per request and ran at 4-27 % of the HBM peak there (tools/coverage_map_cells.py).  Here a
+// wave takes 64 requests at a time: lane r builds K (and the Piola matrix) of request r into LDS, then the lanes walk the
+// CONTIGUOUS output of the 64 requests, lane <-> consecutive doubles -- request, table and position by two divisions, the
+// (at most 10) reference values of a position through L1 -- so that every store instruction writes 512 consecutive bytes.
+template <int SD, int ORDER> __global__ __launch_bounds__(256) void shared_points_flat_kernel(const SharedArgs a) {
+    constexpr int NTAB = NTab<SD, ORDER>::value;
+    constexpr int NH = SD * (SD + 1) / 2;
+    __shared__ double sK[4][64][SD * SD], sP[4][64][SD * SD];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int table = a.rows * a.npts;
+    const int total = NTAB * table;
+    const float rtotal = 1.0f / (float)total, rtable = 1.0f / (float)table, rnpts = 1.0f / (float)a.npts;
+    const bool piola = a.kind != 0 && a.vdim == SD;
+    for (long long base = ((long long)blockIdx.x * 4 + wave) * 64; base < a.nreq; base += (long long)gridDim.x * 4 * 64) {
+        {
+            const long long rq = min(base + lane, a.nreq - 1);
+            double A[SD][SD], b[SD], K[SD][SD];
+            cell_map<SD>(a.verts + (size_t)rq * (SD + 1) * SD, A, b);
+#pragma unroll
+            for (int c = 0; c < SD; ++c)
+#pragma unroll
+                for (int d = 0; d < SD; ++d) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < SD; ++k) t += a.A0inv[c * SD + k] * A[k][d];
+                    K[c][d] = t;
+                    sK[wave][lane][c * SD + d] = t;
+                }
+#pragma unroll
+            for (int c = 0; c < SD; ++c)
+#pragma unroll
+                for (int e = 0; e < SD; ++e) {
+                    double v = c == e ? 1.0 : 0.0;
+                    if (a.kind == 1) v = K[e][c];
+                    if (a.kind == 2) {
+                        if constexpr (SD == 2) v = (c == e ? K[1 - c][1 - e] : -K[c][e]);
+                        else if constexpr (SD == 3) {
+                            constexpr int nx[3] = {1, 2, 0}, nn[3] = {2, 0, 1};
+                            v = K[nx[e]][nx[c]] * K[nn[e]][nn[c]] - K[nx[e]][nn[c]] * K[nn[e]][nx[c]];
+                        } else v = 1.0;
+                    }
+                    sP[wave][lane][c * SD + e] = v;
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        const int nblk = (int)min(64LL, a.nreq - base);
+        double* o = a.out + (size_t)base * total;
+        for (int pos = lane; pos < nblk * total; pos += 64) {
+            int rq = (int)((float)pos * rtotal);          // (exact after one correction step: pos < 64 * 4096)
+            rq -= (rq * total > pos);
+            rq += ((rq + 1) * total <= pos);
+            const int e = pos - rq * total;
+            int t = (int)((float)e * rtable);
+            t -= (t * table > e);
+            t += ((t + 1) * table <= e);
+            const int rem = e - t * table;
+            const double* K = sK[wave][rq];
+            // source tables of output table t and their weights: values <- values; gradient d <- column d of K;
+            // Hessian (d, e) <- K (x) K symmetrised (mis() order)
+            int s0 = 0, ns = 1;
+            if (t >= 1 && t <= SD) s0 = 1, ns = SD;
+            if (t > SD) s0 = 1 + SD, ns = NH;
+            int hd = 0, he = 0;   // (d, e) of Hessian table t
+            if constexpr (ORDER >= 2) {
+                if (t > SD) {
+                    int q = t - 1 - SD;
+                    while (q >= SD - hd) q -= SD - hd, ++hd;
+                    he = hd + q;
+                }
+            }
+            int row = 0, p = rem, dof = 0, cmp = 0;
+            if (piola) {
+                row = (int)((float)rem * rnpts);
+                row -= (row * a.npts > rem);
+                row += ((row + 1) * a.npts <= rem);
+                p = rem - row * a.npts;
+                dof = row / SD;
+                cmp = row - dof * SD;
+            }
+            double acc = 0.0;
+            int hc = 0, c1 = 0, c2 = 0;   // running (c, c') of the Hessian source tables
+            for (int sidx = 0; sidx < ns; ++sidx) {
+                double ws = 1.0;
+                if (t >= 1 && t <= SD) ws = K[sidx * SD + (t - 1)];
+                if constexpr (ORDER >= 2) {
+                    if (t > SD) {
+                        ws = c1 == c2 ? K[c1 * SD + hd] * K[c1 * SD + he] : K[c1 * SD + hd] * K[c2 * SD + he] + K[c2 * SD + hd] * K[c1 * SD + he];
+                        if (++c2 == SD) ++c1, c2 = c1;
+                    }
+                }
+                double v;
+                if (piola) {
+                    v = 0.0;
+                    for (int q = 0; q < SD; ++q) v += sP[wave][rq][cmp * SD + q] * a.ref[(size_t)(s0 + sidx) * table + (dof * SD + q) * a.npts + p];
+                } else {
+                    v = a.ref[(size_t)(s0 + sidx) * table + rem];
+                }
+                acc += ws * v;
+            }
+            (void)hc;
+            o[pos] = acc;   // (plain: consecutive lanes, consecutive doubles; the blocks of neighbouring waves share lines)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Register-resident version: every thread of the (persistent) workgroup owns NP fixed pairs of
 // consecutive output positions of a table and keeps the reference values of all source tables for
 // them in registers (for Piola maps: of the SD components of the dof each position belongs to).

@@ -758,7 +758,6 @@ __global__ __launch_bounds__(256, WPS) void tabulate_simplex_stacked(const Stack
             auto mix_stage = [&](v4d (&cur)[CT], int q, int slot, int prev_rowbase, const double (&af)[KS], double (&an)[KS], auto flush) {
                 // (uniform tile base + 32-bit lane offset: scalar-base addressing; per-lane 64-bit pointers for the four
                 // stages of a dof tile get strength-reduced into ~50 registers of induction variables and spill)
-                const double* anp = a.afrag + (size_t)(q + 1) * KS * 64;  // (the buffer ends with a zero tile)
 #pragma unroll
                 for (int c = 0; c < CT; ++c) cur[c] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
