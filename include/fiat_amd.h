@@ -135,7 +135,9 @@ int fx_vandermonde_solve_batch(fx_ctx* ctx, int64_t nsys, int ndof, int m,
 
 /* ---- 1-D Lagrange by barycentric interpolation and tensor products -----------
  * LagrangeLineExpansionSet / barycentric_interpolation / make_dmat
- * (barycentric_interpolation.py:22-93).  nodes: host [nn]. */
+ * (barycentric_interpolation.py:22-93).  nodes: host [nn], 1 <= nn <= 256 (FX_ENOTIMPL beyond); the tensor-product and
+ * prism entries below take factors of up to 16 nodes (their kernels keep a factor's basis in registers) and return
+ * FX_ENOTIMPL for more -- fx_line_tabulate_batch serves any element this call creates. */
 int fx_line_element_create(fx_ctx* ctx, int nn, const double* nodes, fx_line_element** elem);
 int fx_line_element_destroy(fx_line_element* elem);
 
