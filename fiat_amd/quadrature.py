@@ -224,6 +224,8 @@ def create_quadrature(ref_el, degree, scheme="default", entity=None):
         degrees = tuple(degree) if numpy.ndim(degree) else (degree,) * len(ref_el.cells)
         assert len(degrees) == len(ref_el.cells)
         return make_tensor_product_quadrature(*(create_quadrature(c, d, scheme) for c, d in zip(ref_el.cells, degrees)))
+    if isinstance(ref_el, reference_element.Hypercube):     # the rule of the product of intervals it flattens
+        return create_quadrature(ref_el.product, degree, scheme)
     if degree < 0:
         raise ValueError("Need positive degree, not %d" % degree)
     if scheme == "KMV":

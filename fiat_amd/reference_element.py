@@ -509,6 +509,10 @@ def physical_simplex(vertices):
     return UFCSimplex(_SHAPES[sd], vertices, _UFC_TOPOLOGY[sd])
 
 
+def _dimension_sum(d):
+    return sum(_dimension_sum(x) for x in d) if isinstance(d, tuple) else d
+
+
 class TensorProductCell(Cell):
     """Product of cells -- intervals (quadrilateral, hexahedron), triangle x interval (prism), or products of
     products: ``cells`` are kept as given, so a nested element (A x B) x C lives on a nested cell whose entity
@@ -556,6 +560,44 @@ class TensorProductCell(Cell):
         """Product of the factors' volumes (FIAT/reference_element.py:1247-1249)."""
         return float(numpy.prod([c.volume() for c in self.cells]))
 
+    def _factor_entities(self, dims, entity):
+        """Entity ``entity`` of dimension tuple ``dims`` = the product of these entities of the factors (row-major numbering)."""
+        counts = tuple(len(c.get_topology()[d]) for c, d in zip(self.cells, dims))
+        return tuple(int(i) for i in numpy.unravel_index(entity, counts))
+
+    def get_entity_transform(self, dims, entity):
+        """Coordinates on the reference sub-entity of dimensions ``dims`` (the factors' sub-entity coordinates, concatenated)
+        -> coordinates in the cell: every factor's own transform on its slice (FIAT/reference_element.py:1221-1245)."""
+        picks = self._factor_entities(dims, entity)
+        parts = [c.get_entity_transform(d, e) for c, d, e in zip(self.cells, dims, picks)]
+        widths = [_dimension_sum(d) for d in dims]
+
+        def transform(point):
+            point = numpy.asarray(point, dtype=float)
+            out, start = [], 0
+            for t, w, c in zip(parts, widths, self.cells):
+                piece = point[..., start:start + w]
+                if w == 0:   # a vertex of this factor: its coordinates, once per point
+                    v = numpy.asarray(t(numpy.zeros((1, 0)))).reshape(-1)
+                    piece = numpy.broadcast_to(v, point.shape[:-1] + v.shape)
+                else:
+                    piece = t(piece)
+                out.append(piece)
+                start += w
+            return numpy.concatenate(out, axis=-1)
+        return transform
+
+    def compute_reference_normal(self, facet_dim, facet_i):
+        """Unit normal (infinity norm) of a facet: the normal of the one factor whose entity is a facet of it, the other
+        factors contribute zeros (FIAT/reference_element.py:1251-1264)."""
+        picks = self._factor_entities(facet_dim, facet_i)
+        out = []
+        for c, d, e in zip(self.cells, facet_dim, picks):
+            sd = c.get_spatial_dimension()
+            out.append(numpy.asarray(c.compute_reference_normal(d, e), dtype=float) if _dimension_sum(d) == sd - 1
+                       else numpy.zeros(sd))
+        return numpy.concatenate(out)
+
     def distance_to_point_l1(self, point, rescale=False):
         """Sum of the factors' distances to their slices of the point (FIAT/reference_element.py:1291-1301)."""
         point = numpy.asarray(point, dtype=float)
@@ -585,3 +627,150 @@ class TensorProductCell(Cell):
 
     def __hash__(self):
         return hash(("TensorProductCell", self.cells))
+
+
+class Hypercube(Cell):
+    """A product of intervals seen as ONE cell: the entities of the product whose dimension tuples sum to d, taken in the
+    sorted order of those tuples and then by number, are the entities 0, 1, ... of dimension d (FIAT/reference_element.py:
+    1420-1534, flatten_entities :1830-1839, compute_unflattening_map :1854-1866)."""
+
+    def __init__(self, dimension, product):
+        self.dimension = dimension
+        self.product = product
+        self.unflattening_map = {}
+        topology, counters = {}, {}
+        ptop = product.get_topology()
+        for dims in sorted(ptop):
+            flat = _dimension_sum(dims)
+            for number in sorted(ptop[dims]):
+                i = counters.get(flat, 0)
+                counters[flat] = i + 1
+                topology.setdefault(flat, {})[i] = ptop[dims][number]
+                self.unflattening_map[(flat, i)] = (dims, number)
+        super().__init__({2: QUADRILATERAL, 3: HEXAHEDRON}[dimension], product.get_vertices(), topology)
+
+    def get_dimension(self):
+        return self.get_spatial_dimension()
+
+    def construct_subelement(self, dimension):
+        sd = self.get_spatial_dimension()
+        if dimension > sd:
+            raise ValueError(f"Invalid dimension: {(dimension,)}")
+        if dimension == sd:
+            return self
+        return flatten_reference_cube(self.product.construct_subelement((dimension,) + (0,) * (len(self.product.cells) - 1)))
+
+    def get_entity_transform(self, dim, entity_i):
+        return self.product.get_entity_transform(*self.unflattening_map[(dim, entity_i)])
+
+    def volume(self):
+        return self.product.volume()
+
+    def compute_reference_normal(self, facet_dim, facet_i):
+        assert facet_dim == self.get_spatial_dimension() - 1
+        return self.product.compute_reference_normal(*self.unflattening_map[(facet_dim, facet_i)])
+
+    def contains_point(self, point, epsilon=0):
+        return self.product.contains_point(point, epsilon=epsilon)
+
+    def distance_to_point_l1(self, point, rescale=False):
+        return self.product.distance_to_point_l1(point, rescale=rescale)
+
+    def flat_cells(self):
+        return self.product.flat_cells()
+
+    def __gt__(self, other):
+        return self.product > other
+
+    def __lt__(self, other):
+        return self.product < other
+
+    def __ge__(self, other):
+        return self.product >= other
+
+    def __le__(self, other):
+        return self.product <= other
+
+    def __hash__(self):
+        return hash((type(self).__name__, self.shape, self.vertices))
+
+
+class UFCHypercube(Hypercube):
+    """[0, 1]^d, vertices in lexicographic order (FIAT/reference_element.py:1536-1560)."""
+
+    def __init__(self, dim):
+        super().__init__(dim, TensorProductCell(*[ufc_simplex(1)] * dim))
+
+    def construct_subelement(self, dimension):
+        sd = self.get_spatial_dimension()
+        if dimension > sd:
+            raise ValueError(f"Invalid dimension: {dimension}")
+        return self if dimension == sd else ufc_hypercube(dimension)
+
+
+class UFCQuadrilateral(UFCHypercube):
+    def __init__(self):
+        super().__init__(2)
+
+
+class UFCHexahedron(UFCHypercube):
+    def __init__(self):
+        super().__init__(3)
+
+
+def ufc_hypercube(spatial_dim):
+    """Point, UFC interval, quadrilateral or hexahedron (FIAT/reference_element.py:1657-1677)."""
+    if spatial_dim == 0:
+        return Point()
+    if spatial_dim == 1:
+        return ufc_simplex(1)
+    if spatial_dim == 2:
+        return UFCQuadrilateral()
+    if spatial_dim == 3:
+        return UFCHexahedron()
+    raise RuntimeError(f"Can't create UFC hypercube of dimension {spatial_dim}.")
+
+
+def is_ufc(cell):
+    """FIAT/reference_element.py:1778-1787."""
+    if isinstance(cell, (Point, UFCSimplex, UFCHypercube)) and not isinstance(cell, SymmetricSimplex):
+        return type(cell).__name__ != "UFCSimplex" or numpy.allclose(cell.get_vertices(), ufc_simplex(cell.get_spatial_dimension()).get_vertices())
+    if isinstance(cell, TensorProductCell):
+        return all(is_ufc(c) for c in cell.cells)
+    return False
+
+
+def is_hypercube(cell):
+    """FIAT/reference_element.py:1790-1799: hypercubes, intervals, and products of them."""
+    if isinstance(cell, Hypercube) or (isinstance(cell, Simplex) and cell.get_shape() == LINE and not cell.is_macrocell()):
+        return True
+    if isinstance(cell, TensorProductCell):
+        return all(is_hypercube(c) for c in cell.cells)
+    return False
+
+
+def flatten_reference_cube(ref_el):
+    """A product of intervals (or of hypercubes and intervals) as the hypercube of its dimension; points, intervals and
+    hypercubes as they are (FIAT/reference_element.py:1812-1827)."""
+    if ref_el.get_spatial_dimension() <= 1:
+        return ref_el
+    if isinstance(ref_el, TensorProductCell):
+        if is_ufc(ref_el):
+            return ufc_hypercube(ref_el.get_spatial_dimension())
+        return Hypercube(ref_el.get_spatial_dimension(), ref_el)
+    if is_hypercube(ref_el):
+        return ref_el
+    raise TypeError("Can't flatten cell of type %s" % type(ref_el).__name__)
+
+
+def ufc_cell(cell):
+    """Reference cell of a cell name ("interval", "triangle", ..., "quadrilateral", "a * b") or of an object with a
+    ``cellname`` (FIAT/reference_element.py:1730-1755)."""
+    celltype = cell if isinstance(cell, str) else cell.cellname
+    if " * " in celltype:
+        return TensorProductCell(*(ufc_cell(c) for c in celltype.split(" * ")))
+    names = {"vertex": lambda: ufc_simplex(0), "interval": lambda: ufc_simplex(1), "triangle": lambda: ufc_simplex(2),
+             "tetrahedron": lambda: ufc_simplex(3), "quadrilateral": lambda: ufc_hypercube(2), "hexahedron": lambda: ufc_hypercube(3)}
+    if celltype not in names:
+        raise RuntimeError(f"Don't know how to create UFC cell of type {str(celltype)}")
+    return names[celltype]()

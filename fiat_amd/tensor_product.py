@@ -208,11 +208,16 @@ class FlattenedDimensions:
     total dimension (FIAT/tensor_product.py:363-434)."""
 
     def __init__(self, element):
+        from .reference_element import UFCHexahedron, UFCQuadrilateral
         self.element = element
-        self.ref_el = element.get_reference_element()
-        if self.ref_el.get_spatial_dimension() not in (2, 3):
-            raise ValueError("Illegal element dimension %s" % self.ref_el.get_spatial_dimension())
-        self.unflattening_map = flat_entity_map(self.ref_el)
+        product = element.get_reference_element()
+        dim = product.get_spatial_dimension()
+        if dim not in (2, 3):
+            raise ValueError("Illegal element dimension %s" % dim)
+        # the element lives on the UFC quadrilateral / hexahedron (FIAT/tensor_product.py:373-381); tabulation goes through
+        # the product element with the entity numbers mapped back
+        self.ref_el = UFCQuadrilateral() if dim == 2 else UFCHexahedron()
+        self.unflattening_map = flat_entity_map(product)
 
     def get_reference_element(self):
         return self.ref_el

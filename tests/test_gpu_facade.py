@@ -220,12 +220,16 @@ def test_flattened_dimensions_equal_the_product_element(fa):
     P1 = fa.Lagrange(I, 1)
     quad = fa.TensorProductElement(P1, P1)
     flat_quad = fa.FlattenedDimensions(quad)
+    from fiat_amd.reference_element import UFCHexahedron, UFCQuadrilateral
+    assert isinstance(flat_quad.get_reference_element(), UFCQuadrilateral)      # (FIAT/tensor_product.py:373-381)
     assert quad.value_shape() == ()
     t, f = quad.tabulate(1, [(0.1, 0.2)]), flat_quad.tabulate(1, [(0.1, 0.2)])
     for dc in [(0, 0), (1, 0), (0, 1)]:
         assert np.allclose(t[dc], f[dc], rtol=1e-5, atol=1e-8) and t[dc].shape[0] == 4
     hexa = fa.TensorProductElement(quad, P1)
     flat_hex = fa.FlattenedDimensions(fa.TensorProductElement(flat_quad, P1))
+    assert isinstance(flat_hex.get_reference_element(), UFCHexahedron)
+    assert {d: len(e) for d, e in flat_hex.entity_dofs().items()} == {0: 8, 1: 12, 2: 6, 3: 1}
     t, f = hexa.tabulate(1, [(0.1, 0.2, 0.3)]), flat_hex.tabulate(1, [(0.1, 0.2, 0.3)])
     for dd in [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)]:
         assert np.allclose(t[dd], f[dd], rtol=1e-5, atol=1e-8) and t[dd].shape[0] == 8

@@ -223,9 +223,14 @@ def test_symmetric_simplex_and_gll_line_rule():
 def _cells():
     from fiat_amd import reference_element as re
     I, T, S = re.ufc_simplex(1), re.ufc_simplex(2), re.ufc_simplex(3)
-    return {"interval": I, "triangle": T, "tetrahedron": S, "interval_x_interval": re.TensorProductCell(I, I),
-            "triangle_x_interval": re.TensorProductCell(T, I),
-            "quadrilateral_x_interval": re.TensorProductCell(re.TensorProductCell(I, I), I)}
+    Q, H = re.UFCQuadrilateral(), re.UFCHexahedron()
+    DI = re.default_simplex(1)
+    DII = re.TensorProductCell(DI, DI)
+    return {"interval": I, "triangle": T, "tetrahedron": S, "quadrilateral": Q, "hexahedron": H,
+            "interval_x_interval": re.TensorProductCell(I, I), "triangle_x_interval": re.TensorProductCell(T, I),
+            "quadrilateral_x_interval": re.TensorProductCell(Q, I),
+            "default_interval": DI, "default_triangle": re.default_simplex(2), "default_tetrahedron": re.default_simplex(3),
+            "default_interval_x_interval": DII, "default_hypercube": re.Hypercube(2, DII)}
 
 
 # (cell, point, epsilon, expected) and (cell, point, distance): the reference's own known answers
@@ -248,6 +253,15 @@ def _contains_cases():
         out += [("tetrahedron", p, 1e-11, True), ("tetrahedron", p, 1e-13, False)]
     out += [("tetrahedron", [0.5 + e, 0.5, 0.5], 1e-13, False), ("tetrahedron", [0.5, 0.5 + e, 0.5], 1e-13, False),
             ("tetrahedron", [0.5, 0.5, 0.5 + e], 1e-13, False)]
+    out += [("quadrilateral", [0.5, 0.5], 0.0, True), ("hexahedron", [0.5, 0.5, 0.5], 0.0, True)]
+    for p in ([0.0, 0.0], [1.0, 0.0], [0.0, 1.0], [1.0, 1.0]):
+        out += [("quadrilateral", p, 1e-14, True)]
+    for p in ([-e, 0.5], [1 + e, 0.5], [0.5, -e], [0.5, 1 + e]):
+        out += [("quadrilateral", p, 1e-11, True), ("quadrilateral", p, 1e-13, False)]
+    for p in ([0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [1.0, 1.0, 0.0], [1.0, 0.0, 1.0], [0.0, 1.0, 1.0], [1.0, 1.0, 1.0]):
+        out += [("hexahedron", p, 1e-14, True)]
+    for p in ([-e, 0.5, 0.5], [0.5, -e, 0.5], [0.5, 0.5, -e], [1 + e, 0.5, 0.5], [0.5, 1 + e, 0.5], [0.5, 0.5, 1 + e]):
+        out += [("hexahedron", p, 1e-11, True), ("hexahedron", p, 1e-13, False)]
     out += [("interval_x_interval", [0.5, 0.5], 0.0, True)]
     for p in ([0.0, 0.0], [1.0, 0.0], [0.0, 1.0], [1.0, 1.0]):
         out += [("interval_x_interval", p, 1e-14, True)]
@@ -290,14 +304,50 @@ def test_volumes_and_reference_normals_known_answers():
     facet normals of the UFC interval / triangle / tetrahedron as listed there."""
     from fiat_amd import reference_element as re
     cells = _cells()
-    for name, vol in (("interval", 1), ("triangle", 1 / 2), ("tetrahedron", 1 / 6), ("interval_x_interval", 1),
-                      ("triangle_x_interval", 1 / 2), ("quadrilateral_x_interval", 1)):
+    for name, vol in (("interval", 1), ("triangle", 1 / 2), ("quadrilateral", 1), ("tetrahedron", 1 / 6), ("interval_x_interval", 1),
+                      ("triangle_x_interval", 1 / 2), ("quadrilateral_x_interval", 1), ("hexahedron", 1)):
         assert np.allclose(vol, cells[name].volume()), name
     assert np.allclose(1, re.Point().volume())
     normals = {"interval": [[-1], [1]], "triangle": [[1, 1], [-1, 0], [0, -1]],
-               "tetrahedron": [[1, 1, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1]]}
+               "quadrilateral": [[-1, 0], [1, 0], [0, -1], [0, 1]],
+               "tetrahedron": [[1, 1, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1]],
+               "hexahedron": [[-1, 0, 0], [1, 0, 0], [0, -1, 0], [0, 1, 0], [0, 0, -1], [0, 0, 1]]}
     for name, ns in normals.items():
         cell = cells[name]
         facet_dim = cell.get_spatial_dimension() - 1
         for facet_number in range(len(cell.get_topology()[facet_dim])):
             assert np.allclose(ns[facet_number], cell.compute_reference_normal(facet_dim, facet_number)), (name, facet_number)
+
+
+def test_product_cell_normals_ufc_and_hypercube_status_known_answers():
+    """test/FIAT/unit/test_reference_element.py:134-157 (horizontal and vertical facet normals of the extruded cells),
+    :405-463 (is_ufc, is_hypercube, flattening keeps the UFC status) with the cells listed there."""
+    from fiat_amd import reference_element as re
+    cells = _cells()
+    for name in ("interval_x_interval", "triangle_x_interval", "quadrilateral_x_interval"):
+        cell = cells[name]
+        dim = cell.get_spatial_dimension()
+        assert np.allclose((0,) * (dim - 1) + (-1,), cell.compute_reference_normal((dim - 1, 0), 0))   # bottom facet
+        assert np.allclose((0,) * (dim - 1) + (1,), cell.compute_reference_normal((dim - 1, 0), 1))    # top facet
+    vert = {"interval_x_interval": [[-1, 0], [1, 0]], "triangle_x_interval": [[1, 1, 0], [-1, 0, 0], [0, -1, 0]],
+            "quadrilateral_x_interval": [[-1, 0, 0], [1, 0, 0], [0, -1, 0], [0, 1, 0]]}
+    for name, ns in vert.items():
+        cell = cells[name]
+        vert_dim = (cell.get_spatial_dimension() - 2, 1)
+        for facet_number in range(len(cell.get_topology()[vert_dim])):
+            assert np.allclose(ns[facet_number], cell.compute_reference_normal(vert_dim, facet_number)), (name, facet_number)
+    ufc = {"interval": True, "triangle": True, "quadrilateral": True, "tetrahedron": True, "interval_x_interval": True,
+           "triangle_x_interval": True, "quadrilateral_x_interval": True, "hexahedron": True, "default_interval": False,
+           "default_triangle": False, "default_tetrahedron": False, "default_interval_x_interval": False, "default_hypercube": False}
+    hyper = {"interval": True, "triangle": False, "quadrilateral": True, "tetrahedron": False, "interval_x_interval": True,
+             "triangle_x_interval": False, "quadrilateral_x_interval": True, "hexahedron": True, "default_interval": True,
+             "default_triangle": False, "default_tetrahedron": False, "default_interval_x_interval": True, "default_hypercube": True}
+    for name in ufc:
+        assert re.is_ufc(cells[name]) == ufc[name], name
+        assert re.is_hypercube(cells[name]) == hyper[name], name
+    for name in ("interval", "quadrilateral", "interval_x_interval", "quadrilateral_x_interval", "hexahedron",
+                 "default_interval", "default_interval_x_interval", "default_hypercube"):
+        assert re.is_ufc(re.flatten_reference_cube(cells[name])) == re.is_ufc(cells[name]), name
+    assert isinstance(re.ufc_cell("quadrilateral"), re.UFCQuadrilateral) and isinstance(re.ufc_cell("interval * interval"), re.TensorProductCell)
+    with pytest.raises(RuntimeError):
+        re.ufc_cell("pentagon")

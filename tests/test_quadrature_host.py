@@ -135,3 +135,23 @@ def test_quadrature_on_product_cells_as_in_the_reference_tests():
     qa, qb = fiat_amd.create_quadrature(T, 4), fiat_amd.create_quadrature(I, 4)
     q = fiat_amd.create_quadrature(extr_triangle, (4, 4))
     assert len(q.get_points()) == len(qa.get_points()) * len(qb.get_points())
+
+
+def test_quadrature_on_hypercubes_as_in_the_reference_tests():
+    """test/FIAT/unit/test_quadrature.py:143-163: create_quadrature on the UFC quadrilateral / hexahedron integrates
+    (x + y [+ z])^d exactly, d < 8, and on quadrilateral x interval (x + y)^a z^b for a < 5, b < 4."""
+    import fiat_amd
+    from fiat_amd import reference_element as re
+    Q, H = re.UFCQuadrilateral(), re.UFCHexahedron()
+    for degree in range(8):
+        q = fiat_amd.create_quadrature(Q, degree)
+        assert np.allclose(q.integrate(lambda x: sum(x) ** degree), (2 ** (degree + 2) - 2) / ((degree + 1) * (degree + 2)))
+        q = fiat_amd.create_quadrature(H, degree)
+        assert np.allclose(q.integrate(lambda x: sum(x) ** degree),
+                           -3 * (2 ** (degree + 3) - 3 ** (degree + 2) - 1) / ((degree + 1) * (degree + 2) * (degree + 3)))
+    extr = re.TensorProductCell(Q, re.ufc_simplex(1))
+    for basedeg in range(5):
+        for extrdeg in range(4):
+            q = fiat_amd.create_quadrature(extr, (basedeg, extrdeg))
+            assert np.allclose(q.integrate(lambda x: (x[0] + x[1]) ** basedeg * x[2] ** extrdeg),
+                               (2 ** (basedeg + 2) - 2) / ((basedeg + 1) * (basedeg + 2)) * 1 / (extrdeg + 1))
