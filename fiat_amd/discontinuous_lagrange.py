@@ -64,9 +64,8 @@ class DiscontinuousLagrange(finite_element.CiarletElement):
         splitting, lattice_family = parse_lagrange_variant(variant, discontinuous=True)
         if splitting is not None:
             ref_el = splitting(ref_el)
-        on_line = ref_el.get_shape() == LINE
-        if on_line and ref_el.is_macrocell():
-            raise NotImplementedError("macro Lagrange elements on intervals")
+        # (split intervals: the orthonormal set of the split interval instead of the piecewise primal 1-D basis, as in lagrange.py)
+        on_line = ref_el.get_shape() == LINE and not ref_el.is_macrocell()
         layout = BrokenLagrangeDualSet if lattice_family in _BOUNDARY_FAMILIES else DiscontinuousLagrangeDualSet
         dual = layout(ref_el, degree, lattice_family)
         if on_line:

@@ -251,3 +251,20 @@ class ExpansionSet:
 
     def __hash__(self):
         return hash((type(self).__name__, self.ref_el, self.continuity))
+
+
+# The reference's per-cell class names (FIAT/expansions.py:638-716: ExpansionSet.__new__ dispatches on the cell shape; here one
+# class serves every simplex, the named ones check the dimension they are asked for)
+def _dimension_checked(name, dim, what):
+    class _Named(ExpansionSet):
+        def __init__(self, ref_el, **kwargs):
+            if ref_el.get_spatial_dimension() != dim:
+                raise ValueError(f"Must have a {what}")
+            super().__init__(ref_el, **kwargs)
+    _Named.__name__ = _Named.__qualname__ = name
+    return _Named
+
+
+LineExpansionSet = _dimension_checked("LineExpansionSet", 1, "line")
+TriangleExpansionSet = _dimension_checked("TriangleExpansionSet", 2, "triangle")
+TetrahedronExpansionSet = _dimension_checked("TetrahedronExpansionSet", 3, "tetrahedron")

@@ -169,3 +169,19 @@ def polynomial_set_union_normalized(A, B):
     return PolynomialSet(A.get_reference_element(), max(A.get_degree(), B.get_degree()),
                          max(A.get_embedded_degree(), B.get_embedded_degree()),
                          A.get_expansion_set(), coeffs)
+
+
+def make_bubbles(ref_el, degree, codim=0, shape=(), scale="L2 piola"):
+    """The members of the C0 ("bubble") hierarchy of degree <= ``degree`` that belong to the entities of co-dimension ``codim``
+    -- for codim 0 the interior bubbles of the cell -- as a polynomial set, every value component of ``shape`` carrying its own
+    copy (FIAT/polynomial_set.py:285-301; test/FIAT/unit/test_polynomial.py:123-135 checks their duality with the "dual" variant)."""
+    full = ONPolynomialSet(ref_el, degree, shape=shape, scale=scale, variant="bubble")
+    sd = ref_el.get_spatial_dimension()
+    if sd == 0:
+        return full
+    owners = expansions.polynomial_entity_ids(ref_el, degree, continuity="C0")[sd - codim]
+    members = [i for entity in sorted(owners) for i in owners[entity]]
+    if shape != ():
+        per_component = full.get_num_members() // int(numpy.prod(shape, dtype=int))
+        members = [i + c * per_component for i in members for c in range(int(numpy.prod(shape, dtype=int)))]
+    return full.take(members)

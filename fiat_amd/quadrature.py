@@ -93,6 +93,27 @@ class GaussLobattoLegendreQuadratureLineRule(QuadratureRule):
         super().__init__(ref_el, pts, wts)
 
 
+class RadauQuadratureLineRule(QuadratureRule):
+    """m-point Gauss-Radau rule on the interval with the right (default) or left end point as a node, exact to degree 2m - 2
+    (FIAT/quadrature.py:137-168): the interior nodes are Gauss-Jacobi nodes for the weight that vanishes at the fixed end,
+    with that weight divided out of their weights; the end point takes what is left of the interval's length."""
+
+    def __init__(self, ref_el, m, right=True):
+        if m < 1:
+            raise ValueError("Gauss-Radau quadrature invalid for fewer than 1 points")
+        end = 1 if right else 0
+        x0 = tuple(float(c) for c in ref_el.get_vertices()[end])
+        length = ref_el.volume()
+        pts, wts = (), ()
+        if m > 1:
+            inner = GaussJacobiQuadratureLineRule(ref_el, m - 1, end, 1 - end)
+            x = inner.get_points().reshape(-1)
+            wts = tuple(inner.get_weights() / ((2.0 / length) * numpy.abs(x0[0] - x)))
+            pts = tuple(inner.pts)
+        w0 = length - sum(wts)
+        super().__init__(ref_el, (*pts, x0) if right else (x0, *pts), (*wts, w0) if right else (w0, *wts))
+
+
 def _collapsed_rule(dim, m):
     """Product of Gauss-Jacobi(j, 0) rules on the cube mapped by the Duffy
     transformation onto the (-1,1)^dim simplex (Karniadakis & Sherwin)."""

@@ -165,6 +165,27 @@ class Cell:
     def get_shape(self):
         return self.shape
 
+    def get_connectivity(self):
+        """{(d0, d1): [entities of dimension d1 incident to entity 0, 1, ... of dimension d0]}: the sub-entities for d1 < d0,
+        the entities it is a sub-entity of otherwise (itself for d1 == d0), each list sorted by number
+        (FIAT/reference_element.py:166-185, 221-227; known answers for the tetrahedron and hexahedron in
+        test/FIAT/unit/test_reference_element.py:42-57)."""
+        if getattr(self, "_connectivity", None) is None:
+            top = self.get_topology()
+            sets = {d: {e: frozenset(v) for e, v in top[d].items()} for d in top}
+            conn = {}
+            for d0 in sorted(top):
+                for d1 in sorted(top):
+                    rows = []
+                    for e0 in sorted(top[d0]):
+                        if d1 < d0:
+                            rows.append(tuple(e1 for e1 in sorted(top[d1]) if sets[d1][e1] <= sets[d0][e0]))
+                        else:
+                            rows.append(tuple(e1 for e1 in sorted(top[d1]) if sets[d0][e0] <= sets[d1][e1]))
+                    conn[(d0, d1)] = rows
+            self._connectivity = conn
+        return self._connectivity
+
     def get_vertices(self):
         return self.vertices
 
@@ -248,31 +269,39 @@ class Simplex(Cell):
             return 1.0
         return abs(numpy.linalg.det(v[1:] - v[0])) / math.factorial(sd)
 
-    def compute_barycentric_coordinates(self, points, rescale=False):
-        """Barycentric coordinates of points (npts, sd) with respect to the cell's vertices, (npts, sd + 1); ``rescale``:
-        each coordinate times the height of its vertex over the opposite facet, so that it measures a distance
-        (FIAT/reference_element.py:616-644, the single-cell case)."""
+    def compute_barycentric_coordinates(self, points, entity=None, rescale=False):
+        """Barycentric coordinates of points (npts, sd) with respect to the vertices of ``entity`` = (dim, id) -- default: the
+        first cell --, (npts, dim + 1); for an entity of lower dimension: those coordinates of a cell containing it that belong
+        to its vertices.  ``rescale``: each coordinate times the height of its vertex over the opposite facet, so that it
+        measures a distance (FIAT/reference_element.py:616-644)."""
         points = numpy.asarray(points, dtype=float)
         if points.size == 0:
             return points
-        v = numpy.asarray(self.vertices, dtype=float)
         sd = self.get_spatial_dimension()
+        top = self.get_topology()
+        dim, number = (sd, 0) if entity is None else entity
+        cell_vids, keep = top[dim][number], slice(None)
+        if dim != sd:     # a cell that contains the entity; keep the coordinates of the entity's vertices
+            inside = set(cell_vids)
+            cell_vids = next(top[sd][c] for c in sorted(top[sd]) if inside <= set(top[sd][c]))
+            keep = [i for i, v in enumerate(cell_vids) if v in inside]
+        v = numpy.asarray(self.get_vertices_of_subcomplex(cell_vids), dtype=float)
         # lambda = G [x; 1] with G the inverse of the matrix of homogeneous vertex coordinates
-        G = numpy.linalg.inv(numpy.vstack([v.T, numpy.ones(sd + 1)]))
+        G = numpy.linalg.inv(numpy.vstack([v.T, numpy.ones(sd + 1)]))[keep]
         lam = points.reshape(-1, sd) @ G[:, :sd].T + G[:, sd]
         if rescale:
             lam = lam / numpy.linalg.norm(G[:, :sd], axis=1)
-        return lam.reshape(points.shape[:-1] + (sd + 1,))
+        return lam.reshape(points.shape[:-1] + (lam.shape[-1],))
 
-    def distance_to_point_l1(self, points, rescale=False):
-        """0 inside the cell, otherwise minus the sum of the negative barycentric coordinates
+    def distance_to_point_l1(self, points, entity=None, rescale=False):
+        """0 inside the entity (default: the first cell), otherwise minus the sum of the negative barycentric coordinates
         (FIAT/reference_element.py:651-780: the binning criterion of macro elements, here on the host)."""
-        lam = self.compute_barycentric_coordinates(points, rescale=rescale)
+        lam = self.compute_barycentric_coordinates(points, entity=entity, rescale=rescale)
         return numpy.maximum(-lam, 0.0).sum(axis=-1)
 
-    def contains_point(self, point, epsilon=0.0):
+    def contains_point(self, point, epsilon=0.0, entity=None):
         """FIAT/reference_element.py:782-801."""
-        return bool(self.distance_to_point_l1(point) <= epsilon)
+        return bool(self.distance_to_point_l1(point, entity=entity) <= epsilon)
 
     def make_points(self, dim, entity_id, order, variant=None, interior=1):
         """Lattice points in the interior of a sub-entity."""
@@ -358,6 +387,9 @@ class Simplex(Cell):
 
     def construct_subelement(self, dimension):
         raise NotImplementedError
+
+
+ReferenceElement = Simplex     # (the reference's name for "a simplex given by vertices and topology", FIAT/reference_element.py:930)
 
 
 class UFCSimplex(Simplex):

@@ -84,6 +84,16 @@ class TensorProductElement:
     def get_coeffs(self):
         raise NotImplementedError("get_coeffs not implemented")
 
+    # a product element has no polynomial set of its own (FIAT/tensor_product.py:221-229, 349-356)
+    def get_nodal_basis(self):
+        raise NotImplementedError("get_nodal_basis not implemented")
+
+    def dmats(self):
+        raise NotImplementedError("dmats not implemented")
+
+    def get_num_members(self, arg):
+        raise NotImplementedError("get_num_members not implemented")
+
     def is_nodal(self):
         """Nodal iff both factors are (FIAT/tensor_product.py:357-360)."""
         return all([self.A.is_nodal(), self.B.is_nodal()])
@@ -250,6 +260,15 @@ class FlattenedDimensions:
 
     def get_coeffs(self):
         return self.element.get_coeffs()
+
+    def get_nodal_basis(self):
+        return self.element.get_nodal_basis()
+
+    def dmats(self):
+        return self.element.dmats()
+
+    def get_num_members(self, arg):
+        return self.element.get_num_members(arg)
 
     def entity_dofs(self):
         """{flat dimension: {flat number: dofs}} of the product element's entity dofs."""

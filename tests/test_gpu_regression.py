@@ -47,7 +47,7 @@ def test_expansions_jet(golden):
     g = golden("regression")
     T = reference_element.DefaultTetrahedron()
     pts = reference_element.make_lattice(T.get_vertices(), 2)
-    jet = expansions.ExpansionSet(T).tabulate_jet(1, pts, 2)
+    jet = expansions.TetrahedronExpansionSet(T).tabulate_jet(1, pts, 2)
     assert len(jet) == 3
     for r, datum in enumerate(jet):
         assert np.array(datum).shape == g[f"jet_tet_{r}"].shape

@@ -374,3 +374,21 @@ def test_gls_second_kind_bubbles_as_in_the_reference_test(sd, degree):
         for t in rts:
             phi_nt = np.tensordot(np.outer(t, n), phi_at_pts, axes=((0, 1), (1, 2)))
             assert np.allclose(np.dot(phi_nt ** 2, qwts), 0)
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_bubble_duality_degree_10_on_the_device(dim):
+    """test/FIAT/unit/test_polynomial.py:123-135: the interior bubbles of the C0 hierarchy of degree 10 (make_bubbles,
+    FIAT/polynomial_set.py:285-301), scaled by their first value, are dual to themselves under the default rule of degree
+    2 degree - d - 1 up to the factor 2^d -- tabulated on the device."""
+    import fiat_amd as fa
+    from fiat_amd import polynomial_set
+    cell = fa.default_simplex(dim)
+    B = polynomial_set.make_bubbles(cell, 10)
+    Q = fa.create_quadrature(cell, 2 * B.degree - dim - 1)
+    qpts, qwts = Q.get_points(), Q.get_weights()
+    phi = B.tabulate(qpts)[(0,) * dim]
+    phi_dual = phi / abs(phi[0])
+    results = 2 ** dim * np.dot(np.multiply(phi_dual, qwts), phi.T)
+    assert np.allclose(results, np.diag(np.diag(results)))
+    assert np.allclose(np.diag(results), 1.0)

@@ -351,3 +351,21 @@ def test_product_cell_normals_ufc_and_hypercube_status_known_answers():
     assert isinstance(re.ufc_cell("quadrilateral"), re.UFCQuadrilateral) and isinstance(re.ufc_cell("interval * interval"), re.TensorProductCell)
     with pytest.raises(RuntimeError):
         re.ufc_cell("pentagon")
+
+
+def test_connectivity_known_answers():
+    """test/FIAT/unit/test_reference_element.py:39-86: face-edge connectivity of the UFC tetrahedron and hexahedron as UFC
+    expects it; (d, 0) connectivity is the topology; (D, d) connectivity is one row 0, 1, 2, ..."""
+    cells = _cells()
+    assert cells["tetrahedron"].get_connectivity()[(2, 1)] == [(0, 1, 2), (0, 3, 4), (1, 3, 5), (2, 4, 5)]
+    assert cells["hexahedron"].get_connectivity()[(2, 1)] == [(0, 1, 4, 5), (2, 3, 6, 7), (0, 2, 8, 9), (1, 3, 10, 11), (4, 6, 8, 10),
+                                                               (5, 7, 9, 11)]
+    from fiat_amd import reference_element as re
+    for cell in (re.Point(), cells["interval"], cells["triangle"], cells["tetrahedron"], cells["quadrilateral"], cells["hexahedron"]):
+        D = cell.get_spatial_dimension()
+        for dim0 in range(D + 1):
+            connectivity, topology = cell.get_connectivity()[(dim0, 0)], cell.get_topology()[dim0]
+            assert len(connectivity) == len(topology) and all(connectivity[i] == t for i, t in topology.items())
+        for dim1 in range(D + 1):
+            connectivity = cell.get_connectivity()[(D, dim1)]
+            assert len(connectivity) == 1 and connectivity[0] == tuple(range(len(connectivity[0])))

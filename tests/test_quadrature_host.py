@@ -96,7 +96,7 @@ def test_composite_rules_on_split_cells(golden):
 
 def test_line_rules_and_argument_errors_as_in_the_reference_tests():
     """test/FIAT/unit/test_quadrature.py:104-108 (points / weights mismatch is a ValueError), :166-168 (negative degree is a
-    ValueError), :187-196 and :211-220: the m-point Gauss-Lobatto-Legendre / Gauss-Legendre rules on the UFC interval integrate
+    ValueError), :187-220: the m-point Gauss-Lobatto-Legendre / Gauss-Radau / Gauss-Legendre rules on the UFC interval integrate
     x^d exactly for d < 2m - 2 / d < 2m, m = 2..9 (numpy.round(error, 14) == 0 as there)."""
     import fiat_amd
     from fiat_amd import quadrature
@@ -113,6 +113,11 @@ def test_line_rules_and_argument_errors_as_in_the_reference_tests():
         gl = quadrature.GaussLegendreQuadratureLineRule(interval, points)
         for degree in range(2 * points):
             assert np.round(gl.integrate(lambda x: x[0] ** degree) - 1. / (degree + 1), 14) == 0.
+        for right in (True, False):      # (:199-208: Gauss-Radau, exact for d < 2m - 1, the fixed end point among the nodes)
+            radau = quadrature.RadauQuadratureLineRule(interval, points, right=right)
+            assert np.isclose(radau.get_points().ravel()[-1 if right else 0], 1.0 if right else 0.0)
+            for degree in range(2 * points - 1):
+                assert np.round(radau.integrate(lambda x: x[0] ** degree) - 1. / (degree + 1), 14) == 0.
 
 
 def test_quadrature_on_product_cells_as_in_the_reference_tests():
