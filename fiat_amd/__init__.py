@@ -22,7 +22,9 @@ from .macro import (AlfeldSplit, IsoSplit, PowellSabin12Split, PowellSabinSplit,
                     WorseyFarinSplit)
 from .finite_element import CiarletElement, FiniteElement  # noqa: F401
 from .lagrange import GaussLobattoLegendre, Lagrange  # noqa: F401
-from .discontinuous_lagrange import P0, DiscontinuousLagrange, GaussLegendre  # noqa: F401
+from .discontinuous_lagrange import DiscontinuousLagrange, GaussLegendre  # noqa: F401
+from .P0 import P0  # noqa: F401  (through the sub-module of the same name, as FIAT/__init__.py does: a later ``import fiat_amd.P0``
+#                                  finds it loaded and does not rebind ``fiat_amd.P0`` from the class to the module)
 from .nedelec import Nedelec  # noqa: F401
 from .raviart_thomas import RaviartThomas  # noqa: F401
 from .brezzi_douglas_marini import BrezziDouglasMarini  # noqa: F401
@@ -53,3 +55,6 @@ supported_elements = {
     "TensorProductElement": TensorProductElement,
     "FlattenedDimensions": FlattenedDimensions,
 }
+
+# (FIAT/__init__.py:130-131)
+extra_elements = {"P0": P0}

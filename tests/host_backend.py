@@ -113,12 +113,50 @@ def _tables_squared_norm(tables, weights, ctx=None, stream=None):
     return torch.as_tensor(np.einsum("nrcp,nrcp,p->nr", t, t, np.asarray(weights, dtype=float)))
 
 
+class _MacroPolySet:
+    """runtime.MacroPolySet with the oracle doing the arithmetic (macro_expansion_tabulate: binning, multiplicity, scatter)."""
+
+    def __init__(self, sd, n, variant, scale, parent_verts, cell_verts, cell_node_map, nmacro, cell_scale=None,
+                 coeffs=None, value_shape=(), ctx=None):
+        self.sd, self.n, self.variant, self.scale = sd, n, variant, float(scale)
+        self.parent = np.asarray(parent_verts, dtype=float).reshape(sd + 1, sd)
+        self.cells = [np.asarray(c, dtype=float) for c in np.asarray(cell_verts, dtype=float)]
+        self.cmap = np.asarray(cell_node_map)
+        self.nmacro = int(nmacro)
+        self.cell_scale = None if cell_scale is None else np.asarray(cell_scale, dtype=float)
+        self.value_shape = tuple(value_shape)
+        self.coeffs = None if coeffs is None else np.asarray(coeffs, dtype=float)
+        self.ndof = self.nmacro if coeffs is None else self.coeffs.shape[0]
+
+    def set_coeffs(self, coeffs):
+        self.coeffs = np.asarray(coeffs, dtype=float)
+        self.ndof = self.coeffs.shape[0]
+
+    def out_shape(self, order, nreq, npts):
+        return (nreq, _num_tables(self.sd, order), self.ndof) + self.value_shape + (npts,)
+
+    def tabulate_batch(self, order, pts, verts=None, out=None, stream=None, mapping=None):
+        if verts is not None or mapping not in (None, "affine"):
+            raise NotImplementedError("test stand-in: macro elements on their own parent cell only")
+        if self.cell_scale is not None and not np.allclose(self.cell_scale, 1.0):
+            raise NotImplementedError("test stand-in: one scale for all sub-cells")
+        pts = np.asarray(pts.cpu() if hasattr(pts, "cpu") else pts, dtype=float)
+        res = np.zeros(self.out_shape(order, pts.shape[0], pts.shape[1]))
+        for r in range(pts.shape[0]):
+            base = fo.macro_expansion_tabulate(self.parent, self.cells, self.cmap, self.nmacro, self.n, pts[r], order, self.scale,
+                                               self.variant)
+            for t, a in enumerate(fo.jet_indices(self.sd, order)):
+                res[r, t] = base[a] if self.coeffs is None else fo.contract(self.coeffs, {a: base[a]})[a]
+        return torch.as_tensor(res)
+
+
 @pytest.fixture
 def oracle_backend(monkeypatch):
     from fiat_amd import runtime
     monkeypatch.setattr(runtime, "Context", _Ctx)
     monkeypatch.setattr(runtime, "SimplexPolySet", _SimplexPolySet)
     monkeypatch.setattr(runtime, "LineLagrange", _LineLagrange)
+    monkeypatch.setattr(runtime, "MacroPolySet", _MacroPolySet)
     monkeypatch.setattr(runtime, "riesz_assemble", _riesz_assemble)
     monkeypatch.setattr(runtime, "vandermonde_solve_batch", _vandermonde_solve_batch)
     monkeypatch.setattr(runtime, "map_points", _map_points)

@@ -94,14 +94,14 @@ for sub in ("reference_element", "quadrature", "quadrature_schemes", "expansions
 
 @pytest.fixture(autouse=True)
 def _oracle(monkeypatch):
-    for name, obj in (("Context", hb._Ctx), ("SimplexPolySet", hb._SimplexPolySet), ("LineLagrange", hb._LineLagrange),
+    for name, obj in (("Context", hb._Ctx), ("SimplexPolySet", hb._SimplexPolySet), ("LineLagrange", hb._LineLagrange), ("MacroPolySet", hb._MacroPolySet),
                       ("riesz_assemble", hb._riesz_assemble), ("vandermonde_solve_batch", hb._vandermonde_solve_batch),
                       ("map_points", hb._map_points), ("tables_squared_norm", hb._tables_squared_norm)):
         monkeypatch.setattr(runtime, name, obj)
 
 
 # module-level code of some test files builds elements at import time: install the CPU stand-ins globally as well
-for _name, _obj in (("Context", hb._Ctx), ("SimplexPolySet", hb._SimplexPolySet), ("LineLagrange", hb._LineLagrange),
+for _name, _obj in (("Context", hb._Ctx), ("SimplexPolySet", hb._SimplexPolySet), ("LineLagrange", hb._LineLagrange), ("MacroPolySet", hb._MacroPolySet),
                     ("riesz_assemble", hb._riesz_assemble), ("vandermonde_solve_batch", hb._vandermonde_solve_batch),
                     ("map_points", hb._map_points), ("tables_squared_norm", hb._tables_squared_norm)):
     setattr(runtime, _name, _obj)
