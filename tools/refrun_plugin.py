@@ -7,7 +7,7 @@ device (tests/host_backend.py).  A gap finder for host-side behaviour:
 
 (``-B`` / ``sys.dont_write_bytecode`` and ``-p no:cacheprovider``: the reference tree is read-only by rule, nothing is written into it.)
 
-Round 3: 1276 of the reference's 2 003 unit tests pass this way; the rest need the device (macro elements, fused tensor kernels:
+Round 3: 1385 of the reference's 2 003 unit tests pass this way; the rest need the device (macro elements, fused tensor kernels:
 covered by tests/test_gpu_*.py), gem / sympy, or families outside SURVEY section 8.  It found: no ``get_connectivity``, no
 ``RadauQuadratureLineRule``, no ``make_bubbles``, ``distance_to_point_l1`` without ``entity=``, DG refused on split intervals,
 AttributeError instead of NotImplementedError from ``TensorProductElement.get_nodal_basis``, and the missing module names
