@@ -57,6 +57,38 @@ while time.time() - t0 < budget:
     n += 1
     if not np.isfinite(a).all() or err > 1e-9:
         print("MISMATCH", key, "order", order, "npts", npts, "nreq", nreq, "verts", verts is not None, "push", push, kern, err, flush=True)
+# one rule in many cells (tabulate_cells: flat / wave / register-resident streaming kernels) against per-request points with the
+# element's push-forward on the generic route
+t2, ncells = time.time(), 0
+while time.time() - t2 < budget / 4:
+    fam, lo, hi = FAMS[rng.integers(len(FAMS))]
+    sd = int(rng.integers(2, 4))
+    deg = int(rng.integers(lo, min(hi, 4) + 1))
+    if fam in ("Nedelec", "RaviartThomas", "BrezziDouglasMarini", "NedelecSecondKind") and sd == 3 and deg > 3:
+        deg = 3
+    key = (fam, sd, deg)
+    if key not in cache:
+        cache[key] = getattr(fa, fam)(fa.ufc_simplex(sd), deg)
+    el = cache[key]
+    order = int(rng.integers(0, 3))
+    npts = int(rng.choice([1, 2, 3, 4, 6, 7, 11, 12, 16, 23, 24, 33]))
+    nreq = int(rng.choice([1, 2, 63, 64, 65, 130, 1000, 4097]))
+    e = rng.exponential(size=(npts, sd + 1))
+    bary = e / e.sum(-1, keepdims=True)
+    ref = np.array(fa.ufc_simplex(sd).get_vertices(), dtype=float)
+    A = np.eye(sd) + 0.2 * rng.standard_normal((nreq, sd, sd))
+    verts = np.einsum("vd,red->rve", ref, A) + rng.standard_normal((nreq, 1, sd))
+    ctx.set_policy()
+    a = el.tabulate_cells(order, bary @ ref, verts).cpu().numpy()
+    ctx.set_policy("no_fixed", "no_small", "no_stacked", "no_coop")
+    b = el.tabulate_batch(order, np.einsum("pv,rvd->rpd", bary, verts), verts=verts, pushforward=True).cpu().numpy()
+    ctx.set_policy()
+    axes = tuple(range(2, a.ndim))
+    err = float((np.abs(a - b).max(axis=axes) / np.maximum(1.0, np.abs(b).max(axis=axes))).max())
+    worst = max(worst, err)
+    ncells += 1
+    if not np.isfinite(a).all() or err > 1e-9:
+        print("MISMATCH cells", key, "order", order, "npts", npts, "nreq", nreq, err, flush=True)
 # tensor products and prisms: lane-local / fused kernels against the per-request and general routes (policy no_small)
 I = fa.ufc_simplex(1)
 tp_cache = {}
@@ -101,4 +133,4 @@ while time.time() - t1 < budget / 4:
     if not np.isfinite(a).all() or err > 1e-9:
         print("MISMATCH tensor", key, "order", order, "npts", npts, "nreq", nreq, err, flush=True)
 ctx.check()
-print(f"{n} random cases + {m} tensor / prism cases, worst relative difference {worst:.2e}")
+print(f"{n} random cases + {ncells} one-rule-many-cells cases + {m} tensor / prism cases, worst relative difference {worst:.2e}")
