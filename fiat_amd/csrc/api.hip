@@ -998,8 +998,8 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 9: return launch_stacked<2, 6, 3, 1, 0, mixr_wps(2, 6), false, 3, false, mixr1(2, 6, 3, 1)>(L, s);
         case 10: return launch_stacked<2, 5, 3, 2, 0, mixr_wps(2, 5), false, 3, false, mixr1(2, 5, 3, 2)>(L, s);
         case 11: return L.kodd ? launch_stacked<2, 5, 2, 1, 0, 1, false, 3, true, true>(L, s) : launch_stacked<2, 5, 2, 1, 0, mixr_wps(2, 5), false, 3, false, mixr1(2, 5, 2, 1)>(L, s);
-        case 12: return launch_stacked<2, 5, 3, 1, 0, mixr_wps(2, 5), false, 3, false, mixr1(2, 5, 3, 1)>(L, s);
-        case 13: return launch_stacked<3, 4, 3, 2, 0, 1, false, 4, false, mixr1(3, 4, 3, 2)>(L, s);
+        case 12: return L.kodd ? launch_stacked<2, 5, 3, 1, 0, 1, false, 3, true, true>(L, s) : launch_stacked<2, 5, 3, 1, 0, mixr_wps(2, 5), false, 3, false, mixr1(2, 5, 3, 1)>(L, s);
+        case 13: return L.kodd ? launch_stacked<3, 4, 3, 2, 0, 1, false, 4, true, true>(L, s) : launch_stacked<3, 4, 3, 2, 0, 1, false, 4, false, mixr1(3, 4, 3, 2)>(L, s);
         case 14: return launch_stacked<3, 4, 2, 1, 0, 1, false, 4, false, mixr1(3, 4, 2, 1)>(L, s);
         case 15: return launch_stacked<3, 4, 3, 1, 0, 1, false, 4, false, mixr1(3, 4, 3, 1)>(L, s);
         case 16: return L.kpiola ? (L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 4, true, true, 1>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 4, false, true, 1>(L, s)) : L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 4, true, true>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 4, false, mixr1(3, 3, 3, 2)>(L, s);
@@ -1073,7 +1073,7 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 84: return L.kpiola ? launch_stacked<2, 3, 3, 2, 0, 1, false, 3, false, true, 1>(L, s) : launch_stacked<2, 3, 3, 2, 0, mixr_wps(2, 3), false, 3, false, mixr1(2, 3, 3, 2)>(L, s);
         case 85: return L.kpiola ? launch_stacked<2, 4, 3, 3, 0, 1, false, 3, false, true, 1>(L, s) : launch_stacked<2, 4, 3, 3, 0, mixr_wps(2, 4), false, 3, false, mixr1(2, 4, 3, 3)>(L, s);
         case 86: return L.kpiola ? launch_stacked<2, 4, 3, 2, 0, 1, false, 3, false, true, 1>(L, s) : launch_stacked<2, 4, 3, 2, 0, mixr_wps(2, 4), false, 3, false, mixr1(2, 4, 3, 2)>(L, s);
-        case 87: return L.kpiola ? launch_stacked<2, 4, 2, 1, 0, 1, false, 3, false, true, 1>(L, s) : launch_stacked<2, 4, 2, 1, 0, mixr_wps(2, 4), false, 3, false, mixr1(2, 4, 2, 1)>(L, s);
+        case 87: return L.kpiola ? launch_stacked<2, 4, 2, 1, 0, 1, false, 3, false, true, 1>(L, s) : L.kodd ? launch_stacked<2, 4, 2, 1, 0, 1, false, 3, true, true>(L, s) : launch_stacked<2, 4, 2, 1, 0, mixr_wps(2, 4), false, 3, false, mixr1(2, 4, 2, 1)>(L, s);
         case 88: return launch_stacked<3, 7, 2, 1>(L, s);
         case 89: return launch_stacked<3, 7, 2, 1, 0, 1, true>(L, s);
         case 90: return launch_stacked<2, 7, 3, 1>(L, s);
@@ -1088,7 +1088,7 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 99: return L.kpiola ? (L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 10, true, true, 1>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 10, false, true, 1>(L, s)) : L.kodd ? launch_stacked<3, 3, 3, 2, 0, 1, false, 10, true, true>(L, s) : launch_stacked<3, 3, 3, 2, 0, 1, false, 10, false, true>(L, s);
         case 100: return L.kpiola ? launch_stacked<3, 3, 2, 1, 0, 1, false, 10, false, true, 1>(L, s) : launch_stacked<3, 3, 2, 1, 0, 1, false, 10, false, true>(L, s);
         case 101: return L.kpiola ? launch_stacked<3, 3, 3, 1, 0, 1, false, 10, false, true, 1>(L, s) : launch_stacked<3, 3, 3, 1, 0, 1, false, 10, false, true>(L, s);
-        case 102: return launch_stacked<3, 4, 3, 2, 0, 1, false, 10, false, true>(L, s);
+        case 102: return L.kodd ? launch_stacked<3, 4, 3, 2, 0, 1, false, 10, true, true>(L, s) : launch_stacked<3, 4, 3, 2, 0, 1, false, 10, false, true>(L, s);
         case 103: return launch_stacked<3, 4, 2, 1, 0, 1, false, 10, false, true>(L, s);
         case 104: return launch_stacked<3, 4, 3, 1, 0, 1, false, 10, false, true>(L, s);
         case 105: return launch_stacked<3, 5, 2, 1, 0, 1, false, 10, false, true>(L, s);
@@ -1098,10 +1098,10 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 109: return L.kpiola ? launch_stacked<2, 3, 3, 2, 0, 1, false, 6, false, true, 1>(L, s) : launch_stacked<2, 3, 3, 2, 0, mixr_wps(2, 3), false, 6, false, true>(L, s);
         case 110: return L.kpiola ? launch_stacked<2, 4, 3, 3, 0, 1, false, 6, false, true, 1>(L, s) : launch_stacked<2, 4, 3, 3, 0, mixr_wps(2, 4), false, 6, false, true>(L, s);
         case 111: return L.kpiola ? launch_stacked<2, 4, 3, 2, 0, 1, false, 6, false, true, 1>(L, s) : launch_stacked<2, 4, 3, 2, 0, mixr_wps(2, 4), false, 6, false, true>(L, s);
-        case 112: return L.kpiola ? launch_stacked<2, 4, 2, 1, 0, 1, false, 6, false, true, 1>(L, s) : launch_stacked<2, 4, 2, 1, 0, mixr_wps(2, 4), false, 6, false, true>(L, s);
+        case 112: return L.kpiola ? launch_stacked<2, 4, 2, 1, 0, 1, false, 6, false, true, 1>(L, s) : L.kodd ? launch_stacked<2, 4, 2, 1, 0, 1, false, 6, true, true>(L, s) : launch_stacked<2, 4, 2, 1, 0, mixr_wps(2, 4), false, 6, false, true>(L, s);
         case 113: return launch_stacked<2, 5, 3, 2, 0, mixr_wps(2, 5), false, 6, false, true>(L, s);
         case 114: return L.kodd ? launch_stacked<2, 5, 2, 1, 0, 1, false, 6, true, true>(L, s) : launch_stacked<2, 5, 2, 1, 0, mixr_wps(2, 5), false, 6, false, true>(L, s);
-        case 115: return launch_stacked<2, 5, 3, 1, 0, mixr_wps(2, 5), false, 6, false, true>(L, s);
+        case 115: return L.kodd ? launch_stacked<2, 5, 3, 1, 0, 1, false, 6, true, true>(L, s) : launch_stacked<2, 5, 3, 1, 0, mixr_wps(2, 5), false, 6, false, true>(L, s);
         case 116: return launch_stacked<2, 6, 3, 2, 0, mixr_wps(2, 6), false, 6, false, true>(L, s);
         case 117: return launch_stacked<2, 6, 2, 1, 0, mixr_wps(2, 6), false, 6, false, true>(L, s);
         case 118: return launch_stacked<2, 6, 3, 1, 0, mixr_wps(2, 6), false, 6, false, true>(L, s);
@@ -1684,7 +1684,11 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     // (RT2 at order 1 stays on the generic kernel: 44.7 % of the HBM peak there, 39.2 % on the twin)
                     if (pio) mix_odd = !pio_even;
                     if (mix_odd && !pio && !((k.sd == 2 && k.n == 5 && k.ct == 2 && k.g == 1) || (k.sd == 3 && k.n == 3 && k.ct == 3 && k.g == 2) ||
-                                             (k.rtc == -3 && k.sd == 3 && k.n == 2 && k.ct == 3 && k.g == 4)))
+                                             (k.rtc == -3 && k.sd == 3 && k.n == 2 && k.ct == 3 && k.g == 4) ||
+                                             // off-default rules of odd size: P4 tetrahedra at 17-24 points (the 23-point rule), P4 triangles at
+                                             // 25-32, P5 triangles at 33-48 (the 33-point rule)
+                                             (k.sd == 3 && k.n == 4 && k.ct == 3 && k.g == 2) || (k.sd == 2 && k.n == 4 && k.ct == 2 && k.g == 1) ||
+                                             (k.sd == 2 && k.n == 5 && k.ct == 3 && k.g == 1)))
                         continue;
                     if (npts > 16 * k.ct / k.g || tighter_instance(k) || !fills_tiles(k)) continue;
                 } else if (chunked) {  // point-chunked: whatever the whole-request instances above did not take

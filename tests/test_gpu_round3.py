@@ -225,6 +225,8 @@ MIXR = [("Lagrange", 3, 2, 11, 2, "3,2,3,4,-3"), ("Lagrange", 3, 2, 14, 2, "3,2,
         # odd table sizes: the 8-byte twins
         ("Lagrange", 2, 5, 25, 2, "2,5,2,1,-3"), ("Lagrange", 2, 5, 25, 1, "2,5,2,1,-2"), ("Nedelec", 3, 3, 23, 2, "3,3,3,2,-3"),
         ("Nedelec", 3, 3, 23, 1, "3,3,3,2,-2"), ("RaviartThomas", 3, 2, 11, 2, "3,2,3,4,-3"),
+        ("Lagrange", 3, 4, 23, 1, "3,4,3,2,-2"), ("Lagrange", 3, 4, 23, 2, "3,4,3,2,-3"), ("Lagrange", 2, 4, 25, 1, "2,4,2,1,-2"),
+        ("Lagrange", 2, 4, 25, 2, "2,4,2,1,-3"), ("Lagrange", 2, 5, 33, 1, "2,5,3,1,-2"), ("Lagrange", 2, 5, 33, 2, "2,5,3,1,-3"),
         # order 1 on the accumulators (every instance also runs in test_gpu_parity's per-request-cell cases)
         ("Lagrange", 3, 6, 23, 1, "3,6,3,2,-2"), ("Lagrange", 3, 6, 44, 1, "3,6,3,1,-2"), ("Nedelec", 3, 2, 11, 1, "3,2,3,4,-2"),
         ("Lagrange", 3, 5, 24, 1, "3,5,3,2,-2"), ("Nedelec", 2, 3, 12, 1, "2,3,3,4,-2"), ("Lagrange", 2, 6, 30, 1, "2,6,2,1,-2"),
