@@ -377,6 +377,9 @@ def run(args):
         if world > 1:
             dist.barrier()
 
+    if args.policy:
+        from fiat_amd import runtime
+        runtime.Context.get().set_policy(*args.policy.split(","))
     cls = HexWorkload if args.workload.startswith("hex") else SimplexWorkload
     wl = cls(args.workload, args.batch, rank, shared=args.shared_points)
     batch = wl.batch
@@ -500,7 +503,8 @@ def run(args):
                        "sharding": "independent requests, contiguous blocks per rank, no data-path collective",
                        "world_size": world, "launch": "self-spawned ranks" if os.environ.get("FIAT_AMD_BENCH_SPAWNED") else
                                      ("torch.distributed.run" if world > 1 else "single process"),
-                       "clock_ramp_ms_before_warmup": CLOCK_RAMP_MS, "clock_ramp_steps": ramp_steps},
+                       "clock_ramp_ms_before_warmup": CLOCK_RAMP_MS, "clock_ramp_steps": ramp_steps,
+                       **({"policy": args.policy} if args.policy else {})},
             "roofline": roofline,
             "max_rel_err_vs_oracle": max_err,
             "requests_checked_vs_oracle": getattr(wl, "checked", None),
@@ -713,6 +717,8 @@ def main():
                     help="variant (SURVEY.md 8d): ONE 23-point rule on the reference cell pushed forward to per-request "
                          "physical cells (fx_tabulate_batch_shared) instead of per-request random points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--policy", default="", help="measurement only: kernel-selection policy names (fx_ctx_set_policy), comma separated; "
+                                                 "disclosed in config.policy -- the default line is the one without it")
     ap.add_argument("--check", type=int, default=-1,
                     help="requests verified against the CPU oracle after timing (-1: the whole batch, 0: none)")
     args = ap.parse_args()

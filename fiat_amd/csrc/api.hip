@@ -1627,6 +1627,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
         // peak here against 23 / 13 % on the generic kernel; below one row tile nothing is left to amortise)
         // (15 rows: values-only P4 triangles 27-30 % lane-local -> 38-49 % here; 10 rows -- P3 triangles, P2 tetrahedra -- stay
         // lane-local, 39-43 % against 34-39 %)
+        // (round 3, tools/coverage_map.py --audit: since the lane-local kernel packs several requests per lane group it serves
+        // the 15-row tables faster wherever it holds them -- 6 / 16 / 25 / 32 points: 165 / 157 / 211 / 157 us against
+        // 249 / 191 / 412 / 282 us here -- so below one full row tile this kernel only takes what the lane-local one refuses)
         static const long long stacked_min_rows = ab_env("FIAT_AMD_STACKED_MIN_ROWS") ? atoll(ab_env("FIAT_AMD_STACKED_MIN_ROWS")) : 15;
         const long long R = (long long)ntab * rows;
         const int RT = (int)((R + 15) / 16);
@@ -1641,7 +1644,15 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
         // 21 -> 58 % and 19 -> 38 % of the HBM peak, tools/coverage_map.py --verts --order 2 [--policy no_small])
         const bool small_keeps = L.small_id >= 0 && verts;
         const bool over_small = order == 2 && ((e->sd == 2 && e->n >= 4) || (e->sd == 3 && e->n >= 2));
-        if (!nostacked && L.fixed_id < 0 && (!small_keeps || over_small) && !L.fused_mapping && !e->raw_expansion && order <= 2) {
+        // (round 3, tools/coverage_map.py --audit + tools/instance_ab.py --own-cell, ABAB at 1.5 GB of tables: on the element's own
+        // cell the stacked kernel now beats the paired instances of P3 tetrahedra with gradients outside the 21..24-point
+        // benchmark shape -- 12 / 14 / 28 / 32 / 44 points: 294 / 296 / 304 / 282 / 284 us paired, 270 / 256 / 259 / 249 / 257 us
+        // here -- and of P4 tetrahedra, 400 / 373 us -> 316 / 303 us at 22 / 24 points; with per-request cells the paired kernel
+        // applies the chain rule on its accumulators and keeps every shape, 285-345 us against 365-750 us.  Those entries yield
+        // when an instance here holds the request.)
+        const bool fixed_yields = L.fixed_id >= 0 && !verts && !L.fused_mapping && order == 1 && e->sd == 3 &&
+                                  ((e->n == 3 && kFixedShapes[L.fixed_id].nt != 6) || e->n == 4);
+        if (!nostacked && (L.fixed_id < 0 || fixed_yields) && (!small_keeps || over_small) && !L.fused_mapping && !e->raw_expansion && order <= 2) {
             // among the instances of one kind that hold the request, the one with the fewest padding columns
             auto tighter_instance = [&](const StackedShape& k) {
                 for (const StackedShape& o : kStackedShapes)
@@ -1666,10 +1677,17 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 // small shapes with register-resident fragments: A/B partner of the paired kernel only (measured
                 // equal on C2, 302 vs 303 us -- both sit on the store-path plateau -- and the paired kernel's
                 // recurrence derivatives are two digits more accurate), opt-in with FIAT_AMD_STACKED_SMALL=1
-                if (k.rtc > 0 ? (RT != k.rtc || verts || !stacked_small) : R < stacked_min_rows) continue;
+                if (k.rtc > 0 ? (RT != k.rtc || verts || !stacked_small) : (R < stacked_min_rows || (R < 16 && L.small_id >= 0))) continue;
                 // (per-request cells with derivatives on the low-degree shapes: the second pass over the tables costs more
                 // than the generic kernel's in-kernel chain rule -- tools/small_vs_stacked.py --verts, 18-29 % against 25-48 %)
                 if (!inmix && verts && order >= 1 && (k.n <= 2 || (k.sd == 2 && k.n <= 4))) continue;
+                // (own cell, gradients of P3 / P4 triangles where the lane-local kernel holds the request -- round 3, ABAB with
+                // tools/instance_ab.py --own-cell [--policy no_stacked]: P3 at 6 / 7 / 10 / 15 / 25 points 195 / 197 / 172 / 170 / 199 us
+                // here against 149 / 149 / 144 / 157 / 149 us lane-local, while 8 / 12 / 16 / 24 points are level or better here;
+                // P4 at odd sizes up to 16 points falls to the point-chunked instance, 407 us against 264 us at 15 points)
+                if (!verts && order == 1 && L.small_id >= 0 && k.sd == 2 &&
+                    ((k.n == 3 && npts % 8 != 0 && npts != 12) || (k.n == 4 && k.rtc == -1 && npts <= 16)))
+                    continue;
                 if (k.rtc == -2 || k.rtc == -3 || k.rtc == -6) {  // per-request cells, order 1 / 2: chain rule across the tables inside the kernel (dof-major tiles)
                     const bool nomix = (ctx->policy & FX_POLICY_NO_STACKED_MIX) != 0;
                     if (nomix || !verts || order != (k.rtc == -2 ? 1 : k.rtc == -3 ? 2 : 0)) continue;
@@ -1774,6 +1792,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 if (pio) L.fused_mapping = true;
                 L.stacked_id = (int)i;
                 L.small_id = -1;
+                if (fixed_yields) L.fixed_id = -1;
                 break;
             }
         }

@@ -352,7 +352,9 @@ def test_kernel_selection(rt, golden):
     p3 = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=g["c2_p3tet_q6_coeffs"])
     assert p3.kernel_name(1, 1000, 23) == "fxk::tabulate_simplex_pair"
     assert p3.kernel_name(1, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_pair"
-    assert p3.kernel_name(1, 1000, 40) == "fxk::tabulate_simplex_pair"       # one request per wave, 10 column tiles
+    assert p3.kernel_name(1, 1000, 40, has_verts=True) == "fxk::tabulate_simplex_pair"   # one request per wave, 10 column tiles
+    assert p3.kernel_name(1, 1000, 40) == "fxk::tabulate_simplex_stacked"    # own cell, off the 21..24-point shape: the paired entry yields
+    assert p3.kernel_name(1, 1000, 10) == "fxk::tabulate_simplex_pair"       # ... unless no stacked instance holds the request
     assert p3.kernel_name(1, 1000, 50) == "fxk::tabulate_simplex_stacked"    # 49..64 points: four column tiles
     assert p3.kernel_name(1, 1000, 70) == "fxk::tabulate_simplex_stacked"    # point-chunked units
     assert p3.kernel_name(1, 1000, 7) == "fxk::tabulate_simplex_kernel"      # fewer points than any registered tiling
@@ -395,12 +397,17 @@ def test_concurrent_streams(rt, golden):
 
 @pytest.mark.parametrize("npts", [9, 11, 12, 13, 14, 16, 17, 19, 20, 25, 27, 29, 31, 32, 33, 36, 40, 41, 44, 46, 48])
 @pytest.mark.parametrize("nreq,cells", [(1, False), (2, True), (515, False), (1030, True)])
-def test_p3_tet_paired_kernel_point_counts(rt, golden, npts, nreq, cells):
+def test_p3_tet_paired_kernel_point_counts(rt, golden, kernel_policy, npts, nreq, cells):
     """The paired kernel is instantiated for 3..6 column tiles (two requests per wave: P3 tetrahedra
-    with 9..24 points) and for 8 / 10 / 12 tiles with one request per wave (25..48 points)."""
+    with 9..24 points) and for 8 / 10 / 12 tiles with one request per wave (25..48 points).  On the element's own cell
+    these entries yield to the stacked kernel by default (plan_launch, fixed_yields): policy "no_stacked" keeps them."""
     from oracle import c_oracle
     co = golden("elements")["c2_p3tet_q6_coeffs"]
     ps = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=co)
+    if not cells:
+        if npts >= 12:
+            assert ps.kernel_name(1, nreq, npts) == "fxk::tabulate_simplex_stacked"
+        kernel_policy("no_stacked")
     assert ps.kernel_name(1, nreq, npts, has_verts=cells) == "fxk::tabulate_simplex_pair"
     rng = np.random.default_rng(3000 + 10 * npts + nreq)
     pts = rand_points(rng, 3, (nreq, npts))
@@ -421,12 +428,17 @@ def test_p3_tet_paired_kernel_point_counts(rt, golden, npts, nreq, cells):
 @pytest.mark.parametrize("fam,deg", [("Lagrange", 4), ("RaviartThomas", 2), ("DiscontinuousLagrange", 4)])
 @pytest.mark.parametrize("npts", [21, 23, 24])
 @pytest.mark.parametrize("nreq,cells", [(1, False), (3, True), (2049, False), (1500, True)])
-def test_one_request_per_wave_instances(rt, fam, deg, npts, nreq, cells):
-    """P4 / RT2 tetrahedra: the K-streamed kernel with one request per wave and a half-request image."""
+def test_one_request_per_wave_instances(rt, kernel_policy, fam, deg, npts, nreq, cells):
+    """P4 / RT2 tetrahedra: the K-streamed kernel with one request per wave and a half-request image (P4 on the element's
+    own cell: behind policy "no_stacked", the entry yields to the stacked kernel by default)."""
     import fiat_amd
     from oracle import c_oracle
     el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(3), deg)
     ps = el.device_polyset()
+    if not cells and deg == 4:
+        if (35 * 4 * npts) % 2 == 0:
+            assert ps.kernel_name(1, nreq, npts) == "fxk::tabulate_simplex_stacked"
+        kernel_policy("no_stacked")
     assert ps.kernel_name(1, nreq, npts, has_verts=cells) == "fxk::tabulate_simplex_pair"
     rng = np.random.default_rng(7000 + 10 * npts + nreq + deg)
     pts = rand_points(rng, 3, (nreq, npts))
@@ -533,7 +545,7 @@ def test_stacked_matrix_kernel_small_shape_ab(rt, golden, kernel_policy, npts, n
     err = (np.abs(out - ref).max(axis=axes) / np.maximum(1.0, np.abs(ref).max(axis=axes))).max(axis=0)
     assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), err
     kernel_policy()
-    assert ps.kernel_name(1, nreq, npts) == "fxk::tabulate_simplex_pair"
+    assert ps.kernel_name(1, nreq, npts) == ("fxk::tabulate_simplex_pair" if 21 <= npts <= 24 else "fxk::tabulate_simplex_stacked")
 
 
 @pytest.mark.parametrize("fam,deg,order,npts", [("Lagrange", 5, 1, 16), ("Lagrange", 5, 2, 23), ("Lagrange", 6, 1, 23),

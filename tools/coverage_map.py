@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Which kernel serves which realistic request shape, and how close to the HBM / fp64 rooflines it runs (measurement tooling):
 families x cell x degree x derivative order, points = the default quadrature rule of degree 2 * degree (what a mass /
-stiffness assembly asks for).  python tools/coverage_map.py [--verts [--pushforward]] [--order K] [--policy no_small,no_stacked] [--only "Lagrange sd3"]"""
+stiffness assembly asks for).  python tools/coverage_map.py [--verts [--pushforward]] [--order K] [--policy no_small,no_stacked] [--only "Lagrange sd3"] [--qdeg-offset K] [--audit]
+(--audit: every shape also under each kernel-selection policy; lists the shapes another family serves > 7 % faster)"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,8 +14,10 @@ orders = [int(sys.argv[sys.argv.index("--order") + 1])] if "--order" in sys.argv
 from fiat_amd import runtime
 if "--policy" in sys.argv:
     runtime.Context.get().set_policy(*sys.argv[sys.argv.index("--policy") + 1].split(","))
+qoff = int(sys.argv[sys.argv.index("--qdeg-offset") + 1]) if "--qdeg-offset" in sys.argv else 0   # rule degree 2 * degree + this
 only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""
-rows = []
+rows, audit = [], []
+AUDIT = [("no_stacked",), ("no_small",), ("no_stacked", "no_small"), ("no_fixed",), ("no_stacked_mix",), ("stacked_small",)]
 for sd in (2, 3):
     cell = fiat_amd.ufc_simplex(sd)
     for fam, degs in FAMS:
@@ -25,7 +28,7 @@ for sd in (2, 3):
                 continue
             el = getattr(fiat_amd, fam)(cell, deg)
             ps = el.device_polyset()
-            npts = len(fiat_amd.create_quadrature(cell, max(1, 2 * deg)).get_points())
+            npts = len(fiat_amd.create_quadrature(cell, max(1, 2 * deg + qoff)).get_points())
             for order in orders:
                 shape1 = ps.out_shape(order, 1, npts)
                 per_req = 8 * (npts * sd + int(np.prod(shape1[1:])))
@@ -53,6 +56,24 @@ for sd in (2, 3):
                     t = statistics.median(run() for _ in range(3))
                 else:
                     t = statistics.median(ps.time_tabulate_batch(order, pts, verts, out, 5) for _ in range(3))
+                if "--audit" in sys.argv and "--pushforward" not in sys.argv:   # is the planner's choice the fastest family here?
+                    ctx, alt = runtime.Context.get(), {}
+                    for rnd in range(3):                      # interleaved, the default among them: clock and placement drift cancel
+                        for pol in [()] + AUDIT:
+                            ctx.set_policy(*pol)
+                            try:
+                                tt = ps.time_tabulate_batch(order, pts, verts, out, 5)
+                                alt.setdefault(pol, ([], ps.kernel_name(order, nreq, npts, has_verts=verts is not None, instance=True)))[0].append(tt)
+                            except Exception as e:
+                                alt[pol] = ([float("inf")], str(e)[:40])
+                    alt = {q: (statistics.median(v[0]), v[1]) for q, v in alt.items()}
+                    t = alt.pop(())[0]
+                    ctx.set_policy()
+                    best = min(alt, key=lambda q: alt[q][0])
+                    if alt[best][0] < 0.93 * t:
+                        audit.append(f"{fam} sd{sd} k{deg} order {order} npts {npts}: default {t*1e3:.1f} us, "
+                                     f"{'+'.join(best)} {alt[best][0]*1e3:.1f} us ({alt[best][1]})")
+                        print("   AUDIT " + audit[-1] + "\n      " + "  ".join(f"{'+'.join(q)}={v[0]*1e3:.1f}" for q, v in alt.items()), flush=True)
                 nexp = ps.coeffs.shape[-1] if hasattr(ps, "coeffs") else 0
                 frac = per_req * nreq / t / 1e6 / 80
                 kern = ps.kernel_name(order, nreq, npts, has_verts=verts is not None)
@@ -60,6 +81,9 @@ for sd in (2, 3):
                                    f"{t*1e3:8.1f} us {nreq/t/1e3:9.1f} M/s {frac:5.1f} % HBM  {kern}"))
                 print(rows[-1][1], flush=True)
                 del pts, out
+if audit:
+    print(f"\n-- audit: {len(audit)} shapes where another kernel family beats the planner's choice by > 7 % --")
+    print("\n".join(audit))
 print("\n-- slowest 25 --")
 for frac, line in sorted(rows)[:25]:
     print(line)
