@@ -1643,7 +1643,13 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
         // (order 2 with per-request cells: the rtc -3 instances beat the lane-local kernel on P4 triangles and P2 tetrahedra,
         // 21 -> 58 % and 19 -> 38 % of the HBM peak, tools/coverage_map.py --verts --order 2 [--policy no_small])
         const bool small_keeps = L.small_id >= 0 && verts;
-        const bool over_small = order == 2 && ((e->sd == 2 && e->n >= 4) || (e->sd == 3 && e->n >= 2));
+        // (round 3 audit, ABAB with tools/instance_ab.py [--policy no_small]: gradients of P4 triangles 264 / 213 / 260 / 293 / 218 us
+        // lane-local at 12 / 16 / 24 / 25 / 32 points against 193 / 164 / 162 / 259 / 164 us on the rtc -2 instances; Hessians of P3
+        // triangles at 15 / 16 points 280 / 259 against 216 / 202 us -- level or behind at the other sizes; P3 triangles and P2
+        // tetrahedra with gradients stay lane-local, 151-220 against 177-262 us)
+        const bool over_small = (order == 2 && ((e->sd == 2 && e->n >= 4) || (e->sd == 3 && e->n >= 2) ||
+                                                (e->sd == 2 && e->n == 3 && npts >= 13 && npts <= 16))) ||
+                                (order == 1 && e->sd == 2 && e->n == 4);
         // (round 3, tools/coverage_map.py --audit + tools/instance_ab.py --own-cell, ABAB at 1.5 GB of tables: on the element's own
         // cell the stacked kernel now beats the paired instances of P3 tetrahedra with gradients outside the 21..24-point
         // benchmark shape -- 12 / 14 / 28 / 32 / 44 points: 294 / 296 / 304 / 282 / 284 us paired, 270 / 256 / 259 / 249 / 257 us
@@ -1672,7 +1678,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 const bool inmix = k.rtc == -2 || k.rtc == -3 || k.rtc == -4 || k.rtc == -5 || k.rtc == -6;  // chain rule / Piola map inside the kernel
                 const bool chunked = k.rtc == -1 || k.rtc == -4 || k.rtc == -5;
                 if (inmix != (i2 == i)) continue;
-                if (small_keeps && k.rtc != -3) continue;
+                if (small_keeps && k.rtc != -3 && k.rtc != -2) continue;
                 if (k.sd != e->sd || k.n != e->n) continue;
                 // small shapes with register-resident fragments: A/B partner of the paired kernel only (measured
                 // equal on C2, 302 vs 303 us -- both sit on the store-path plateau -- and the paired kernel's
@@ -1681,6 +1687,10 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 // (per-request cells with derivatives on the low-degree shapes: the second pass over the tables costs more
                 // than the generic kernel's in-kernel chain rule -- tools/small_vs_stacked.py --verts, 18-29 % against 25-48 %)
                 if (!inmix && verts && order >= 1 && (k.n <= 2 || (k.sd == 2 && k.n <= 4))) continue;
+                // (the same for vector-valued degree-3 tetrahedra at up to 16 points, round 3 audit: N3 / RT3 / BDM3 with Hessians at
+                // 11 / 16 points 525 / 450, 447 / 425, 492 / 461 us on the three-request instance plus mixing pass against 404 / 312,
+                // 375 / 288, 426 / 312 us generic; N3 with gradients 392 / 324 against 338 / 221, but 379 against 398-444 at 14 points: kept there)
+                if (!inmix && verts && k.sd == 3 && k.n == 3 && e->vdim > 1 && (order == 2 ? npts <= 16 : order == 1 && (npts <= 12 || npts == 16))) continue;
                 // (own cell, gradients of P3 / P4 triangles where the lane-local kernel holds the request -- round 3, ABAB with
                 // tools/instance_ab.py --own-cell [--policy no_stacked]: P3 at 6 / 7 / 10 / 15 / 25 points 195 / 197 / 172 / 170 / 199 us
                 // here against 149 / 149 / 144 / 157 / 149 us lane-local, while 8 / 12 / 16 / 24 points are level or better here;
@@ -1714,6 +1724,19 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     if (inmix) {  // ... with the chain rule inside: rules of more than one chunk
                         const bool nomix = (ctx->policy & FX_POLICY_NO_STACKED_MIX) != 0;
                         if (nomix || !verts || order != (k.rtc == -4 ? 1 : 2) || npts <= 16 * k.ct) continue;
+                        // (49..64 points: the second chunk of 48 is mostly padding.  Round 3 audit, ABAB tools/instance_ab.py
+                        // [--policy no_stacked_mix]: where a whole-request instance of four column tiles exists and the stacked
+                        // matrix is small, that instance plus the mixing pass is faster -- gradients of P3 / P4 / P5 tetrahedra at
+                        // 50 points 532 / 557 / 614 -> 392 / 428 / 516 us, P5 / P6 triangles 567 / 479 -> 421 / 423 us, Hessians of P3
+                        // tetrahedra and P5 triangles 512 / 513 -> 411 / 424 us; from ~250 stacked rows on the pass over the tables
+                        // costs more than the padding: N3 tetrahedra 318 against 395 us, Hessians of P4 / P5 tetrahedra 397 / 446
+                        // against 467 / 539 us, and of P6 triangles at 168 rows 397 against 426 us)
+                        if (npts <= 64 && even && R <= 224 && !(order == 2 && k.sd == 2 && k.n == 6)) {
+                            bool whole = false;
+                            for (const StackedShape& o : kStackedShapes)
+                                whole = whole || (o.sd == k.sd && o.n == k.n && o.rtc == 0 && o.g == 1 && o.ct == 4);
+                            if (whole) continue;
+                        }
                     }
                 } else {
                     // (16-byte stores of whole request chunks; a few instances have an 8-byte twin for odd request sizes)
