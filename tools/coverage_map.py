@@ -56,14 +56,16 @@ for sd in (2, 3):
                     t = statistics.median(run() for _ in range(3))
                 else:
                     t = statistics.median(ps.time_tabulate_batch(order, pts, verts, out, 5) for _ in range(3))
-                if "--audit" in sys.argv and "--pushforward" not in sys.argv:   # is the planner's choice the fastest family here?
+                if "--audit" in sys.argv:   # is the planner's choice the fastest family here?
                     ctx, alt = runtime.Context.get(), {}
                     for rnd in range(3):                      # interleaved, the default among them: clock and placement drift cancel
                         for pol in [()] + AUDIT:
                             ctx.set_policy(*pol)
                             try:
-                                tt = ps.time_tabulate_batch(order, pts, verts, out, 5)
-                                alt.setdefault(pol, ([], ps.kernel_name(order, nreq, npts, has_verts=verts is not None, instance=True)))[0].append(tt)
+                                pf = "--pushforward" in sys.argv
+                                tt = run() if pf else ps.time_tabulate_batch(order, pts, verts, out, 5)
+                                alt.setdefault(pol, ([], ps.kernel_name(order, nreq, npts, has_verts=verts is not None, instance=True,
+                                                                        mapping=el.mapping()[0] if pf and el.mapping()[0] != "affine" else None)))[0].append(tt)
                             except Exception as e:
                                 alt[pol] = ([float("inf")], str(e)[:40])
                     alt = {q: (statistics.median(v[0]), v[1]) for q, v in alt.items()}

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The quadrature-rule case over realistic shapes (measurement tooling): ONE rule of degree 2 * degree on the reference cell,
 pushed forward to many physical cells (``tabulate_cells`` = fx_tabulate_batch_shared, with the element's Piola map).
-Bytes counted: per-request cell + tables.  python tools/coverage_map_cells.py [--order K]"""
+Bytes counted: per-request cell + tables.  python tools/coverage_map_cells.py [--order K] [--audit]
+(--audit: each shape also under the no_shared_wave / no_shared_reg policies; lists shapes another kernel serves > 7 % faster)"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -42,6 +43,24 @@ for sd in (2, 3):
                     e1.record(); torch.cuda.synchronize()
                     ts.append(e0.elapsed_time(e1) / 5)
                 t = statistics.median(ts)
+                if "--audit" in sys.argv:   # the other kernels of fx_tabulate_batch_shared, interleaved with the default
+                    ctx, alt = runtime.Context.get(), {}
+                    for rnd in range(3):
+                        for pol in [(), ("no_shared_wave",), ("no_shared_reg",), ("no_shared_wave", "no_shared_reg")]:
+                            ctx.set_policy(*pol)
+                            fn()
+                            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            for _ in range(5): fn()
+                            e1.record(); torch.cuda.synchronize()
+                            alt.setdefault(pol, []).append(e0.elapsed_time(e1) / 5)
+                    ctx.set_policy()
+                    alt = {q: statistics.median(v) for q, v in alt.items()}
+                    t = alt.pop(())
+                    best = min(alt, key=alt.get)
+                    if alt[best] < 0.93 * t:
+                        print(f"   AUDIT {fam} sd{sd} k{deg} order {order} npts {npts}: default {t*1e3:.1f} us; " +
+                              "  ".join(f"{'+'.join(q)}={v*1e3:.1f}" for q, v in alt.items()), flush=True)
                 frac = per_req * nreq / t / 1e6 / 80
                 rows.append((frac, f"{fam:22s} sd{sd} k{deg} order {order} npts {npts:3d} rows {int(np.prod(shape1[2:-1])):4d} {el.mapping()[0][:12]:12s}: "
                                    f"{t*1e3:8.1f} us {nreq/t/1e3:9.1f} M/s {frac:5.1f} % HBM"))

@@ -3,10 +3,19 @@ sys.path.insert(0, os.getcwd())
 import numpy as np, torch, fiat_amd
 from fiat_amd import runtime
 ctx = runtime.Context.get()
-for fam, sd, deg, qd, order in (("Lagrange", 3, 3, 6, 1), ("Lagrange", 3, 2, 4, 1), ("Lagrange", 2, 2, 4, 1), ("Lagrange", 3, 1, 2, 1), ("Lagrange", 3, 3, 6, 0)):
+# python tools/shared_probe.py ["family,sd,degree,points,order;..."]: one point set in many cells under the shared-kernel policies
+# (points < 0: the default rule of degree -points)
+SHAPES = (("Lagrange", 3, 3, -6, 1), ("Lagrange", 3, 2, -4, 1), ("Lagrange", 2, 2, -4, 1), ("Lagrange", 3, 1, -2, 1), ("Lagrange", 3, 3, -6, 0))
+if len(sys.argv) > 1:
+    SHAPES = [(f, int(a), int(b), int(c), int(d)) for f, a, b, c, d in (x.split(",") for x in sys.argv[1].split(";"))]
+for fam, sd, deg, qd, order in SHAPES:
     cell = fiat_amd.ufc_simplex(sd)
     el = getattr(fiat_amd, fam)(cell, deg); ps = el.device_polyset()
-    rule = torch.as_tensor(np.asarray(fiat_amd.create_quadrature(cell, qd).get_points())).cuda()
+    if qd < 0:
+        rule = torch.as_tensor(np.asarray(fiat_amd.create_quadrature(cell, -qd).get_points())).cuda()
+    else:
+        e = np.random.default_rng(6).exponential(size=(qd, sd + 1))
+        rule = torch.as_tensor((e / e.sum(axis=-1, keepdims=True))[:, 1:].copy()).cuda()
     npts = rule.shape[0]
     per_req = 8 * ((sd + 1) * sd + int(np.prod(ps.out_shape(order, 1, npts)[1:])))
     nreq = int(1.5e9 // per_req)
