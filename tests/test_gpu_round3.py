@@ -394,3 +394,51 @@ def test_bubble_duality_degree_10_on_the_device(dim):
     results = 2 ** dim * np.dot(np.multiply(phi_dual, qwts), phi.T)
     assert np.allclose(results, np.diag(np.diag(results)))
     assert np.allclose(np.diag(results), 1.0)
+
+
+# (family, sd, degree, points, order, per-request cells) -> kernel (and registry instance) the planner must choose after the round-3
+# audit (profiles/r03c_planner_audit.txt)
+ROUTES = [
+    ("Lagrange", 2, 4, 16, 0, False, "small"), ("Lagrange", 2, 4, 25, 0, False, "small"),            # 15 rows: below one row tile
+    ("Lagrange", 2, 3, 7, 1, False, "small"), ("Lagrange", 2, 3, 12, 1, False, "stacked<2,3,3,4,0>"),
+    ("Lagrange", 2, 3, 16, 1, False, "stacked<2,3,3,3,0>"), ("Lagrange", 2, 4, 15, 1, False, "small"),
+    ("Lagrange", 3, 3, 32, 1, False, "stacked<3,3,2,1,0>"), ("Lagrange", 3, 3, 32, 1, True, "pair"),  # paired entries yield on the own cell only
+    ("Lagrange", 3, 3, 23, 1, False, "pair"), ("Lagrange", 3, 3, 10, 1, False, "pair"),
+    ("Lagrange", 3, 4, 24, 1, False, "stacked<3,4,3,2,0>"), ("Lagrange", 3, 4, 24, 1, True, "pair"),
+    ("Lagrange", 2, 4, 16, 1, True, "stacked<2,4,3,3,-2>"), ("Lagrange", 2, 4, 7, 1, True, "small"),
+    ("Lagrange", 2, 3, 16, 2, True, "stacked<2,3,3,3,-3>"), ("Lagrange", 2, 3, 12, 2, True, "small"),
+    ("Lagrange", 2, 3, 16, 1, True, "small"), ("Lagrange", 3, 2, 11, 1, True, "small"),
+    ("Lagrange", 3, 4, 57, 1, True, "stacked<3,4,4,1,0>"), ("Lagrange", 3, 4, 70, 1, True, "stacked<3,4,3,1,-4>"),
+    ("Lagrange", 3, 4, 57, 2, True, "stacked<3,4,2,1,-5>"), ("Lagrange", 3, 3, 57, 2, True, "stacked<3,3,4,1,0>"),
+    ("Lagrange", 2, 5, 50, 1, True, "stacked<2,5,4,1,0>"), ("Lagrange", 2, 6, 57, 2, True, "stacked<2,6,3,1,-5>"),
+    ("Nedelec", 3, 3, 57, 1, True, "stacked<3,3,3,1,-4>"), ("Nedelec", 3, 3, 16, 2, True, "kernel"),
+    ("Nedelec", 3, 3, 14, 1, True, "stacked<3,3,3,3,0>"), ("RaviartThomas", 3, 3, 11, 2, True, "kernel"),
+    ("Nedelec", 3, 3, 23, 2, True, "stacked<3,3,3,2,-3>")]
+
+
+@pytest.mark.parametrize("family,sd,degree,npts,order,cells,kernel", ROUTES,
+                         ids=[f"{r[0][:2]}{r[2]}-sd{r[1]}-{r[3]}pt-o{r[4]}-{'cells' if r[5] else 'own'}" for r in ROUTES])
+def test_planner_routes_after_the_audit(family, sd, degree, npts, order, cells, kernel, kernel_policy):
+    """The kernel family (and stacked-registry instance) plan_launch picks for the shapes the round-3 audit re-routed and for
+    their neighbours that stayed, and that the chosen route gives the generic kernel's tables (which the reference goldens pin)."""
+    import fiat_amd as fa
+    from oracle import fiat_oracle as fo
+    el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
+    ps = el.device_polyset()
+    nreq = 203
+    name = ps.kernel_name(order, nreq, npts, has_verts=cells, instance=True)
+    assert name == "fxk::tabulate_simplex_" + kernel, name
+    rng = np.random.default_rng(11 * npts + degree + order)
+    e = rng.exponential(size=(nreq, npts, sd + 1))
+    pts, verts = (e / e.sum(-1, keepdims=True))[..., 1:].copy(), None
+    if cells:
+        A = np.eye(sd) + 0.15 * rng.standard_normal((nreq, sd, sd))
+        A[::5, :, 0] *= -1.0
+        verts = np.einsum("vd,red->rve", fo.UFC_SIMPLEX[sd], A) + rng.standard_normal((nreq, 1, sd))
+        pts = np.einsum("rpv,rvd->rpd", e / e.sum(-1, keepdims=True), verts)
+    got = el.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    kernel_policy("no_stacked", "no_small", "no_fixed", "no_coop")
+    assert ps.kernel_name(order, nreq, npts, has_verts=cells).endswith("tabulate_simplex_kernel")
+    want = el.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    for t in range(got.shape[1]):
+        assert rel(got[:, t], want[:, t]) <= (1e-12 if t == 0 else 1e-10), (name, t, rel(got[:, t], want[:, t]))
