@@ -878,6 +878,9 @@ const StackedShape kStackedShapes[] = {
     // accumulators (simplex_stacked.hpp PIO; with derivatives: the PIO twins of the rtc -2 / -3 instances of these shapes)
     {3, 2, 3, 4, -6}, {3, 2, 3, 3, -6}, {3, 2, 3, 2, -6}, {3, 2, 2, 1, -6}, {3, 3, 3, 2, -6}, {3, 3, 2, 1, -6}, {3, 3, 3, 1, -6},
     {2, 3, 3, 4, -6}, {2, 3, 3, 3, -6}, {2, 3, 3, 2, -6}, {2, 4, 3, 3, -6}, {2, 4, 3, 2, -6}, {2, 4, 2, 1, -6},
+    // point chunks of two column tiles: rules whose 32-point chunks need fewer column tiles than their 48-point chunks
+    // (49..64 points: 4 against 6; 97..128 points -- the 122-point rule of degree 6 -- 8 against 9)
+    {3, 6, 2, 1, -1}, {3, 5, 2, 1, -1},
 };
 // shapes whose in-kernel chain-rule instances (rtc -2 / -3 / -6) have a twin that applies the Piola map too
 constexpr bool stacked_has_pio(int sd, int n) { return (sd == 3 && (n == 2 || n == 3)) || (sd == 2 && (n == 3 || n == 4)); }
@@ -1134,6 +1137,8 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 145: return launch_stacked<2, 4, 3, 3, 0, 1, false, 1, false, true, 1>(L, s);
         case 146: return launch_stacked<2, 4, 3, 2, 0, 1, false, 1, false, true, 1>(L, s);
         case 147: return launch_stacked<2, 4, 2, 1, 0, 1, false, 1, false, true, 1>(L, s);
+        case 148: return launch_stacked<3, 6, 2, 1, 0, 1, true>(L, s);
+        case 149: return launch_stacked<3, 5, 2, 1, 0, 1, true>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown stacked kernel %d", L.stacked_id);
 }
@@ -1721,6 +1726,16 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     if (npts > 16 * k.ct / k.g || tighter_instance(k) || !fills_tiles(k)) continue;
                 } else if (chunked) {  // point-chunked: whatever the whole-request instances above did not take
                     if (npts < 13 || nreq * (long long)((npts + 16 * k.ct - 1) / (16 * k.ct)) > 0x7fffffffLL) continue;
+                    if (k.rtc == -1 && k.sd == 3 && (k.n == 6 || k.n == 5)) {
+                        // two-tile or three-tile chunks: the fewer column tiles.  Measured (tools/instance_ab.py --own-cell, 0.8 GB): degree 6
+                        // at the 122-point rule, values / gradients / Hessians 581 / 469 / 540 us on 48-point chunks (9 tiles) -> 535 / 364 /
+                        // 353 us on 32-point chunks (8 tiles); at 57 points (6 -> 4 tiles) gradients 426 us.  On a tie (74 points: 6 tiles
+                        // either way) degree 6 is faster on 48-point chunks (402 against 448 us) and degree 5 within the spread of the two
+                        // measurement protocols (361-370 us in sustained runs, 410-428 in the map's short ones, against 385-400): ties stay
+                        // on 48-point chunks
+                        const long long t2 = 2LL * ((npts + 31) / 32), t3 = 3LL * ((npts + 47) / 48);
+                        if ((k.ct == 2) != (t2 < t3)) continue;
+                    }
                     if (inmix) {  // ... with the chain rule inside: rules of more than one chunk
                         const bool nomix = (ctx->policy & FX_POLICY_NO_STACKED_MIX) != 0;
                         if (nomix || !verts || order != (k.rtc == -4 ? 1 : 2) || npts <= 16 * k.ct) continue;

@@ -413,7 +413,12 @@ ROUTES = [
     ("Lagrange", 2, 5, 50, 1, True, "stacked<2,5,4,1,0>"), ("Lagrange", 2, 6, 57, 2, True, "stacked<2,6,3,1,-5>"),
     ("Nedelec", 3, 3, 57, 1, True, "stacked<3,3,3,1,-4>"), ("Nedelec", 3, 3, 16, 2, True, "kernel"),
     ("Nedelec", 3, 3, 14, 1, True, "stacked<3,3,3,3,0>"), ("RaviartThomas", 3, 3, 11, 2, True, "kernel"),
-    ("Nedelec", 3, 3, 23, 2, True, "stacked<3,3,3,2,-3>")]
+    ("Nedelec", 3, 3, 23, 2, True, "stacked<3,3,3,2,-3>"),
+    # point chunks of two or three column tiles: whichever needs fewer tiles
+    ("Lagrange", 3, 6, 122, 1, False, "stacked<3,6,2,1,-1>"), ("Lagrange", 3, 6, 74, 1, False, "stacked<3,6,3,1,-1>"),
+    ("Lagrange", 3, 6, 57, 0, False, "stacked<3,6,2,1,-1>"), ("DiscontinuousLagrange", 3, 6, 121, 2, False, "stacked<3,6,2,1,-1>"),
+    ("Lagrange", 3, 5, 74, 2, False, "stacked<3,5,3,1,-1>"), ("Lagrange", 3, 5, 74, 0, False, "stacked<3,5,3,1,-1>"),
+    ("Lagrange", 3, 5, 111, 1, False, "stacked<3,5,2,1,-1>")]
 
 
 @pytest.mark.parametrize("family,sd,degree,npts,order,cells,kernel", ROUTES,
