@@ -881,6 +881,7 @@ const StackedShape kStackedShapes[] = {
     // point chunks of two column tiles: rules whose 32-point chunks need fewer column tiles than their 48-point chunks
     // (49..64 points: 4 against 6; 97..128 points -- the 122-point rule of degree 6 -- 8 against 9)
     {3, 6, 2, 1, -1}, {3, 5, 2, 1, -1},
+    {3, 6, 2, 1, -4}, {3, 5, 2, 1, -4},  // ... with the order-1 chain rule of per-request cells inside
 };
 // shapes whose in-kernel chain-rule instances (rtc -2 / -3 / -6) have a twin that applies the Piola map too
 constexpr bool stacked_has_pio(int sd, int n) { return (sd == 3 && (n == 2 || n == 3)) || (sd == 2 && (n == 3 || n == 4)); }
@@ -1139,6 +1140,8 @@ int run_stacked(const Launch& L, hipStream_t s) {
         case 147: return launch_stacked<2, 4, 2, 1, 0, 1, false, 1, false, true, 1>(L, s);
         case 148: return launch_stacked<3, 6, 2, 1, 0, 1, true>(L, s);
         case 149: return launch_stacked<3, 5, 2, 1, 0, 1, true>(L, s);
+        case 150: return launch_stacked<3, 6, 2, 1, 0, 1, true, 4, false, true>(L, s);
+        case 151: return launch_stacked<3, 5, 2, 1, 0, 1, true, 4, false, true>(L, s);
     }
     return fail(FX_EINVAL, "internal: unknown stacked kernel %d", L.stacked_id);
 }
@@ -1726,7 +1729,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     if (npts > 16 * k.ct / k.g || tighter_instance(k) || !fills_tiles(k)) continue;
                 } else if (chunked) {  // point-chunked: whatever the whole-request instances above did not take
                     if (npts < 13 || nreq * (long long)((npts + 16 * k.ct - 1) / (16 * k.ct)) > 0x7fffffffLL) continue;
-                    if (k.rtc == -1 && k.sd == 3 && (k.n == 6 || k.n == 5)) {
+                    if ((k.rtc == -1 || k.rtc == -4) && k.sd == 3 && (k.n == 6 || k.n == 5)) {
                         // two-tile or three-tile chunks: the fewer column tiles.  Measured (tools/instance_ab.py --own-cell, 0.8 GB): degree 6
                         // at the 122-point rule, values / gradients / Hessians 581 / 469 / 540 us on 48-point chunks (9 tiles) -> 535 / 364 /
                         // 353 us on 32-point chunks (8 tiles); at 57 points (6 -> 4 tiles) gradients 426 us.  On a tie (74 points: 6 tiles

@@ -231,7 +231,7 @@ MIXR = [("Lagrange", 3, 2, 11, 2, "3,2,3,4,-3"), ("Lagrange", 3, 2, 14, 2, "3,2,
         ("Lagrange", 3, 6, 23, 1, "3,6,3,2,-2"), ("Lagrange", 3, 6, 44, 1, "3,6,3,1,-2"), ("Nedelec", 3, 2, 11, 1, "3,2,3,4,-2"),
         ("Lagrange", 3, 5, 24, 1, "3,5,3,2,-2"), ("Nedelec", 2, 3, 12, 1, "2,3,3,4,-2"), ("Lagrange", 2, 6, 30, 1, "2,6,2,1,-2"),
         # point chunks
-        ("Lagrange", 3, 6, 122, 1, "3,6,3,1,-4"), ("Lagrange", 3, 5, 74, 1, "3,5,3,1,-4"), ("Lagrange", 3, 4, 70, 1, "3,4,3,1,-4"), ("Nedelec", 3, 3, 57, 1, "3,3,3,1,-4"),
+        ("Lagrange", 3, 6, 122, 1, "3,6,2,1,-4"), ("Lagrange", 3, 6, 74, 1, "3,6,3,1,-4"), ("Lagrange", 3, 5, 122, 1, "3,5,2,1,-4"), ("Lagrange", 3, 6, 57, 1, "3,6,2,1,-4"), ("Lagrange", 3, 5, 74, 1, "3,5,3,1,-4"), ("Lagrange", 3, 4, 70, 1, "3,4,3,1,-4"), ("Nedelec", 3, 3, 57, 1, "3,3,3,1,-4"),
         ("Lagrange", 3, 3, 97, 1, "3,3,3,1,-4"), ("Nedelec", 3, 2, 49, 1, "3,2,3,1,-4"), ("Lagrange", 2, 6, 73, 1, "2,6,3,1,-4"),
         ("Lagrange", 2, 5, 55, 1, "2,5,3,1,-4"),
         ("Lagrange", 3, 6, 122, 2, "3,6,2,1,-5"), ("Lagrange", 3, 5, 74, 2, "3,5,2,1,-5"), ("Lagrange", 3, 4, 45, 2, "3,4,2,1,-5"),
