@@ -21,6 +21,7 @@ import argparse
 import json
 import math
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -36,6 +37,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # fp64 MFMA: 32 FLOP/clk/SIMD measured (v_mfma_f64_16x16x4 = 64 cycles, tools/ubench2.hip; the fp64 FMA rate)
 # x 1024 SIMDs x 2.4 GHz.  The guide's peak table has no fp64 row.
 F64_PEAK_TFLOPS = 32 * 1024 * 2.4e9 / 1e12
+PEER_GRACE_S = 15.0     # ranks != 0 keep waiting this much longer than rank 0's all-gather watchdog (run(): rank 0 prints)
+TERM_GRACE_S = 5.0      # spawn_ranks: after the first failed rank the others get this long to leave on their own
 CLOCK_RAMP_MS = 60.0    # untimed launches before the W warm-up steps: the shader clock needs tens of ms after idle
 
 WORKLOADS = {
@@ -294,25 +297,27 @@ class HexWorkload:
 
 
 # ---------------------------------------------------------------------------------------------------
-def spawn_ranks(args):
-    """``bench.py --gpus N`` without a launcher: start the N ranks from a parent that never touches the GPU
-    (torch.cuda.device_count() does not initialise it on this image)."""
-    import torch
+def spawn_ranks(nranks, cmd=None, need_gpus=True):
+    """``bench.py --gpus N`` without a launcher: start the N ranks (``cmd``, default this script with its own
+    arguments) from a parent that never touches the GPU (torch.cuda.device_count() does not initialise it on this
+    image)."""
     backend = os.environ.get("FIAT_AMD_BENCH_BACKEND", "nccl")
-    ngpu = torch.cuda.device_count()
-    if backend == "nccl" and ngpu < args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but only {ngpu} GPU(s) visible (RCCL needs one GPU per rank; "
-              f"FIAT_AMD_BENCH_BACKEND=gloo rehearses the multi-rank path on fewer)", file=sys.stderr)
-        return 2
+    if need_gpus and backend == "nccl":
+        import torch
+        ngpu = torch.cuda.device_count()
+        if ngpu < nranks:
+            print(f"bench.py: --gpus {nranks} but only {ngpu} GPU(s) visible (RCCL needs one GPU per rank; "
+                  f"FIAT_AMD_BENCH_BACKEND=gloo rehearses the multi-rank path on fewer)", file=sys.stderr)
+            return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen(cmd or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stderr=subprocess.PIPE, text=True, bufsize=1))
 
     def relay(r, pipe):     # every line of a child's stderr carries its rank
@@ -323,9 +328,11 @@ def spawn_ranks(args):
     relays = [threading.Thread(target=relay, args=(r, p.stderr), daemon=True) for r, p in enumerate(procs)]
     for t in relays:
         t.start()
-    # wait for all; as soon as one rank fails the others are terminated (they would wait in a collective for ever)
-    rc, failed = 0, None
-    live = set(range(args.gpus))
+    # wait for all; once one rank has failed the others (they would wait in a collective for ever) get TERM_GRACE_S to
+    # notice and leave on their own -- rank 0 with its line -- then SIGTERM (run() turns that into the line + status 3),
+    # then SIGKILL
+    rc, failed, t_failed, stage = 0, None, 0.0, 0
+    live = set(range(nranks))
     while live:
         for r in sorted(live):
             code = procs[r].poll()
@@ -335,10 +342,20 @@ def spawn_ranks(args):
             if code != 0:
                 rc = max(rc, abs(code))
                 if failed is None:
-                    failed = r
-                    print(f"bench.py: rank {r} exited with status {code}; terminating the other ranks", file=sys.stderr)
-                    for q in live:
-                        procs[q].terminate()
+                    failed, t_failed = r, time.monotonic()
+                    print(f"bench.py: rank {r} exited with status {code}; the other ranks have {TERM_GRACE_S:.0f} s to leave",
+                          file=sys.stderr)
+        if failed is not None and live:
+            waited = time.monotonic() - t_failed
+            if stage == 0 and waited > TERM_GRACE_S:
+                stage = 1
+                print(f"bench.py: terminating the other ranks {sorted(live)}", file=sys.stderr)
+                for q in live:
+                    procs[q].terminate()
+            elif stage == 1 and waited > TERM_GRACE_S + 10.0:
+                stage = 2
+                for q in live:
+                    procs[q].kill()
         if live:
             time.sleep(0.05)
     for t in relays:
@@ -512,46 +529,81 @@ def run(args):
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = wl.cpu_baseline()
 
-    # with-gather leg: after the line is complete, under a watchdog -- a stuck exchange must not cost the
-    # compute-only measurement, and it must not look like success either: the line is still printed, the process
-    # then exits with status 3 (never re-exec'ed: it has touched the GPU)
-    lock = threading.Lock()
-    printed = [False]
-
-    def emit(extra=None):
-        with lock:
-            if extra is not None and line is not None:
-                line["allgather"] = extra
-            if rank == 0 and not printed[0]:
-                printed[0] = True
-                print(json.dumps(line), flush=True)
-
-    failed = False
     if world > 1 and not args.no_allgather and len(wl.parts) == 1 and not args.shared_points:
-        def bail():
-            emit({"error": f"no result within {args.allgather_timeout} s"})
-            print(f"bench.py: the all-gather leg did not finish within {args.allgather_timeout} s", file=sys.stderr, flush=True)
-            os._exit(3)
-        dog = threading.Timer(args.allgather_timeout, bail)
-        dog.daemon = True
-        dog.start()
-        try:
-            res = allgather_leg(wl, world, rank, args, barrier)
-        except Exception as exc:     # report, keep the compute-only result, fail the process
-            res = {"error": f"{type(exc).__name__}: {exc}"}
-            failed = True
-        dog.cancel()
-        if isinstance(res, dict) and res.get("verify") is not None and not res["verify"].get("ok", False):
-            failed = True
-        emit(res)
+        failed = guarded_leg(line, rank, args.allgather_timeout, barrier,
+                             lambda: allgather_leg(wl, world, rank, args, barrier))
     else:
-        emit()
+        failed = False
+        if rank == 0:
+            print(json.dumps(line), flush=True)
     if failed:
         print("bench.py: the all-gather leg failed (see the line's \"allgather\" field)", file=sys.stderr, flush=True)
         sys.stdout.flush()
         os._exit(3)     # peers may be stuck in a collective: no orderly teardown of the process group
     if world > 1:
         dist.destroy_process_group()
+
+
+def guarded_leg(line, rank, timeout, barrier, leg):
+    """Run ``leg()`` (the with-gather measurement) after the compute-only ``line`` is complete, under a watchdog: a stuck
+    exchange must not cost the compute-only measurement, and it must not look like success either -- rank 0 still prints
+    the line, with ``allgather: {"error": ...}`` inside, and the process leaves with status 3 (never re-exec'ed: it has
+    touched the GPU).  Returns True when the leg failed in an orderly way (the line is printed either way).  The line
+    survives every ordering of the ranks' deaths:
+      * rank 0's watchdog is armed BEFORE the barrier that opens the leg, the peers' watchdogs after it and with
+        PEER_GRACE_S more on the clock, so rank 0 always gives up first and prints;
+      * a launcher (spawn_ranks above, torch.distributed.run) that sees another rank die SIGTERMs this one while its
+        main thread sits inside a collective, where no Python signal handler can run: the C-level handler writes the
+        signal number to a pipe (signal.set_wakeup_fd) and a watcher thread prints the line and leaves with status 3."""
+    lock = threading.Lock()
+    printed = [False]
+
+    def emit(extra):
+        with lock:
+            if line is not None:
+                line["allgather"] = extra
+            if rank == 0 and not printed[0]:
+                printed[0] = True
+                print(json.dumps(line), flush=True)
+
+    rfd, wfd = os.pipe()
+    os.set_blocking(wfd, False)
+    signal.signal(signal.SIGTERM, lambda *_: None)      # installs the C handler that feeds the wake-up pipe
+    signal.set_wakeup_fd(wfd, warn_on_full_buffer=False)
+
+    def on_signal():
+        os.read(rfd, 1)
+        emit({"error": "terminated by the launcher: a peer rank failed before the all-gather leg finished"})
+        print(f"bench.py: rank {rank} terminated during the all-gather leg", file=sys.stderr, flush=True)
+        os._exit(3)
+    threading.Thread(target=on_signal, daemon=True).start()
+
+    def bail():
+        emit({"error": f"no result within {timeout} s"})
+        print(f"bench.py: the all-gather leg did not finish within {timeout} s", file=sys.stderr, flush=True)
+        os._exit(3)
+
+    def arm(seconds):
+        dog = threading.Timer(seconds, bail)
+        dog.daemon = True
+        dog.start()
+        return dog
+    failed = False
+    dog = arm(timeout) if rank == 0 else None
+    try:
+        barrier()       # the peers wait here for rank 0's extra work (fill probe, oracle check)
+        if rank != 0:
+            dog = arm(timeout + PEER_GRACE_S)
+        res = leg()
+    except Exception as exc:     # report, keep the compute-only result, fail the process
+        res = {"error": f"{type(exc).__name__}: {exc}"}
+        failed = True
+    if dog is not None:
+        dog.cancel()
+    if isinstance(res, dict) and res.get("verify") is not None and not res["verify"].get("ok", False):
+        failed = True
+    emit(res)
+    return failed
 
 
 def allgather_leg(wl, world, rank, args, barrier):
@@ -567,8 +619,11 @@ def allgather_leg(wl, world, rank, args, barrier):
     reps = max(2, min(10, args.steps // 4))
     res = {"impl": gather.impl, "algo": args.allgather_algo if gather.impl == "rccl" else "torch.distributed",
            "gathered_bytes_per_gpu": world * out.numel() * 8, "reps": reps}
-    if os.environ.get("FIAT_AMD_BENCH_FORCE_GATHER_TIMEOUT") and rank == world - 1:
-        time.sleep(args.allgather_timeout + 30.0)     # test hook (tests/test_bench_launch.py): a rank that never joins
+    # test hooks (tests/test_bench_launch.py): the named rank never joins the exchange / dies in it
+    if os.environ.get("FIAT_AMD_BENCH_FORCE_GATHER_TIMEOUT", "") == str(rank):
+        time.sleep(args.allgather_timeout + 60.0)
+    if os.environ.get("FIAT_AMD_BENCH_FORCE_GATHER_CRASH", "") == str(rank):
+        os._exit(7)
     # replicated or staged?  Decided COLLECTIVELY: rank 0 keeps an extra buffer in the allocator's cache, so the ranks'
     # own free-memory readings differ and could choose different (mismatched) collectives.
     torch.cuda.empty_cache()
@@ -726,7 +781,7 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         os.environ["FIAT_AMD_BENCH_SPAWNED"] = "1"
-        sys.exit(spawn_ranks(args))
+        sys.exit(spawn_ranks(args.gpus))
     run(args)
 
 

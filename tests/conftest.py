@@ -14,6 +14,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Kernel-vs-oracle parity first, launcher / subprocess tests last: under ``-x`` a failure of the multi-rank launcher
+    (tests/test_bench_launch.py spawns gloo ranks and torch.distributed.run) must never again hide the parity tests."""
+    last = ("test_bench_launch.py",)
+    items.sort(key=lambda it: 1 if os.path.basename(str(it.fspath)) in last else 0)     # stable: keeps the rest in order
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

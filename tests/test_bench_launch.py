@@ -43,23 +43,110 @@ def test_failing_ranks_fail_the_launcher_with_labelled_stderr():
                          env=_env(FIAT_AMD_BENCH_BACKEND="gloo"), timeout=600)
     assert res.returncode != 0 and not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert "[rank 0] " in res.stderr or "[rank 1] " in res.stderr
-    assert "needs an MI355X" in res.stderr and "terminating the other ranks" in res.stderr
+    assert "needs an MI355X" in res.stderr and "the other ranks have" in res.stderr
+
+
+# ---- the guarded all-gather leg, rehearsed on CPU: every ordering of the ranks' deaths leaves ONE line and status != 0
+REHEARSAL = os.path.join(ROOT, "tests", "native", "guard_rehearsal.py")
+
+
+def _port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rehearse(launcher, world=2, **hooks):
+    if launcher == "spawn":
+        cmd = [sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; "
+               "sys.exit(bench.spawn_ranks(%d, cmd=[sys.executable, %r], need_gpus=False))" % (ROOT, world, REHEARSAL)]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+               "127.0.0.1", "--master-port", str(_port()), REHEARSAL]
+    res = subprocess.run(cmd, capture_output=True, text=True, env=_env(**dict({"GUARD_TIMEOUT": "6"}, **hooks)), timeout=300)
+    lines = [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]
+    return res, lines
+
+
+@pytest.mark.parametrize("launcher", ["spawn", "torchrun"])
+def test_guarded_leg_success_prints_one_line(launcher):
+    res, lines = _rehearse(launcher)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["allgather"] == {"sum": 2.0} and lines[0]["value"] == 1.0
+
+
+@pytest.mark.parametrize("launcher", ["spawn", "torchrun"])
+@pytest.mark.parametrize("stuck", [0, 1])
+def test_guarded_leg_hung_rank_leaves_the_line_and_fails(launcher, stuck):
+    """A rank that never joins the exchange, while rank 0 reaches the leg 3 s after its peer (its oracle check): rank 0's
+    watchdog is the first to fire whichever rank hangs, so the line always says "no result within"."""
+    res, lines = _rehearse(launcher, GUARD_HANG=str(stuck), GUARD_RANK0_EXTRA="3")
+    assert res.returncode != 0, res.stderr[-2000:]
+    assert len(lines) == 1, (res.stdout[-2000:], res.stderr[-2000:])
+    assert lines[0]["value"] == 1.0 and "no result within 6" in lines[0]["allgather"]["error"]
+
+
+@pytest.mark.parametrize("launcher", ["spawn", "torchrun"])
+def test_guarded_leg_dead_peer_leaves_the_line_and_fails(launcher):
+    """The peer dies inside the leg: rank 0, blocked in the collective, either sees the connection drop or is SIGTERMed by
+    the launcher -- both end in the line with an error inside and a non-zero status."""
+    res, lines = _rehearse(launcher, GUARD_CRASH="1")
+    assert res.returncode != 0, res.stderr[-2000:]
+    assert len(lines) == 1, (res.stdout[-2000:], res.stderr[-2000:])
+    assert lines[0]["value"] == 1.0 and lines[0]["allgather"]["error"]
+
+
+def test_guarded_leg_sigterm_inside_a_blocked_collective():
+    """The pure launcher-kill ordering, without help from gloo: three ranks, rank 2 hangs OUTSIDE any collective (so no
+    connection drops), rank 1 dies; the parent's SIGTERM reaches rank 0 while its main thread is blocked in all_reduce and
+    the wake-up pipe's watcher thread prints the line."""
+    res, lines = _rehearse("spawn", world=3, GUARD_CRASH="1", GUARD_HANG="2", GUARD_TIMEOUT="60")
+    assert res.returncode != 0, res.stderr[-2000:]
+    assert len(lines) == 1, (res.stdout[-2000:], res.stderr[-2000:])
+    assert lines[0]["allgather"]["error"] and "rank 0 terminated during the all-gather leg" in res.stderr \
+        or "Connection" in lines[0]["allgather"]["error"]
+
+
+def test_guarded_leg_orderly_failure():
+    res, lines = _rehearse("spawn", GUARD_RAISE="0")
+    assert res.returncode != 0 and len(lines) == 1 and "exchange refused" in lines[0]["allgather"]["error"]
 
 
 @pytest.mark.gpu
-def test_stuck_allgather_leg_is_a_failure_not_a_success():
-    """A rank that never joins the exchange: the watchdog still prints the compute-only line (with the error inside) and
-    the job exits NON-ZERO -- a hung collective must not look like success to the driver."""
+@pytest.mark.parametrize("stuck", [1, 0])
+def test_stuck_allgather_leg_is_a_failure_not_a_success(stuck):
+    """A rank that never joins the exchange: rank 0's watchdog (always the first to fire) still prints the compute-only line,
+    with the error inside, and the job exits NON-ZERO -- a hung collective must not look like success to the driver."""
     res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2000", "--check", "50",
                           "--no-cpu-baseline", "--allgather-timeout", "20"], capture_output=True, text=True,
-                         env=_env(FIAT_AMD_BENCH_BACKEND="gloo", FIAT_AMD_BENCH_FORCE_GATHER_TIMEOUT="1"), timeout=900)
+                         env=_env(FIAT_AMD_BENCH_BACKEND="gloo", FIAT_AMD_BENCH_FORCE_GATHER_TIMEOUT=str(stuck)), timeout=900)
     assert res.returncode != 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]
+    assert len(lines) == 1, (res.stdout[-2000:], res.stderr[-3000:])
     line = json.loads(lines[0])
-    # rank 0 either runs into its own watchdog or sees the peer (whose watchdog fired first) drop the connection
-    assert line["value"] > 0 and line["allgather"]["error"]
+    assert line["value"] > 0 and "no result within 20" in line["allgather"]["error"]
     assert "[rank " in res.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hook", ["FIAT_AMD_BENCH_FORCE_GATHER_TIMEOUT", "FIAT_AMD_BENCH_FORCE_GATHER_CRASH"])
+def test_torchrun_launch_with_a_failing_peer_keeps_the_line(hook):
+    """The driver's launch line with rank 1 hanging / dying inside the exchange: torch.distributed.run SIGTERMs the siblings
+    of the first failed rank -- the compute-only line must be on stdout regardless."""
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(_port()), BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--batch", "2000", "--check", "50", "--allgather-timeout", "20"], capture_output=True, text=True,
+                         env=_env(FIAT_AMD_BENCH_BACKEND="gloo", **{hook: "1"}), timeout=900)
+    assert res.returncode != 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (res.stdout[-2000:], res.stderr[-3000:])
+    line = json.loads(lines[0])
+    assert line["value"] > 0 and line["n_gpus"] == 2 and line["allgather"]["error"]
+    if hook.endswith("TIMEOUT"):
+        assert "no result within 20" in line["allgather"]["error"]
 
 
 @pytest.mark.gpu
