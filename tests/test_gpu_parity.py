@@ -404,11 +404,6 @@ def test_p3_tet_paired_kernel_point_counts(rt, golden, kernel_policy, npts, nreq
     from oracle import c_oracle
     co = golden("elements")["c2_p3tet_q6_coeffs"]
     ps = rt.SimplexPolySet(3, 3, variant="bubble", scale=1, coeffs=co)
-    if not cells:
-        if npts >= 12:
-            assert ps.kernel_name(1, nreq, npts) == "fxk::tabulate_simplex_stacked"
-        kernel_policy("no_stacked")
-    assert ps.kernel_name(1, nreq, npts, has_verts=cells) == "fxk::tabulate_simplex_pair"
     rng = np.random.default_rng(3000 + 10 * npts + nreq)
     pts = rand_points(rng, 3, (nreq, npts))
     verts = None
@@ -417,12 +412,22 @@ def test_p3_tet_paired_kernel_point_counts(rt, golden, kernel_policy, npts, nreq
         b = rng.standard_normal((nreq, 1, 3))
         verts = np.einsum("vd,red->rve", fo.UFC_SIMPLEX[3], A) + b
         pts = np.einsum("rpd,red->rpe", pts, A) + b
-    out = ps.tabulate_batch(1, pts, verts=verts).cpu().numpy()
     ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[3], 3, co, 1, pts, verts=verts, scale=1, variant="bubble")
-    num = np.abs(out - ref).max(axis=(2, 3))
-    den = np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))
-    err = (num / den).max(axis=0)
-    assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), err
+
+    def check(route):
+        out = ps.tabulate_batch(1, pts, verts=verts).cpu().numpy()
+        num = np.abs(out - ref).max(axis=(2, 3))
+        den = np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))
+        err = (num / den).max(axis=0)
+        assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), (route, err)
+
+    if not cells:
+        if npts >= 12:
+            assert ps.kernel_name(1, nreq, npts) == "fxk::tabulate_simplex_stacked"
+            check("default route: stacked")        # the route a user gets, against the oracle, before the policy switch
+        kernel_policy("no_stacked")
+    assert ps.kernel_name(1, nreq, npts, has_verts=cells) == "fxk::tabulate_simplex_pair"
+    check("pair")
 
 
 @pytest.mark.parametrize("fam,deg", [("Lagrange", 4), ("RaviartThomas", 2), ("DiscontinuousLagrange", 4)])
@@ -435,11 +440,6 @@ def test_one_request_per_wave_instances(rt, kernel_policy, fam, deg, npts, nreq,
     from oracle import c_oracle
     el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(3), deg)
     ps = el.device_polyset()
-    if not cells and deg == 4:
-        if (35 * 4 * npts) % 2 == 0:
-            assert ps.kernel_name(1, nreq, npts) == "fxk::tabulate_simplex_stacked"
-        kernel_policy("no_stacked")
-    assert ps.kernel_name(1, nreq, npts, has_verts=cells) == "fxk::tabulate_simplex_pair"
     rng = np.random.default_rng(7000 + 10 * npts + nreq + deg)
     pts = rand_points(rng, 3, (nreq, npts))
     verts = None
@@ -448,15 +448,26 @@ def test_one_request_per_wave_instances(rt, kernel_policy, fam, deg, npts, nreq,
         b = rng.standard_normal((nreq, 1, 3))
         verts = np.einsum("vd,red->rve", fo.UFC_SIMPLEX[3], A) + b
         pts = np.einsum("rpd,red->rpe", pts, A) + b
-    out = ps.tabulate_batch(1, pts, verts=verts).cpu().numpy()
     n = deg if fam != "RaviartThomas" else 2
     ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[3], n, el.get_coeffs(), 1, pts, verts=verts, scale=el._expansion_scale,
-                                  variant=el._expansion_variant).reshape(out.shape)
-    axes = tuple(range(2, out.ndim))
-    num = np.abs(out - ref).max(axis=axes)
-    den = np.maximum(1.0, np.abs(ref).max(axis=axes))
-    err = (num / den).max(axis=0)
-    assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), err
+                                  variant=el._expansion_variant)
+
+    def check(route):
+        out = ps.tabulate_batch(1, pts, verts=verts).cpu().numpy()
+        r = ref.reshape(out.shape)
+        axes = tuple(range(2, out.ndim))
+        num = np.abs(out - r).max(axis=axes)
+        den = np.maximum(1.0, np.abs(r).max(axis=axes))
+        err = (num / den).max(axis=0)
+        assert err[0] <= TOL_VAL and (len(err) == 1 or err[1:].max() <= TOL_DER), (route, err)
+
+    if not cells and deg == 4:
+        if (35 * 4 * npts) % 2 == 0:
+            assert ps.kernel_name(1, nreq, npts) == "fxk::tabulate_simplex_stacked"
+            check("default route: stacked")
+        kernel_policy("no_stacked")
+    assert ps.kernel_name(1, nreq, npts, has_verts=cells) == "fxk::tabulate_simplex_pair"
+    check("pair")
 
 
 @pytest.mark.parametrize("order", [1, 2])

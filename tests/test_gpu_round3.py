@@ -21,6 +21,21 @@ def rel(x, ref):
     return np.abs(x - ref).max() / max(1.0, np.abs(ref).max())
 
 
+def oracle_tables(el, sd, order, pts, verts, shape):
+    """The pinned C oracle's tables (recurrence on the physical cells when ``verts`` is given) of a batch."""
+    from oracle import c_oracle
+    from oracle import fiat_oracle as fo
+    n = el.get_nodal_basis().get_embedded_degree()
+    return c_oracle.tabulate_batch(fo.UFC_SIMPLEX[sd], n, el.get_coeffs(), order, pts, verts=verts, scale=el._expansion_scale,
+                                   variant=el._expansion_variant).reshape(shape)
+
+
+def check_vs_oracle(got, el, sd, order, pts, verts, tag):
+    ref = oracle_tables(el, sd, order, pts, verts, got.shape)
+    for t in range(got.shape[1]):
+        assert rel(got[:, t], ref[:, t]) <= (1e-12 if t == 0 else 1e-10), (tag, "oracle", t, rel(got[:, t], ref[:, t]))
+
+
 def stacked(fa, tab, sd, order):
     return np.stack([tab[a] for k in range(order + 1) for a in fa.mis(sd, k)])
 
@@ -166,7 +181,7 @@ def test_gls_against_the_reference(golden, sd, k):
 @pytest.mark.parametrize("order", [0, 1, 2])
 def test_odd_request_sizes_with_per_request_cells(family, sd, degree, npts, order, kernel_policy):
     """Requests of an odd number of doubles (odd rows x odd points) with per-request cells now take the stacked kernel's
-    8-byte flush twin (+ the table-mixing pass) instead of the point-chunked instance: equal to the generic kernel."""
+    8-byte flush twin (+ the table-mixing pass) instead of the point-chunked instance: against the C oracle on the physical cells, and equal to the generic kernel."""
     import fiat_amd as fa
     el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
     rng = np.random.default_rng(77 + order)
@@ -179,6 +194,7 @@ def test_odd_request_sizes_with_per_request_cells(family, sd, degree, npts, orde
     pts = np.einsum("rpv,rvd->rpd", e / e.sum(-1, keepdims=True), verts)
     got = el.tabulate_batch(order, pts, verts=verts).cpu().numpy()
     name = el.device_polyset().kernel_name(order, nreq, npts, has_verts=True)
+    check_vs_oracle(got, el, sd, order, pts, verts, name)
     kernel_policy("no_stacked", "no_small", "no_fixed", "no_coop")
     want = el.tabulate_batch(order, pts, verts=verts).cpu().numpy()
     assert el.device_polyset().kernel_name(order, nreq, npts, has_verts=True).endswith("tabulate_simplex_kernel")
@@ -193,7 +209,7 @@ def test_odd_request_sizes_with_per_request_cells(family, sd, degree, npts, orde
 @pytest.mark.parametrize("order", [0, 1, 2])
 def test_expansion_degrees_7_and_8_on_the_stacked_kernel(family, sd, degree, npts, order, kernel_policy):
     """Round 3 registered expansion degrees 7 (tetrahedra, triangles) and 8 (triangles) with the stacked-matrix kernel
-    (whole-request and point-chunked instances): equal to the generic kernel, which the reference goldens pin
+    (whole-request and point-chunked instances): against the C oracle, and equal to the generic kernel, which the reference goldens pin
     (test_expansion_degrees_7_to_10, nodality of P7 in test_gpu_facade)."""
     import fiat_amd as fa
     el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
@@ -205,6 +221,7 @@ def test_expansion_degrees_7_and_8_on_the_stacked_kernel(family, sd, degree, npt
     name = ps.kernel_name(order, nreq, npts)
     assert name.endswith("tabulate_simplex_stacked"), name
     got = el.tabulate_batch(order, pts).cpu().numpy()
+    check_vs_oracle(got, el, sd, order, pts, None, name)
     kernel_policy("no_stacked", "no_small", "no_fixed", "no_coop")
     assert ps.kernel_name(order, nreq, npts).endswith("tabulate_simplex_kernel")
     want = el.tabulate_batch(order, pts).cpu().numpy()
@@ -425,7 +442,7 @@ ROUTES = [
                          ids=[f"{r[0][:2]}{r[2]}-sd{r[1]}-{r[3]}pt-o{r[4]}-{'cells' if r[5] else 'own'}" for r in ROUTES])
 def test_planner_routes_after_the_audit(family, sd, degree, npts, order, cells, kernel, kernel_policy):
     """The kernel family (and stacked-registry instance) plan_launch picks for the shapes the round-3 audit re-routed and for
-    their neighbours that stayed, and that the chosen route gives the generic kernel's tables (which the reference goldens pin)."""
+    their neighbours that stayed, and that the chosen route gives the C oracle's tables (and the generic kernel's)."""
     import fiat_amd as fa
     from oracle import fiat_oracle as fo
     el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
@@ -442,6 +459,7 @@ def test_planner_routes_after_the_audit(family, sd, degree, npts, order, cells, 
         verts = np.einsum("vd,red->rve", fo.UFC_SIMPLEX[sd], A) + rng.standard_normal((nreq, 1, sd))
         pts = np.einsum("rpv,rvd->rpd", e / e.sum(-1, keepdims=True), verts)
     got = el.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    check_vs_oracle(got, el, sd, order, pts, verts, name)
     kernel_policy("no_stacked", "no_small", "no_fixed", "no_coop")
     assert ps.kernel_name(order, nreq, npts, has_verts=cells).endswith("tabulate_simplex_kernel")
     want = el.tabulate_batch(order, pts, verts=verts).cpu().numpy()
