@@ -29,6 +29,7 @@
 #include "jacobi_kernel.hpp"
 #include "tensor_small.hpp"
 #include "prism_small.hpp"
+#include "wg_launch.hpp"
 
 namespace {
 
@@ -882,6 +883,10 @@ const StackedShape kStackedShapes[] = {
     // (49..64 points: 4 against 6; 97..128 points -- the 122-point rule of degree 6 -- 8 against 9)
     {3, 6, 2, 1, -1}, {3, 5, 2, 1, -1},
     {3, 6, 2, 1, -4}, {3, 5, 2, 1, -4},  // ... with the order-1 chain rule of per-request cells inside
+    // round 4, rtc -7: the request-per-workgroup kernel (simplex_wg.hpp, its own translation unit wg.hip) -- rules of 49..128
+    // points, expansion values of the whole request in LDS, a row tile leaves as 16 x npts contiguous doubles; ct = the most
+    // column tiles an instance has (the launch takes ceil(npts / 16)).  Visited before the point-chunked instances.
+    {3, 6, 8, 1, -7}, {3, 5, 8, 1, -7}, {3, 4, 8, 1, -7}, {3, 3, 8, 1, -7}, {2, 6, 8, 1, -7}, {2, 5, 8, 1, -7},
 };
 // shapes whose in-kernel chain-rule instances (rtc -2 / -3 / -6) have a twin that applies the Piola map too
 constexpr bool stacked_has_pio(int sd, int n) { return (sd == 3 && (n == 2 || n == 3)) || (sd == 2 && (n == 3 || n == 4)); }
@@ -900,6 +905,31 @@ constexpr bool mixr1(int sd, int n, int ct, int g) {
 // (ABAB, orders 1 and 2: 0.83-0.94 of the one-wave launch time on the three-tile instances, 0.98-1.00 on the two-tile ones;
 // degrees 3 and 4: 0.97-1.06, left at one)
 constexpr int mixr_wps(int sd, int n) { return sd == 2 && n >= 5 ? 2 : 1; }
+// chain rule across the derivative tables of requests with their own cells, in place (after a kernel that wrote the
+// derivatives with respect to the ELEMENT's cell)
+template <int SD>
+int stacked_mix_pass(const Launch& L, hipStream_t s) {
+    if (L.khead.verts && L.kmix_order >= 1) {
+        fxk::TableMixArgs ma;
+        ma.out = L.khead.out;
+        ma.verts = L.khead.verts;
+        if (!invert_small(SD, L.khead.A0, ma.A0inv)) return fail(FX_EINVAL, "degenerate cell");
+        const int ntab = fx::binom(SD + L.kmix_order, SD);
+        ma.n = L.khead.R / ntab * L.khead.npts;
+        ma.order = L.kmix_order;
+        ma.slices = std::max(1, std::min(8, (ma.n + 2047) / 2048));
+        ma.nreq = L.khead.nreq;
+        // small requests: blocks of requests per (persistent) workgroup, ~2048 positions a pass
+        ma.rb = ma.n >= 1024 ? 1 : std::max(1, std::min(fxk::MIX_RB, 2048 / std::max(1, ma.n)));
+        if (L.khead.nreq * ma.slices > 0x7fffffffLL) return fail(FX_EINVAL, "batch too large for the table-mixing pass");
+        if ((long long)fxk::MIX_RB * ma.n > 0x3fffffffLL) return fail(FX_EINVAL, "request too large for the table-mixing pass");
+        const long long blocks = ma.rb > 1 ? std::min<long long>((L.khead.nreq + ma.rb - 1) / ma.rb, (long long)L.ncu * 16) : L.khead.nreq * ma.slices;
+        hipLaunchKernelGGL((fxk::table_mix_kernel<SD>), dim3((unsigned)std::max<long long>(1, blocks)), dim3(256), 0, s, ma);
+        HIP_TRY(hipGetLastError());
+    }
+    return FX_OK;
+}
+
 template <int SD, int N, int CT, int G, int RTC = 0, int WPS = 1, bool CHUNK = false, int MIXT = 0, bool ODD = false, bool MIXR = false, int PIO = 0>
 int launch_stacked(const Launch& L, hipStream_t s) {
     constexpr int NC = fxk::FixedNC<SD, N>::value;
@@ -964,23 +994,20 @@ int launch_stacked(const Launch& L, hipStream_t s) {
         if (ab_env("FIAT_AMD_VERBOSE")) fprintf(stderr, "[fiat_amd] range check done <%d,%d,%d,%d,mixt %d>\n", SD, N, CT, G, MIXT);
     }
 #endif
-    if (L.khead.verts && L.kmix_order >= 1 && MIXT == 0 && PIO == 0) {  // chain rule across the derivative tables, in place
-        fxk::TableMixArgs ma;
-        ma.out = L.khead.out;
-        ma.verts = L.khead.verts;
-        if (!invert_small(SD, L.khead.A0, ma.A0inv)) return fail(FX_EINVAL, "degenerate cell");
-        const int ntab = fx::binom(SD + L.kmix_order, SD);
-        ma.n = L.khead.R / ntab * L.khead.npts;
-        ma.order = L.kmix_order;
-        ma.slices = std::max(1, std::min(8, (ma.n + 2047) / 2048));
-        ma.nreq = L.khead.nreq;
-        // small requests: blocks of requests per (persistent) workgroup, ~2048 positions a pass
-        ma.rb = ma.n >= 1024 ? 1 : std::max(1, std::min(fxk::MIX_RB, 2048 / std::max(1, ma.n)));
-        if (L.khead.nreq * ma.slices > 0x7fffffffLL) return fail(FX_EINVAL, "batch too large for the table-mixing pass");
-        if ((long long)fxk::MIX_RB * ma.n > 0x3fffffffLL) return fail(FX_EINVAL, "request too large for the table-mixing pass");
-        const long long blocks = ma.rb > 1 ? std::min<long long>((L.khead.nreq + ma.rb - 1) / ma.rb, (long long)L.ncu * 16) : L.khead.nreq * ma.slices;
-        hipLaunchKernelGGL((fxk::table_mix_kernel<SD>), dim3((unsigned)std::max<long long>(1, blocks)), dim3(256), 0, s, ma);
-        HIP_TRY(hipGetLastError());
+    if (MIXT == 0 && PIO == 0) return stacked_mix_pass<SD>(L, s);
+    return FX_OK;
+}
+
+// the request-per-workgroup kernel (rtc -7; simplex_wg.hpp, compiled in wg.hip)
+int launch_wg(const Launch& L, hipStream_t s) {
+    const StackedShape& k = kStackedShapes[L.stacked_id];
+    const int ct = (L.khead.npts + 15) / 16;
+    hipError_t e = fxwg::launch_simplex_wg(k.sd, k.n, ct, L.kodd, L.khead, L.fcoef.data(), (int)L.fcoef.size(), L.klds_bytes, L.kgrid, L.trash,
+                                           reinterpret_cast<unsigned int*>(L.queue), s);
+    if (e != hipSuccess) return fail(FX_EHIP, "tabulate_simplex_wg<%d,%d,%d>: %s", k.sd, k.n, ct, hipGetErrorString(e));
+    switch (k.sd) {
+        case 2: return stacked_mix_pass<2>(L, s);
+        case 3: return stacked_mix_pass<3>(L, s);
     }
     return FX_OK;
 }
@@ -989,6 +1016,8 @@ int run_stacked(const Launch& L, hipStream_t s) {
     // (WPS = 2 variants: instances a few registers above 256 recompiled for two waves per SIMD -- values and gradients have short
     // row sweeps, the second wave covers a group's production phase: P6 triangles 27-35 -> 32-43 %, P4 tetrahedra at 13-24
     // points 28-45 -> 32-50 %; with Hessians the sweep is MFMA-bound and one 512-register wave is faster, tools/wps_probe.py)
+    if (L.stacked_id >= 0 && L.stacked_id < (int)(sizeof(kStackedShapes) / sizeof(kStackedShapes[0])) && kStackedShapes[L.stacked_id].rtc == -7)
+        return launch_wg(L, s);
     switch (L.stacked_id) {  // (same order as kStackedShapes)
         case 0: return launch_stacked<3, 3, 3, 2, 5, 3>(L, s);
         case 1: return launch_stacked<3, 3, 2, 1, 5, 3>(L, s);
@@ -1679,13 +1708,16 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             // columns the in-kernel chain-rule instance runs at 18 % where the generic kernel reaches 43 %)
             auto fills_tiles = [&](const StackedShape& k) { return 3LL * k.g * npts > 2LL * 16 * k.ct; };
             // (first the instances that apply the chain rule themselves, then the rest, each in table order)
-            for (size_t i2 = 0; i2 < 2 * (sizeof(kStackedShapes) / sizeof(kStackedShapes[0])) && L.stacked_id < 0; ++i2) {
-                const size_t i = i2 % (sizeof(kStackedShapes) / sizeof(kStackedShapes[0]));
+            // (then the request-per-workgroup instances, then the rest)
+            constexpr size_t NSH = sizeof(kStackedShapes) / sizeof(kStackedShapes[0]);
+            for (size_t i2 = 0; i2 < 3 * NSH && L.stacked_id < 0; ++i2) {
+                const size_t i = i2 % NSH, pass = i2 / NSH;
                 const StackedShape& k = kStackedShapes[i];
                 bool mix_odd = false, pio = false;
                 const bool inmix = k.rtc == -2 || k.rtc == -3 || k.rtc == -4 || k.rtc == -5 || k.rtc == -6;  // chain rule / Piola map inside the kernel
                 const bool chunked = k.rtc == -1 || k.rtc == -4 || k.rtc == -5;
-                if (inmix != (i2 == i)) continue;
+                const bool wgk = k.rtc == -7;
+                if (pass != (inmix ? 0u : wgk ? 1u : 2u)) continue;
                 if (small_keeps && k.rtc != -3 && k.rtc != -2) continue;
                 if (k.sd != e->sd || k.n != e->n) continue;
                 // small shapes with register-resident fragments: A/B partner of the paired kernel only (measured
@@ -1727,6 +1759,17 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                                              (k.sd == 2 && k.n == 5 && k.ct == 3 && k.g == 1)))
                         continue;
                     if (npts > 16 * k.ct / k.g || tighter_instance(k) || !fills_tiles(k)) continue;
+                } else if (wgk) {  // a request per workgroup: rules of 49..128 points (fewer: the whole-request instances)
+                    const int ctw = (npts + 15) / 16;
+                    if ((ctx->policy & FX_POLICY_NO_WG) || npts <= 48 || npts > 16 * k.ct || !fxwg::has_instance(k.sd, k.n, ctw, !even)) continue;
+                    // (49..64 points: where a whole-request instance of four column tiles exists it keeps the rule)
+                    if (npts <= 64 && even) {
+                        bool whole = false;
+                        for (const StackedShape& o : kStackedShapes)
+                            whole = whole || (o.sd == k.sd && o.n == k.n && o.rtc == 0 && o.g == 1 && o.ct == 4);
+                        if (whole) continue;
+                    }
+                    if (nreq + 3LL * ctx->num_cu > 0x7fffffffLL) continue;
                 } else if (chunked) {  // point-chunked: whatever the whole-request instances above did not take
                     if (npts < 13 || nreq * (long long)((npts + 16 * k.ct - 1) / (16 * k.ct)) > 0x7fffffffLL) continue;
                     if ((k.rtc == -1 || k.rtc == -4) && k.sd == 3 && (k.n == 6 || k.n == 5)) {
@@ -1818,8 +1861,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 const bool mixr = pio || k.rtc == -3 || k.rtc == -4 || k.rtc == -5 || (k.rtc == -2 && (mix_odd || mixr1(k.sd, k.n, k.ct, k.g) || (k.sd == 3 && k.n == 6 && k.ct == 3)));
                 const int slots = fxk::stacked_mix_slots(e->sd, dofmajor ? ntab : 0, mixr);
                 L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * (fxk::stacked_image_doubles(k.ct, (e->nexp + 3) / 4, slots) + (mixr ? fxk::STACKED_KBUF : 0))) * 8;
+                if (wgk) L.klds_bytes = fxwg::lds_bytes(k.sd, k.n, (npts + 15) / 16);
                 if (L.klds_bytes > ctx->lds_per_cu) continue;
-                const long long groups = chunked ? nreq * ((npts + 16 * k.ct - 1) / (16 * k.ct)) : (nreq + k.g - 1) / k.g;
+                const long long groups = wgk ? nreq * STACKED_NW : chunked ? nreq * ((npts + 16 * k.ct - 1) / (16 * k.ct)) : (nreq + k.g - 1) / k.g;
                 // one workgroup per CU = one wave per SIMD (measured: a second wave per SIMD at half the registers
                 // spills in the production phase and gains nothing, 1.45 -> 1.48 ms: the kernel is bound by the
                 // shared fp64 MFMA/VALU pipe, not by latencies)
@@ -1828,7 +1872,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 L.trash = ctx->d_trash;
                 L.queue = ctx->d_queue + (size_t)(ctx->launch_seq++ % FX_QUEUE_SLOTS) * 16;
                 L.kmix_order = order;
-                L.kodd = (k.rtc == 0 && !even) || mix_odd;
+                L.kodd = ((k.rtc == 0 || wgk) && !even) || mix_odd;
                 L.kpiola = pio ? mapping : 0;
                 if (pio) L.fused_mapping = true;
                 L.stacked_id = (int)i;
@@ -2265,8 +2309,9 @@ int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, in
     if (rc != FX_OK) return rc;
     if ((has_verts & 2) && L.stacked_id >= 0 && L.fixed_id < 0) {  // with the instance of the stacked-matrix registry
         const StackedShape& k = kStackedShapes[L.stacked_id];
-        snprintf(name, (size_t)name_len, "fxk::tabulate_simplex_stacked<%d,%d,%d,%d,%d>%s", k.sd, k.n, k.ct, k.g, k.rtc,
-                 L.kpiola ? "+piola" : "");
+        if (k.rtc == -7) snprintf(name, (size_t)name_len, "fxk::tabulate_simplex_wg<%d,%d,%d>", k.sd, k.n, (npts + 15) / 16);
+        else snprintf(name, (size_t)name_len, "fxk::tabulate_simplex_stacked<%d,%d,%d,%d,%d>%s", k.sd, k.n, k.ct, k.g, k.rtc,
+                      L.kpiola ? "+piola" : "");
         return FX_OK;
     }
     const char* k = "fxk::tabulate_simplex_kernel";
@@ -2275,7 +2320,7 @@ int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, in
             : L.fkind == 1 ? "fxk::tabulate_simplex_stream"
                            : "fxk::tabulate_simplex_pair";
     else if (L.stacked_id >= 0)
-        k = "fxk::tabulate_simplex_stacked";
+        k = kStackedShapes[L.stacked_id].rtc == -7 ? "fxk::tabulate_simplex_wg" : "fxk::tabulate_simplex_stacked";
     else if (L.coop_id >= 0) k = "fxk::tabulate_simplex_coop";
     else if (L.small_id >= 0) k = "fxk::tabulate_simplex_small";
     snprintf(name, (size_t)name_len, "%s", k);

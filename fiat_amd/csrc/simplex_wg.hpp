@@ -1,0 +1,370 @@
+// Request-per-workgroup simplex tabulation kernel (gfx950): rules of more points than one wave's column budget.
+//
+// The same matrix product as simplex_stacked.hpp,
+//     out[req][(table, row)][point] = A_stack[(table, row)][k] * Phi_k(point)     (FIAT/polynomial_set.py:68-72 with the
+//     derivative tables as rows of one matrix, FIAT/expansions.py:438-446),
+// laid out for requests of 49..128 points (the 74- and 122-point rules of degree-5 / 6 tetrahedra, FIAT/xg_quad_data.py).
+// The stacked kernel serves those as point chunks: a unit is 32 or 48 points of one request, its row tiles leave as 8-byte
+// stores of 256- / 384-byte row segments whose first and last lines are shared with units that run elsewhere at another time,
+// and every chunk re-reads all of A_stack from L2 (ablation without MFMAs: 395 of 478 us -- the store pattern bounds it).
+// Here ONE WORKGROUP owns a request:
+//   * production: thread <-> point, the order-0 recurrence once per point, every member to a [4 KS][16 CT] slab in LDS
+//     (degree 6, 122 points: 84 x 128 doubles = 86 KB);
+//   * sweep: the four waves (one per SIMD) take the row tiles of A_stack round robin.  A wave holds the A fragments of its
+//     tile in registers (streamed from L2 one tile ahead: A_stack is read ONCE per request instead of once per chunk), reads
+//     the B fragments of K-step ks + 1 from the slab while the CT MFMAs of K-step ks run, and keeps the 16 x 16 CT result in
+//     accumulators;
+//   * flush: a finished row tile is 16 x npts CONTIGUOUS doubles of the output (stacked rows are contiguous,
+//     [ntab][rows][npts] is [R][npts]): accumulators -> per-wave LDS image -> 16-byte non-temporal stores of whole 128-byte
+//     lines, software-pipelined under the MFMAs of the wave's next tile (two accumulator sets, unrolled by two), LDS and
+//     memory instructions spread over the K-steps exactly as in simplex_stacked.hpp.
+// Requests are handed to the workgroups dynamically, two ahead (ids from one device-scope counter: the first two of a
+// workgroup are static), so that the next request's points are in registers when the sweep ends.  Every wave of every
+// workgroup leaves the request loop at the same id >= nreq: the grid always drains.
+#pragma once
+#include "coop_kernel.hpp"  // wg_lds_barrier
+#include "simplex_stacked.hpp"
+
+namespace fxk {
+
+constexpr int WG_NW = 4;  // one wave per SIMD
+// LDS doubles: control block, recurrence coefficients [3 (4 KS - 1)] (rounded up), expansion values [4 KS][16 CT], per-wave
+// row-tile images [16][<= 16 CT] + dump row
+constexpr int wg_image_doubles(int CT) { return 16 * 16 * CT + 64; }
+constexpr int wg_coef_doubles(int KS) { return (3 * 4 * KS + 7) & ~7; }
+constexpr int wg_lds_doubles(int CT, int KS) { return WQ_CTL_DOUBLES + wg_coef_doubles(KS) + 4 * KS * 16 * CT + WG_NW * wg_image_doubles(CT); }
+
+// Production is split over the waves by MEMBERS: the chains of the last recurrence level (two thirds of the members of a
+// tetrahedron's expansion set) are independent of each other, so the NSUB wave sets each run the lower levels (needed as
+// chain heads) and their share of the last level's chains -- degree 6: 27 + 28 steps a wave instead of 83.
+template <int SD, int N, int NSUB> struct StepSubsets {
+    static constexpr int NS = StepTable<SD, N>::NSTEPS;
+    int owner[NS] = {};  // -1: every subset computes it (subset 0 stores it), else the one subset that computes and stores it
+    int load[NSUB] = {};
+    constexpr StepSubsets() {
+        StepTable<SD, N> T{};
+        int cur_owner = 0;
+        for (int s = 0; s < T.count; ++s) {
+            if (SD < 2 || T.codim[s] < SD - 1) {
+                owner[s] = -1;
+                continue;
+            }
+            if (T.prv[s] < 0) {  // first step of a chain: to the least loaded subset
+                int best = 0;
+                for (int q = 1; q < NSUB; ++q)
+                    if (load[q] < load[best]) best = q;
+                cur_owner = best;
+            }
+            owner[s] = cur_owner;
+            load[cur_owner]++;
+        }
+    }
+};
+
+// PC: waves that share a row tile (each takes CT / PC of its column tiles); PR = 4 / PC row tiles are in work at a time.
+//   PC 1: a wave owns whole row tiles, waves never wait for each other inside a request -- but a request's RT row tiles go
+//         round robin over four waves (values only, degree 6: 6 tiles -> 2, 2, 1, 1: a third of the MFMA slots idle);
+//   PC 2: two waves per row tile, a step of the workgroup finishes two row tiles (6 tiles -> 3 steps, no idle slots; 21 -> 11
+//         steps, 53 -> 27).  The two halves meet in a row-tile image shared by the pair (double-buffered: one workgroup
+//         barrier per step), and each wave then writes every other 1-KB piece of the finished tile.
+template <int SD, int N, int CT, bool ODD, int PC>
+__global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const StackedArgs<FixedNC<SD, N>::value> a, double* __restrict__ trash,
+                                                                   unsigned int* __restrict__ gctr) {
+    constexpr StepTable<SD, N> TBL{};
+    constexpr int NEXP = StepTable<SD, N>::NEXP;
+    constexpr int KS = (NEXP + 3) / 4;
+    constexpr int LDC = 16 * CT;  // columns of the slab
+    constexpr int DUMP = 16 * LDC;
+    using FlushT = typename std::conditional<ODD, double, v2d>::type;
+    constexpr int EPP = ODD ? 1 : 2;                        // doubles per flush piece
+    constexpr int NRD = (16 * LDC / EPP + 63) / 64;         // image reads = output stores per row tile
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned int* ctl = reinterpret_cast<unsigned int*>(lds);
+    double* cof = lds + WQ_CTL_DOUBLES;           // [nsteps][3] = A, B, C of the recurrence steps
+    double* phi = cof + wg_coef_doubles(KS);
+    static_assert((PC == 1 || PC == 2) && CT % PC == 0, "column tiles split evenly over the waves of a row tile");
+    constexpr int PR = WG_NW / PC, CTW = CT / PC;
+    const int pr = wave / PC, pc = wave % PC;     // (wave-uniform) row group, column group
+    // four row-tile images: PC 1 one per wave; PC 2 two per pair of waves (step parity)
+    double* const imgs = phi + 4 * KS * LDC;
+    auto image_of = [&](int parity) { return imgs + (size_t)(PC == 1 ? wave : pr * 2 + parity) * wg_image_doubles(CT); };
+
+    typedef const __attribute__((address_space(4))) double CDouble;
+    typedef StackedArgs<FixedNC<SD, N>::value> ArgsT;
+    const __attribute__((address_space(4))) char* kargs =
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    CDouble* kcoef = (CDouble*)(kargs + __builtin_offsetof(ArgsT, coef));
+
+    const int npts = a.npts;
+    const int kk = lane >> 4, col = lane & 15;
+    const long long nreq = a.nreq;
+
+    // image offsets of this lane's accumulator elements: element jj of column tile c is row 4 jj + kk, column 16 c + col.
+    // Tiles c < CT - 1 lie inside the rule (npts > 16 (CT - 1)): base of row 4 jj + kk plus the immediate 16 c; the last tile's
+    // padding columns go to the dump row.
+    // (this wave's column tiles are c0 .. c0 + CTW - 1)
+    const int c0 = pc * CTW;
+    int ibase[4], ilast[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        ibase[jj] = (4 * jj + kk) * npts + col + 16 * c0;
+        ilast[jj] = (pc < PC - 1 || 16 * (CT - 1) + col < npts) ? ibase[jj] + 16 * (CTW - 1) : DUMP + lane;
+    }
+
+    // production: WPP waves cover the LDC columns, NSUB such wave sets split the members (StepSubsets)
+    constexpr int WPP = LDC > 64 ? 2 : 1, NSUB = WG_NW / WPP;
+    constexpr StepSubsets<SD, N, NSUB> SUBS{};
+    const int pcol = (wave % WPP) * 64 + lane;   // column this thread produces
+    const int psub = wave / WPP;                 // (wave-uniform) its member subset
+    auto load_points = [&](long long req, double (&x)[SD]) {
+        const long long rr = req < nreq ? req : nreq - 1;
+        const int pt = min(pcol, npts - 1);  // (threads past the rule recompute its last point: padding columns)
+        const double* pp = a.pts + ((size_t)rr * npts + pt) * SD;
+#pragma unroll
+        for (int d = 0; d < SD; ++d) x[d] = pcol < LDC ? pp[d] : 0.0;
+    };
+    // once per launch: the recurrence coefficients from the kernel arguments to LDS (broadcast reads in the recurrence: in
+    // order with the slab writes, so the waits are exact counts -- scalar loads return out of order and made every step wait
+    // for lgkmcnt(0), i.e. for its own load AND the previous member's LDS write: 83 serialised round trips per request), and
+    // the zero rows that pad the slab to whole K-steps
+    for (int i = tid; i < 3 * (NEXP - 1); i += 64 * WG_NW) cof[i] = kcoef[i];
+    for (int i = tid; i < (4 * KS - NEXP) * LDC; i += 64 * WG_NW) phi[NEXP * LDC + i] = 0.0;
+    wg_lds_barrier();
+
+    long long cur = blockIdx.x, nxt = (long long)blockIdx.x + gridDim.x;
+    double xcur[SD], xnext[SD];
+    load_points(cur, xcur);
+
+    while (cur < nreq) {
+        // ---------------- expansion values of the whole request -> LDS slab ----------------
+        if (pcol < LDC) {
+            double X[SD];
+            if (a.verts) {  // (uniform branch) physical point -> default simplex through the request's cell
+                double J[SD][SD], bb[SD];
+                cell_map<SD>(a.verts + (size_t)cur * (SD + 1) * SD, J, bb);
+#pragma unroll
+                for (int i = 0; i < SD; ++i) {
+                    double t = bb[i];
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) t += J[i][d] * xcur[d];
+                    X[i] = t;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < SD; ++i) {
+                    double t = a.b0[i];
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) t += a.A0[i * SD + d] * xcur[d];
+                    X[i] = t;
+                }
+            }
+            auto produce_subset = [&](auto sub_c) {
+                constexpr int SUB = decltype(sub_c)::value;
+                double mem[NEXP];
+                double ufa = 0.0, ufb = 0.0, ufc = 0.0;
+                int fcodim = -1;
+                mem[0] = a.phi0;
+                if constexpr (SUB == 0) phi[pcol] = mem[0];
+#pragma unroll
+                for (int s = 0; s < NEXP - 1; ++s) {
+                    if (SUBS.owner[s] >= 0 && SUBS.owner[s] != SUB) continue;
+                    const double cA = cof[3 * s], cB = cof[3 * s + 1], cC = cof[3 * s + 2];
+                    if (TBL.codim[s] != fcodim) {
+                        fcodim = TBL.codim[s];
+                        point_factors<SD>(fcodim, X, ufa, ufb, ufc);
+                    }
+                    const double f = cA * ufa - cB * ufb;
+                    double v = mem[TBL.cur[s]] * f;
+                    if (TBL.prv[s] >= 0) v -= cC * ufc * mem[TBL.prv[s]];
+                    mem[TBL.dst[s]] = v;
+                    if (SUBS.owner[s] == SUB || (SUBS.owner[s] < 0 && SUB == 0)) phi[(s + 1) * LDC + pcol] = v;
+                }
+            };
+            if constexpr (NSUB == 2) {
+                if (psub == 0) produce_subset(std::integral_constant<int, 0>{});
+                else produce_subset(std::integral_constant<int, 1>{});
+            } else {
+                if (psub == 0) produce_subset(std::integral_constant<int, 0>{});
+                else if (psub == 1) produce_subset(std::integral_constant<int, 1>{});
+                else if (psub == 2) produce_subset(std::integral_constant<int, 2>{});
+                else produce_subset(std::integral_constant<int, 3>{});
+            }
+        }
+        wg_lds_barrier();  // slab complete
+
+        // next request's points and the id of the one after it: in flight during the sweep
+        load_points(nxt, xnext);
+        unsigned int tick = 0;
+        if (tid == 0) tick = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+        // ---------------- sweep: row tiles pr, pr + PR, ... of A_stack, column tiles c0 .. c0 + CTW - 1 ----------------
+        const int RT = a.RT;
+        // steps of this wave: PC 1 its own row tiles; PC 2 the same count for every wave (the barriers must match; a pair
+        // whose last tile does not exist multiplies the zero tile and skips the image)
+        const int nsteps = PC == 1 ? (RT > pr ? (RT - pr + PR - 1) / PR : 0) : (RT + PR - 1) / PR;
+        const int last_rows = a.R - 16 * (RT - 1);
+        double* const obase = a.out + (size_t)cur * a.R * npts;
+
+        auto image_put = [&](double* img, const v4d (&acc)[CTW], int nrows) {  // nrows: compile-time 16 in the pipelined stages
+#pragma unroll
+            for (int c = 0; c < CTW; ++c)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int o = c < CTW - 1 ? ibase[jj] + 16 * c : ilast[jj];
+                    img[4 * jj + kk < nrows ? o : DUMP + lane] = acc[c][jj];
+                }
+        };
+        // piece r of a row tile's image (nrows x npts contiguous doubles, EPP doubles a piece, 64 pieces an instruction); pieces
+        // past the end repeat the last one (same value to the same address).  Full tiles: the first NFULL instructions lie
+        // inside whatever the rule's size.  A wave of a pair takes the instructions r = PC q + pc.
+        constexpr int NFULL = 16 * (16 * (CT - 1) + 1) / EPP / 64;
+        constexpr int NRW = (NRD + PC - 1) / PC;  // flush instructions per wave and row tile
+        auto piece = [&](int r, int nrows) {
+            return (nrows == 16 && r < NFULL) ? r * 64 + lane : min(r * 64 + lane, nrows * npts / EPP - 1);
+        };
+        auto image_get = [&](const double* img, FlushT& f, int q, int nrows) {
+            f = reinterpret_cast<const FlushT*>(img)[piece(PC * q + pc, nrows)];
+        };
+        auto image_out = [&](const FlushT& f, int q, int tile, int nrows) {
+            // (wave-uniform tile base + 32-bit lane offset: scalar-base addressing, no 64-bit lane addresses to hoist and spill)
+            char* tb = reinterpret_cast<char*>(obase + (size_t)16 * tile * npts);
+            FlushT* g2 = reinterpret_cast<FlushT*>(tb + (unsigned)piece(PC * q + pc, nrows) * (unsigned)sizeof(FlushT));
+            if constexpr (ODD) *g2 = f;  // 8-byte pieces, lines shared with the neighbours: plain stores
+            else stream_store(g2, f);
+        };
+        // B fragments of K-step ks: members 4 ks + kk at this lane's column of the wave's column tiles
+        auto load_b = [&](double (&b)[CTW], int ks) {
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) b[c] = phi[(4 * ks + kk) * LDC + 16 * (c0 + c) + col];
+        };
+        auto load_a = [&](double (&af)[KS], int tile, int k0, int k1) {
+            const int t = min(tile, RT);  // (the fragment buffer ends with a zero tile)
+            const double* ap = a.afrag + (size_t)t * KS * 64 + lane;
+#pragma unroll
+            for (int ks = k0; ks < k1 && ks < KS; ++ks) af[ks] = ap[ks * 64];
+        };
+        // One pipeline stage = one step: MFMAs of tile `tile` (fragments af) into acc; meanwhile the previous step's tile (a
+        // full one, in the LDS image `imgr`) goes out and the fragments of the next step's tile come in.  The memory
+        // instructions are spread over the K-steps (a wave issues in order: a burst between two MFMAs idles the matrix pipe):
+        // fragment loads in the first third -- older than every output store of the stage, so the wait for them is an exact
+        // vmcnt(#stores) -- then the image leaves in batches of PB instructions, read in one K-step and stored in the next.  At
+        // the end the accumulators go to the image `imgw` (the only LDS traffic not under MFMAs: 4 CTW ds_write_b64).
+        constexpr int T3 = KS / 3;
+        constexpr int LPK = (KS + T3 - 1) / T3;
+        constexpr int NB = KS - T3 - 1;                 // batches: read at K-step T3 + j, stored at T3 + j + 1
+        constexpr int PB = (NRW + NB - 1) / NB;
+        static_assert(T3 >= 1 && NB >= 1, "at least one K-step for the fragment loads and two for the flush");
+        double b0[CTW], b1[CTW];
+        v4d acc[CTW];
+        auto stage = [&](int step, const double* imgr, double* imgw, const double (&af)[KS], double (&an)[KS], bool flush) {
+            const int tile = pr + PR * step;
+            FlushT fb[2][PB];
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) acc[c] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                // (b0 holds the fragments of even K-steps, b1 of odd ones; K-step 0 of the next stage is loaded by the last.)
+                // The memory instructions of a K-step go FIRST, then its MFMAs: left to itself hipcc sinks the LDS reads of the
+                // next K-step's fragments below the MFMAs, where the following K-step waits for them at once.
+                if (ks & 1) load_b(b0, ks + 1 < KS ? ks + 1 : 0);
+                else load_b(b1, ks + 1 < KS ? ks + 1 : 0);
+                if (ks < T3) load_a(an, tile + PR, ks * LPK, (ks + 1) * LPK);
+                if (flush && ks >= T3) {
+                    const int j = ks - T3;
+                    if (j >= 1) {
+#pragma unroll
+                        for (int q = 0; q < PB; ++q)
+                            if ((j - 1) * PB + q < NRW) image_out(fb[(j - 1) & 1][q], (j - 1) * PB + q, tile - PR, 16);
+                    }
+                    if (j < NB) {
+#pragma unroll
+                        for (int q = 0; q < PB; ++q)
+                            if (j * PB + q < NRW) image_get(imgr, fb[j & 1][q], j * PB + q, 16);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks & 1) {
+#pragma unroll
+                    for (int c = 0; c < CTW; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], b1[c], acc[c], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CTW; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], b0[c], acc[c], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr ((KS & 1) != 0) {  // (odd KS: the last K-step used b0 and loaded K-step 0 into b1 -- keep "b0 = K-step 0")
+#pragma unroll
+                for (int c = 0; c < CTW; ++c) b0[c] = b1[c];
+            }
+            wave_lds_fence();  // (PC 1: this wave's image has been read; PC 2: imgw was read a step ago, behind a barrier)
+            if (tile < RT) image_put(imgw, acc, tile == RT - 1 ? last_rows : 16);
+            // first use of the prefetched fragments in the same block as the stores: exact vmcnt
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(an[ks]));
+            if constexpr (PC > 1) wg_lds_barrier();  // the pair's image is complete (and the one before it has been read)
+            else wave_lds_fence();
+        };
+
+        if (nsteps > 0) {
+            double fa0[KS], fa1[KS];
+            load_a(fa0, pr, 0, KS);
+            load_b(b0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa0[ks]));
+            // even steps: fragments fa0, image 0; odd steps: fa1, image 1 (PC 1: the wave's one image)
+            stage(0, image_of(1), image_of(0), fa0, fa1, false);  // first step: nothing to flush yet
+            int i = 1;
+            for (; i + 1 < nsteps; i += 2) {
+                stage(i, image_of(0), image_of(1), fa1, fa0, true);
+                stage(i + 1, image_of(1), image_of(0), fa0, fa1, true);
+            }
+            if (i < nsteps) {
+                stage(i, image_of(0), image_of(1), fa1, fa0, true);
+                ++i;
+            }
+            // the last step's tile (the only one that may have fewer than 16 rows, or -- PC 2 -- not exist)
+            {
+                const int tile = pr + PR * (i - 1);
+                const double* imgr = image_of((i - 1) & 1);
+                if (tile < RT) {
+                    const int nrows = tile == RT - 1 ? last_rows : 16;
+                    constexpr int HB = NRW < 8 ? NRW : 8;
+#pragma unroll
+                    for (int r0 = 0; r0 < NRW; r0 += HB) {
+                        FlushT fl[HB];
+#pragma unroll
+                        for (int q = 0; q < HB; ++q)
+                            if (r0 + q < NRW) image_get(imgr, fl[q], r0 + q, nrows);
+#pragma unroll
+                        for (int q = 0; q < HB; ++q)
+                            if (r0 + q < NRW) image_out(fl[q], r0 + q, tile, nrows);
+                    }
+                }
+                wave_lds_fence();
+            }
+            // first use of the prefetched points / request id in the same block as the last stores: exact vmcnt
+#pragma unroll
+            for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
+            asm volatile("" : "+v"(tick));
+        }
+        if (tid == 0) ctl[0] = tick;
+        wg_lds_barrier();  // every wave is done with the slab; the next id is published
+        const long long nxt2 = 2LL * gridDim.x + __builtin_amdgcn_readfirstlane(ctl[0]);
+        cur = nxt;
+        nxt = nxt2;
+#pragma unroll
+        for (int d = 0; d < SD; ++d) xcur[d] = xnext[d];
+    }
+    // the counter cleans up after itself (as work_queue.hpp): the last workgroup to leave zeroes it
+    if (tid == 0) {
+        if (__hip_atomic_fetch_add(gctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            __hip_atomic_store(gctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(gctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace fxk

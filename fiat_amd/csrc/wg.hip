@@ -1,0 +1,94 @@
+// Host side of the request-per-workgroup kernel (simplex_wg.hpp): its own translation unit, so that the ~60 instances
+// compile beside api.hip instead of inside it.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "simplex_wg.hpp"
+#include "wg_launch.hpp"
+
+namespace {
+
+// (two waves per row tile wherever the column tiles split evenly: DESIGN.md 4.5c)
+constexpr int wg_pc(int ct) { return ct % 2 == 0 ? 2 : 1; }
+
+template <int SD, int N, int CT, bool ODD>
+hipError_t launch(const fxk::StackedArgs<0>& h, const double* coef, int ncoef, int lds_bytes, int grid, double* trash, unsigned int* queue,
+                  hipStream_t s) {
+    constexpr int NC = fxk::FixedNC<SD, N>::value;
+    constexpr int KS = (fxk::StepTable<SD, N>::NEXP + 3) / 4;
+    if (ncoef != NC || lds_bytes != fxk::wg_lds_doubles(CT, KS) * 8 || h.npts > 16 * CT || h.npts < 1) return hipErrorInvalidValue;
+    fxk::StackedArgs<NC> ka;
+    memset(&ka, 0, sizeof ka);
+    ka.pts = h.pts;
+    ka.verts = h.verts;
+    ka.out = h.out;
+    ka.afrag = h.afrag;
+    ka.phi0 = h.phi0;
+    memcpy(ka.A0, h.A0, sizeof ka.A0);
+    memcpy(ka.b0, h.b0, sizeof ka.b0);
+    ka.nreq = h.nreq;
+    ka.npts = h.npts;
+    ka.R = h.R;
+    ka.RT = h.RT;
+    memcpy(ka.coef, coef, NC * sizeof(double));
+    auto kern = fxk::tabulate_simplex_wg<SD, N, CT, ODD, wg_pc(CT)>;
+    static thread_local bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * fxk::WG_NW), lds_bytes, s, ka, trash, queue);
+    return hipGetLastError();
+}
+
+template <int SD, int N, int CT>
+hipError_t launch_odd(bool odd, const fxk::StackedArgs<0>& h, const double* coef, int ncoef, int lds_bytes, int grid, double* trash,
+                      unsigned int* queue, hipStream_t s) {
+    return odd ? launch<SD, N, CT, true>(h, coef, ncoef, lds_bytes, grid, trash, queue, s)
+               : launch<SD, N, CT, false>(h, coef, ncoef, lds_bytes, grid, trash, queue, s);
+}
+
+template <int SD, int N>
+hipError_t launch_ct(int ct, bool odd, const fxk::StackedArgs<0>& h, const double* coef, int ncoef, int lds_bytes, int grid, double* trash,
+                     unsigned int* queue, hipStream_t s) {
+    constexpr int KS = (fxk::StepTable<SD, N>::NEXP + 3) / 4;
+    switch (ct) {
+        case 4: return launch_odd<SD, N, 4>(odd, h, coef, ncoef, lds_bytes, grid, trash, queue, s);
+        case 5: return launch_odd<SD, N, 5>(odd, h, coef, ncoef, lds_bytes, grid, trash, queue, s);
+        case 6: return launch_odd<SD, N, 6>(odd, h, coef, ncoef, lds_bytes, grid, trash, queue, s);
+        case 7: if constexpr (fxk::wg_lds_doubles(7, KS) * 8 <= 160 * 1024) return launch_odd<SD, N, 7>(odd, h, coef, ncoef, lds_bytes, grid, trash, queue, s); break;
+        case 8: if constexpr (fxk::wg_lds_doubles(8, KS) * 8 <= 160 * 1024) return launch_odd<SD, N, 8>(odd, h, coef, ncoef, lds_bytes, grid, trash, queue, s); break;
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+namespace fxwg {
+
+int lds_bytes(int sd, int n, int ct) {
+    const int nexp = sd == 3 ? (n + 1) * (n + 2) * (n + 3) / 6 : (n + 1) * (n + 2) / 2;
+    return fxk::wg_lds_doubles(ct, (nexp + 3) / 4) * 8;
+}
+
+bool has_instance(int sd, int n, int ct, bool odd) {
+    if (ct < 4 || ct > 8 || lds_bytes(sd, n, ct) > 160 * 1024) return false;
+    (void)odd;
+    return (sd == 3 && n >= 3 && n <= 6) || (sd == 2 && (n == 5 || n == 6));
+}
+
+hipError_t launch_simplex_wg(int sd, int n, int ct, bool odd, const fxk::StackedArgs<0>& h, const double* coef, int ncoef, int lds, int grid,
+                             double* trash, unsigned int* queue, hipStream_t s) {
+    if (!has_instance(sd, n, ct, odd)) return hipErrorInvalidValue;
+    if (sd == 3 && n == 6) return launch_ct<3, 6>(ct, odd, h, coef, ncoef, lds, grid, trash, queue, s);
+    if (sd == 3 && n == 5) return launch_ct<3, 5>(ct, odd, h, coef, ncoef, lds, grid, trash, queue, s);
+    if (sd == 3 && n == 4) return launch_ct<3, 4>(ct, odd, h, coef, ncoef, lds, grid, trash, queue, s);
+    if (sd == 3 && n == 3) return launch_ct<3, 3>(ct, odd, h, coef, ncoef, lds, grid, trash, queue, s);
+    if (sd == 2 && n == 6) return launch_ct<2, 6>(ct, odd, h, coef, ncoef, lds, grid, trash, queue, s);
+    if (sd == 2 && n == 5) return launch_ct<2, 5>(ct, odd, h, coef, ncoef, lds, grid, trash, queue, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace fxwg

@@ -69,7 +69,8 @@ int fx_ctx_info(fx_ctx* ctx, int* num_cu, int* lds_bytes_per_cu, char* name, int
 #define FX_POLICY_NO_MACRO_SMALL (1u << 8) /* fx_macro_tabulate_batch: lane-local kernel */
 #define FX_POLICY_KERNEL_IMAGE (1u << 9)   /* shape-specialised family: LDS-image variant */
 #define FX_POLICY_KERNEL_STREAM (1u << 10) /* shape-specialised family: one request per wave, K-streamed */
-#define FX_POLICY_ALL ((1u << 11) - 1)
+#define FX_POLICY_NO_WG (1u << 11)         /* request-per-workgroup kernel (rules of 49..128 points): point chunks instead */
+#define FX_POLICY_ALL ((1u << 12) - 1)
 int fx_ctx_set_policy(fx_ctx* ctx, unsigned flags);
 int fx_ctx_get_policy(const fx_ctx* ctx, unsigned* flags);
 

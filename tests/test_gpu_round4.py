@@ -1,0 +1,118 @@
+"""Round-4 parity cases on the HIP path.
+
+* the request-per-workgroup kernel (fiat_amd/csrc/simplex_wg.hpp): rules of 49..128 points -- the 74- and 122-point rules
+  of degree-5 / 6 tetrahedra (FIAT/xg_quad_data.py via FIAT/quadrature_schemes.py), the tabulation of
+  FIAT/polynomial_set.py:68-72 with FIAT/expansions.py:140-267 underneath -- against the pinned C oracle at the north-star
+  tolerances (1e-12 values, 1e-10 derivatives): every (degree, column-tile count) family, orders 0-2, odd table sizes (the
+  8-byte flush twins), per-request cells (values: the cell only enters the production phase; derivatives behind policy
+  no_stacked_mix: kernel + table-mixing pass), batches of 1 request, fewer requests than workgroups, and several requests
+  per workgroup (the dynamic hand-out)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_VAL, TOL_DER = 1e-12, 1e-10
+
+
+def rel(x, ref):
+    return np.abs(x - ref).max() / max(1.0, np.abs(ref).max())
+
+
+def oracle_tables(el, sd, order, pts, verts, shape):
+    from oracle import c_oracle
+    from oracle import fiat_oracle as fo
+    n = el.get_nodal_basis().get_embedded_degree()
+    return c_oracle.tabulate_batch(fo.UFC_SIMPLEX[sd], n, el.get_coeffs(), order, pts, verts=verts, scale=el._expansion_scale,
+                                   variant=el._expansion_variant).reshape(shape)
+
+
+def batch(sd, nreq, npts, seed, cells):
+    from oracle import fiat_oracle as fo
+    rng = np.random.default_rng(seed)
+    e = rng.exponential(size=(nreq, npts, sd + 1))
+    bary = e / e.sum(-1, keepdims=True)
+    if not cells:
+        return bary[..., 1:].copy(), None
+    A = np.eye(sd) + 0.15 * rng.standard_normal((nreq, sd, sd))
+    A[::3, :, 0] *= -1.0        # both orientations
+    verts = np.einsum("vd,red->rve", fo.UFC_SIMPLEX[sd], A) + rng.standard_normal((nreq, 1, sd))
+    return np.einsum("rpv,rvd->rpd", bary, verts), verts
+
+
+# (family, sd, degree, points) -> column tiles of the instance
+WG = [("DiscontinuousLagrange", 3, 6, 122), ("Lagrange", 3, 6, 74), ("Lagrange", 3, 6, 57), ("Lagrange", 3, 6, 49), ("Lagrange", 3, 6, 128),
+      ("Lagrange", 3, 6, 97), ("Lagrange", 3, 5, 74), ("Lagrange", 3, 5, 122), ("DiscontinuousLagrange", 3, 5, 111), ("Lagrange", 3, 5, 65),
+      ("Lagrange", 3, 4, 70), ("Lagrange", 3, 4, 97), ("Lagrange", 3, 4, 122), ("Lagrange", 3, 3, 70), ("Lagrange", 3, 3, 97),
+      ("Nedelec", 3, 3, 74), ("RaviartThomas", 3, 3, 81), ("Lagrange", 2, 6, 73), ("Lagrange", 2, 5, 79), ("Lagrange", 2, 6, 128),
+      # odd table sizes: the 8-byte flush twins (35 x 97, 21 x 79 / 63 x 79 doubles a request ...)
+      ("Lagrange", 3, 4, 97), ("Lagrange", 2, 5, 79), ("DiscontinuousLagrange", 2, 5, 65), ("RaviartThomas", 3, 3, 81)]
+
+
+@pytest.mark.parametrize("family,sd,degree,npts", WG, ids=[f"{m[0][:3]}{m[2]}-sd{m[1]}-{m[3]}pt" for m in WG])
+@pytest.mark.parametrize("order", [0, 1, 2])
+@pytest.mark.parametrize("nreq", [1, 77, 700])
+def test_request_per_workgroup_kernel(family, sd, degree, npts, order, nreq):
+    import fiat_amd as fa
+    el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
+    ps = el.device_polyset()
+    n = el.get_nodal_basis().get_embedded_degree()
+    name = ps.kernel_name(order, nreq, npts, instance=True)
+    assert name == f"fxk::tabulate_simplex_wg<{sd},{n},{(npts + 15) // 16}>", name
+    assert ps.kernel_name(order, nreq, npts) == "fxk::tabulate_simplex_wg"
+    pts, _ = batch(sd, nreq, npts, 31 * npts + degree + order, False)
+    got = ps.tabulate_batch(order, pts).cpu().numpy()
+    ref = oracle_tables(el, sd, order, pts, None, got.shape)
+    for t in range(got.shape[1]):
+        assert rel(got[:, t], ref[:, t]) <= (TOL_VAL if t == 0 else TOL_DER), (name, t, rel(got[:, t], ref[:, t]))
+    # a second launch on the same context: the request counter of the first one cleaned up after itself
+    again = ps.tabulate_batch(order, pts).cpu().numpy()
+    assert np.array_equal(again, got)
+
+
+@pytest.mark.parametrize("family,sd,degree,npts", [("Lagrange", 3, 6, 122), ("Lagrange", 3, 5, 74), ("Lagrange", 3, 4, 97), ("Lagrange", 2, 6, 73),
+                                                   ("Nedelec", 3, 3, 74)])
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_request_per_workgroup_kernel_with_cells(family, sd, degree, npts, order, kernel_policy):
+    """Per-request cells: values straight from the kernel (the cell maps the points in the production phase); with
+    derivatives the chain-rule instances of the stacked kernel own the shape by default, and policy no_stacked_mix sends it
+    here + through the table-mixing pass."""
+    import fiat_amd as fa
+    el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
+    ps = el.device_polyset()
+    nreq = 333
+    if order >= 1:
+        assert "stacked" in ps.kernel_name(order, nreq, npts, has_verts=True)
+        kernel_policy("no_stacked_mix")
+    assert ps.kernel_name(order, nreq, npts, has_verts=True) == "fxk::tabulate_simplex_wg"
+    pts, verts = batch(sd, nreq, npts, 7 * npts + order, True)
+    got = ps.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    ref = oracle_tables(el, sd, order, pts, verts, got.shape)
+    for t in range(got.shape[1]):
+        assert rel(got[:, t], ref[:, t]) <= (TOL_VAL if t == 0 else TOL_DER), (t, rel(got[:, t], ref[:, t]))
+
+
+@pytest.mark.parametrize("npts,order", [(122, 2), (74, 1), (57, 0)])
+def test_policy_no_wg_keeps_the_point_chunked_route(npts, order, kernel_policy):
+    import fiat_amd as fa
+    el = fa.Lagrange(fa.ufc_simplex(3), 6)
+    ps = el.device_polyset()
+    assert ps.kernel_name(order, 100, npts) == "fxk::tabulate_simplex_wg"
+    pts, _ = batch(3, 100, npts, npts, False)
+    got = ps.tabulate_batch(order, pts).cpu().numpy()
+    kernel_policy("no_wg")
+    assert ps.kernel_name(order, 100, npts) == "fxk::tabulate_simplex_stacked"
+    want = ps.tabulate_batch(order, pts).cpu().numpy()
+    ref = oracle_tables(el, 3, order, pts, None, got.shape)
+    for t in range(got.shape[1]):
+        tol = TOL_VAL if t == 0 else TOL_DER
+        assert rel(got[:, t], ref[:, t]) <= tol and rel(want[:, t], ref[:, t]) <= tol
+
+
+def test_rule_sizes_next_to_the_window():
+    """48 points stay with the whole-request instances, 129 with the point chunks."""
+    import fiat_amd as fa
+    ps = fa.Lagrange(fa.ufc_simplex(3), 6).device_polyset()
+    assert ps.kernel_name(1, 100, 48) == "fxk::tabulate_simplex_stacked"
+    assert ps.kernel_name(1, 100, 129) == "fxk::tabulate_simplex_stacked"
+    assert ps.kernel_name(1, 100, 128) == "fxk::tabulate_simplex_wg"
