@@ -18,14 +18,38 @@
 //     [ntab][rows][npts] is [R][npts]): accumulators -> per-wave LDS image -> 16-byte non-temporal stores of whole 128-byte
 //     lines, software-pipelined under the MFMAs of the wave's next tile (two accumulator sets, unrolled by two), LDS and
 //     memory instructions spread over the K-steps exactly as in simplex_stacked.hpp.
-// Requests are handed to the workgroups dynamically, two ahead (ids from one device-scope counter: the first two of a
-// workgroup are static), so that the next request's points are in registers when the sweep ends.  Every wave of every
-// workgroup leaves the request loop at the same id >= nreq: the grid always drains.
+// Requests go to the persistent workgroups round robin (request b, b + G, ... to workgroup b of G): the kernel is bound by
+// the fp64 pipe, which every CU runs at the same rate -- unlike the store-bound kernels, whose XCDs drift apart and need the
+// dynamic queue of work_queue.hpp -- and a device-scope ticket per request cost its full latency (hipcc waits for the
+// returned value at once).  The next request's points are loaded during the sweep.  Every wave of a workgroup leaves the
+// request loop at the same id >= nreq: the grid always drains.
 #pragma once
 #include "coop_kernel.hpp"  // wg_lds_barrier
 #include "simplex_stacked.hpp"
 
+#ifndef FX_WG_ABL
+#define FX_WG_ABL 0  // measurement builds: 1 no recurrence, 2 no MFMAs, 4 no flush (image reads + output stores), 8 no image writes
+#endif
+
+#ifndef FX_WG_DBG
+#define FX_WG_DBG 0  // 1: every global access range-checked against the lim_* fields, offenders redirected to / reported in `trash`
+#endif
+
 namespace fxk {
+
+#if FX_WG_DBG
+// site: 1 pts, 3 afrag, 4 out; trash[4096 + 4 site ..] = {count, first offending index, limit, request}
+__device__ __forceinline__ long long wg_dbg_check(long long idx, long long lim, int site, long long req, double* trash) {
+    if (idx >= 0 && idx < lim) return idx;
+    double* t = trash + 4096 + 4 * site;
+    if (atomicAdd(reinterpret_cast<unsigned long long*>(t), 1ULL) == 0ULL) {
+        t[1] = (double)idx;
+        t[2] = (double)lim;
+        t[3] = (double)req;
+    }
+    return -1;
+}
+#endif
 
 constexpr int WG_NW = 4;  // one wave per SIMD
 // LDS doubles: control block, recurrence coefficients [3 (4 KS - 1)] (rounded up), expansion values [4 KS][16 CT], per-wave
@@ -82,7 +106,6 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned int* ctl = reinterpret_cast<unsigned int*>(lds);
     double* cof = lds + WQ_CTL_DOUBLES;           // [nsteps][3] = A, B, C of the recurrence steps
     double* phi = cof + wg_coef_doubles(KS);
     static_assert((PC == 1 || PC == 2) && CT % PC == 0, "column tiles split evenly over the waves of a row tile");
@@ -123,6 +146,9 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
         const long long rr = req < nreq ? req : nreq - 1;
         const int pt = min(pcol, npts - 1);  // (threads past the rule recompute its last point: padding columns)
         const double* pp = a.pts + ((size_t)rr * npts + pt) * SD;
+#if FX_WG_DBG
+        if (wg_dbg_check(((long long)rr * npts + pt) * SD, a.lim_pts - SD + 1, 1, req, trash) < 0) pp = trash;
+#endif
 #pragma unroll
         for (int d = 0; d < SD; ++d) x[d] = pcol < LDC ? pp[d] : 0.0;
     };
@@ -171,6 +197,7 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
 #pragma unroll
                 for (int s = 0; s < NEXP - 1; ++s) {
                     if (SUBS.owner[s] >= 0 && SUBS.owner[s] != SUB) continue;
+                    if ((FX_WG_ABL & 1) && nreq > 8) continue;
                     const double cA = cof[3 * s], cB = cof[3 * s + 1], cC = cof[3 * s + 2];
                     if (TBL.codim[s] != fcodim) {
                         fcodim = TBL.codim[s];
@@ -195,10 +222,8 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
         }
         wg_lds_barrier();  // slab complete
 
-        // next request's points and the id of the one after it: in flight during the sweep
+        // next request's points: in flight during the sweep
         load_points(nxt, xnext);
-        unsigned int tick = 0;
-        if (tid == 0) tick = __hip_atomic_fetch_add(gctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         // ---------------- sweep: row tiles pr, pr + PR, ... of A_stack, column tiles c0 .. c0 + CTW - 1 ----------------
         const int RT = a.RT;
@@ -232,6 +257,14 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
             // (wave-uniform tile base + 32-bit lane offset: scalar-base addressing, no 64-bit lane addresses to hoist and spill)
             char* tb = reinterpret_cast<char*>(obase + (size_t)16 * tile * npts);
             FlushT* g2 = reinterpret_cast<FlushT*>(tb + (unsigned)piece(PC * q + pc, nrows) * (unsigned)sizeof(FlushT));
+#if FX_WG_DBG
+            if (wg_dbg_check(((long long)cur * a.R + 16LL * tile) * npts + (long long)EPP * piece(PC * q + pc, nrows), a.lim_out - (EPP - 1), 4, cur, trash) < 0 ||
+                reinterpret_cast<double*>(g2) != a.out + (((long long)cur * a.R + 16LL * tile) * npts + (long long)EPP * piece(PC * q + pc, nrows))) {
+                if (reinterpret_cast<double*>(g2) != a.out + (((long long)cur * a.R + 16LL * tile) * npts + (long long)EPP * piece(PC * q + pc, nrows)))
+                    wg_dbg_check(-2, 0, 5, cur, trash);   // site 5: the address differs from the index it should have
+                g2 = reinterpret_cast<FlushT*>(trash);
+            }
+#endif
             if constexpr (ODD) *g2 = f;  // 8-byte pieces, lines shared with the neighbours: plain stores
             else stream_store(g2, f);
         };
@@ -243,6 +276,9 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
         auto load_a = [&](double (&af)[KS], int tile, int k0, int k1) {
             const int t = min(tile, RT);  // (the fragment buffer ends with a zero tile)
             const double* ap = a.afrag + (size_t)t * KS * 64 + lane;
+#if FX_WG_DBG
+            if (wg_dbg_check((long long)t * KS * 64 + lane + (KS - 1) * 64, a.lim_afrag, 3, cur, trash) < 0) ap = trash;
+#endif
 #pragma unroll
             for (int ks = k0; ks < k1 && ks < KS; ++ks) af[ks] = ap[ks * 64];
         };
@@ -257,79 +293,120 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
         constexpr int NB = KS - T3 - 1;                 // batches: read at K-step T3 + j, stored at T3 + j + 1
         constexpr int PB = (NRW + NB - 1) / NB;
         static_assert(T3 >= 1 && NB >= 1, "at least one K-step for the fragment loads and two for the flush");
+        // Inside a K-step the memory instructions are dealt out over its CTW MFMAs (slice c in front of MFMA c): a wave issues
+        // in order, and what stands between two MFMAs issues while the first one occupies the pipe for 64 cycles -- a block of
+        // memory instructions behind the last MFMA of a K-step has only that one MFMA to hide under.
+        // Two accumulator sets: the finished tile of step s - 1 goes to its LDS image during the first K-steps of step s
+        // (PC 2: then the pair's barrier), and leaves for HBM during the rest of step s.
+        constexpr int NPUT = 4 * CTW;                       // image writes of a tile
+        constexpr int PPS = (NPUT + T3 * CTW - 1) / (T3 * CTW) > 2 ? (NPUT + T3 * CTW - 1) / (T3 * CTW) : 2;  // ... a slice (two; more when KS is small)
+        constexpr int KPUT = (NPUT + PPS * CTW - 1) / (PPS * CTW);  // K-steps they take
+        static_assert(KPUT <= T3, "the image is complete before its first read");
         double b0[CTW], b1[CTW];
-        v4d acc[CTW];
-        auto stage = [&](int step, const double* imgr, double* imgw, const double (&af)[KS], double (&an)[KS], bool flush) {
+        auto stage = [&](int step, v4d (&acc)[CTW], const v4d (&prev)[CTW], double* img, const double (&af)[KS], double (&an)[KS], bool flush) {
             const int tile = pr + PR * step;
             FlushT fb[2][PB];
+            const double* ap = a.afrag + (size_t)min(tile + PR, RT) * KS * 64 + lane;  // (the fragment buffer ends with a zero tile)
 #pragma unroll
             for (int c = 0; c < CTW; ++c) acc[c] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                // (b0 holds the fragments of even K-steps, b1 of odd ones; K-step 0 of the next stage is loaded by the last.)
-                // The memory instructions of a K-step go FIRST, then its MFMAs: left to itself hipcc sinks the LDS reads of the
-                // next K-step's fragments below the MFMAs, where the following K-step waits for them at once.
-                if (ks & 1) load_b(b0, ks + 1 < KS ? ks + 1 : 0);
-                else load_b(b1, ks + 1 < KS ? ks + 1 : 0);
-                if (ks < T3) load_a(an, tile + PR, ks * LPK, (ks + 1) * LPK);
-                if (flush && ks >= T3) {
-                    const int j = ks - T3;
-                    if (j >= 1) {
+                const int kn = ks + 1 < KS ? ks + 1 : 0;  // (K-step 0 of the next stage is loaded by the last)
 #pragma unroll
-                        for (int q = 0; q < PB; ++q)
-                            if ((j - 1) * PB + q < NRW) image_out(fb[(j - 1) & 1][q], (j - 1) * PB + q, tile - PR, 16);
+                for (int c = 0; c < CTW; ++c) {
+                    // ---- memory slice c ----
+                    // B fragment c of the next K-step (b0 holds even K-steps, b1 odd ones)
+                    if (ks & 1) b0[c] = phi[(4 * kn + kk) * LDC + 16 * (c0 + c) + col];
+                    else b1[c] = phi[(4 * kn + kk) * LDC + 16 * (c0 + c) + col];
+                    // A fragments of the next step's tile: first third of the stage (older than every output store of the stage)
+                    if (ks < T3) {
+#pragma unroll
+                        for (int l = ks * LPK; l < (ks + 1) * LPK && l < KS; ++l)
+                            if (l % CTW == c) an[l] = ap[l * 64];
                     }
-                    if (j < NB) {
+                    if (flush && !((FX_WG_ABL & 4) && nreq > 8)) {
+                        // the previous step's accumulators -> image
+                        if (ks < KPUT && !((FX_WG_ABL & 8) && nreq > 8)) {
 #pragma unroll
-                        for (int q = 0; q < PB; ++q)
-                            if (j * PB + q < NRW) image_get(imgr, fb[j & 1][q], j * PB + q, 16);
+                            for (int w = 0; w < PPS; ++w) {
+                                const int p = (ks * CTW + c) * PPS + w;  // image write p: column tile p / 4, element p % 4
+                                if (p < NPUT) {
+                                    const int pc_ = p >> 2, jj = p & 3;
+                                    img[pc_ < CTW - 1 ? ibase[jj] + 16 * pc_ : ilast[jj]] = prev[pc_][jj];
+                                }
+                            }
+                        }
+                        // ... and out: batch j read at K-step T3 + j, stored at T3 + j + 1
+                        if (ks >= T3) {
+                            const int j = ks - T3;
+                            if (j >= 1) {
+#pragma unroll
+                                for (int q = 0; q < PB; ++q)
+                                    if (q % CTW == c && (j - 1) * PB + q < NRW) image_out(fb[(j - 1) & 1][q], (j - 1) * PB + q, tile - PR, 16);
+                            }
+                            if (j < NB) {
+#pragma unroll
+                                for (int q = 0; q < PB; ++q)
+                                    if ((q + CTW / 2) % CTW == c && j * PB + q < NRW) image_get(img, fb[j & 1][q], j * PB + q, 16);
+                            }
+                        }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- MFMA c ----
+                    if ((FX_WG_ABL & 2) && nreq > 8) acc[c][0] += af[ks] + ((ks & 1) ? b1[c] : b0[c]);  // (one add keeps the operands alive)
+                    else if (ks & 1) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], b1[c], acc[c], 0, 0, 0);
+                    else acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], b0[c], acc[c], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (ks & 1) {
-#pragma unroll
-                    for (int c = 0; c < CTW; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], b1[c], acc[c], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < CTW; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], b0[c], acc[c], 0, 0, 0);
+                if (flush && ks == KPUT - 1) {  // the image is written: (PC 2) both halves, behind the pair's barrier
+                    if constexpr (PC > 1) wg_lds_barrier();
+                    else wave_lds_fence();
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr ((KS & 1) != 0) {  // (odd KS: the last K-step used b0 and loaded K-step 0 into b1 -- keep "b0 = K-step 0")
 #pragma unroll
                 for (int c = 0; c < CTW; ++c) b0[c] = b1[c];
             }
-            wave_lds_fence();  // (PC 1: this wave's image has been read; PC 2: imgw was read a step ago, behind a barrier)
-            if (tile < RT) image_put(imgw, acc, tile == RT - 1 ? last_rows : 16);
+            wave_lds_fence();  // the image has been read
             // first use of the prefetched fragments in the same block as the stores: exact vmcnt
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(an[ks]));
-            if constexpr (PC > 1) wg_lds_barrier();  // the pair's image is complete (and the one before it has been read)
-            else wave_lds_fence();
         };
 
         if (nsteps > 0) {
             double fa0[KS], fa1[KS];
+            v4d accA[CTW], accB[CTW];
             load_a(fa0, pr, 0, KS);
             load_b(b0, 0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa0[ks]));
-            // even steps: fragments fa0, image 0; odd steps: fa1, image 1 (PC 1: the wave's one image)
-            stage(0, image_of(1), image_of(0), fa0, fa1, false);  // first step: nothing to flush yet
+            // even steps: fragments fa0, accumulators A; odd steps: fa1, B.  The tile of step s lives in image s & 1 (PC 1: the
+            // wave's one image) from the first K-steps of step s + 1 until that step has sent it out.
+            stage(0, accA, accB, image_of(1), fa0, fa1, false);  // first step: nothing to flush yet
             int i = 1;
             for (; i + 1 < nsteps; i += 2) {
-                stage(i, image_of(0), image_of(1), fa1, fa0, true);
-                stage(i + 1, image_of(1), image_of(0), fa0, fa1, true);
+                stage(i, accB, accA, image_of(0), fa1, fa0, true);
+                stage(i + 1, accA, accB, image_of(1), fa0, fa1, true);
             }
             if (i < nsteps) {
-                stage(i, image_of(0), image_of(1), fa1, fa0, true);
+                stage(i, accB, accA, image_of(0), fa1, fa0, true);
                 ++i;
             }
-            // the last step's tile (the only one that may have fewer than 16 rows, or -- PC 2 -- not exist)
+            // the last step's tile (the only one that may have fewer than 16 rows, or -- PC 2 -- not exist): image, then out
+            {
+                const int tile = pr + PR * (i - 1);
+                double* imgl = image_of((i - 1) & 1);
+                if (tile < RT && !((FX_WG_ABL & 8) && nreq > 8)) {
+                    if ((i - 1) & 1) image_put(imgl, accB, tile == RT - 1 ? last_rows : 16);
+                    else image_put(imgl, accA, tile == RT - 1 ? last_rows : 16);
+                }
+                if constexpr (PC > 1) wg_lds_barrier();
+                else wave_lds_fence();
+            }
             {
                 const int tile = pr + PR * (i - 1);
                 const double* imgr = image_of((i - 1) & 1);
-                if (tile < RT) {
+                if (tile < RT && !((FX_WG_ABL & 4) && nreq > 8)) {
                     const int nrows = tile == RT - 1 ? last_rows : 16;
                     constexpr int HB = NRW < 8 ? NRW : 8;
 #pragma unroll
@@ -345,25 +422,15 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                 }
                 wave_lds_fence();
             }
-            // first use of the prefetched points / request id in the same block as the last stores: exact vmcnt
+            // first use of the prefetched points in the same block as the last stores: exact vmcnt
 #pragma unroll
             for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
-            asm volatile("" : "+v"(tick));
         }
-        if (tid == 0) ctl[0] = tick;
-        wg_lds_barrier();  // every wave is done with the slab; the next id is published
-        const long long nxt2 = 2LL * gridDim.x + __builtin_amdgcn_readfirstlane(ctl[0]);
+        wg_lds_barrier();  // every wave is done with the slab
         cur = nxt;
-        nxt = nxt2;
+        nxt += gridDim.x;
 #pragma unroll
         for (int d = 0; d < SD; ++d) xcur[d] = xnext[d];
-    }
-    // the counter cleans up after itself (as work_queue.hpp): the last workgroup to leave zeroes it
-    if (tid == 0) {
-        if (__hip_atomic_fetch_add(gctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-            __hip_atomic_store(gctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(gctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 }
 

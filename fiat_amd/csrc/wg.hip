@@ -2,6 +2,7 @@
 // compile beside api.hip instead of inside it.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstring>
 
 #include "simplex_wg.hpp"
@@ -31,6 +32,10 @@ hipError_t launch(const fxk::StackedArgs<0>& h, const double* coef, int ncoef, i
     ka.npts = h.npts;
     ka.R = h.R;
     ka.RT = h.RT;
+    ka.lim_pts = h.lim_pts;
+    ka.lim_verts = h.lim_verts;
+    ka.lim_out = h.lim_out;
+    ka.lim_afrag = h.lim_afrag;
     memcpy(ka.coef, coef, NC * sizeof(double));
     auto kern = fxk::tabulate_simplex_wg<SD, N, CT, ODD, wg_pc(CT)>;
     static thread_local bool attr = false;
@@ -39,7 +44,33 @@ hipError_t launch(const fxk::StackedArgs<0>& h, const double* coef, int ncoef, i
         if (e != hipSuccess) return e;
         attr = true;
     }
+#if FX_WG_DBG == 3
+    {   // is the counter slot clean when the launch takes it?
+        unsigned int q4[4];
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(q4, queue, sizeof q4, hipMemcpyDeviceToHost) == hipSuccess && (q4[0] | q4[1] | q4[2] | q4[3]))
+            fprintf(stderr, "[fiat_amd] WG DIRTY SLOT %p: %u %u %u %u (nreq %lld grid %d)\n", (void*)queue, q4[0], q4[1], q4[2], q4[3], (long long)h.nreq, grid);
+    }
+#endif
+#if FX_WG_DBG
+    static int dbg_launches = 0;
+    if (dbg_launches++ == 0) (void)hipMemsetAsync(trash + 4096, 0, 24 * sizeof(double), s);
+#endif
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * fxk::WG_NW), lds_bytes, s, ka, trash, queue);
+#if FX_WG_DBG
+    if (FX_WG_DBG == 1 || dbg_launches % 16 == 0) {   // range-check build: report accesses that left their buffers (redirected to the scratch area by the kernel); 2: every 16th launch only (launches stay back to back)
+        double rep[24];
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(rep, trash + 4096, sizeof rep, hipMemcpyDeviceToHost) != hipSuccess) return hipErrorUnknown;
+        static const char* site[] = {"", "pts", "", "afrag", "out", "out-address"};
+        for (int k = 1; k <= 5; ++k) {
+            unsigned long long cnt;
+            memcpy(&cnt, &rep[4 * k], sizeof cnt);
+            if (cnt)
+                fprintf(stderr, "[fiat_amd] WG RANGE CHECK <%d,%d,%d>: %llu accesses outside `%s`: first index %.0f, limit %.0f, request %.0f\n", SD, N, CT,
+                        cnt, site[k], rep[4 * k + 1], rep[4 * k + 2], rep[4 * k + 3]);
+        }
+        (void)hipMemset(trash + 4096, 0, sizeof rep);
+    }
+#endif
     return hipGetLastError();
 }
 
