@@ -451,6 +451,8 @@ def run(args):
                 "kernel_ms": kernel_ms if len(kt) == 1 else [k[1] for k in kt],
                 "algorithmic_bytes_per_launch": abytes if len(kt) == 1 else [k[2] for k in kt],
                 "requests_per_launch": batch if len(kt) == 1 else [p["n"] for p in wl.parts]}
+    # the driver's own protocol without the clock ramp (W + K launches from an idle GPU), same algorithmic bytes
+    roofline["frac_cold"] = abytes / (ms_per_step_cold * 1e-3) / 1e9 / HBM_PEAK_GBS
     if len(kt) > 1:
         roofline["per_kernel_frac"] = [k[2] / (k[1] * 1e-3) / 1e9 / HBM_PEAK_GBS for k in kt]
     # context: what this box writes with a plain fill of the same bytes (the attainable write rate varies
@@ -471,6 +473,7 @@ def run(args):
     if aflops / abytes > F64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS:
         tf = aflops / (kernel_ms * 1e-3) / 1e12
         roofline = dict(roofline, bound="mfma", achieved=tf, peak=F64_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / F64_PEAK_TFLOPS,
+                        frac_cold=aflops / (ms_per_step_cold * 1e-3) / 1e12 / F64_PEAK_TFLOPS,
                         algorithmic_flops_per_launch=aflops,
                         hbm={"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS})
     # north_star asks for both: achieved HBM GB/s AND fp64 (MFMA) utilisation against the gfx950 peak
@@ -734,18 +737,51 @@ def verify_gather(wl, gather, world, rank, per, out, tail):
         gather.all_gather(mine, world * nv, out=full)
         sync()
         one_shot = [bool(torch.equal(blocks[p], mine)) for p in range(world)]
+        bad = [gather_mismatch("one_shot", p, blocks[p], mine, rank) for p in range(world) if not one_shot[p]]
         full.fill_(float("nan"))
         chunk = max(1, nv // 5 + 1)                                 # ragged last chunk
         gather.tabulate_allgather(wl.produce_rows, nv, nv, chunk, full)
         sync()
         chunked = [bool(torch.equal(blocks[p], mine)) for p in range(world)]
+        bad += [gather_mismatch("chunked", p, blocks[p], mine, rank, chunk) for p in range(world) if not chunked[p]]
     finally:
         inputs[:nv].copy_(saved)
     ok = torch.tensor([1.0 if all(one_shot) and all(chunked) else 0.0], dtype=torch.float64,
                       device=dev if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    return {"ok": bool(ok.item() == 1.0), "requests": nv, "one_shot_blocks_equal": one_shot, "chunked_blocks_equal": chunked,
-            "rank": rank}
+    res = {"ok": bool(ok.item() == 1.0), "requests": nv, "one_shot_blocks_equal": one_shot, "chunked_blocks_equal": chunked,
+           "rank": rank}
+    if not res["ok"]:
+        # where, on EVERY rank (the line is rank 0's): a first-run stride / offset bug of the direct exchange must be
+        # diagnosable from the one line -- which peer's block, from which offset, how much of it, and what is there instead
+        everyone = [None] * world
+        dist.all_gather_object(everyone, bad[:2 * world])
+        res["mismatches"] = [m for per_rank in everyone for m in (per_rank or [])][:4 * world]
+    return res
+
+
+def gather_mismatch(leg, peer, got, want, rank, chunk=None):
+    """One differing block of the gathered tables, as seen by ``rank``: first differing double (flat offset inside the block,
+    and the request / table row it falls in), how many doubles differ and how many of those were never written (still NaN),
+    and whether the block equals the expected one shifted by a whole number of requests (the signature of a wrong stride)."""
+    import torch
+    g, w = got.reshape(got.shape[0], -1), want.reshape(want.shape[0], -1)
+    diff = ~((g == w) | (torch.isnan(g) & torch.isnan(w)))
+    idx = torch.nonzero(diff.reshape(-1))
+    first = int(idx[0].item()) if idx.numel() else -1
+    per_req = g.shape[1]
+    info = {"leg": leg, "seen_by_rank": rank, "peer_block": peer, "first_offset": first, "first_request": first // per_req,
+            "offset_in_request": first % per_req, "differing": int(idx.numel()), "never_written": int((diff & torch.isnan(g)).sum().item()),
+            "doubles_per_block": int(g.numel())}
+    if chunk:
+        info["chunk_requests"] = chunk
+    for shift in (1, -1, chunk or 0, -(chunk or 0)):
+        if shift and abs(shift) < g.shape[0]:
+            a, b = (g[shift:], w[:-shift]) if shift > 0 else (g[:shift], w[-shift:])
+            if bool(torch.equal(a, b)):
+                info["equals_expected_shifted_by_requests"] = shift
+                break
+    return info
 
 
 def main():

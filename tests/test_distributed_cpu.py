@@ -168,5 +168,14 @@ def test_allgather_verify_world2(sabotage):
         assert r["requests"] == 37 and r["ok"] == (not sabotage), r
         if sabotage:
             assert not r["one_shot_blocks_equal"][1 - rank] and r["one_shot_blocks_equal"][rank]
+            # ... and says where, for every rank's view, in the one dict rank 0 prints: the foreign block, from its first
+            # request on (the sabotage rolls whole requests by one), none of it unwritten, and the shift it amounts to
+            mm = r["mismatches"]
+            assert {(m["seen_by_rank"], m["peer_block"]) for m in mm} == {(0, 1), (1, 0)}, mm
+            one = [m for m in mm if m["leg"] == "one_shot" and m["seen_by_rank"] == rank][0]
+            assert one["peer_block"] == 1 - rank and one["first_request"] == 0 and one["never_written"] == 0
+            assert one["differing"] > 0 and one["doubles_per_block"] == 37 * 12
+            assert any(m["leg"] == "chunked" and m.get("chunk_requests") == 37 // 5 + 1 for m in mm)
         else:
+            assert "mismatches" not in r
             assert all(r["one_shot_blocks_equal"]) and all(r["chunked_blocks_equal"])

@@ -356,14 +356,16 @@ def test_kernel_selection(rt, golden):
     assert p3.kernel_name(1, 1000, 40) == "fxk::tabulate_simplex_stacked"    # own cell, off the 21..24-point shape: the paired entry yields
     assert p3.kernel_name(1, 1000, 10) == "fxk::tabulate_simplex_pair"       # ... unless no stacked instance holds the request
     assert p3.kernel_name(1, 1000, 50) == "fxk::tabulate_simplex_stacked"    # 49..64 points: four column tiles
-    assert p3.kernel_name(1, 1000, 70) == "fxk::tabulate_simplex_stacked"    # point-chunked units
+    assert p3.kernel_name(1, 1000, 70) == "fxk::tabulate_simplex_wg"         # 65..128 points: a request per workgroup (round 4; were point chunks)
+    assert p3.kernel_name(1, 1000, 130) == "fxk::tabulate_simplex_stacked"   # point-chunked units
     assert p3.kernel_name(1, 1000, 7) == "fxk::tabulate_simplex_kernel"      # fewer points than any registered tiling
     assert p3.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_stacked"    # Hessians: 200 stacked rows
     assert p3.kernel_name(2, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_stacked"   # + table-mixing pass
     dg6 = rt.SimplexPolySet(3, 6, coeffs=g["c4_dg6tet_q6_coeffs"])
     assert dg6.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_stacked"          # requests on the element's cell
     assert dg6.kernel_name(2, 1000, 23, has_verts=True) == "fxk::tabulate_simplex_stacked"  # per-request cells: + table-mixing pass
-    assert dg6.kernel_name(2, 1000, 122) == "fxk::tabulate_simplex_stacked"         # point-chunked units (C4 stress variant)
+    assert dg6.kernel_name(2, 1000, 122) == "fxk::tabulate_simplex_wg"              # a request per workgroup (C4 stress variant; round 3: point chunks)
+    assert dg6.kernel_name(2, 1000, 200) == "fxk::tabulate_simplex_stacked"         # point-chunked units
 
 
 def test_concurrent_streams(rt, golden):
@@ -473,7 +475,7 @@ def test_one_request_per_wave_instances(rt, kernel_policy, fam, deg, npts, nreq,
 @pytest.mark.parametrize("order", [1, 2])
 @pytest.mark.parametrize("npts,nreq", [(13, 8), (16, 100), (17, 5), (23, 1), (23, 2050), (24, 333), (25, 64), (32, 129), (33, 7),
                                        (40, 100), (48, 65), (49, 3), (64, 130)])
-def test_stacked_matrix_kernel(rt, golden, order, npts, nreq):
+def test_stacked_matrix_kernel(rt, golden, order, npts, nreq, kernel_policy):
     """Degree-6 tetrahedron on the element's own cell: all derivative tables as rows of ONE stacked matrix
     [C; C D^alpha] (simplex_stacked.hpp), every (column tiles, requests per group) instance, odd batch sizes
     (a last group with a missing request), against the C oracle's recurrence derivatives; and a physical
@@ -482,6 +484,9 @@ def test_stacked_matrix_kernel(rt, golden, order, npts, nreq):
     g = golden("elements")
     co = g["c4_dg6tet_q6_coeffs"]
     ps = rt.SimplexPolySet(3, 6, coeffs=co)
+    if npts > 48:   # (round 4: the default route of 49..128 points is the request-per-workgroup kernel, tests/test_gpu_round4.py)
+        assert ps.kernel_name(order, nreq, npts) == "fxk::tabulate_simplex_wg"
+        kernel_policy("no_wg")
     assert ps.kernel_name(order, nreq, npts) == "fxk::tabulate_simplex_stacked"
     rng = np.random.default_rng(100 * npts + nreq + order)
     pts = rand_points(rng, 3, (nreq, npts))
@@ -620,7 +625,7 @@ def test_stacked_matrix_kernel_with_per_request_cells(kernel_policy, mix, fam, s
     ("DiscontinuousLagrange", 3, 6, 2, 122, False), ("DiscontinuousLagrange", 3, 6, 1, 65, True), ("Lagrange", 3, 3, 1, 70, False),
     ("Lagrange", 3, 5, 1, 97, False), ("Lagrange", 2, 6, 2, 73, True), ("DiscontinuousLagrange", 2, 5, 1, 15, False),
     ("Nedelec", 3, 3, 1, 49, False), ("Lagrange", 3, 4, 2, 200, False), ("RaviartThomas", 3, 3, 1, 23, True)])
-def test_stacked_matrix_kernel_point_chunks(fam, sd, deg, order, npts, cells):
+def test_stacked_matrix_kernel_point_chunks(fam, sd, deg, order, npts, cells, kernel_policy):
     """Point-chunked units of the stacked-matrix kernel (16 CT points of one request per unit, 8-byte row stores): more
     than 64 points per request (the C4 stress variant: 122 points), a last chunk of any size, and odd table sizes
     that the 16-byte whole-request instances cannot take; against the C oracle."""
@@ -629,6 +634,7 @@ def test_stacked_matrix_kernel_point_chunks(fam, sd, deg, order, npts, cells):
     el = getattr(fiat_amd, fam)(fiat_amd.ufc_simplex(sd), deg)
     ps = el.device_polyset()
     nreq = 57
+    kernel_policy("no_wg")   # (round 4: on the element's own cell rules of 49..128 points take the request-per-workgroup kernel by default)
     assert ps.kernel_name(order, nreq, npts, has_verts=cells) == "fxk::tabulate_simplex_stacked"
     rng = np.random.default_rng(7 * deg + npts + order + sd)
     pts = rand_points(rng, sd, (nreq, npts))

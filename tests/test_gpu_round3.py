@@ -431,11 +431,12 @@ ROUTES = [
     ("Nedelec", 3, 3, 57, 1, True, "stacked<3,3,3,1,-4>"), ("Nedelec", 3, 3, 16, 2, True, "kernel"),
     ("Nedelec", 3, 3, 14, 1, True, "stacked<3,3,3,3,0>"), ("RaviartThomas", 3, 3, 11, 2, True, "kernel"),
     ("Nedelec", 3, 3, 23, 2, True, "stacked<3,3,3,2,-3>"),
-    # point chunks of two or three column tiles: whichever needs fewer tiles
-    ("Lagrange", 3, 6, 122, 1, False, "stacked<3,6,2,1,-1>"), ("Lagrange", 3, 6, 74, 1, False, "stacked<3,6,3,1,-1>"),
-    ("Lagrange", 3, 6, 57, 0, False, "stacked<3,6,2,1,-1>"), ("DiscontinuousLagrange", 3, 6, 121, 2, False, "stacked<3,6,2,1,-1>"),
-    ("Lagrange", 3, 5, 74, 2, False, "stacked<3,5,3,1,-1>"), ("Lagrange", 3, 5, 74, 0, False, "stacked<3,5,3,1,-1>"),
-    ("Lagrange", 3, 5, 111, 1, False, "stacked<3,5,2,1,-1>")]
+    # round 4: rules of 49..128 points on the element's own cell take the request-per-workgroup kernel (were point chunks of two
+    # or three column tiles; those instances stay behind policy no_wg: tests/test_gpu_round4.py)
+    ("Lagrange", 3, 6, 122, 1, False, "wg<3,6,8>"), ("Lagrange", 3, 6, 74, 1, False, "wg<3,6,5>"),
+    ("Lagrange", 3, 6, 57, 0, False, "wg<3,6,4>"), ("DiscontinuousLagrange", 3, 6, 121, 2, False, "wg<3,6,8>"),
+    ("Lagrange", 3, 5, 74, 2, False, "wg<3,5,5>"), ("Lagrange", 3, 5, 74, 0, False, "wg<3,5,5>"),
+    ("Lagrange", 3, 5, 111, 1, False, "wg<3,5,7>")]
 
 
 @pytest.mark.parametrize("family,sd,degree,npts,order,cells,kernel", ROUTES,

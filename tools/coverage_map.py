@@ -76,20 +76,35 @@ for sd in (2, 3):
                         audit.append(f"{fam} sd{sd} k{deg} order {order} npts {npts}: default {t*1e3:.1f} us, "
                                      f"{'+'.join(best)} {alt[best][0]*1e3:.1f} us ({alt[best][1]})")
                         print("   AUDIT " + audit[-1] + "\n      " + "  ".join(f"{'+'.join(q)}={v[0]*1e3:.1f}" for q, v in alt.items()), flush=True)
-                nexp = ps.coeffs.shape[-1] if hasattr(ps, "coeffs") else 0
+                # both rooflines: algorithmic bytes against the 8 TB/s HBM peak, contraction flops (2 x stacked rows x expansion
+                # members x points) against the fp64 peak of bench.py; the BINDING one is the larger time.  Degree >= 5 on
+                # tetrahedra is fp64-bound (2 nexp / 8 flop per output byte against a machine balance of 9.8).
+                import math
+                nexp = math.comb(el.get_nodal_basis().get_embedded_degree() + sd, sd)
+                flops = 2.0 * int(np.prod(shape1[1:-1])) * nexp * npts * nreq
                 frac = per_req * nreq / t / 1e6 / 80
+                ffrac = flops / t / 1e9 / bench.F64_PEAK_TFLOPS * 100          # (t in ms)
+                bind = max(frac, ffrac)
+                resident = per_req * nreq < 0.5e9       # the whole output stays in the 256 MB Infinity Cache: not an HBM measurement
                 kern = ps.kernel_name(order, nreq, npts, has_verts=verts is not None)
                 rows.append((frac, f"{fam:22s} sd{sd} k{deg} order {order} npts {npts:3d} rows {int(np.prod(shape1[2:-1])):4d}: "
-                                   f"{t*1e3:8.1f} us {nreq/t/1e3:9.1f} M/s {frac:5.1f} % HBM  {kern}"))
+                                   f"{t*1e3:8.1f} us {nreq/t/1e3:9.1f} M/s {frac:5.1f} % HBM {ffrac:5.1f} % fp64 -> {bind:5.1f} % {'fp64' if ffrac > frac else 'HBM '}"
+                                   f"{' (cache-resident)' if resident else ''}  {kern}", bind, resident))
                 print(rows[-1][1], flush=True)
                 del pts, out
 if audit:
     print(f"\n-- audit: {len(audit)} shapes where another kernel family beats the planner's choice by > 7 % --")
     print("\n".join(audit))
-print("\n-- slowest 25 --")
-for frac, line in sorted(rows)[:25]:
-    print(line)
-fr = np.array(sorted(r[0] for r in rows))
-if len(fr):
-    print(f"\n{len(fr)} shapes: geometric mean {np.exp(np.mean(np.log(fr))):.1f} % of the HBM peak, median {np.median(fr):.1f}, "
-          f"quartiles {np.percentile(fr, 25):.1f} / {np.percentile(fr, 75):.1f}, min {fr[0]:.1f}, max {fr[-1]:.1f}")
+print("\n-- slowest 25 (by the binding roofline) --")
+for r in sorted(rows, key=lambda r: r[2])[:25]:
+    print(r[1])
+res = [r for r in rows if r[3]]
+if res:
+    print(f"\n{len(res)} cache-resident shapes (outputs below 0.5 GB: their 'HBM' figure measures the Infinity Cache), excluded from the means:")
+    for r in res:
+        print("  " + r[1])
+for label, k in (("HBM peak", 0), ("binding roofline (HBM or fp64)", 2)):
+    fr = np.array(sorted(r[k] for r in rows if not r[3]))
+    if len(fr):
+        print(f"\n{len(fr)} shapes, % of the {label}: geometric mean {np.exp(np.mean(np.log(fr))):.1f}, median {np.median(fr):.1f}, "
+              f"quartiles {np.percentile(fr, 25):.1f} / {np.percentile(fr, 75):.1f}, min {fr[0]:.1f}, max {fr[-1]:.1f}")
