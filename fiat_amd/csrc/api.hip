@@ -586,6 +586,7 @@ struct Launch {
     int stacked_id = -1;
     fxk::StackedArgs<0> khead;
     int kgrid = 0, klds_bytes = 0, kmix_order = 0;
+    int wg_ct = 0;      // request-per-workgroup kernel: column tiles of the instance (its slab holds khead.gslab requests)
     // cooperative large-shape kernel
     int coop_id = -1;
     fxk::CoopArgs cargs;
@@ -1001,7 +1002,7 @@ int launch_stacked(const Launch& L, hipStream_t s) {
 // the request-per-workgroup kernel (rtc -7; simplex_wg.hpp, compiled in wg.hip)
 int launch_wg(const Launch& L, hipStream_t s) {
     const StackedShape& k = kStackedShapes[L.stacked_id];
-    const int ct = (L.khead.npts + 15) / 16;
+    const int ct = L.wg_ct;
     hipError_t e = fxwg::launch_simplex_wg(k.sd, k.n, ct, L.kodd, L.khead, L.fcoef.data(), (int)L.fcoef.size(), L.klds_bytes, L.kgrid, L.trash,
                                            reinterpret_cast<unsigned int*>(L.queue), s);
     if (e != hipSuccess) return fail(FX_EHIP, "tabulate_simplex_wg<%d,%d,%d>: %s", k.sd, k.n, ct, hipGetErrorString(e));
@@ -1714,6 +1715,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 const size_t i = i2 % NSH, pass = i2 / NSH;
                 const StackedShape& k = kStackedShapes[i];
                 bool mix_odd = false, pio = false;
+                int wg_g = 1, wg_ctw = 0;
                 const bool inmix = k.rtc == -2 || k.rtc == -3 || k.rtc == -4 || k.rtc == -5 || k.rtc == -6;  // chain rule / Piola map inside the kernel
                 const bool chunked = k.rtc == -1 || k.rtc == -4 || k.rtc == -5;
                 const bool wgk = k.rtc == -7;
@@ -1759,11 +1761,21 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                                              (k.sd == 2 && k.n == 5 && k.ct == 3 && k.g == 1)))
                         continue;
                     if (npts > 16 * k.ct / k.g || tighter_instance(k) || !fills_tiles(k)) continue;
-                } else if (wgk) {  // a request per workgroup: rules of 49..128 points (fewer: the whole-request instances)
-                    const int ctw = (npts + 15) / 16;
-                    if ((ctx->policy & FX_POLICY_NO_WG) || npts <= 48 || npts > 16 * k.ct || !fxwg::has_instance(k.sd, k.n, ctw, !even)) continue;
+                } else if (wgk) {  // a request (or, policy wg_small, a group of small requests) per workgroup
+                    if ((ctx->policy & FX_POLICY_NO_WG) || npts > 16 * k.ct) continue;
+                    if (npts <= 48 && !(ctx->policy & FX_POLICY_WG_SMALL)) continue;   // (fewer points: the whole-request instances)
+                    // requests per slab of <= 128 columns; the instance's column tiles (an even number where several requests
+                    // share the slab: two waves per row tile)
+                    wg_g = npts > 64 ? 1 : std::min(12, 128 / npts);
+                    wg_ctw = std::max(4, (wg_g * npts + 15) / 16);
+                    if (wg_ctw == 7) wg_ctw = 8;        // (no seven-tile instance)
+                    if (wg_ctw == 5) {                   // one wave per row tile on 5 column tiles, or two on 3 + 3: the fewer MFMA slots per wave
+                        const long long one = (long long)((RT + 3) / 4) * 5, two = (long long)((RT + 1) / 2) * 3;
+                        if (two < one) wg_ctw = 6;
+                    }
+                    if (!fxwg::has_instance(k.sd, k.n, wg_ctw, !even)) continue;
                     // (49..64 points: where a whole-request instance of four column tiles exists it keeps the rule)
-                    if (npts <= 64 && even) {
+                    if (npts > 48 && npts <= 64 && even && !(ctx->policy & FX_POLICY_WG_SMALL)) {
                         bool whole = false;
                         for (const StackedShape& o : kStackedShapes)
                             whole = whole || (o.sd == k.sd && o.n == k.n && o.rtc == 0 && o.g == 1 && o.ct == 4);
@@ -1861,9 +1873,13 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 const bool mixr = pio || k.rtc == -3 || k.rtc == -4 || k.rtc == -5 || (k.rtc == -2 && (mix_odd || mixr1(k.sd, k.n, k.ct, k.g) || (k.sd == 3 && k.n == 6 && k.ct == 3)));
                 const int slots = fxk::stacked_mix_slots(e->sd, dofmajor ? ntab : 0, mixr);
                 L.klds_bytes = (fxk::WQ_CTL_DOUBLES + STACKED_NW * (fxk::stacked_image_doubles(k.ct, (e->nexp + 3) / 4, slots) + (mixr ? fxk::STACKED_KBUF : 0))) * 8;
-                if (wgk) L.klds_bytes = fxwg::lds_bytes(k.sd, k.n, (npts + 15) / 16);
+                if (wgk) {
+                    L.klds_bytes = fxwg::lds_bytes(k.sd, k.n, wg_ctw);
+                    L.wg_ct = wg_ctw;
+                    ka.gslab = wg_g;
+                }
                 if (L.klds_bytes > ctx->lds_per_cu) continue;
-                const long long groups = wgk ? nreq * STACKED_NW : chunked ? nreq * ((npts + 16 * k.ct - 1) / (16 * k.ct)) : (nreq + k.g - 1) / k.g;
+                const long long groups = wgk ? ((nreq + wg_g - 1) / wg_g) * STACKED_NW : chunked ? nreq * ((npts + 16 * k.ct - 1) / (16 * k.ct)) : (nreq + k.g - 1) / k.g;
                 // one workgroup per CU = one wave per SIMD (measured: a second wave per SIMD at half the registers
                 // spills in the production phase and gains nothing, 1.45 -> 1.48 ms: the kernel is bound by the
                 // shared fp64 MFMA/VALU pipe, not by latencies)
@@ -2309,7 +2325,8 @@ int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, in
     if (rc != FX_OK) return rc;
     if ((has_verts & 2) && L.stacked_id >= 0 && L.fixed_id < 0) {  // with the instance of the stacked-matrix registry
         const StackedShape& k = kStackedShapes[L.stacked_id];
-        if (k.rtc == -7) snprintf(name, (size_t)name_len, "fxk::tabulate_simplex_wg<%d,%d,%d>", k.sd, k.n, (npts + 15) / 16);
+        if (k.rtc == -7) snprintf(name, (size_t)name_len, "fxk::tabulate_simplex_wg<%d,%d,%d>%s", k.sd, k.n, L.wg_ct,
+                                  L.khead.gslab > 1 ? ("x" + std::to_string(L.khead.gslab)).c_str() : "");
         else snprintf(name, (size_t)name_len, "fxk::tabulate_simplex_stacked<%d,%d,%d,%d,%d>%s", k.sd, k.n, k.ct, k.g, k.rtc,
                       L.kpiola ? "+piola" : "");
         return FX_OK;

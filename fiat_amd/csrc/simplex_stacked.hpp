@@ -46,6 +46,7 @@ template <int NC> struct StackedArgs {
     // FX_DBG & 1024 builds: sizes (in doubles) of the buffers behind pts / verts / out / afrag; every global access
     // of the kernel is range-checked against them, redirected to the scratch area when outside and reported there
     long long lim_pts, lim_verts, lim_out, lim_afrag;
+    int gslab;  // (simplex_wg.hpp) requests that share a slab of 16 CT columns
 };
 
 #if FX_DBG & 1024

@@ -125,32 +125,70 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
     const int kk = lane >> 4, col = lane & 15;
     const long long nreq = a.nreq;
 
-    // image offsets of this lane's accumulator elements: element jj of column tile c is row 4 jj + kk, column 16 c + col.
-    // Tiles c < CT - 1 lie inside the rule (npts > 16 (CT - 1)): base of row 4 jj + kk plus the immediate 16 c; the last tile's
-    // padding columns go to the dump row.
-    // (this wave's column tiles are c0 .. c0 + CTW - 1)
+    // A slab holds G consecutive requests of npts points each (G npts <= 16 CT; G = 1 for rules of more than 64 points):
+    // column j <-> (request j / npts of the group, point j % npts).  The row-tile image is [request][16 rows][npts], so that a
+    // request's part of a row tile -- 16 x npts contiguous doubles of the output -- is contiguous in the image too.
+    const int G = a.gslab;
+    const int cols = G * npts;
+    const int BLKD = 16 * npts;                 // doubles of one request in a row-tile image
+    const float rnpts = 1.0f / (float)npts;
+    // image offsets of this lane's accumulator elements: element jj of column tile c0 + c is row 4 jj + kk, column 16 (c0 + c) +
+    // col; padding columns go to the dump row.  (This wave's column tiles are c0 .. c0 + CTW - 1.)
     const int c0 = pc * CTW;
-    int ibase[4], ilast[4];
+    int ioff[CTW][4];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        ibase[jj] = (4 * jj + kk) * npts + col + 16 * c0;
-        ilast[jj] = (pc < PC - 1 || 16 * (CT - 1) + col < npts) ? ibase[jj] + 16 * (CTW - 1) : DUMP + lane;
+    for (int c = 0; c < CTW; ++c) {
+        const int j = 16 * (c0 + c) + col;
+        const int g = idiv_small(j, rnpts);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) ioff[c][jj] = j < cols ? g * BLKD + (4 * jj + kk) * npts + (j - g * npts) : DUMP + lane;
     }
+    // flush pieces of this wave (EPP doubles each, 64 an instruction; instruction q of the wave is r = PC q + pc of the tile):
+    // piece u = 64 r + lane lies in request u / BLK of the group at position u % BLK (BLK = 16 npts / EPP pieces a request);
+    // pieces past the group's last request repeat its last piece.  pu_l: index into the image, pu_o: byte offset from the
+    // group's first request in the output (requests are R npts doubles apart) -- loop invariants of the launch, except in a
+    // last group of fewer than G requests (rebuilt there: the missing requests repeat the group's last one).
+    constexpr int NRW = (NRD + PC - 1) / PC;
+    const int BLK = BLKD / EPP;
+    const float rblk = 1.0f / (float)BLK;
+    const unsigned RN8 = (unsigned)a.R * (unsigned)npts * 8u;
+    int pu_l[NRW];
+    unsigned pu_o[NRW];
+    auto build_pieces = [&](int gmax, int nrows) {  // requests 0..gmax of the group exist; nrows rows in the tile
+        const int blkn = nrows * npts / EPP;
+#pragma unroll
+        for (int q = 0; q < NRW; ++q) {
+            const int u = min((PC * q + pc) * 64 + lane, G * BLK - 1);
+            const int g = idiv_small(u, rblk);
+            const int w = min(u - g * BLK, blkn - 1);
+            pu_l[q] = g * BLK + w;
+            pu_o[q] = (unsigned)min(g, gmax) * RN8 + (unsigned)w * (unsigned)(8 * EPP);
+        }
+    };
+    build_pieces(G - 1, 16);
 
     // production: WPP waves cover the LDC columns, NSUB such wave sets split the members (StepSubsets)
     constexpr int WPP = LDC > 64 ? 2 : 1, NSUB = WG_NW / WPP;
     constexpr StepSubsets<SD, N, NSUB> SUBS{};
     const int pcol = (wave % WPP) * 64 + lane;   // column this thread produces
     const int psub = wave / WPP;                 // (wave-uniform) its member subset
-    auto load_points = [&](long long req, double (&x)[SD]) {
-        const long long rr = req < nreq ? req : nreq - 1;
-        const int pt = min(pcol, npts - 1);  // (threads past the rule recompute its last point: padding columns)
-        const double* pp = a.pts + ((size_t)rr * npts + pt) * SD;
+    // the column this thread produces: (request pg of the group, point pp); threads past the group recompute its last column
+    const int pj = min(pcol, cols - 1);
+    const int pg = idiv_small(pj, rnpts);
+    const int pp_ = pj - pg * npts;
+    const long long ngroups = (nreq + G - 1) / G;
+    auto request_of = [&](long long grp) {  // this thread's request in group grp (groups / requests past the batch: the last one)
+        const long long g0 = (grp < ngroups ? grp : ngroups - 1) * G;
+        return g0 + pg < nreq ? g0 + pg : nreq - 1;
+    };
+    auto load_points = [&](long long grp, double (&x)[SD]) {
+        const long long rr = request_of(grp);
+        const double* ppt = a.pts + ((size_t)rr * npts + pp_) * SD;
 #if FX_WG_DBG
-        if (wg_dbg_check(((long long)rr * npts + pt) * SD, a.lim_pts - SD + 1, 1, req, trash) < 0) pp = trash;
+        if (wg_dbg_check(((long long)rr * npts + pp_) * SD, a.lim_pts - SD + 1, 1, grp, trash) < 0) ppt = trash;
 #endif
 #pragma unroll
-        for (int d = 0; d < SD; ++d) x[d] = pcol < LDC ? pp[d] : 0.0;
+        for (int d = 0; d < SD; ++d) x[d] = pcol < LDC ? ppt[d] : 0.0;
     };
     // once per launch: the recurrence coefficients from the kernel arguments to LDS (broadcast reads in the recurrence: in
     // order with the slab writes, so the waits are exact counts -- scalar loads return out of order and made every step wait
@@ -164,13 +202,20 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
     double xcur[SD], xnext[SD];
     load_points(cur, xcur);
 
-    while (cur < nreq) {
-        // ---------------- expansion values of the whole request -> LDS slab ----------------
+    while (cur < ngroups) {
+        // A fragments of this wave's first row tile: in flight during the production phase
+        double fa0[KS], fa1[KS];
+        {
+            const double* ap0 = a.afrag + (size_t)min(pr, a.RT) * KS * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) fa0[ks] = ap0[ks * 64];
+        }
+        // ---------------- expansion values of the group's requests -> LDS slab ----------------
         if (pcol < LDC) {
             double X[SD];
-            if (a.verts) {  // (uniform branch) physical point -> default simplex through the request's cell
+            if (a.verts) {  // (uniform branch) physical point -> default simplex through the cell of the column's request
                 double J[SD][SD], bb[SD];
-                cell_map<SD>(a.verts + (size_t)cur * (SD + 1) * SD, J, bb);
+                cell_map<SD>(a.verts + (size_t)request_of(cur) * (SD + 1) * SD, J, bb);
 #pragma unroll
                 for (int i = 0; i < SD; ++i) {
                     double t = bb[i];
@@ -231,38 +276,25 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
         // whose last tile does not exist multiplies the zero tile and skips the image)
         const int nsteps = PC == 1 ? (RT > pr ? (RT - pr + PR - 1) / PR : 0) : (RT + PR - 1) / PR;
         const int last_rows = a.R - 16 * (RT - 1);
-        double* const obase = a.out + (size_t)cur * a.R * npts;
+        double* const obase = a.out + (size_t)cur * G * a.R * npts;   // the group's first request
+        const int gmax = (int)min((long long)G - 1, nreq - 1 - cur * G);
+        if (gmax < G - 1) build_pieces(gmax, 16);              // (the batch's last group, when short)
 
-        auto image_put = [&](double* img, const v4d (&acc)[CTW], int nrows) {  // nrows: compile-time 16 in the pipelined stages
+        auto image_put = [&](double* img, const v4d (&acc)[CTW], int nrows) {  // the wave's last tile: may have fewer than 16 rows
 #pragma unroll
             for (int c = 0; c < CTW; ++c)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int o = c < CTW - 1 ? ibase[jj] + 16 * c : ilast[jj];
-                    img[4 * jj + kk < nrows ? o : DUMP + lane] = acc[c][jj];
-                }
+                for (int jj = 0; jj < 4; ++jj) img[4 * jj + kk < nrows ? ioff[c][jj] : DUMP + lane] = acc[c][jj];
         };
-        // piece r of a row tile's image (nrows x npts contiguous doubles, EPP doubles a piece, 64 pieces an instruction); pieces
-        // past the end repeat the last one (same value to the same address).  Full tiles: the first NFULL instructions lie
-        // inside whatever the rule's size.  A wave of a pair takes the instructions r = PC q + pc.
-        constexpr int NFULL = 16 * (16 * (CT - 1) + 1) / EPP / 64;
-        constexpr int NRW = (NRD + PC - 1) / PC;  // flush instructions per wave and row tile
-        auto piece = [&](int r, int nrows) {
-            return (nrows == 16 && r < NFULL) ? r * 64 + lane : min(r * 64 + lane, nrows * npts / EPP - 1);
-        };
-        auto image_get = [&](const double* img, FlushT& f, int q, int nrows) {
-            f = reinterpret_cast<const FlushT*>(img)[piece(PC * q + pc, nrows)];
-        };
-        auto image_out = [&](const FlushT& f, int q, int tile, int nrows) {
+        auto image_get = [&](const double* img, FlushT& f, int q) { f = reinterpret_cast<const FlushT*>(img)[pu_l[q]]; };
+        auto image_out = [&](const FlushT& f, int q, int tile) {
             // (wave-uniform tile base + 32-bit lane offset: scalar-base addressing, no 64-bit lane addresses to hoist and spill)
             char* tb = reinterpret_cast<char*>(obase + (size_t)16 * tile * npts);
-            FlushT* g2 = reinterpret_cast<FlushT*>(tb + (unsigned)piece(PC * q + pc, nrows) * (unsigned)sizeof(FlushT));
+            FlushT* g2 = reinterpret_cast<FlushT*>(tb + pu_o[q]);
 #if FX_WG_DBG
-            if (wg_dbg_check(((long long)cur * a.R + 16LL * tile) * npts + (long long)EPP * piece(PC * q + pc, nrows), a.lim_out - (EPP - 1), 4, cur, trash) < 0 ||
-                reinterpret_cast<double*>(g2) != a.out + (((long long)cur * a.R + 16LL * tile) * npts + (long long)EPP * piece(PC * q + pc, nrows))) {
-                if (reinterpret_cast<double*>(g2) != a.out + (((long long)cur * a.R + 16LL * tile) * npts + (long long)EPP * piece(PC * q + pc, nrows)))
-                    wg_dbg_check(-2, 0, 5, cur, trash);   // site 5: the address differs from the index it should have
-                g2 = reinterpret_cast<FlushT*>(trash);
+            {
+                const long long idx = (reinterpret_cast<double*>(g2) - a.out);
+                if (wg_dbg_check(idx, a.lim_out - (EPP - 1), 4, cur, trash) < 0) g2 = reinterpret_cast<FlushT*>(trash);
             }
 #endif
             if constexpr (ODD) *g2 = f;  // 8-byte pieces, lines shared with the neighbours: plain stores
@@ -331,8 +363,7 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                             for (int w = 0; w < PPS; ++w) {
                                 const int p = (ks * CTW + c) * PPS + w;  // image write p: column tile p / 4, element p % 4
                                 if (p < NPUT) {
-                                    const int pc_ = p >> 2, jj = p & 3;
-                                    img[pc_ < CTW - 1 ? ibase[jj] + 16 * pc_ : ilast[jj]] = prev[pc_][jj];
+                                    img[ioff[p >> 2][p & 3]] = prev[p >> 2][p & 3];
                                 }
                             }
                         }
@@ -342,12 +373,12 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                             if (j >= 1) {
 #pragma unroll
                                 for (int q = 0; q < PB; ++q)
-                                    if (q % CTW == c && (j - 1) * PB + q < NRW) image_out(fb[(j - 1) & 1][q], (j - 1) * PB + q, tile - PR, 16);
+                                    if (q % CTW == c && (j - 1) * PB + q < NRW) image_out(fb[(j - 1) & 1][q], (j - 1) * PB + q, tile - PR);
                             }
                             if (j < NB) {
 #pragma unroll
                                 for (int q = 0; q < PB; ++q)
-                                    if ((q + CTW / 2) % CTW == c && j * PB + q < NRW) image_get(img, fb[j & 1][q], j * PB + q, 16);
+                                    if ((q + CTW / 2) % CTW == c && j * PB + q < NRW) image_get(img, fb[j & 1][q], j * PB + q);
                             }
                         }
                     }
@@ -374,9 +405,7 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
         };
 
         if (nsteps > 0) {
-            double fa0[KS], fa1[KS];
             v4d accA[CTW], accB[CTW];
-            load_a(fa0, pr, 0, KS);
             load_b(b0, 0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa0[ks]));
@@ -408,17 +437,19 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                 const double* imgr = image_of((i - 1) & 1);
                 if (tile < RT && !((FX_WG_ABL & 4) && nreq > 8)) {
                     const int nrows = tile == RT - 1 ? last_rows : 16;
+                    if (nrows < 16) build_pieces(gmax, nrows);   // (the pieces of a request's rows that exist; rebuilt below)
                     constexpr int HB = NRW < 8 ? NRW : 8;
 #pragma unroll
                     for (int r0 = 0; r0 < NRW; r0 += HB) {
                         FlushT fl[HB];
 #pragma unroll
                         for (int q = 0; q < HB; ++q)
-                            if (r0 + q < NRW) image_get(imgr, fl[q], r0 + q, nrows);
+                            if (r0 + q < NRW) image_get(imgr, fl[q], r0 + q);
 #pragma unroll
                         for (int q = 0; q < HB; ++q)
-                            if (r0 + q < NRW) image_out(fl[q], r0 + q, tile, nrows);
+                            if (r0 + q < NRW) image_out(fl[q], r0 + q, tile);
                     }
+                    if (nrows < 16) build_pieces(G - 1, 16);
                 }
                 wave_lds_fence();
             }

@@ -18,7 +18,9 @@ hipError_t launch(const fxk::StackedArgs<0>& h, const double* coef, int ncoef, i
                   hipStream_t s) {
     constexpr int NC = fxk::FixedNC<SD, N>::value;
     constexpr int KS = (fxk::StepTable<SD, N>::NEXP + 3) / 4;
-    if (ncoef != NC || lds_bytes != fxk::wg_lds_doubles(CT, KS) * 8 || h.npts > 16 * CT || h.npts < 1) return hipErrorInvalidValue;
+    if (ncoef != NC || lds_bytes != fxk::wg_lds_doubles(CT, KS) * 8 || h.npts < 1 || h.gslab < 1 || (long long)h.gslab * h.npts > 16 * CT ||
+        (long long)grid * h.gslab > h.nreq + h.gslab - 1)
+        return hipErrorInvalidValue;
     fxk::StackedArgs<NC> ka;
     memset(&ka, 0, sizeof ka);
     ka.pts = h.pts;
@@ -32,6 +34,7 @@ hipError_t launch(const fxk::StackedArgs<0>& h, const double* coef, int ncoef, i
     ka.npts = h.npts;
     ka.R = h.R;
     ka.RT = h.RT;
+    ka.gslab = h.gslab;
     ka.lim_pts = h.lim_pts;
     ka.lim_verts = h.lim_verts;
     ka.lim_out = h.lim_out;
@@ -89,7 +92,6 @@ hipError_t launch_ct(int ct, bool odd, const fxk::StackedArgs<0>& h, const doubl
         case 4: return launch_odd<SD, N, 4>(odd, h, coef, ncoef, lds_bytes, grid, trash, queue, s);
         case 5: return launch_odd<SD, N, 5>(odd, h, coef, ncoef, lds_bytes, grid, trash, queue, s);
         case 6: return launch_odd<SD, N, 6>(odd, h, coef, ncoef, lds_bytes, grid, trash, queue, s);
-        case 7: if constexpr (fxk::wg_lds_doubles(7, KS) * 8 <= 160 * 1024) return launch_odd<SD, N, 7>(odd, h, coef, ncoef, lds_bytes, grid, trash, queue, s); break;
         case 8: if constexpr (fxk::wg_lds_doubles(8, KS) * 8 <= 160 * 1024) return launch_odd<SD, N, 8>(odd, h, coef, ncoef, lds_bytes, grid, trash, queue, s); break;
     }
     return hipErrorInvalidValue;
@@ -105,7 +107,8 @@ int lds_bytes(int sd, int n, int ct) {
 }
 
 bool has_instance(int sd, int n, int ct, bool odd) {
-    if (ct < 4 || ct > 8 || lds_bytes(sd, n, ct) > 160 * 1024) return false;
+    // (seven column tiles: the one-wave-per-row-tile layout spills there -- the planner takes eight, two waves per row tile)
+    if (ct < 4 || ct > 8 || ct == 7 || lds_bytes(sd, n, ct) > 160 * 1024) return false;
     (void)odd;
     return (sd == 3 && n >= 3 && n <= 6) || (sd == 2 && (n == 5 || n == 6));
 }

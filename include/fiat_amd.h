@@ -70,7 +70,8 @@ int fx_ctx_info(fx_ctx* ctx, int* num_cu, int* lds_bytes_per_cu, char* name, int
 #define FX_POLICY_KERNEL_IMAGE (1u << 9)   /* shape-specialised family: LDS-image variant */
 #define FX_POLICY_KERNEL_STREAM (1u << 10) /* shape-specialised family: one request per wave, K-streamed */
 #define FX_POLICY_NO_WG (1u << 11)         /* request-per-workgroup kernel (rules of 49..128 points): point chunks instead */
-#define FX_POLICY_ALL ((1u << 12) - 1)
+#define FX_POLICY_WG_SMALL (1u << 12)      /* opt in: the request-per-workgroup kernel with several small requests per workgroup (<= 64 points) */
+#define FX_POLICY_ALL ((1u << 13) - 1)
 int fx_ctx_set_policy(fx_ctx* ctx, unsigned flags);
 int fx_ctx_get_policy(const fx_ctx* ctx, unsigned* flags);
 

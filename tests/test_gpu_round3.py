@@ -434,9 +434,9 @@ ROUTES = [
     # round 4: rules of 49..128 points on the element's own cell take the request-per-workgroup kernel (were point chunks of two
     # or three column tiles; those instances stay behind policy no_wg: tests/test_gpu_round4.py)
     ("Lagrange", 3, 6, 122, 1, False, "wg<3,6,8>"), ("Lagrange", 3, 6, 74, 1, False, "wg<3,6,5>"),
-    ("Lagrange", 3, 6, 57, 0, False, "wg<3,6,4>"), ("DiscontinuousLagrange", 3, 6, 121, 2, False, "wg<3,6,8>"),
+    ("Lagrange", 3, 6, 57, 0, False, "wg<3,6,8>x2"), ("DiscontinuousLagrange", 3, 6, 121, 2, False, "wg<3,6,8>"),
     ("Lagrange", 3, 5, 74, 2, False, "wg<3,5,5>"), ("Lagrange", 3, 5, 74, 0, False, "wg<3,5,5>"),
-    ("Lagrange", 3, 5, 111, 1, False, "wg<3,5,7>")]
+    ("Lagrange", 3, 5, 111, 1, False, "wg<3,5,8>")]
 
 
 @pytest.mark.parametrize("family,sd,degree,npts,order,cells,kernel", ROUTES,

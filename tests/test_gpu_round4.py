@@ -58,7 +58,13 @@ def test_request_per_workgroup_kernel(family, sd, degree, npts, order, nreq):
     ps = el.device_polyset()
     n = el.get_nodal_basis().get_embedded_degree()
     name = ps.kernel_name(order, nreq, npts, instance=True)
-    assert name == f"fxk::tabulate_simplex_wg<{sd},{n},{(npts + 15) // 16}>", name
+    # column tiles of the instance: ceil(npts / 16), or one more where that layout has fewer MFMA slots per wave (5 -> 6 for
+    # few row tiles) or no instance (7 -> 8)
+    # (rules of 49..64 points: two requests share the slab)
+    g = 2 if npts <= 64 else 1
+    ct = (g * npts + 15) // 16
+    sfx = "x2" if g == 2 else ""
+    assert name in (f"fxk::tabulate_simplex_wg<{sd},{n},{ct}>{sfx}", f"fxk::tabulate_simplex_wg<{sd},{n},{ct + 1}>{sfx}") and "7>" not in name, name
     assert ps.kernel_name(order, nreq, npts) == "fxk::tabulate_simplex_wg"
     pts, _ = batch(sd, nreq, npts, 31 * npts + degree + order, False)
     got = ps.tabulate_batch(order, pts).cpu().numpy()
@@ -116,3 +122,34 @@ def test_rule_sizes_next_to_the_window():
     assert ps.kernel_name(1, 100, 48) == "fxk::tabulate_simplex_stacked"
     assert ps.kernel_name(1, 100, 129) == "fxk::tabulate_simplex_stacked"
     assert ps.kernel_name(1, 100, 128) == "fxk::tabulate_simplex_wg"
+
+
+# (family, sd, degree, points) -> requests per slab, column tiles
+WG_SMALL = [("Lagrange", 3, 6, 23, 5, 8), ("Lagrange", 3, 5, 14, 9, 8), ("DiscontinuousLagrange", 3, 5, 23, 5, 8), ("Lagrange", 2, 5, 25, 5, 8),
+            ("Lagrange", 2, 6, 33, 3, 8), ("Lagrange", 3, 4, 44, 2, 6), ("Lagrange", 3, 6, 44, 2, 6), ("Lagrange", 3, 5, 31, 4, 8),
+            ("Nedelec", 3, 3, 23, 5, 8), ("RaviartThomas", 3, 3, 14, 9, 8), ("Lagrange", 3, 3, 57, 2, 8), ("Lagrange", 3, 6, 64, 2, 8),
+            ("Lagrange", 2, 5, 16, 8, 8), ("Lagrange", 3, 4, 11, 11, 8)]
+
+
+@pytest.mark.parametrize("family,sd,degree,npts,g,ct", WG_SMALL, ids=[f"{m[0][:3]}{m[2]}-sd{m[1]}-{m[3]}pt" for m in WG_SMALL])
+@pytest.mark.parametrize("order", [0, 1, 2])
+@pytest.mark.parametrize("nreq,cells", [(1, False), (7, False), (1031, False), (2400, False), (333, True)])
+def test_groups_of_small_requests_per_workgroup(family, sd, degree, npts, g, ct, order, nreq, cells, kernel_policy):
+    """Policy wg_small: several requests of <= 64 points share the slab of a workgroup (simplex_wg.hpp, gslab > 1): the image
+    of a row tile is [request][16][npts], a request's rows leave as contiguous pieces.  Odd table sizes (8-byte twins), a last
+    group with missing requests (1031 = 5 x 206 + 1 ...), fewer groups than workgroups, per-request cells (values from the
+    kernel; derivatives + the table-mixing pass), against the C oracle."""
+    import fiat_amd as fa
+    el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
+    ps = el.device_polyset()
+    n = el.get_nodal_basis().get_embedded_degree()
+    kernel_policy("wg_small", "no_fixed", "no_small", "no_stacked_mix")
+    name = ps.kernel_name(order, nreq, npts, has_verts=cells, instance=True)
+    if cells and order >= 1 and "simplex_wg" not in name:
+        pytest.skip("per-request cells with derivatives: the planner keeps this shape off the two-pass routes (" + name + ")")
+    assert name == f"fxk::tabulate_simplex_wg<{sd},{n},{ct}>x{g}", name
+    pts, verts = batch(sd, nreq, npts, 17 * npts + degree + order + nreq, cells)
+    got = ps.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    ref = oracle_tables(el, sd, order, pts, verts, got.shape)
+    for t in range(got.shape[1]):
+        assert rel(got[:, t], ref[:, t]) <= (TOL_VAL if t == 0 else TOL_DER), (name, t, rel(got[:, t], ref[:, t]))

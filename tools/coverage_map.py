@@ -17,7 +17,8 @@ if "--policy" in sys.argv:
 qoff = int(sys.argv[sys.argv.index("--qdeg-offset") + 1]) if "--qdeg-offset" in sys.argv else 0   # rule degree 2 * degree + this
 only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""
 rows, audit = [], []
-AUDIT = [("no_stacked",), ("no_small",), ("no_stacked", "no_small"), ("no_fixed",), ("no_stacked_mix",), ("stacked_small",)]
+AUDIT = [("no_stacked",), ("no_small",), ("no_stacked", "no_small"), ("no_fixed",), ("no_stacked_mix",), ("stacked_small",), ("no_wg",),
+         ("wg_small",), ("wg_small", "no_fixed", "no_small")]
 for sd in (2, 3):
     cell = fiat_amd.ufc_simplex(sd)
     for fam, degs in FAMS:
