@@ -1763,7 +1763,14 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     if (npts > 16 * k.ct / k.g || tighter_instance(k) || !fills_tiles(k)) continue;
                 } else if (wgk) {  // a request (or, policy wg_small, a group of small requests) per workgroup
                     if ((ctx->policy & FX_POLICY_NO_WG) || npts > 16 * k.ct) continue;
-                    if (npts <= 48 && !(ctx->policy & FX_POLICY_WG_SMALL)) continue;   // (fewer points: the whole-request instances)
+                    // (fewer points: the whole-request instances of the per-wave kernel -- except where several requests per
+                    // workgroup are robustly ahead in sustained runs, tools/instance_ab.py --own-cell [--policy wg_small], 0.8 GB:
+                    // P5 triangles with derivatives at 25..33 points 232 / 183 / 252 -> 189 / 169 / 225 us, degree-6 tetrahedra with
+                    // Hessians at 33..48 points 432 -> 352 us.  Elsewhere the two are within +-10 % of each other with either sign,
+                    // and the map's short interleaved runs disagree with the sustained ones: opt-in, policy wg_small)
+                    const bool wg_small_default = !verts && ((k.sd == 2 && k.n == 5 && order >= 1 && npts >= 25 && npts <= 33) ||
+                                                             (k.sd == 3 && k.n == 6 && order == 2 && npts >= 33 && npts <= 48));
+                    if (npts <= 48 && !(ctx->policy & FX_POLICY_WG_SMALL) && !wg_small_default) continue;
                     // requests per slab of <= 128 columns; the instance's column tiles (an even number where several requests
                     // share the slab: two waves per row tile)
                     wg_g = npts > 64 ? 1 : std::min(12, 128 / npts);
@@ -2105,9 +2112,6 @@ int fx_tabulate_batch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq,
                       const double* verts, double* out, void* stream) {
     if (ctx && e && order > 2) {  // differentiation-matrix route (ensure_high_order)
         if (order > FX_MAX_ORDER) return fail(FX_ENOTIMPL, "derivative order %d > %d is not implemented on the device", order, FX_MAX_ORDER);
-        if (verts && order > 4)
-            return fail(FX_ENOTIMPL, "derivative order %d with per-request cells is not implemented (orders <= 4 are; an element "
-                        "built on the physical cell serves any order)", order);
         if (nreq < 0 || npts < 0) return fail(FX_EINVAL, "negative batch size");
         if (nreq == 0 || npts == 0) return FX_OK;
         int rc = ensure_high_order(ctx, const_cast<fx_element*>(e), order);
@@ -2817,7 +2821,57 @@ int project_derivative_matrices(fx_ctx* ctx, fx_element* e, int order, std::vect
 }
 
 // chain rule across the tables of orders 1..order (3 or 4) for per-request cells (table_mix_high_kernel)
+// ... and of any order up to FX_MAX_ORDER (table_mix_any_kernel): orders 5..8
+int mix_any_order(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, const double* verts, double* out, hipStream_t s) {
+    const int sd = e->sd;
+    fxk::TableMixAnyArgs ma;
+    memset(&ma, 0, sizeof ma);
+    ma.out = out;
+    ma.verts = verts;
+    if (!invert_small(sd, e->A0, ma.A0inv)) return fail(FX_EINVAL, "degenerate cell");
+    ma.n = e->ndof * e->vdim * npts;
+    ma.slices = std::max(1, std::min(16, (ma.n + 1023) / 1024));
+    ma.nreq = nreq;
+    ma.order = order;
+    if (order > 9 || nreq * ma.slices > 0x7fffffffLL) return fail(FX_EINVAL, "batch too large for the table-mixing pass");
+    std::vector<std::vector<int>> prev = fx::multi_indices(sd, 0);
+    int t = 1, moff = 0;
+    ma.first[0] = 0;
+    ma.cnt[0] = 1;
+    for (int k = 1; k <= order; ++k) {
+        const std::vector<std::vector<int>> cur = fx::multi_indices(sd, k);
+        ma.first[k] = t;
+        ma.cnt[k] = (int)cur.size();
+        ma.moff[k] = moff;
+        moff += (int)(cur.size() * cur.size());
+        for (const std::vector<int>& al : cur) {
+            if (t >= fxk::MIXA_MAXT) return fail(FX_ENOTIMPL, "too many derivative tables for the mixing pass");
+            int lead = 0;
+            while (al[lead] == 0) ++lead;
+            ma.lead[t] = (unsigned char)lead;
+            for (int c = 0; c < 3; ++c) {
+                ma.down[t][c] = -1;
+                if (c < sd && al[c] > 0) {
+                    std::vector<int> be = al;
+                    be[c] -= 1;
+                    ma.down[t][c] = (signed char)(std::find(prev.begin(), prev.end(), be) - prev.begin());
+                }
+            }
+            ++t;
+        }
+        prev = cur;
+    }
+    const int lds = (16 + moff) * 8;
+    const dim3 grid((unsigned)std::max<long long>(1, nreq * ma.slices));
+    if (sd == 1) hipLaunchKernelGGL((fxk::table_mix_any_kernel<1>), grid, dim3(256), lds, s, ma);
+    else if (sd == 2) hipLaunchKernelGGL((fxk::table_mix_any_kernel<2>), grid, dim3(256), lds, s, ma);
+    else hipLaunchKernelGGL((fxk::table_mix_any_kernel<3>), grid, dim3(256), lds, s, ma);
+    HIP_TRY(hipGetLastError());
+    return FX_OK;
+}
+
 int mix_high_order(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int npts, const double* verts, double* out, hipStream_t s) {
+    if (order > 4) return mix_any_order(ctx, e, order, nreq, npts, verts, out, s);
     const int sd = e->sd;
     fxk::TableMixHighArgs ma;
     memset(&ma, 0, sizeof ma);

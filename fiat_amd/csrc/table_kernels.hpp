@@ -352,6 +352,78 @@ __global__ __launch_bounds__(256) void table_mix_high_kernel(const TableMixHighA
     }
 }
 
+// ---- the same chain rule at ANY order up to FX_MAX_ORDER (orders 5..8 with per-request cells; round 4) ----
+// Run-time order: M_1..M_order in dynamic LDS (3-D, order 8: 4916 doubles), one workgroup per (request, slice of positions);
+// the tables of one order of a position in registers (<= 45 in 3-D).  FIAT/expansions.py:411-447 applies the chain rule through
+// Jinv at any order; this is its per-request form.
+constexpr int MIXA_MAXT = 165;   // tables up to order 8 in 3-D
+struct TableMixAnyArgs {
+    double* out;          // [nreq][ntab][n]   n = rows * npts
+    const double* verts;  // [nreq][SD+1][SD]
+    double A0inv[9];
+    int n, slices, order;
+    long long nreq;
+    int first[10], cnt[10], moff[10];   // per order k: first table, number of tables, offset of M_k in LDS (doubles)
+    signed char down[MIXA_MAXT][3];     // index, within the previous order, of alpha_t - e_c (-1: alpha_t[c] == 0)
+    unsigned char lead[MIXA_MAXT];      // first non-zero entry of alpha_t
+};
+
+template <int SD>
+__global__ __launch_bounds__(256) void table_mix_any_kernel(const TableMixAnyArgs a) {
+    constexpr int CMAX = SD == 1 ? 1 : SD == 2 ? 9 : 45;   // tables of one order, order <= 8
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* sK = sm;            // [SD * SD]
+    double* sM = sm + 16;       // M_1 .. M_order
+    const long long r = (long long)(blockIdx.x / a.slices);
+    const int slice = (int)(blockIdx.x % a.slices);
+    if (threadIdx.x == 0) {
+        double A[SD][SD], b[SD];
+        cell_map<SD>(a.verts + (size_t)r * (SD + 1) * SD, A, b);
+        for (int c = 0; c < SD; ++c)
+            for (int d = 0; d < SD; ++d) {
+                double t = 0.0;
+                for (int k = 0; k < SD; ++k) t += a.A0inv[c * SD + k] * A[k][d];
+                sK[c * SD + d] = t;
+            }
+    }
+    __syncthreads();
+    for (int k = 1; k <= a.order; ++k) {  // M_k[t][s] from M_{k-1}
+        const int cnt = a.cnt[k], pcnt = a.cnt[k - 1], first = a.first[k];
+        for (int e = threadIdx.x; e < cnt * cnt; e += 256) {
+            const int t = e / cnt, s2 = e - t * cnt;
+            const int d = a.lead[first + t];
+            const int tp = a.down[first + t][d];
+            double acc = 0.0;
+            for (int c = 0; c < SD; ++c) {
+                const int sp = a.down[first + s2][c];
+                if (sp >= 0) acc += sK[c * SD + d] * (k > 1 ? sM[a.moff[k - 1] + tp * pcnt + sp] : 1.0);
+            }
+            sM[a.moff[k] + e] = acc;
+        }
+        __syncthreads();
+    }
+    const int ntab = a.first[a.order] + a.cnt[a.order];
+    double* base = a.out + (size_t)r * ntab * a.n;
+    for (int i = slice * 256 + threadIdx.x; i < a.n; i += a.slices * 256) {
+        for (int k = 1; k <= a.order; ++k) {
+            const int cnt = a.cnt[k], first = a.first[k];
+            const double* M = sM + a.moff[k];
+            double in[CMAX];
+#pragma unroll
+            for (int s = 0; s < CMAX; ++s) in[s] = s < cnt ? base[(size_t)(first + s) * a.n + i] : 0.0;
+#pragma unroll 1
+            for (int t = 0; t < cnt; ++t) {
+                const double* Mt = M + t * cnt;
+                double acc = 0.0;
+#pragma unroll
+                for (int s = 0; s < CMAX; ++s)
+                    if (s < cnt) acc += Mt[s] * in[s];
+                base[(size_t)(first + t) * a.n + i] = acc;
+            }
+        }
+    }
+}
+
 // ---- tensor products of ANY two tabulated factors (TensorProductElement.tabulate, FIAT/tensor_product.py:231-336) ----
 // out[r][t][a * rowsB + b][c][p] = A[r][tA(t)][a][cA][p] * B[r][tB(t)][b][cB][p]   for alpha_t = (alpha_A, alpha_B):
 // scalar x scalar (:274-292), vector x scalar (:293-317) and scalar x vector (:318-335) are the same formula with the

@@ -239,8 +239,13 @@ def test_order_3_on_a_physical_cell_and_limits(golden):
         assert np.abs(t4[a]).max() <= 1e-8
     with pytest.raises(NotImplementedError):
         el.tabulate(9, g["hi_phys_pts"])
-    with pytest.raises(NotImplementedError):   # per-request cells: orders <= 4
-        el.tabulate_batch(5, g["hi_phys_pts"][None], verts=g["hi_phys_verts"][None])
+    # per-request cells: any order the own-cell route serves (round 4: table_mix_any_kernel; tests/test_gpu_round4.py); all
+    # derivatives of a cubic beyond the third vanish on the request's cell too
+    t5 = el.tabulate_batch(5, g["hi_phys_pts"][None], verts=g["hi_phys_verts"][None]).cpu().numpy()[0]
+    n3 = sum(len(fiat_amd.mis(3, k)) for k in range(4))
+    assert np.abs(t5[n3:]).max() <= 1e-6 and np.abs(t5[:n3] - np.stack([tab[a] for k in range(4) for a in fiat_amd.mis(3, k)])).max() <= 1e-8
+    with pytest.raises(NotImplementedError):
+        el.tabulate_batch(9, g["hi_phys_pts"][None], verts=g["hi_phys_verts"][None])
 
 
 def _chain_rule_tables(fa, ref_tab, sd, order, Kt):

@@ -153,3 +153,75 @@ def test_groups_of_small_requests_per_workgroup(family, sd, degree, npts, g, ct,
     ref = oracle_tables(el, sd, order, pts, verts, got.shape)
     for t in range(got.shape[1]):
         assert rel(got[:, t], ref[:, t]) <= (TOL_VAL if t == 0 else TOL_DER), (name, t, rel(got[:, t], ref[:, t]))
+
+
+# ---- derivative orders 5 and 6, on the element's cell and with per-request cells (tests/golden/round4.npz) ------------------
+HO = [("dg6tet", 3, lambda fa, c: fa.DiscontinuousLagrange(c, 6), True), ("p6tri", 2, lambda fa, c: fa.Lagrange(c, 6), True),
+      ("p5tet", 3, lambda fa, c: fa.Lagrange(c, 5), True), ("n4tri", 2, lambda fa, c: fa.Nedelec(c, 4), False),
+      ("on7int", 1, lambda fa, c: fa.ONPolynomialSet(c, 7), False)]
+
+
+def _chain_rule_tables(fa, ref_tab, sd, order, Kt):
+    """d^alpha_x from the reference's tables with respect to X: Kt[c, d] = dX_c / dx_d, sum over ordered source directions
+    (NumPy, independent of the device pass)."""
+    import itertools
+    keys = [a for k in range(order + 1) for a in fa.mis(sd, k)]
+    pos = {a: i for i, a in enumerate(keys)}
+    out = []
+    for alpha in keys:
+        dirs = [d for d, m in enumerate(alpha) for _ in range(m)]
+        acc = 0.0
+        for src in itertools.product(range(sd), repeat=len(dirs)):
+            beta = tuple(src.count(c) for c in range(sd))
+            acc = acc + float(np.prod([Kt[c, d] for c, d in zip(src, dirs)])) * ref_tab[pos[beta]]
+        out.append(acc)
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("name,sd,make,rebuild", HO, ids=[h[0] for h in HO])
+@pytest.mark.parametrize("order", [5, 6])
+def test_orders_5_and_6_vs_reference(golden, name, sd, make, rebuild, order):
+    """Orders the earlier fixtures do not reach.  (a) On the element's own cell: `tabulate(order, points)` equals the
+    reference's tables (FIAT/expansions.py:66-137 / :438-446).  (b) Per-request cells (`table_mix_any_kernel`, FIAT/expansions.py:
+    411-447 through Jinv): equal to the reference's elements built ON the physical cells (affine families, incl. a negatively
+    oriented cell), and to the chain rule applied in NumPy to the REFERENCE's reference-cell tables (all families).  Tolerance:
+    the north-star 1e-10 for derivatives, relative to the largest entry of the table's order (sixth derivatives of degree-6
+    bases reach 1e6)."""
+    import fiat_amd as fa
+    g = golden("round4")
+    ref = np.array(fa.ufc_simplex(sd).get_vertices(), dtype=float)
+    verts, pts, ref_pts = g[f"ho_{name}_verts"], g[f"ho_{name}_pts"], g[f"ho_{name}_refpts"]
+    base = make(fa, fa.ufc_simplex(sd))
+    is_element = hasattr(base, "dual_basis")
+    dev = base if is_element else base.device_polyset()
+    firsts = np.cumsum([0] + [len(fa.mis(sd, k)) for k in range(order + 1)])
+
+    def close(got, want, tag):
+        assert got.shape == want.shape, (tag, got.shape, want.shape)
+        for k in range(order + 1):
+            sl = slice(firsts[k], firsts[k + 1])
+            err = np.abs(got[sl] - want[sl]).max() / max(1.0, np.abs(want[sl]).max())
+            assert err <= (1e-12 if k == 0 else 1e-10), (tag, k, err)
+
+    got = dev.tabulate_batch(order, ref_pts).cpu().numpy()
+    cells = dev.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    for r in range(verts.shape[0]):
+        want_ref = g[f"ho_{name}_o{order}_ref{r}"]
+        close(got[r].reshape(want_ref.shape), want_ref, "own cell")
+        J = (verts[r][1:] - verts[r][0]).T @ np.linalg.inv((ref[1:] - ref[0]).T)          # dx/dX
+        close(cells[r].reshape(want_ref.shape), _chain_rule_tables(fa, want_ref, sd, order, np.linalg.inv(J)), "cells, chain rule")
+        if rebuild:
+            close(cells[r].reshape(want_ref.shape), g[f"ho_{name}_o{order}_phys{r}"], "cells, reference element on the physical cell")
+
+
+def test_two_vector_valued_factors_are_refused_like_the_reference():
+    """FIAT/tensor_product.py:268-271 raises NotImplementedError("tabulate does not support two vector-valued inputs"); so does
+    the facade (the reference has no such tabulation to be equal to)."""
+    import fiat_amd as fa
+    tri, seg = fa.ufc_simplex(2), fa.ufc_simplex(1)
+    # (the reference already fails while it builds the dual basis of such a product -- NotImplementedError("unsupported
+    # functional type"), :99-205 -- so the facade refuses at construction, with the message of the tabulation)
+    with pytest.raises(NotImplementedError, match="two vector-valued"):
+        fa.TensorProductElement(fa.RaviartThomas(tri, 1), fa.RaviartThomas(tri, 1))
+    ok = fa.TensorProductElement(fa.RaviartThomas(tri, 1), fa.Lagrange(seg, 1))     # one vector-valued factor: served
+    assert ok.tabulate(0, np.array([[0.2, 0.3, 0.5]]))[(0, 0, 0)].shape == (6, 2, 1)
