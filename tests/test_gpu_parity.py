@@ -93,8 +93,9 @@ def test_bad_arguments(rt):
     ps = rt.SimplexPolySet(2, 2)
     with pytest.raises(NotImplementedError):
         ps.tabulate_batch(9, np.zeros((1, 2, 2)))          # orders 3..8 run through differentiation matrices
-    with pytest.raises(NotImplementedError):          # per-request cells: orders <= 4
-        ps.tabulate_batch(5, np.zeros((1, 2, 2)), verts=np.array([[[0.0, 0], [1, 0], [0, 1]]]))
+    with pytest.raises(NotImplementedError):          # ... with per-request cells too (round 4: any order <= 8, tests/test_gpu_round4.py)
+        ps.tabulate_batch(9, np.zeros((1, 2, 2)), verts=np.array([[[0.0, 0], [1, 0], [0, 1]]]))
+    assert ps.tabulate_batch(5, np.zeros((1, 2, 2)) + 0.25, verts=np.array([[[0.0, 0], [1, 0], [0, 1]]])).shape[1] == 21
     with pytest.raises(ValueError):
         ps.tabulate_batch(1, np.zeros((1, 2, 3)))
     # empty batches are fine
