@@ -1931,14 +1931,21 @@ namespace {
 // register-resident shared-point kernel: NP units (pairs, or single doubles for odd tables) per thread and table slice; NP is
 // capped so that the reference values stay in registers (NP * EL * NTAB * NE doubles), larger tables take more slices
 template <int SD, int ORDER, bool PIOLA, int EL>
-bool launch_shared_reg_sliced(int units, const fxk::SharedArgs& sa, int grid, hipStream_t s) {
+bool launch_shared_reg_sliced(int units, const fxk::SharedArgs& sa_in, int ncu, hipStream_t s) {
     constexpr int NTAB = fxk::NTab<SD, ORDER>::value;
     constexpr int PER = EL * NTAB * (PIOLA ? SD : 1);                       // doubles per unit slot
     constexpr int NPMAX = PER >= 80 ? 1 : PER >= 40 ? 2 : PER >= 27 ? 3 : 4;  // <= ~120 doubles of reference values per thread
     const int need = (units + 255) / 256;
     const int np = std::min(need, NPMAX);
     const int slices = (need + np - 1) / np;
-    const dim3 g((unsigned)std::max(1, grid / slices), (unsigned)slices);
+    // requests per block: 64 for large batches (their K in LDS at once); batches of few large requests -- 976 requests of
+    // 820 KB, six slices -- left most CUs idle at 64 a block (96 workgroups: 12 % of the HBM peak), so a block shrinks until
+    // there are ~4 workgroups per CU
+    fxk::SharedArgs sa = sa_in;
+    const long long want = 4LL * ncu;
+    sa.rb = (int)std::max<long long>(1, std::min<long long>(fxk::SHARED_RB, sa.nreq * slices / want));
+    const long long blocks = (sa.nreq + sa.rb - 1) / sa.rb;
+    const dim3 g((unsigned)std::max<long long>(1, std::min<long long>(blocks, std::max<long long>(1, 8LL * ncu / slices))), (unsigned)slices);
     switch (np) {
         case 1: hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 1, PIOLA, EL>), g, dim3(256), 0, s, sa); return true;
         case 2: if constexpr (NPMAX >= 2) { hipLaunchKernelGGL((fxk::shared_points_reg_kernel<SD, ORDER, 2, PIOLA, EL>), g, dim3(256), 0, s, sa); return true; } break;
@@ -1954,8 +1961,9 @@ bool launch_shared_reg_sliced(int units, const fxk::SharedArgs& sa, int grid, hi
 static inline bool noflat_shared(unsigned policy) { return (policy & FX_POLICY_NO_SHARED_REG) != 0 && (policy & FX_POLICY_NO_SHARED_WAVE) != 0; }
 
 template <int SD>
-int launch_shared(int order, const fxk::SharedArgs& sa, int grid, hipStream_t s, unsigned policy) {
+int launch_shared(int order, const fxk::SharedArgs& sa, int ncu, hipStream_t s, unsigned policy) {
     const int table = sa.rows * sa.npts;
+    const int grid = (int)std::max<long long>(1, std::min<long long>((sa.nreq + fxk::SHARED_RB - 1) / fxk::SHARED_RB, (long long)ncu * 8));
     // tiny requests (<= FX_SHARED_FLAT_MAX doubles of tables): a wave per 64 requests, flat contiguous output
     {
         const long long total = (long long)fx::binom(SD + order, SD) * table;
@@ -1997,25 +2005,27 @@ int launch_shared(int order, const fxk::SharedArgs& sa, int grid, hipStream_t s,
         const bool piola = sa.kind != 0;
         bool ok = false;
         if (table & 1) {
-            if (order == 0) ok = piola ? launch_shared_reg_sliced<SD, 0, true, 1>(table, sa, grid, s) : launch_shared_reg_sliced<SD, 0, false, 1>(table, sa, grid, s);
-            if (order == 1) ok = piola ? launch_shared_reg_sliced<SD, 1, true, 1>(table, sa, grid, s) : launch_shared_reg_sliced<SD, 1, false, 1>(table, sa, grid, s);
+            if (order == 0) ok = piola ? launch_shared_reg_sliced<SD, 0, true, 1>(table, sa, ncu, s) : launch_shared_reg_sliced<SD, 0, false, 1>(table, sa, ncu, s);
+            if (order == 1) ok = piola ? launch_shared_reg_sliced<SD, 1, true, 1>(table, sa, ncu, s) : launch_shared_reg_sliced<SD, 1, false, 1>(table, sa, ncu, s);
             // (odd tables with Hessians -- N3 / RT2 tetrahedra, P5 triangles at their default rules -- ran on the
             // one-workgroup-per-request fallback at 1-20 % of the HBM peak: tools/coverage_map_cells.py)
-            if (order == 2) ok = piola ? launch_shared_reg_sliced<SD, 2, true, 1>(table, sa, grid, s) : launch_shared_reg_sliced<SD, 2, false, 1>(table, sa, grid, s);
+            if (order == 2) ok = piola ? launch_shared_reg_sliced<SD, 2, true, 1>(table, sa, ncu, s) : launch_shared_reg_sliced<SD, 2, false, 1>(table, sa, ncu, s);
         } else {
-            if (order == 0) ok = piola ? launch_shared_reg_sliced<SD, 0, true, 2>(table / 2, sa, grid, s) : launch_shared_reg_sliced<SD, 0, false, 2>(table / 2, sa, grid, s);
-            if (order == 1) ok = piola ? launch_shared_reg_sliced<SD, 1, true, 2>(table / 2, sa, grid, s) : launch_shared_reg_sliced<SD, 1, false, 2>(table / 2, sa, grid, s);
-            if (order == 2) ok = piola ? launch_shared_reg_sliced<SD, 2, true, 2>(table / 2, sa, grid, s) : launch_shared_reg_sliced<SD, 2, false, 2>(table / 2, sa, grid, s);
+            if (order == 0) ok = piola ? launch_shared_reg_sliced<SD, 0, true, 2>(table / 2, sa, ncu, s) : launch_shared_reg_sliced<SD, 0, false, 2>(table / 2, sa, ncu, s);
+            if (order == 1) ok = piola ? launch_shared_reg_sliced<SD, 1, true, 2>(table / 2, sa, ncu, s) : launch_shared_reg_sliced<SD, 1, false, 2>(table / 2, sa, ncu, s);
+            if (order == 2) ok = piola ? launch_shared_reg_sliced<SD, 2, true, 2>(table / 2, sa, ncu, s) : launch_shared_reg_sliced<SD, 2, false, 2>(table / 2, sa, ncu, s);
         }
         if (ok) {
             HIP_TRY(hipGetLastError());
             return FX_OK;
         }
     }
+    // one workgroup per request, persistent (the fallback: reads the reference tables from L2 for every request)
+    const int rgrid = (int)std::max<long long>(1, std::min<long long>(sa.nreq, (long long)ncu * 8));
     switch (order) {
-        case 0: hipLaunchKernelGGL((fxk::shared_points_kernel<SD, 0>), dim3(grid), dim3(256), 0, s, sa); break;
-        case 1: hipLaunchKernelGGL((fxk::shared_points_kernel<SD, 1>), dim3(grid), dim3(256), 0, s, sa); break;
-        default: hipLaunchKernelGGL((fxk::shared_points_kernel<SD, 2>), dim3(grid), dim3(256), 0, s, sa); break;
+        case 0: hipLaunchKernelGGL((fxk::shared_points_kernel<SD, 0>), dim3(rgrid), dim3(256), 0, s, sa); break;
+        case 1: hipLaunchKernelGGL((fxk::shared_points_kernel<SD, 1>), dim3(rgrid), dim3(256), 0, s, sa); break;
+        default: hipLaunchKernelGGL((fxk::shared_points_kernel<SD, 2>), dim3(rgrid), dim3(256), 0, s, sa); break;
     }
     HIP_TRY(hipGetLastError());
     return FX_OK;
@@ -2225,11 +2235,11 @@ int fx_tabulate_batch_shared(fx_ctx* ctx, const fx_element* e, int mapping, int 
     sa.npts = npts;
     sa.kind = mapping;
     // persistent workgroups; the register-resident kernel takes blocks of 256 requests
-    const int grid = (int)std::max<long long>(1, std::min<long long>((nreq + fxk::SHARED_RB - 1) / fxk::SHARED_RB, (long long)ctx->num_cu * 8));
+    sa.rb = fxk::SHARED_RB;
     switch (e->sd) {
-        case 1: return launch_shared<1>(order, sa, grid, s, ctx->policy);
-        case 2: return launch_shared<2>(order, sa, grid, s, ctx->policy);
-        case 3: return launch_shared<3>(order, sa, grid, s, ctx->policy);
+        case 1: return launch_shared<1>(order, sa, ctx->num_cu, s, ctx->policy);
+        case 2: return launch_shared<2>(order, sa, ctx->num_cu, s, ctx->policy);
+        case 3: return launch_shared<3>(order, sa, ctx->num_cu, s, ctx->policy);
     }
     return fail(FX_EINVAL, "Invalid number of spatial dimensions");
 }

@@ -25,6 +25,7 @@ struct SharedArgs {
     double A0inv[9];
     long long nreq;
     int rows, vdim, npts, kind;  // kind: 0 affine, 1 covariant Piola, 2 contravariant Piola
+    int rb;                      // register-resident kernel: requests per block (<= SHARED_RB; fewer when the batch is small, so that every CU has work)
 };
 
 template <int SD, int ORDER> __global__ __launch_bounds__(256) void shared_points_kernel(const SharedArgs a) {
@@ -262,9 +263,10 @@ __global__ __launch_bounds__(256) void shared_points_reg_kernel(const SharedArgs
     // (the divisions and the 3x3 inverse, ~150 fp64 instructions, would otherwise be repeated by
     // every thread for every request), the workgroup then walks through them reading K from LDS.
     __shared__ double sK[SHARED_RB][SD * SD];
-    for (long long base = (long long)blockIdx.x * SHARED_RB; base < a.nreq; base += (long long)gridDim.x * SHARED_RB) {
+    const int RB = a.rb;
+    for (long long base = (long long)blockIdx.x * RB; base < a.nreq; base += (long long)gridDim.x * RB) {
         __syncthreads();  // sK of the previous block is no longer read
-        if (threadIdx.x < SHARED_RB) {
+        if ((int)threadIdx.x < RB) {
             const long long rq = min(base + (long long)threadIdx.x, a.nreq - 1);
             double A[SD][SD], b[SD];
             cell_map<SD>(a.verts + (size_t)rq * (SD + 1) * SD, A, b);
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void shared_points_reg_kernel(const SharedArgs
                 }
         }
         __syncthreads();
-        const int nblk = (int)min((long long)SHARED_RB, a.nreq - base);
+        const int nblk = (int)min((long long)RB, a.nreq - base);
       for (int rb = 0; rb < nblk; ++rb) {
         const long long req = base + rb;
         double K[SD][SD];

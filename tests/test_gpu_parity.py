@@ -485,7 +485,9 @@ def test_stacked_matrix_kernel(rt, golden, order, npts, nreq, kernel_policy):
     g = golden("elements")
     co = g["c4_dg6tet_q6_coeffs"]
     ps = rt.SimplexPolySet(3, 6, coeffs=co)
-    if npts > 48:   # (round 4: the default route of 49..128 points is the request-per-workgroup kernel, tests/test_gpu_round4.py)
+    # (round 4: the default route of 49..128 points -- and of 33..48 points with Hessians -- is the request-per-workgroup kernel,
+    # tests/test_gpu_round4.py)
+    if npts > 48 or (order == 2 and npts >= 33):
         assert ps.kernel_name(order, nreq, npts) == "fxk::tabulate_simplex_wg"
         kernel_policy("no_wg")
     assert ps.kernel_name(order, nreq, npts) == "fxk::tabulate_simplex_stacked"
