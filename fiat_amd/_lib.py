@@ -23,7 +23,7 @@ VARIANTS = {None: 0, "bubble": 1, "dual": 2}
 # kernel-selection policy bits (include/fiat_amd.h FX_POLICY_*)
 POLICY = {"no_fixed": 1 << 0, "no_small": 1 << 1, "no_stacked": 1 << 2, "no_coop": 1 << 3, "stacked_small": 1 << 4,
           "no_stacked_mix": 1 << 5, "no_shared_wave": 1 << 6, "no_shared_reg": 1 << 7, "no_macro_small": 1 << 8,
-          "kernel_image": 1 << 9, "kernel_stream": 1 << 10, "no_wg": 1 << 11, "wg_small": 1 << 12}
+          "kernel_image": 1 << 9, "kernel_stream": 1 << 10, "no_wg": 1 << 11, "wg_small": 1 << 12, "no_small_values": 1 << 13}
 
 
 class FiatAmdError(RuntimeError):

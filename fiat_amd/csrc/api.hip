@@ -1226,7 +1226,16 @@ struct SmallShape {
     int sd, n;
 };
 // (measured against the generic kernel: (2,5) and (3,3) are slower lane-local -- 1600+ FMAs per lane -- and stay generic)
-const SmallShape kSmallShapes[] = {{2, 1}, {2, 2}, {2, 3}, {3, 1}, {3, 2}, {2, 4}, {2, 0}, {3, 0}};  // degree 0 (P0 / DG0: one member, no steps): 6-19 % on the generic kernel
+const SmallShape kSmallShapes[] = {{2, 1}, {2, 2}, {2, 3}, {3, 1}, {3, 2}, {2, 4}, {2, 0}, {3, 0},  // degree 0 (P0 / DG0: one member, no steps): 6-19 % on the generic kernel
+                                   // round 4, VALUES ONLY: rows x members FMAs per lane stay below the HBM time of the lane's output up to ~56
+                                   // members (members / 8 FMAs per output byte), while the MFMA tiles of the other kernels are a third
+                                   // full at these row / point counts (P5 triangles, 21 rows x 25 points: 38 %)
+                                   // Measured, sustained runs, 0.8 GB (tools/instance_ab.py --own-cell [--policy no_small_values]): P5 triangles
+                                   // 345 / 264 / 247 / 551 us -> 222 / 179 / 180 / 218 at 25 / 12 / 30 / 7 points; P3 tetrahedra at 14 points
+                                   // 208 -> 165 (at 23 / 44 points the paired kernel keeps them: 187 / 161 against 176 / 178).  Tried and NOT
+                                   // registered: P6 triangles (0.82 ... 1.12 x by point count), P4 tetrahedra (1.1-1.4 x), P5 tetrahedra
+                                   // (3.7-5.4 x: 358 spilled scalar registers around the 56 x 56 coefficient stream)
+                                   {2, 5}, {3, 3}};
 constexpr int SMALL_NW = 4;
 
 template <int SD, int N>
@@ -1265,6 +1274,12 @@ int run_small(int order, const Launch& L, hipStream_t s) {
         case 5: return launch_small<2, 4>(order, L, s);
         case 6: return launch_small<2, 0>(order, L, s);
         case 7: return launch_small<3, 0>(order, L, s);
+        case 8: case 9:
+            if (order != 0 || L.sargs.piola) break;
+            if (L.small_id == 8) hipLaunchKernelGGL((fxk::tabulate_simplex_small<2, 5, 0, SMALL_NW>), dim3(L.sgrid), dim3(64 * SMALL_NW), L.slds_bytes, s, L.sargs);
+            if (L.small_id == 9) hipLaunchKernelGGL((fxk::tabulate_simplex_small<3, 3, 0, SMALL_NW>), dim3(L.sgrid), dim3(64 * SMALL_NW), L.slds_bytes, s, L.sargs);
+            HIP_TRY(hipGetLastError());
+            return FX_OK;
     }
     return fail(FX_EINVAL, "internal: unknown small kernel %d", L.small_id);
 }
@@ -1279,6 +1294,8 @@ bool small_table_matches(int id, const fx::Program& P) {
         case 5: return table_matches<2, 4>(P);
         case 6: return table_matches<2, 0>(P);
         case 7: return table_matches<3, 0>(P);
+        case 8: return table_matches<2, 5>(P);
+        case 9: return table_matches<3, 3>(P);
     }
     return false;
 }
@@ -1608,6 +1625,9 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
         if (!nosmall && order <= 2 && npts <= 64 && rows <= 96 && reqbytes8 <= 16 * 1024 && e->d_cmat) {
             for (size_t i = 0; i < sizeof(kSmallShapes) / sizeof(kSmallShapes[0]); ++i) {
                 if (kSmallShapes[i].sd != e->sd || kSmallShapes[i].n != e->n) continue;
+                const bool values_only_shape = i >= 8;   // (the round-4 entries)
+                if (values_only_shape && (order != 0 || mapping != FX_MAP_AFFINE || e->vdim != 1 || (ctx->policy & (FX_POLICY_WG_SMALL | FX_POLICY_NO_SMALL_VALUES)))) continue;
+                if (values_only_shape && e->sd == 3 && npts > 16) continue;   // (P3 tetrahedra: up to the 14-point rule)
                 if (!small_table_matches((int)i, e->prog) || (int)e->prog.steps.size() > fxk::SMALL_MAXSTEPS) continue;
                 int P = std::max(1, 64 / npts);
                 while (P > 1 && P * reqbytes8 > 12 * 1024) --P;  // per-wave image: several workgroups per CU
@@ -1620,7 +1640,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                                         e->vdim == e->sd && rows % e->sd == 0 && L.fixed_id < 0 && L.coop_id < 0 && !L.fused_mapping &&
                                         !(e->sd == 3 && e->n == 2 && order == 2);  // (that instance spills 39 registers)
                 if (fuse_small && rows > 24 && order >= 1 && stacked_pio_ok) break;
-                if (fuse_small ? rows > 36 : (rows > 24 || (rows > 16 && P == 1))) break;
+                if (fuse_small ? rows > 36 : !values_only_shape && (rows > 24 || (rows > 16 && P == 1))) break;
                 fxk::SmallArgs& sa = L.sargs;
                 memset(&sa, 0, sizeof sa);
                 if (fuse_small) {
@@ -1740,6 +1760,8 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 if (!verts && order == 1 && L.small_id >= 0 && k.sd == 2 &&
                     ((k.n == 3 && npts % 8 != 0 && npts != 12) || (k.n == 4 && k.rtc == -1 && npts <= 16)))
                     continue;
+                // (values-only P5 triangles where the lane-local kernel holds several requests per wave: round 4)
+                if (order == 0 && L.small_id >= 8) continue;
                 if (k.rtc == -2 || k.rtc == -3 || k.rtc == -6) {  // per-request cells, order 1 / 2: chain rule across the tables inside the kernel (dof-major tiles)
                     const bool nomix = (ctx->policy & FX_POLICY_NO_STACKED_MIX) != 0;
                     if (nomix || !verts || order != (k.rtc == -2 ? 1 : k.rtc == -3 ? 2 : 0)) continue;

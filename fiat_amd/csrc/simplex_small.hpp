@@ -15,7 +15,7 @@
 
 namespace fxk {
 
-constexpr int SMALL_MAXSTEPS = 14;  // (sd, n) = (2, 4): 15 members
+constexpr int SMALL_MAXSTEPS = 20;  // (sd, n) = (2, 5): 21 members and (3, 3): 20 (values only; with derivatives up to (2, 4): 15 members)
 
 struct SmallArgs {
     const double* pts;    // [nreq][npts][SD]

@@ -225,3 +225,26 @@ def test_two_vector_valued_factors_are_refused_like_the_reference():
         fa.TensorProductElement(fa.RaviartThomas(tri, 1), fa.RaviartThomas(tri, 1))
     ok = fa.TensorProductElement(fa.RaviartThomas(tri, 1), fa.Lagrange(seg, 1))     # one vector-valued factor: served
     assert ok.tabulate(0, np.array([[0.2, 0.3, 0.5]]))[(0, 0, 0)].shape == (6, 2, 1)
+
+
+@pytest.mark.parametrize("family,sd,degree,npts", [("Lagrange", 2, 5, 7), ("Lagrange", 2, 5, 12), ("DiscontinuousLagrange", 2, 5, 25),
+                                                   ("Lagrange", 2, 5, 30), ("Lagrange", 2, 5, 64), ("Lagrange", 3, 3, 4),
+                                                   ("DiscontinuousLagrange", 3, 3, 11), ("Lagrange", 3, 3, 14)])
+@pytest.mark.parametrize("nreq,cells", [(1, False), (515, False), (3, True), (1030, True)])
+def test_values_only_requests_on_the_lane_local_kernel(family, sd, degree, npts, nreq, cells, kernel_policy):
+    """Round 4: values-only requests of P5 triangles (21 rows) and of P3 tetrahedra up to the 14-point rule (20 rows) take the
+    lane-local kernel (simplex_small.hpp: rows x members FMAs per lane with scalar coefficients) instead of MFMA tiles that are a
+    third full; with derivatives the shapes stay where they were.  Against the C oracle; the former route behind policy
+    no_small_values gives the same tables."""
+    import fiat_amd as fa
+    el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
+    ps = el.device_polyset()
+    assert ps.kernel_name(0, nreq, npts, has_verts=cells) == "fxk::tabulate_simplex_small"
+    assert ps.kernel_name(1, nreq, npts, has_verts=cells) != "fxk::tabulate_simplex_small"
+    pts, verts = batch(sd, nreq, npts, 3 * npts + nreq, cells)
+    got = ps.tabulate_batch(0, pts, verts=verts).cpu().numpy()
+    ref = oracle_tables(el, sd, 0, pts, verts, got.shape)
+    assert rel(got, ref) <= TOL_VAL, rel(got, ref)
+    kernel_policy("no_small_values")
+    assert ps.kernel_name(0, nreq, npts, has_verts=cells) != "fxk::tabulate_simplex_small"
+    assert rel(ps.tabulate_batch(0, pts, verts=verts).cpu().numpy(), ref) <= TOL_VAL
