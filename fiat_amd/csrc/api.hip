@@ -57,7 +57,10 @@ int fail(int code, const char* fmt, ...) {
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
         hipError_t e_ = (expr);                                                            \
-        if (e_ != hipSuccess) return fail(FX_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) {                                                            \
+            (void)hipGetLastError(); /* reported here: not again by the next launch check */ \
+            return fail(FX_EHIP, "%s: %s", #expr, hipGetErrorString(e_));                  \
+        }                                                                                  \
     } while (0)
 
 const double UFC[3][12] = {
@@ -3108,6 +3111,7 @@ int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
     HIP_TRY(hipMalloc(&d_f, F.size() * sizeof(double)));
     if (hipMemcpy(d_f, F.data(), F.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(d_f);
+        (void)hipGetLastError();  // (the failed call left HIP's sticky error set: the next launch check must not report it)
         return fail(FX_EHIP, "ensure_stacked: copy of the stacked matrix failed");
     }
     if (order >= 1) {  // dof-major tiles for the instances that apply the chain rule across the tables themselves (per-request cells)
@@ -3127,6 +3131,7 @@ int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
             hipMemcpy(d_fd, Fd.data(), Fd.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
             if (d_fd) (void)hipFree(d_fd);
             (void)hipFree(d_f);
+            (void)hipGetLastError();  // (the failed call left HIP's sticky error set: the next launch check must not report it)
             return fail(FX_EHIP, "ensure_stacked: allocation or copy of the dof-major stacked matrix failed");
         }
         e->d_astack_dm[order] = d_fd;
@@ -3152,6 +3157,7 @@ int ensure_stacked(fx_ctx* ctx, fx_element* e, int order) {
             if (e->d_astack_dm[order]) (void)hipFree(e->d_astack_dm[order]);
             e->d_astack_dm[order] = nullptr;
             (void)hipFree(d_f);
+            (void)hipGetLastError();  // (the failed call left HIP's sticky error set: the next launch check must not report it)
             return fail(FX_EHIP, "ensure_stacked: allocation or copy of the component-major stacked matrix failed");
         }
         e->d_astack_dmp[order] = d_fp;

@@ -56,7 +56,8 @@ constexpr int WG_NW = 4;  // one wave per SIMD
 // row-tile images [16][<= 16 CT] + dump row
 constexpr int wg_image_doubles(int CT) { return 16 * 16 * CT + 64; }
 constexpr int wg_coef_doubles(int KS) { return (3 * 4 * KS + 7) & ~7; }
-constexpr int wg_lds_doubles(int CT, int KS) { return WQ_CTL_DOUBLES + wg_coef_doubles(KS) + 4 * KS * 16 * CT + WG_NW * wg_image_doubles(CT); }
+constexpr int WG_KBUF = 128;  // (MIX instances) K = A0^-1 A_req of the group's <= 12 requests
+constexpr int wg_lds_doubles(int CT, int KS) { return WQ_CTL_DOUBLES + WG_KBUF + wg_coef_doubles(KS) + 4 * KS * 16 * CT + WG_NW * wg_image_doubles(CT); }
 
 // Production is split over the waves by MEMBERS: the chains of the last recurrence level (two thirds of the members of a
 // tetrahedron's expansion set) are independent of each other, so the NSUB wave sets each run the lower levels (needed as
@@ -91,7 +92,12 @@ template <int SD, int N, int NSUB> struct StepSubsets {
 //   PC 2: two waves per row tile, a step of the workgroup finishes two row tiles (6 tiles -> 3 steps, no idle slots; 21 -> 11
 //         steps, 53 -> 27).  The two halves meet in a row-tile image shared by the pair (double-buffered: one workgroup
 //         barrier per step), and each wave then writes every other 1-KB piece of the finished tile.
-template <int SD, int N, int CT, bool ODD, int PC>
+// MIX 1 (per-request cells, values + gradients): the row tiles come DOF-MAJOR -- the 1 + SD tables of 16 dofs one after the
+//         other (fragment buffer of the stacked kernel's chain-rule instances) -- a wave keeps the accumulators of all tables of
+//         its dof tile, applies the chain rule d/dx_d = sum_c K[c][d] d/dX_c to them (lane-local in the MFMA result layout; K of
+//         the column's request from LDS) and flushes table by table under the next dof tile's MFMAs: one pass instead of
+//         kernel + table_mix_kernel (FIAT/expansions.py:411-447 through Jinv).
+template <int SD, int N, int CT, bool ODD, int PC, int MIX = 0>
 __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const StackedArgs<FixedNC<SD, N>::value> a, double* __restrict__ trash,
                                                                    unsigned int* __restrict__ gctr) {
     constexpr StepTable<SD, N> TBL{};
@@ -106,7 +112,9 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double* cof = lds + WQ_CTL_DOUBLES;           // [nsteps][3] = A, B, C of the recurrence steps
+    double* kbuf = lds + WQ_CTL_DOUBLES;          // (MIX) [G][SD][SD]
+    double* cof = kbuf + WG_KBUF;                 // [nsteps][3] = A, B, C of the recurrence steps
+    static_assert(MIX == 0 || (MIX == 1 && PC == 2 && SD >= 2), "chain rule on the accumulators: order 1, two waves per row tile");
     double* phi = cof + wg_coef_doubles(KS);
     static_assert((PC == 1 || PC == 2) && CT % PC == 0, "column tiles split evenly over the waves of a row tile");
     constexpr int PR = WG_NW / PC, CTW = CT / PC;
@@ -136,10 +144,12 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
     // col; padding columns go to the dump row.  (This wave's column tiles are c0 .. c0 + CTW - 1.)
     const int c0 = pc * CTW;
     int ioff[CTW][4];
+    int kofs[MIX ? CTW : 1];  // (MIX) where K of the column's request sits in kbuf
 #pragma unroll
     for (int c = 0; c < CTW; ++c) {
         const int j = 16 * (c0 + c) + col;
         const int g = idiv_small(j, rnpts);
+        if constexpr (MIX != 0) kofs[c] = j < cols ? g * SD * SD : 0;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) ioff[c][jj] = j < cols ? g * BLKD + (4 * jj + kk) * npts + (j - g * npts) : DUMP + lane;
     }
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
         // A fragments of this wave's first row tile: in flight during the production phase
         double fa0[KS], fa1[KS];
         {
-            const double* ap0 = a.afrag + (size_t)min(pr, a.RT) * KS * 64 + lane;
+            const double* ap0 = a.afrag + (size_t)(MIX ? min(pr, (a.R / (1 + SD) + 15) / 16) * (1 + SD) : min(pr, a.RT)) * KS * 64 + lane;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) fa0[ks] = ap0[ks * 64];
         }
@@ -265,6 +275,23 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                 else produce_subset(std::integral_constant<int, 3>{});
             }
         }
+        if constexpr (MIX != 0) {  // K = A0^-1 A_req of the group's requests (requests past the batch: its last one)
+            if (tid < G) {
+                const long long g0 = cur * G;
+                const long long rq = g0 + tid < nreq ? g0 + tid : nreq - 1;
+                double J[SD][SD], bb[SD];
+                cell_map<SD>(a.verts + (size_t)rq * (SD + 1) * SD, J, bb);
+#pragma unroll
+                for (int i = 0; i < SD; ++i)
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) {
+                        double t = 0.0;
+#pragma unroll
+                        for (int k = 0; k < SD; ++k) t += a.A0inv[i * SD + k] * J[k][d];
+                        kbuf[tid * SD * SD + i * SD + d] = t;
+                    }
+            }
+        }
         wg_lds_barrier();  // slab complete
 
         // next request's points: in flight during the sweep
@@ -287,9 +314,9 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                 for (int jj = 0; jj < 4; ++jj) img[4 * jj + kk < nrows ? ioff[c][jj] : DUMP + lane] = acc[c][jj];
         };
         auto image_get = [&](const double* img, FlushT& f, int q) { f = reinterpret_cast<const FlushT*>(img)[pu_l[q]]; };
-        auto image_out = [&](const FlushT& f, int q, int tile) {
+        auto image_out = [&](const FlushT& f, int q, int frow) {  // frow: first row (of a request's stacked rows) of the tile
             // (wave-uniform tile base + 32-bit lane offset: scalar-base addressing, no 64-bit lane addresses to hoist and spill)
-            char* tb = reinterpret_cast<char*>(obase + (size_t)16 * tile * npts);
+            char* tb = reinterpret_cast<char*>(obase + (size_t)frow * npts);
             FlushT* g2 = reinterpret_cast<FlushT*>(tb + pu_o[q]);
 #if FX_WG_DBG
             {
@@ -335,10 +362,12 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
         constexpr int KPUT = (NPUT + PPS * CTW - 1) / (PPS * CTW);  // K-steps they take
         static_assert(KPUT <= T3, "the image is complete before its first read");
         double b0[CTW], b1[CTW];
-        auto stage = [&](int step, v4d (&acc)[CTW], const v4d (&prev)[CTW], double* img, const double (&af)[KS], double (&an)[KS], bool flush) {
-            const int tile = pr + PR * step;
+        // (ntile: fragment tile to prefetch, clamped to the zero tile `nzero` that ends the buffer; frow: first output row of the
+        // tile in `prev`)
+        auto stage = [&](int ntile, int nzero, int frow, v4d (&acc)[CTW], const v4d (&prev)[CTW], double* img, const double (&af)[KS], double (&an)[KS],
+                         bool flush) __attribute__((always_inline)) {
             FlushT fb[2][PB];
-            const double* ap = a.afrag + (size_t)min(tile + PR, RT) * KS * 64 + lane;  // (the fragment buffer ends with a zero tile)
+            const double* ap = a.afrag + (size_t)min(ntile, nzero) * KS * 64 + lane;
 #pragma unroll
             for (int c = 0; c < CTW; ++c) acc[c] = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -373,7 +402,7 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                             if (j >= 1) {
 #pragma unroll
                                 for (int q = 0; q < PB; ++q)
-                                    if (q % CTW == c && (j - 1) * PB + q < NRW) image_out(fb[(j - 1) & 1][q], (j - 1) * PB + q, tile - PR);
+                                    if (q % CTW == c && (j - 1) * PB + q < NRW) image_out(fb[(j - 1) & 1][q], (j - 1) * PB + q, frow);
                             }
                             if (j < NB) {
 #pragma unroll
@@ -404,6 +433,7 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
             for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(an[ks]));
         };
 
+        if constexpr (MIX == 0) {
         if (nsteps > 0) {
             v4d accA[CTW], accB[CTW];
             load_b(b0, 0);
@@ -411,14 +441,14 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
             for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa0[ks]));
             // even steps: fragments fa0, accumulators A; odd steps: fa1, B.  The tile of step s lives in image s & 1 (PC 1: the
             // wave's one image) from the first K-steps of step s + 1 until that step has sent it out.
-            stage(0, accA, accB, image_of(1), fa0, fa1, false);  // first step: nothing to flush yet
+            stage(pr + PR, RT, 0, accA, accB, image_of(1), fa0, fa1, false);  // first step: nothing to flush yet
             int i = 1;
             for (; i + 1 < nsteps; i += 2) {
-                stage(i, accB, accA, image_of(0), fa1, fa0, true);
-                stage(i + 1, accA, accB, image_of(1), fa0, fa1, true);
+                stage(pr + PR * (i + 1), RT, 16 * (pr + PR * (i - 1)), accB, accA, image_of(0), fa1, fa0, true);
+                stage(pr + PR * (i + 2), RT, 16 * (pr + PR * i), accA, accB, image_of(1), fa0, fa1, true);
             }
             if (i < nsteps) {
-                stage(i, accB, accA, image_of(0), fa1, fa0, true);
+                stage(pr + PR * (i + 1), RT, 16 * (pr + PR * (i - 1)), accB, accA, image_of(0), fa1, fa0, true);
                 ++i;
             }
             // the last step's tile (the only one that may have fewer than 16 rows, or -- PC 2 -- not exist): image, then out
@@ -447,13 +477,115 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                             if (r0 + q < NRW) image_get(imgr, fl[q], r0 + q);
 #pragma unroll
                         for (int q = 0; q < HB; ++q)
-                            if (r0 + q < NRW) image_out(fl[q], r0 + q, tile);
+                            if (r0 + q < NRW) image_out(fl[q], r0 + q, 16 * tile);
                     }
                     if (nrows < 16) build_pieces(G - 1, 16);
                 }
                 wave_lds_fence();
             }
             // first use of the prefetched points in the same block as the last stores: exact vmcnt
+#pragma unroll
+            for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
+        }
+        } else {
+            // ---------------- dof-major sweep with the chain rule on the accumulators (MIX 1) ----------------
+            constexpr int NTAB = 1 + SD;
+            const int rows = a.R / NTAB;                       // rows per table
+            const int RTd = (rows + 15) / 16;                  // dof tiles; fragment tile (i, t) = i NTAB + t, zero tile NZ
+            const int rows_last = rows - 16 * (RTd - 1);
+            const int NZ = RTd * NTAB;
+            const int ndsteps = (RTd + PR - 1) / PR;           // dof steps of every wave pair (the barriers must match)
+            v4d accA[NTAB][CTW], accB[NTAB][CTW];
+            // d/dx_d = sum_c K[c][d] d/dX_c on the accumulators of one dof tile: element (c, jj) of every table is the same
+            // (row, column) entry -- lane-local; K of the column's request from LDS
+            auto mix = [&](v4d (&acc)[NTAB][CTW]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int c = 0; c < CTW; ++c) {
+                    double Kl[SD][SD];
+#pragma unroll
+                    for (int i = 0; i < SD; ++i)
+#pragma unroll
+                        for (int d = 0; d < SD; ++d) Kl[i][d] = kbuf[kofs[c] + i * SD + d];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        double gr[SD];
+#pragma unroll
+                        for (int i = 0; i < SD; ++i) gr[i] = acc[1 + i][c][jj];
+#pragma unroll
+                        for (int d = 0; d < SD; ++d) {
+                            double t = 0.0;
+#pragma unroll
+                            for (int i = 0; i < SD; ++i) t += Kl[i][d] * gr[i];
+                            acc[1 + d][c][jj] = t;
+                        }
+                    }
+                }
+            };
+            // one dof step: the NTAB tiles of dof tile i = pr + PR ds into `cur`; meanwhile the (mixed) tables of the previous dof
+            // tile leave, table t under the MFMAs of tile t.  DSODD: parity of ds -- which accumulator set is `cur`, and (odd
+            // table counts) which fragment buffer / image the step starts on
+            auto dstep = [&](int ds, auto dsodd_c, bool flush) __attribute__((always_inline)) {
+                constexpr bool DSODD = decltype(dsodd_c)::value;
+                constexpr int PAR = (NTAB & 1) ? (DSODD ? 1 : 0) : 0;
+                const int i = pr + PR * ds;
+                static_for<NTAB>([&](auto t_c) __attribute__((always_inline)) {
+                    constexpr int t = decltype(t_c)::value;
+                    const int ntile = t + 1 < NTAB ? i * NTAB + t + 1 : (i + PR) * NTAB;
+                    const int frow = t * rows + 16 * (i - PR);
+                    if constexpr (((t + PAR) & 1) == 0) {
+                        if constexpr (DSODD) stage(ntile, NZ, frow, accB[t], accA[t], image_of(0), fa0, fa1, flush);
+                        else stage(ntile, NZ, frow, accA[t], accB[t], image_of(0), fa0, fa1, flush);
+                    } else {
+                        if constexpr (DSODD) stage(ntile, NZ, frow, accB[t], accA[t], image_of(1), fa1, fa0, flush);
+                        else stage(ntile, NZ, frow, accA[t], accB[t], image_of(1), fa1, fa0, flush);
+                    }
+                });
+                if constexpr (DSODD) mix(accB);
+                else mix(accA);
+            };
+            load_b(b0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa0[ks]));
+            dstep(0, std::false_type{}, false);
+            int ds = 1;
+            for (; ds + 1 < ndsteps; ds += 2) {
+                dstep(ds, std::true_type{}, true);
+                dstep(ds + 1, std::false_type{}, true);
+            }
+            if (ds < ndsteps) {
+                dstep(ds, std::true_type{}, true);
+                ++ds;
+            }
+            // the tables of the last dof step's tile (the only one that may have fewer than 16 rows, or not exist): image, out
+            {
+                const int i = pr + PR * (ds - 1);
+                const int nrows = i == RTd - 1 ? rows_last : 16;
+                if (i < RTd && nrows < 16) build_pieces(gmax, nrows);
+                static_for<NTAB>([&](auto t_c) __attribute__((always_inline)) {
+                    constexpr int t = decltype(t_c)::value;
+                    double* imgl = image_of(t & 1);
+                    if (i < RTd) {
+                        if ((ds - 1) & 1) image_put(imgl, accB[t], nrows);
+                        else image_put(imgl, accA[t], nrows);
+                    }
+                    wg_lds_barrier();
+                    if (i < RTd) {
+                        constexpr int HB = NRW < 8 ? NRW : 8;
+#pragma unroll
+                        for (int r0 = 0; r0 < NRW; r0 += HB) {
+                            FlushT fl[HB];
+#pragma unroll
+                            for (int q = 0; q < HB; ++q)
+                                if (r0 + q < NRW) image_get(imgl, fl[q], r0 + q);
+#pragma unroll
+                            for (int q = 0; q < HB; ++q)
+                                if (r0 + q < NRW) image_out(fl[q], r0 + q, t * rows + 16 * i);
+                        }
+                    }
+                });
+                if (i < RTd && nrows < 16) build_pieces(G - 1, 16);
+                wave_lds_fence();
+            }
 #pragma unroll
             for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
         }
