@@ -590,6 +590,7 @@ struct Launch {
     fxk::StackedArgs<0> khead;
     int kgrid = 0, klds_bytes = 0, kmix_order = 0;
     int wg_ct = 0;      // request-per-workgroup kernel: column tiles of the instance (its slab holds khead.gslab requests)
+    int wg_mix = 0;     // ... 1: the order-1 chain rule of per-request cells on its accumulators (dof-major fragments, no mixing pass)
     // cooperative large-shape kernel
     int coop_id = -1;
     fxk::CoopArgs cargs;
@@ -1006,9 +1007,10 @@ int launch_stacked(const Launch& L, hipStream_t s) {
 int launch_wg(const Launch& L, hipStream_t s) {
     const StackedShape& k = kStackedShapes[L.stacked_id];
     const int ct = L.wg_ct;
-    hipError_t e = fxwg::launch_simplex_wg(k.sd, k.n, ct, L.kodd, L.khead, L.fcoef.data(), (int)L.fcoef.size(), L.klds_bytes, L.kgrid, L.trash,
+    hipError_t e = fxwg::launch_simplex_wg(k.sd, k.n, ct, L.kodd, L.wg_mix, L.khead, L.fcoef.data(), (int)L.fcoef.size(), L.klds_bytes, L.kgrid, L.trash,
                                            reinterpret_cast<unsigned int*>(L.queue), s);
     if (e != hipSuccess) return fail(FX_EHIP, "tabulate_simplex_wg<%d,%d,%d>: %s", k.sd, k.n, ct, hipGetErrorString(e));
+    if (L.wg_mix) return FX_OK;   // (the chain rule has been applied)
     switch (k.sd) {
         case 2: return stacked_mix_pass<2>(L, s);
         case 3: return stacked_mix_pass<3>(L, s);
@@ -1732,6 +1734,26 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             // columns the in-kernel chain-rule instance runs at 18 % where the generic kernel reaches 43 %)
             auto fills_tiles = [&](const StackedShape& k) { return 3LL * k.g * npts > 2LL * 16 * k.ct; };
             // (first the instances that apply the chain rule themselves, then the rest, each in table order)
+            // the request-per-workgroup kernel applies the order-1 chain rule of per-request cells itself (round 4, MIX instances):
+            // rules of 65..128 points, the window of P5 triangles, or policy wg_small -- the per-wave chain-rule instances yield
+            auto wg_mix_takes = [&](const StackedShape& k) {
+                if ((ctx->policy & (FX_POLICY_NO_WG | FX_POLICY_NO_STACKED_MIX)) || !verts || order != 1 || npts > 128) return false;
+                if (!(npts > 64 || (k.sd == 2 && k.n == 5 && npts >= 25 && npts <= 33) || (ctx->policy & FX_POLICY_WG_SMALL))) return false;
+                const int g = npts > 64 ? 1 : std::min(12, 128 / npts);
+                const int ctn = std::max(4, (g * npts + 15) / 16);
+                const int ctm = fxwg::mix_ct(k.sd, k.n, ctn);
+                if (ctm == 0) return false;
+                // (two waves per row tile work on two dof tiles at a time: with few rows the second pair multiplies padding -- P3 / P4
+                // tetrahedra at 70 / 74 points 424 / 406 us against 388 / 403 us on the point chunks -- so at least 70 % of those
+                // MFMA rows must be dofs; the eight-tile instances of tetrahedra, and of triangles with odd tables, run all four waves on one dof tile)
+                const bool oddm0 = ((long long)rows * npts) % 2 || ((long long)(rows - 16 * ((rows + 15) / 16 - 1)) * npts) % 2;
+                if (!(ctm == 8 && (k.sd == 3 || oddm0))) {   // (wg.hip wg_mix_pc: those instances run four waves per dof tile)
+                    const int rtd = (rows + 15) / 16;
+                    if (10LL * rows < 7LL * 16 * 2 * ((rtd + 1) / 2)) return false;
+                }
+                const bool oddm = ((long long)rows * npts) % 2 || ((long long)(rows - 16 * ((rows + 15) / 16 - 1)) * npts) % 2;
+                return fxwg::has_mix_instance(k.sd, k.n, ctm, oddm) && fxwg::lds_bytes(k.sd, k.n, ctm) <= ctx->lds_per_cu;
+            };
             // (then the request-per-workgroup instances, then the rest)
             constexpr size_t NSH = sizeof(kStackedShapes) / sizeof(kStackedShapes[0]);
             for (size_t i2 = 0; i2 < 3 * NSH && L.stacked_id < 0; ++i2) {
@@ -1739,6 +1761,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 const StackedShape& k = kStackedShapes[i];
                 bool mix_odd = false, pio = false;
                 int wg_g = 1, wg_ctw = 0;
+                bool wg_mix1 = false, wg_odd = false;
                 const bool inmix = k.rtc == -2 || k.rtc == -3 || k.rtc == -4 || k.rtc == -5 || k.rtc == -6;  // chain rule / Piola map inside the kernel
                 const bool chunked = k.rtc == -1 || k.rtc == -4 || k.rtc == -5;
                 const bool wgk = k.rtc == -7;
@@ -1768,6 +1791,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 if (k.rtc == -2 || k.rtc == -3 || k.rtc == -6) {  // per-request cells, order 1 / 2: chain rule across the tables inside the kernel (dof-major tiles)
                     const bool nomix = (ctx->policy & FX_POLICY_NO_STACKED_MIX) != 0;
                     if (nomix || !verts || order != (k.rtc == -2 ? 1 : k.rtc == -3 ? 2 : 0)) continue;
+                    if (k.rtc == -2 && wg_mix_takes(k)) continue;
                     // the element's Piola map too (vector-valued elements: the twin with the components of a dof in one lane,
                     // 12 rows per tile in 3-D); values only: nothing else to mix, so only with the map
                     const bool odd_pio_instance = k.sd == 3 && k.ct == 3 && ((k.n == 2 && k.g == 4) || (k.n == 3 && k.g == 2));
@@ -1786,28 +1810,42 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                                              (k.sd == 2 && k.n == 5 && k.ct == 3 && k.g == 1)))
                         continue;
                     if (npts > 16 * k.ct / k.g || tighter_instance(k) || !fills_tiles(k)) continue;
-                } else if (wgk) {  // a request (or, policy wg_small, a group of small requests) per workgroup
+                } else if (wgk) {  // a request (or a group of small requests) per workgroup
                     if ((ctx->policy & FX_POLICY_NO_WG) || npts > 16 * k.ct) continue;
-                    // (fewer points: the whole-request instances of the per-wave kernel -- except where several requests per
+                    // (fewer than 49 points: the whole-request instances of the per-wave kernel -- except where several requests per
                     // workgroup are robustly ahead in sustained runs, tools/instance_ab.py --own-cell [--policy wg_small], 0.8 GB:
                     // P5 triangles with derivatives at 25..33 points 232 / 183 / 252 -> 189 / 169 / 225 us, degree-6 tetrahedra with
                     // Hessians at 33..48 points 432 -> 352 us.  Elsewhere the two are within +-10 % of each other with either sign,
                     // and the map's short interleaved runs disagree with the sustained ones: opt-in, policy wg_small)
-                    const bool wg_small_default = !verts && ((k.sd == 2 && k.n == 5 && order >= 1 && npts >= 25 && npts <= 33) ||
-                                                             (k.sd == 3 && k.n == 6 && order == 2 && npts >= 33 && npts <= 48));
-                    if (npts <= 48 && !(ctx->policy & FX_POLICY_WG_SMALL) && !wg_small_default) continue;
-                    // requests per slab of <= 128 columns; the instance's column tiles (an even number where several requests
-                    // share the slab: two waves per row tile)
+                    const bool small_window = (k.sd == 2 && k.n == 5 && order >= 1 && npts >= 25 && npts <= 33) ||
+                                              (k.sd == 3 && k.n == 6 && order == 2 && npts >= 33 && npts <= 48);
+                    // per-request cells with gradients: the chain rule on the accumulators (MIX instances); other orders with
+                    // cells: values straight from the kernel, derivatives + the table-mixing pass
+                    const bool nomix = (ctx->policy & FX_POLICY_NO_STACKED_MIX) != 0;
+                    const bool want_mix = verts && order == 1 && !nomix;
+                    if (npts <= 48 && !(ctx->policy & FX_POLICY_WG_SMALL) && !(small_window && (!verts || want_mix))) continue;
+                    // requests per slab of <= 128 columns and the instance's column tiles
                     wg_g = npts > 64 ? 1 : std::min(12, 128 / npts);
                     wg_ctw = std::max(4, (wg_g * npts + 15) / 16);
-                    if (wg_ctw == 7) wg_ctw = 8;        // (no seven-tile instance)
-                    if (wg_ctw == 5) {                   // one wave per row tile on 5 column tiles, or two on 3 + 3: the fewer MFMA slots per wave
-                        const long long one = (long long)((RT + 3) / 4) * 5, two = (long long)((RT + 1) / 2) * 3;
-                        if (two < one) wg_ctw = 6;
+                    if (want_mix) {
+                        // (tetrahedra: 4 column tiles with two waves per row tile or 8 with four; triangles 4 / 6 / 8 with two)
+                        wg_ctw = fxwg::mix_ct(k.sd, k.n, wg_ctw);
+                        wg_odd = ((long long)rows * npts) % 2 || ((long long)(rows - 16 * ((rows + 15) / 16 - 1)) * npts) % 2;
+                        wg_mix1 = wg_ctw > 0 && fxwg::has_mix_instance(k.sd, k.n, wg_ctw, wg_odd) && wg_mix_takes(k);
                     }
-                    if (!fxwg::has_instance(k.sd, k.n, wg_ctw, !even)) continue;
+                    if (!wg_mix1) {
+                        if (verts && order >= 1 && npts <= 48 && !(ctx->policy & FX_POLICY_WG_SMALL)) continue;
+                        wg_odd = !even;
+                        wg_ctw = std::max(4, (wg_g * npts + 15) / 16);
+                        if (wg_ctw == 7) wg_ctw = 8;        // (no seven-tile instance)
+                        if (wg_ctw == 5) {                   // one wave per row tile on 5 column tiles, or two on 3 + 3: the fewer MFMA slots per wave
+                            const long long one = (long long)((RT + 3) / 4) * 5, two = (long long)((RT + 1) / 2) * 3;
+                            if (two < one) wg_ctw = 6;
+                        }
+                        if (!fxwg::has_instance(k.sd, k.n, wg_ctw, wg_odd)) continue;
+                    }
                     // (49..64 points: where a whole-request instance of four column tiles exists it keeps the rule)
-                    if (npts > 48 && npts <= 64 && even && !(ctx->policy & FX_POLICY_WG_SMALL)) {
+                    if (!wg_mix1 && npts > 48 && npts <= 64 && even && !(ctx->policy & FX_POLICY_WG_SMALL)) {
                         bool whole = false;
                         for (const StackedShape& o : kStackedShapes)
                             whole = whole || (o.sd == k.sd && o.n == k.n && o.rtc == 0 && o.g == 1 && o.ct == 4);
@@ -1829,6 +1867,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     if (inmix) {  // ... with the chain rule inside: rules of more than one chunk
                         const bool nomix = (ctx->policy & FX_POLICY_NO_STACKED_MIX) != 0;
                         if (nomix || !verts || order != (k.rtc == -4 ? 1 : 2) || npts <= 16 * k.ct) continue;
+                        if (k.rtc == -4 && wg_mix_takes(k)) continue;
                         // (49..64 points: the second chunk of 48 is mostly padding.  Round 3 audit, ABAB tools/instance_ab.py
                         // [--policy no_stacked_mix]: where a whole-request instance of four column tiles exists and the stacked
                         // matrix is small, that instance plus the mixing pass is faster -- gradients of P3 / P4 / P5 tetrahedra at
@@ -1881,7 +1920,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 ka.pts = pts;
                 ka.verts = verts;
                 ka.out = out;
-                const bool dofmajor = inmix;
+                const bool dofmajor = inmix || wg_mix1;
                 ka.afrag = pio ? e->d_astack_dmp[order] : dofmajor ? e->d_astack_dm[order] : e->d_astack[order];
                 if (!ka.afrag) continue;
                 if (pio) {
@@ -1908,6 +1947,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 if (wgk) {
                     L.klds_bytes = fxwg::lds_bytes(k.sd, k.n, wg_ctw);
                     L.wg_ct = wg_ctw;
+                    L.wg_mix = wg_mix1 ? 1 : 0;
                     ka.gslab = wg_g;
                 }
                 if (L.klds_bytes > ctx->lds_per_cu) continue;
@@ -1920,7 +1960,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 L.trash = ctx->d_trash;
                 L.queue = ctx->d_queue + (size_t)(ctx->launch_seq++ % FX_QUEUE_SLOTS) * 16;
                 L.kmix_order = order;
-                L.kodd = ((k.rtc == 0 || wgk) && !even) || mix_odd;
+                L.kodd = wgk ? wg_odd : ((k.rtc == 0 && !even) || mix_odd);
                 L.kpiola = pio ? mapping : 0;
                 if (pio) L.fused_mapping = true;
                 L.stacked_id = (int)i;
@@ -2365,7 +2405,7 @@ int fx_plan_kernel(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, in
     if ((has_verts & 2) && L.stacked_id >= 0 && L.fixed_id < 0) {  // with the instance of the stacked-matrix registry
         const StackedShape& k = kStackedShapes[L.stacked_id];
         if (k.rtc == -7) snprintf(name, (size_t)name_len, "fxk::tabulate_simplex_wg<%d,%d,%d>%s", k.sd, k.n, L.wg_ct,
-                                  L.khead.gslab > 1 ? ("x" + std::to_string(L.khead.gslab)).c_str() : "");
+                                  ((L.khead.gslab > 1 ? "x" + std::to_string(L.khead.gslab) : std::string()) + (L.wg_mix ? "+mix" : "")).c_str());
         else snprintf(name, (size_t)name_len, "fxk::tabulate_simplex_stacked<%d,%d,%d,%d,%d>%s", k.sd, k.n, k.ct, k.g, k.rtc,
                       L.kpiola ? "+piola" : "");
         return FX_OK;

@@ -89,6 +89,8 @@ template <int SD, int N, int NSUB> struct StepSubsets {
 // PC: waves that share a row tile (each takes CT / PC of its column tiles); PR = 4 / PC row tiles are in work at a time.
 //   PC 1: a wave owns whole row tiles, waves never wait for each other inside a request -- but a request's RT row tiles go
 //         round robin over four waves (values only, degree 6: 6 tiles -> 2, 2, 1, 1: a third of the MFMA slots idle);
+//   PC 4: all four waves on one row tile, two column tiles each (the MIX instances of degree >= 5 tetrahedra at eight column
+//         tiles: the accumulators of 1 + SD tables x 4 column tiles x two sets do not fit the registers);
 //   PC 2: two waves per row tile, a step of the workgroup finishes two row tiles (6 tiles -> 3 steps, no idle slots; 21 -> 11
 //         steps, 53 -> 27).  The two halves meet in a row-tile image shared by the pair (double-buffered: one workgroup
 //         barrier per step), and each wave then writes every other 1-KB piece of the finished tile.
@@ -114,9 +116,9 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double* kbuf = lds + WQ_CTL_DOUBLES;          // (MIX) [G][SD][SD]
     double* cof = kbuf + WG_KBUF;                 // [nsteps][3] = A, B, C of the recurrence steps
-    static_assert(MIX == 0 || (MIX == 1 && PC == 2 && SD >= 2), "chain rule on the accumulators: order 1, two waves per row tile");
+    static_assert(MIX == 0 || (MIX == 1 && PC >= 2 && SD >= 2), "chain rule on the accumulators: order 1, two or four waves per row tile");
     double* phi = cof + wg_coef_doubles(KS);
-    static_assert((PC == 1 || PC == 2) && CT % PC == 0, "column tiles split evenly over the waves of a row tile");
+    static_assert((PC == 1 || PC == 2 || PC == 4) && CT % PC == 0, "column tiles split evenly over the waves of a row tile");
     constexpr int PR = WG_NW / PC, CTW = CT / PC;
     const int pr = wave / PC, pc = wave % PC;     // (wave-uniform) row group, column group
     // four row-tile images: PC 1 one per wave; PC 2 two per pair of waves (step parity)

@@ -13,7 +13,7 @@ namespace {
 // (two waves per row tile wherever the column tiles split evenly: DESIGN.md 4.5c)
 constexpr int wg_pc(int ct) { return ct % 2 == 0 ? 2 : 1; }
 
-template <int SD, int N, int CT, bool ODD>
+template <int SD, int N, int CT, bool ODD, int PC, int MIX>
 hipError_t launch(const fxk::StackedArgs<0>& h, const double* coef, int ncoef, int lds_bytes, int grid, double* trash, unsigned int* queue,
                   hipStream_t s) {
     constexpr int NC = fxk::FixedNC<SD, N>::value;
@@ -30,6 +30,7 @@ hipError_t launch(const fxk::StackedArgs<0>& h, const double* coef, int ncoef, i
     ka.phi0 = h.phi0;
     memcpy(ka.A0, h.A0, sizeof ka.A0);
     memcpy(ka.b0, h.b0, sizeof ka.b0);
+    memcpy(ka.A0inv, h.A0inv, sizeof ka.A0inv);
     ka.nreq = h.nreq;
     ka.npts = h.npts;
     ka.R = h.R;
@@ -40,7 +41,7 @@ hipError_t launch(const fxk::StackedArgs<0>& h, const double* coef, int ncoef, i
     ka.lim_out = h.lim_out;
     ka.lim_afrag = h.lim_afrag;
     memcpy(ka.coef, coef, NC * sizeof(double));
-    auto kern = fxk::tabulate_simplex_wg<SD, N, CT, ODD, wg_pc(CT)>;
+    auto kern = fxk::tabulate_simplex_wg<SD, N, CT, ODD, PC, MIX>;
     static thread_local bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -77,22 +78,37 @@ hipError_t launch(const fxk::StackedArgs<0>& h, const double* coef, int ncoef, i
     return hipGetLastError();
 }
 
+// (the chain-rule instances: tetrahedra on 4 column tiles with two waves per row tile, on 6 up to degree 5 (degree 6 spills 98
+// registers there), on 8 with four waves per row tile; triangles on 4 / 6 / 8 with two)
+constexpr int wg_mix_pc(int sd, int ct, bool odd) { return ct == 8 && (sd == 3 || odd) ? 4 : 2; }
+constexpr bool wg_has_mix(int sd, int n, int ct) { return sd == 3 ? (ct == 4 || ct == 8 || (ct == 6 && n <= 5)) : (ct == 4 || ct == 6 || ct == 8); }
+
 template <int SD, int N, int CT>
-hipError_t launch_odd(bool odd, const fxk::StackedArgs<0>& h, const double* coef, int ncoef, int lds_bytes, int grid, double* trash,
+hipError_t launch_odd(bool odd, int mix, const fxk::StackedArgs<0>& h, const double* coef, int ncoef, int lds_bytes, int grid, double* trash,
                       unsigned int* queue, hipStream_t s) {
-    return odd ? launch<SD, N, CT, true>(h, coef, ncoef, lds_bytes, grid, trash, queue, s)
-               : launch<SD, N, CT, false>(h, coef, ncoef, lds_bytes, grid, trash, queue, s);
+    if (mix) {
+        if constexpr (wg_has_mix(SD, N, CT)) {
+            if (!odd) return launch<SD, N, CT, false, wg_mix_pc(SD, CT, false), 1>(h, coef, ncoef, lds_bytes, grid, trash, queue, s);
+            // (degree-6 tetrahedra on eight column tiles: the 8-byte twin spills 96 registers -- not instantiated; scalar elements of
+            // that degree have 84 rows a table, their requests are never odd)
+            if constexpr (!(SD == 3 && N == 6 && CT == 8))
+                return launch<SD, N, CT, true, wg_mix_pc(SD, CT, true), 1>(h, coef, ncoef, lds_bytes, grid, trash, queue, s);
+        }
+        return hipErrorInvalidValue;
+    }
+    return odd ? launch<SD, N, CT, true, wg_pc(CT), 0>(h, coef, ncoef, lds_bytes, grid, trash, queue, s)
+               : launch<SD, N, CT, false, wg_pc(CT), 0>(h, coef, ncoef, lds_bytes, grid, trash, queue, s);
 }
 
 template <int SD, int N>
-hipError_t launch_ct(int ct, bool odd, const fxk::StackedArgs<0>& h, const double* coef, int ncoef, int lds_bytes, int grid, double* trash,
+hipError_t launch_ct(int ct, bool odd, int mix, const fxk::StackedArgs<0>& h, const double* coef, int ncoef, int lds_bytes, int grid, double* trash,
                      unsigned int* queue, hipStream_t s) {
     constexpr int KS = (fxk::StepTable<SD, N>::NEXP + 3) / 4;
     switch (ct) {
-        case 4: return launch_odd<SD, N, 4>(odd, h, coef, ncoef, lds_bytes, grid, trash, queue, s);
-        case 5: return launch_odd<SD, N, 5>(odd, h, coef, ncoef, lds_bytes, grid, trash, queue, s);
-        case 6: return launch_odd<SD, N, 6>(odd, h, coef, ncoef, lds_bytes, grid, trash, queue, s);
-        case 8: if constexpr (fxk::wg_lds_doubles(8, KS) * 8 <= 160 * 1024) return launch_odd<SD, N, 8>(odd, h, coef, ncoef, lds_bytes, grid, trash, queue, s); break;
+        case 4: return launch_odd<SD, N, 4>(odd, mix, h, coef, ncoef, lds_bytes, grid, trash, queue, s);
+        case 5: return launch_odd<SD, N, 5>(odd, mix, h, coef, ncoef, lds_bytes, grid, trash, queue, s);
+        case 6: return launch_odd<SD, N, 6>(odd, mix, h, coef, ncoef, lds_bytes, grid, trash, queue, s);
+        case 8: if constexpr (fxk::wg_lds_doubles(8, KS) * 8 <= 160 * 1024) return launch_odd<SD, N, 8>(odd, mix, h, coef, ncoef, lds_bytes, grid, trash, queue, s); break;
     }
     return hipErrorInvalidValue;
 }
@@ -113,15 +129,24 @@ bool has_instance(int sd, int n, int ct, bool odd) {
     return (sd == 3 && n >= 3 && n <= 6) || (sd == 2 && (n == 5 || n == 6));
 }
 
-hipError_t launch_simplex_wg(int sd, int n, int ct, bool odd, const fxk::StackedArgs<0>& h, const double* coef, int ncoef, int lds, int grid,
+bool has_mix_instance(int sd, int n, int ct, bool odd) { return has_instance(sd, n, ct, odd) && wg_has_mix(sd, n, ct) && !(odd && sd == 3 && n == 6 && ct == 8); }
+
+int mix_ct(int sd, int n, int ctn) {
+    if (ctn <= 4) return 4;
+    if (sd == 2) return (ctn + 1) & ~1;
+    if (ctn <= 6) return n <= 5 ? 6 : 0;   // (degree 6 on six column tiles spills: the point-chunked instances keep 65..96 points)
+    return 8;
+}
+
+hipError_t launch_simplex_wg(int sd, int n, int ct, bool odd, int mix, const fxk::StackedArgs<0>& h, const double* coef, int ncoef, int lds, int grid,
                              double* trash, unsigned int* queue, hipStream_t s) {
-    if (!has_instance(sd, n, ct, odd)) return hipErrorInvalidValue;
-    if (sd == 3 && n == 6) return launch_ct<3, 6>(ct, odd, h, coef, ncoef, lds, grid, trash, queue, s);
-    if (sd == 3 && n == 5) return launch_ct<3, 5>(ct, odd, h, coef, ncoef, lds, grid, trash, queue, s);
-    if (sd == 3 && n == 4) return launch_ct<3, 4>(ct, odd, h, coef, ncoef, lds, grid, trash, queue, s);
-    if (sd == 3 && n == 3) return launch_ct<3, 3>(ct, odd, h, coef, ncoef, lds, grid, trash, queue, s);
-    if (sd == 2 && n == 6) return launch_ct<2, 6>(ct, odd, h, coef, ncoef, lds, grid, trash, queue, s);
-    if (sd == 2 && n == 5) return launch_ct<2, 5>(ct, odd, h, coef, ncoef, lds, grid, trash, queue, s);
+    if (!has_instance(sd, n, ct, odd) || (mix && !has_mix_instance(sd, n, ct, odd))) return hipErrorInvalidValue;
+    if (sd == 3 && n == 6) return launch_ct<3, 6>(ct, odd, mix, h, coef, ncoef, lds, grid, trash, queue, s);
+    if (sd == 3 && n == 5) return launch_ct<3, 5>(ct, odd, mix, h, coef, ncoef, lds, grid, trash, queue, s);
+    if (sd == 3 && n == 4) return launch_ct<3, 4>(ct, odd, mix, h, coef, ncoef, lds, grid, trash, queue, s);
+    if (sd == 3 && n == 3) return launch_ct<3, 3>(ct, odd, mix, h, coef, ncoef, lds, grid, trash, queue, s);
+    if (sd == 2 && n == 6) return launch_ct<2, 6>(ct, odd, mix, h, coef, ncoef, lds, grid, trash, queue, s);
+    if (sd == 2 && n == 5) return launch_ct<2, 5>(ct, odd, mix, h, coef, ncoef, lds, grid, trash, queue, s);
     return hipErrorInvalidValue;
 }
 

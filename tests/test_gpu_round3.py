@@ -269,7 +269,9 @@ def test_chain_rule_on_the_accumulators_of_the_stacked_kernel(family, sd, degree
     from oracle import fiat_oracle as fo
     el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
     ps = el.device_polyset()
-    kernel_policy("no_small", "no_fixed")       # (the lane-local and the paired kernels keep some of these shapes by default)
+    # (the lane-local and the paired kernels keep some of these shapes by default; round 4: the request-per-workgroup kernel takes
+    # order 1 at 65..128 points, tests/test_gpu_round4.py -- the point-chunked instances stay behind no_wg)
+    kernel_policy("no_small", "no_fixed", "no_wg")
     assert ps.kernel_name(order, nreq, npts, has_verts=True, instance=True) == f"fxk::tabulate_simplex_stacked<{instance}>"
     rng = np.random.default_rng(97 * degree + npts + sd)
     A = np.eye(sd) + 0.15 * rng.standard_normal((nreq, sd, sd))

@@ -87,8 +87,9 @@ def test_request_per_workgroup_kernel_with_cells(family, sd, degree, npts, order
     el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
     ps = el.device_polyset()
     nreq = 333
-    if order >= 1:
-        assert "stacked" in ps.kernel_name(order, nreq, npts, has_verts=True)
+    if order >= 1:   # default: the chain rule inside a kernel (order 1: this one, MIX; order 2: the stacked kernel's point chunks)
+        name = ps.kernel_name(order, nreq, npts, has_verts=True, instance=True)
+        assert ("+mix" in name) if order == 1 else ("stacked" in name), name
         kernel_policy("no_stacked_mix")
     assert ps.kernel_name(order, nreq, npts, has_verts=True) == "fxk::tabulate_simplex_wg"
     pts, verts = batch(sd, nreq, npts, 7 * npts + order, True)
@@ -248,3 +249,38 @@ def test_values_only_requests_on_the_lane_local_kernel(family, sd, degree, npts,
     kernel_policy("no_small_values")
     assert ps.kernel_name(0, nreq, npts, has_verts=cells) != "fxk::tabulate_simplex_small"
     assert rel(ps.tabulate_batch(0, pts, verts=verts).cpu().numpy(), ref) <= TOL_VAL
+
+
+# (family, sd, degree, points) -> instance suffix of the request-per-workgroup kernel with the chain rule inside
+WG_MIX = [("Lagrange", 3, 6, 122, "8>+mix"), ("DiscontinuousLagrange", 3, 5, 74, "6>+mix"), ("Lagrange", 3, 4, 97, "8>+mix"),
+          ("Lagrange", 3, 3, 97, "8>+mix"), ("Nedelec", 3, 3, 74, "6>+mix"), ("Lagrange", 2, 6, 73, "6>+mix"), ("DiscontinuousLagrange", 2, 6, 79, "6>+mix"),
+          ("Lagrange", 2, 6, 128, "8>+mix"), ("Lagrange", 3, 6, 100, "8>+mix"), ("Lagrange", 3, 5, 122, "8>+mix"),
+          # several small requests per slab (the default windows and policy wg_small), odd table sizes
+          ("Lagrange", 2, 5, 25, "8>x5+mix"), ("DiscontinuousLagrange", 2, 5, 33, "8>x3+mix")]
+
+
+@pytest.mark.parametrize("family,sd,degree,npts,suffix", WG_MIX, ids=[f"{m[0][:3]}{m[2]}-sd{m[1]}-{m[3]}pt" for m in WG_MIX])
+@pytest.mark.parametrize("nreq", [1, 5, 333, 1030])
+def test_chain_rule_inside_the_request_per_workgroup_kernel(family, sd, degree, npts, suffix, nreq, kernel_policy):
+    """Per-request cells with gradients on the request-per-workgroup kernel (simplex_wg.hpp MIX 1): dof-major row tiles, the
+    accumulators of the 1 + SD tables of a dof tile mixed with K = A0^-1 A_req of the column's request, table by table out under
+    the next dof tile's MFMAs -- one pass (FIAT/expansions.py:411-447 through Jinv).  Cells of both orientations, batches smaller
+    than the grid and of several groups per workgroup, a last group with missing requests, against the C oracle's recurrence ON the
+    physical cells; the two-pass route (policy no_stacked_mix) gives the same tables.  (Degree-6 tetrahedra at 65..96 points keep the
+    point-chunked chain-rule instances: their six-tile instance would spill.)"""
+    import fiat_amd as fa
+    el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
+    ps = el.device_polyset()
+    n = el.get_nodal_basis().get_embedded_degree()
+    name = ps.kernel_name(1, nreq, npts, has_verts=True, instance=True)
+    assert name == f"fxk::tabulate_simplex_wg<{sd},{n},{suffix}", name
+    pts, verts = batch(sd, nreq, npts, 13 * npts + degree + nreq, True)
+    got = ps.tabulate_batch(1, pts, verts=verts).cpu().numpy()
+    ref = oracle_tables(el, sd, 1, pts, verts, got.shape)
+    for t in range(got.shape[1]):
+        assert rel(got[:, t], ref[:, t]) <= (TOL_VAL if t == 0 else TOL_DER), (name, t, rel(got[:, t], ref[:, t]))
+    kernel_policy("no_stacked_mix")
+    assert "+mix" not in ps.kernel_name(1, nreq, npts, has_verts=True, instance=True)
+    two = ps.tabulate_batch(1, pts, verts=verts).cpu().numpy()
+    for t in range(got.shape[1]):
+        assert rel(two[:, t], ref[:, t]) <= (TOL_VAL if t == 0 else TOL_DER)
