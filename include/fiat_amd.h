@@ -71,7 +71,7 @@ int fx_ctx_info(fx_ctx* ctx, int* num_cu, int* lds_bytes_per_cu, char* name, int
 #define FX_POLICY_KERNEL_STREAM (1u << 10) /* shape-specialised family: one request per wave, K-streamed */
 #define FX_POLICY_NO_WG (1u << 11)         /* request-per-workgroup kernel (rules of 49..128 points): point chunks instead */
 #define FX_POLICY_WG_SMALL (1u << 12)      /* opt in: the request-per-workgroup kernel with several small requests per workgroup (<= 64 points) */
-#define FX_POLICY_NO_SMALL_VALUES (1u << 13) /* lane-local kernel: not for the values-only shapes of degree 5-6 triangles / 3-5 tetrahedra (round 4) */
+#define FX_POLICY_NO_SMALL_VALUES (1u << 13) /* lane-local kernel: not for the values-only P5 triangles / P3 tetrahedra it took over in round 4 */
 #define FX_POLICY_ALL ((1u << 14) - 1)
 int fx_ctx_set_policy(fx_ctx* ctx, unsigned flags);
 int fx_ctx_get_policy(const fx_ctx* ctx, unsigned* flags);
