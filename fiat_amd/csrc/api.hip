@@ -1374,8 +1374,17 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
     const bool pio_even = !(((long long)rows * npts) % 2) && !(((long long)(rows - TRp * ((rows + TRp - 1) / TRp - 1)) * npts) % 2);
     // (odd table sizes: 8-byte twins of the two instances RT2 / N3 tetrahedra meet at their 11- / 23-point rules)
     const bool pio_odd_twin = e->sd == 3 && ((e->n == 2 && npts > 8 && npts <= 12) || (e->n == 3 && npts > 16 && npts <= 24));
+    // ... and is there an instance that holds THIS request: the same predicates as the selection loop below (column budget of a
+    // request, more than two thirds of the group's column tiles filled) -- without the probe the cooperative and the lane-local
+    // kernel gave up their fused variants for shapes no stacked instance then took (N2 / RT2 tetrahedra at <= 8 points: generic
+    // kernel + a separate push-forward pass)
+    bool pio_instance = false;
+    for (const StackedShape& k : kStackedShapes)
+        pio_instance = pio_instance || (k.sd == e->sd && k.n == e->n && k.rtc == (order == 0 ? -6 : order == 1 ? -2 : -3) &&
+                                        npts <= 16 * k.ct / k.g && 3LL * k.g * npts > 2LL * 16 * k.ct);
     const bool stacked_pio_ok = want_piola && !(ctx->policy & (FX_POLICY_NO_STACKED | FX_POLICY_NO_STACKED_MIX)) && !e->raw_expansion &&
-                                stacked_has_pio(e->sd, e->n) && npts <= 48 && (pio_even || pio_odd_twin) && (long long)ntab * rows >= 15;
+                                stacked_has_pio(e->sd, e->n) && npts <= 48 && (pio_even || pio_odd_twin) && (long long)ntab * rows >= 15 &&
+                                pio_instance && order <= 2;
     fxk::TabArgs& a = L.args;
     memset(&a, 0, sizeof a);
     a.pts = pts;
