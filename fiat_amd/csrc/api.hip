@@ -1844,6 +1844,15 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     }
                     if (!wg_mix1) {
                         if (verts && order >= 1 && npts <= 48 && !(ctx->policy & FX_POLICY_WG_SMALL)) continue;
+                        // (65..96 points -- five or six column tiles -- with a short K loop: a stage is a few dozen MFMAs and the
+                        // per-request recurrence + barriers dominate.  tools/instance_ab.py --own-cell [--policy no_wg], 0.8 GB, this
+                        // kernel against the point chunks: P4 tetrahedra at 70 points, values / gradients 779 / 435 against 455 / 270 us,
+                        // P3 528 / 232 against 345 / 217, P5 triangles at 79 points 556 / 358 against 334 / 234, P6 triangles values
+                        // 455 against 320 -- while degree >= 5 tetrahedra (K steps >= 14) and P6 triangles with Hessians win, as does
+                        // everything at 97..128 points.  Policy wg_small opts in regardless.)
+                        if (npts > 64 && (wg_g * npts + 15) / 16 <= 6 && !(ctx->policy & FX_POLICY_WG_SMALL) &&
+                            !((e->nexp + 3) / 4 >= 14 || (k.sd == 2 && k.n == 6 && order == 2)))
+                            continue;
                         wg_odd = !even;
                         wg_ctw = std::max(4, (wg_g * npts + 15) / 16);
                         if (wg_ctw == 7) wg_ctw = 8;        // (no seven-tile instance)

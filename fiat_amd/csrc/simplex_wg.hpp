@@ -214,6 +214,11 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
     double xcur[SD], xnext[SD];
     load_points(cur, xcur);
 
+    // (PC 1) the wave's last full row tile of the previous group, not yet written: accumulators, output base and first row
+    v4d accP[PC == 1 ? CTW : 1];
+    bool pend = false;
+    double* pend_base = a.out;
+    int pend_frow = 0;
     while (cur < ngroups) {
         // A fragments of this wave's first row tile: in flight during the production phase
         double fa0[KS], fa1[KS];
@@ -316,9 +321,9 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                 for (int jj = 0; jj < 4; ++jj) img[4 * jj + kk < nrows ? ioff[c][jj] : DUMP + lane] = acc[c][jj];
         };
         auto image_get = [&](const double* img, FlushT& f, int q) { f = reinterpret_cast<const FlushT*>(img)[pu_l[q]]; };
-        auto image_out = [&](const FlushT& f, int q, int frow) {  // frow: first row (of a request's stacked rows) of the tile
+        auto image_out = [&](const FlushT& f, int q, int frow, double* fbase) {  // frow: first row (of a request's stacked rows) of the tile
             // (wave-uniform tile base + 32-bit lane offset: scalar-base addressing, no 64-bit lane addresses to hoist and spill)
-            char* tb = reinterpret_cast<char*>(obase + (size_t)frow * npts);
+            char* tb = reinterpret_cast<char*>(fbase + (size_t)frow * npts);
             FlushT* g2 = reinterpret_cast<FlushT*>(tb + pu_o[q]);
 #if FX_WG_DBG
             {
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
         // (ntile: fragment tile to prefetch, clamped to the zero tile `nzero` that ends the buffer; frow: first output row of the
         // tile in `prev`)
         auto stage = [&](int ntile, int nzero, int frow, v4d (&acc)[CTW], const v4d (&prev)[CTW], double* img, const double (&af)[KS], double (&an)[KS],
-                         bool flush) __attribute__((always_inline)) {
+                         bool flush, double* fbase) __attribute__((always_inline)) {
             FlushT fb[2][PB];
             const double* ap = a.afrag + (size_t)min(ntile, nzero) * KS * 64 + lane;
 #pragma unroll
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                             if (j >= 1) {
 #pragma unroll
                                 for (int q = 0; q < PB; ++q)
-                                    if (q % CTW == c && (j - 1) * PB + q < NRW) image_out(fb[(j - 1) & 1][q], (j - 1) * PB + q, frow);
+                                    if (q % CTW == c && (j - 1) * PB + q < NRW) image_out(fb[(j - 1) & 1][q], (j - 1) * PB + q, frow, fbase);
                             }
                             if (j < NB) {
 #pragma unroll
@@ -443,45 +448,59 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
             for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa0[ks]));
             // even steps: fragments fa0, accumulators A; odd steps: fa1, B.  The tile of step s lives in image s & 1 (PC 1: the
             // wave's one image) from the first K-steps of step s + 1 until that step has sent it out.
-            stage(pr + PR, RT, 0, accA, accB, image_of(1), fa0, fa1, false);  // first step: nothing to flush yet
+            if constexpr (PC == 1) {
+                // (one wave per row tile: the previous group's last tile, kept in accP, leaves under this group's first MFMAs)
+                if (pend) stage(pr + PR, RT, pend_frow, accA, accP, image_of(1), fa0, fa1, true, pend_base);
+                else stage(pr + PR, RT, 0, accA, accB, image_of(1), fa0, fa1, false, obase);
+            } else {
+                stage(pr + PR, RT, 0, accA, accB, image_of(1), fa0, fa1, false, obase);  // first step: nothing to flush yet
+            }
             int i = 1;
             for (; i + 1 < nsteps; i += 2) {
-                stage(pr + PR * (i + 1), RT, 16 * (pr + PR * (i - 1)), accB, accA, image_of(0), fa1, fa0, true);
-                stage(pr + PR * (i + 2), RT, 16 * (pr + PR * i), accA, accB, image_of(1), fa0, fa1, true);
+                stage(pr + PR * (i + 1), RT, 16 * (pr + PR * (i - 1)), accB, accA, image_of(0), fa1, fa0, true, obase);
+                stage(pr + PR * (i + 2), RT, 16 * (pr + PR * i), accA, accB, image_of(1), fa0, fa1, true, obase);
             }
             if (i < nsteps) {
-                stage(pr + PR * (i + 1), RT, 16 * (pr + PR * (i - 1)), accB, accA, image_of(0), fa1, fa0, true);
+                stage(pr + PR * (i + 1), RT, 16 * (pr + PR * (i - 1)), accB, accA, image_of(0), fa1, fa0, true, obase);
                 ++i;
             }
-            // the last step's tile (the only one that may have fewer than 16 rows, or -- PC 2 -- not exist): image, then out
-            {
-                const int tile = pr + PR * (i - 1);
+            // the last step's tile (the only one that may have fewer than 16 rows, or -- PC 2 -- not exist).  One wave per row tile
+            // (PC 1, always one request per slab): a full tile stays in registers (accP) and leaves under the first MFMAs of the
+            // wave's next group -- with one or two row tiles per wave and group (values-only requests) the flush was a fifth of
+            // the launch.  Otherwise: image, then out.
+            const int ltile = pr + PR * (i - 1);
+            const int lrows = ltile == RT - 1 ? last_rows : 16;
+            bool defer = false;
+            if constexpr (PC == 1) defer = lrows == 16 && !(FX_WG_ABL & 12);
+            if (defer) {
+#pragma unroll
+                for (int c = 0; c < CTW; ++c) accP[c] = ((i - 1) & 1) ? accB[c] : accA[c];
+                pend = true;
+                pend_base = obase;
+                pend_frow = 16 * ltile;
+            } else {
+                if constexpr (PC == 1) pend = false;
                 double* imgl = image_of((i - 1) & 1);
-                if (tile < RT && !((FX_WG_ABL & 8) && nreq > 8)) {
-                    if ((i - 1) & 1) image_put(imgl, accB, tile == RT - 1 ? last_rows : 16);
-                    else image_put(imgl, accA, tile == RT - 1 ? last_rows : 16);
+                if (ltile < RT && !((FX_WG_ABL & 8) && nreq > 8)) {
+                    if ((i - 1) & 1) image_put(imgl, accB, lrows);
+                    else image_put(imgl, accA, lrows);
                 }
                 if constexpr (PC > 1) wg_lds_barrier();
                 else wave_lds_fence();
-            }
-            {
-                const int tile = pr + PR * (i - 1);
-                const double* imgr = image_of((i - 1) & 1);
-                if (tile < RT && !((FX_WG_ABL & 4) && nreq > 8)) {
-                    const int nrows = tile == RT - 1 ? last_rows : 16;
-                    if (nrows < 16) build_pieces(gmax, nrows);   // (the pieces of a request's rows that exist; rebuilt below)
+                if (ltile < RT && !((FX_WG_ABL & 4) && nreq > 8)) {
+                    if (lrows < 16) build_pieces(gmax, lrows);   // (the pieces of a request's rows that exist; rebuilt below)
                     constexpr int HB = NRW < 8 ? NRW : 8;
 #pragma unroll
                     for (int r0 = 0; r0 < NRW; r0 += HB) {
                         FlushT fl[HB];
 #pragma unroll
                         for (int q = 0; q < HB; ++q)
-                            if (r0 + q < NRW) image_get(imgr, fl[q], r0 + q);
+                            if (r0 + q < NRW) image_get(imgl, fl[q], r0 + q);
 #pragma unroll
                         for (int q = 0; q < HB; ++q)
-                            if (r0 + q < NRW) image_out(fl[q], r0 + q, 16 * tile);
+                            if (r0 + q < NRW) image_out(fl[q], r0 + q, 16 * ltile, obase);
                     }
-                    if (nrows < 16) build_pieces(G - 1, 16);
+                    if (lrows < 16) build_pieces(G - 1, 16);
                 }
                 wave_lds_fence();
             }
@@ -535,11 +554,11 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                     const int ntile = t + 1 < NTAB ? i * NTAB + t + 1 : (i + PR) * NTAB;
                     const int frow = t * rows + 16 * (i - PR);
                     if constexpr (((t + PAR) & 1) == 0) {
-                        if constexpr (DSODD) stage(ntile, NZ, frow, accB[t], accA[t], image_of(0), fa0, fa1, flush);
-                        else stage(ntile, NZ, frow, accA[t], accB[t], image_of(0), fa0, fa1, flush);
+                        if constexpr (DSODD) stage(ntile, NZ, frow, accB[t], accA[t], image_of(0), fa0, fa1, flush, obase);
+                        else stage(ntile, NZ, frow, accA[t], accB[t], image_of(0), fa0, fa1, flush, obase);
                     } else {
-                        if constexpr (DSODD) stage(ntile, NZ, frow, accB[t], accA[t], image_of(1), fa1, fa0, flush);
-                        else stage(ntile, NZ, frow, accA[t], accB[t], image_of(1), fa1, fa0, flush);
+                        if constexpr (DSODD) stage(ntile, NZ, frow, accB[t], accA[t], image_of(1), fa1, fa0, flush, obase);
+                        else stage(ntile, NZ, frow, accA[t], accB[t], image_of(1), fa1, fa0, flush, obase);
                     }
                 });
                 if constexpr (DSODD) mix(accB);
@@ -581,7 +600,7 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                                 if (r0 + q < NRW) image_get(imgl, fl[q], r0 + q);
 #pragma unroll
                             for (int q = 0; q < HB; ++q)
-                                if (r0 + q < NRW) image_out(fl[q], r0 + q, t * rows + 16 * i);
+                                if (r0 + q < NRW) image_out(fl[q], r0 + q, t * rows + 16 * i, obase);
                         }
                     }
                 });
@@ -596,6 +615,24 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
         nxt += gridDim.x;
 #pragma unroll
         for (int d = 0; d < SD; ++d) xcur[d] = xnext[d];
+    }
+    if constexpr (PC == 1 && MIX == 0) {  // the tile still in registers
+        if (pend) {
+            double* imgl = imgs + (size_t)wave * wg_image_doubles(CT);
+#pragma unroll
+            for (int c = 0; c < CTW; ++c)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) imgl[ioff[c][jj]] = accP[c][jj];
+            wave_lds_fence();
+            char* tb = reinterpret_cast<char*>(pend_base + (size_t)pend_frow * npts);
+#pragma unroll
+            for (int q = 0; q < NRW; ++q) {
+                const FlushT f = reinterpret_cast<const FlushT*>(imgl)[pu_l[q]];
+                FlushT* g2 = reinterpret_cast<FlushT*>(tb + pu_o[q]);
+                if constexpr (ODD) *g2 = f;
+                else stream_store(g2, f);
+            }
+        }
     }
 }
 

@@ -357,7 +357,8 @@ def test_kernel_selection(rt, golden):
     assert p3.kernel_name(1, 1000, 40) == "fxk::tabulate_simplex_stacked"    # own cell, off the 21..24-point shape: the paired entry yields
     assert p3.kernel_name(1, 1000, 10) == "fxk::tabulate_simplex_pair"       # ... unless no stacked instance holds the request
     assert p3.kernel_name(1, 1000, 50) == "fxk::tabulate_simplex_stacked"    # 49..64 points: four column tiles
-    assert p3.kernel_name(1, 1000, 70) == "fxk::tabulate_simplex_wg"         # 65..128 points: a request per workgroup (round 4; were point chunks)
+    assert p3.kernel_name(1, 1000, 100) == "fxk::tabulate_simplex_wg"        # 97..128 points: a request per workgroup (round 4; were point chunks)
+    assert p3.kernel_name(1, 1000, 70) == "fxk::tabulate_simplex_stacked"    # 65..96 points with a short K loop: point-chunked units
     assert p3.kernel_name(1, 1000, 130) == "fxk::tabulate_simplex_stacked"   # point-chunked units
     assert p3.kernel_name(1, 1000, 7) == "fxk::tabulate_simplex_kernel"      # fewer points than any registered tiling
     assert p3.kernel_name(2, 1000, 23) == "fxk::tabulate_simplex_stacked"    # Hessians: 200 stacked rows
