@@ -1744,10 +1744,14 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
             auto fills_tiles = [&](const StackedShape& k) { return 3LL * k.g * npts > 2LL * 16 * k.ct; };
             // (first the instances that apply the chain rule themselves, then the rest, each in table order)
             // the request-per-workgroup kernel applies the order-1 chain rule of per-request cells itself (round 4, MIX instances):
-            // rules of 65..128 points, the window of P5 triangles, or policy wg_small -- the per-wave chain-rule instances yield
+            // rules of 49..128 points, the window of P5 triangles, or policy wg_small -- the per-wave chain-rule instances yield
             auto wg_mix_takes = [&](const StackedShape& k) {
                 if ((ctx->policy & (FX_POLICY_NO_WG | FX_POLICY_NO_STACKED_MIX)) || !verts || order != 1 || npts > 128) return false;
-                if (!(npts > 64 || (k.sd == 2 && k.n == 5 && npts >= 25 && npts <= 33) || (ctx->policy & FX_POLICY_WG_SMALL))) return false;
+                // (49..64 points, two requests per slab: tools/instance_ab.py [--policy wg_small], sustained, 0.8 GB -- N3 / RT3 tetrahedra at
+                // 57 / 50 points 315 / 316 -> 199 / 190 us, P3 / P4 / P5 / P6 at 57 points 384 / 412 / 464 / 544 -> 279 / 328 / 333 / 434, P6
+                // triangles at 49 / 60 points 427 / 394 -> 302 / 253, P5 at 55 points 515 -> 313: the former routes were a second
+                // 48-point chunk that is mostly padding, or a four-tile whole-request instance plus the table-mixing pass)
+                if (!(npts > 48 || (k.sd == 2 && k.n == 5 && npts >= 25 && npts <= 33) || (ctx->policy & FX_POLICY_WG_SMALL))) return false;
                 const int g = npts > 64 ? 1 : std::min(12, 128 / npts);
                 const int ctn = std::max(4, (g * npts + 15) / 16);
                 const int ctm = fxwg::mix_ct(k.sd, k.n, ctn);

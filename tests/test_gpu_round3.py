@@ -427,10 +427,10 @@ ROUTES = [
     ("Lagrange", 2, 4, 16, 1, True, "stacked<2,4,3,3,-2>"), ("Lagrange", 2, 4, 7, 1, True, "small"),
     ("Lagrange", 2, 3, 16, 2, True, "stacked<2,3,3,3,-3>"), ("Lagrange", 2, 3, 12, 2, True, "small"),
     ("Lagrange", 2, 3, 16, 1, True, "small"), ("Lagrange", 3, 2, 11, 1, True, "small"),
-    ("Lagrange", 3, 4, 57, 1, True, "stacked<3,4,4,1,0>"), ("Lagrange", 3, 4, 70, 1, True, "stacked<3,4,3,1,-4>"),
+    ("Lagrange", 3, 4, 57, 1, True, "wg<3,4,8>x2+mix"), ("Lagrange", 3, 4, 70, 1, True, "stacked<3,4,3,1,-4>"),
     ("Lagrange", 3, 4, 57, 2, True, "stacked<3,4,2,1,-5>"), ("Lagrange", 3, 3, 57, 2, True, "stacked<3,3,4,1,0>"),
     ("Lagrange", 2, 5, 50, 1, True, "stacked<2,5,4,1,0>"), ("Lagrange", 2, 6, 57, 2, True, "stacked<2,6,3,1,-5>"),
-    ("Nedelec", 3, 3, 57, 1, True, "stacked<3,3,3,1,-4>"), ("Nedelec", 3, 3, 16, 2, True, "kernel"),
+    ("Nedelec", 3, 3, 57, 1, True, "wg<3,3,8>x2+mix"), ("Nedelec", 3, 3, 16, 2, True, "kernel"),
     ("Nedelec", 3, 3, 14, 1, True, "stacked<3,3,3,3,0>"), ("RaviartThomas", 3, 3, 11, 2, True, "kernel"),
     ("Nedelec", 3, 3, 23, 2, True, "stacked<3,3,3,2,-3>"),
     # round 4: rules of 49..128 points on the element's own cell take the request-per-workgroup kernel (were point chunks of two

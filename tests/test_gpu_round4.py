@@ -262,6 +262,9 @@ def test_values_only_requests_on_the_lane_local_kernel(family, sd, degree, npts,
 WG_MIX = [("Lagrange", 3, 6, 122, "8>+mix"), ("DiscontinuousLagrange", 3, 5, 74, "6>+mix"), ("Lagrange", 3, 4, 97, "8>+mix"),
           ("Lagrange", 3, 3, 97, "8>+mix"), ("Nedelec", 3, 3, 74, "6>+mix"), ("Lagrange", 2, 6, 73, "6>+mix"), ("DiscontinuousLagrange", 2, 6, 79, "6>+mix"),
           ("Lagrange", 2, 6, 128, "8>+mix"), ("Lagrange", 3, 6, 100, "8>+mix"), ("Lagrange", 3, 5, 122, "8>+mix"),
+          # 49..64 points: two requests per slab
+          ("Nedelec", 3, 3, 57, "8>x2+mix"), ("Lagrange", 3, 6, 57, "8>x2+mix"), ("Lagrange", 3, 4, 64, "8>x2+mix"), ("Lagrange", 2, 6, 49, "8>x2+mix"),
+          ("Lagrange", 2, 5, 55, "8>x2+mix"),
           # several small requests per slab (the default windows and policy wg_small), odd table sizes
           ("Lagrange", 2, 5, 25, "8>x5+mix"), ("DiscontinuousLagrange", 2, 5, 33, "8>x3+mix")]
 
