@@ -1751,7 +1751,19 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 // 57 / 50 points 315 / 316 -> 199 / 190 us, P3 / P4 / P5 / P6 at 57 points 384 / 412 / 464 / 544 -> 279 / 328 / 333 / 434, P6
                 // triangles at 49 / 60 points 427 / 394 -> 302 / 253, P5 at 55 points 515 -> 313: the former routes were a second
                 // 48-point chunk that is mostly padding, or a four-tile whole-request instance plus the table-mixing pass)
-                if (!(npts > 48 || (k.sd == 2 && k.n == 5 && npts >= 25 && npts <= 33) || (ctx->policy & FX_POLICY_WG_SMALL))) return false;
+                // (... and two windows the off-default audits found, tools/coverage_map.py --audit --verts --qdeg-offset -1, confirmed in
+                // sustained runs: vector-valued degree-3 tetrahedra at 13..15 points -- N3 / RT3 / BDM3 at the 14-point rule 407 / 352 / 374 ->
+                // 229 / 174 / 181 us, nine requests per slab against the three-request instance + table-mixing pass -- and tables of an odd
+                // number of doubles at 17..48 points, which only the point chunks or a whole-request instance + mixing pass held: P5
+                // triangles at 19 points 589 -> 307 us, P4 tetrahedra at 31 points 401 -> 314)
+                // (where the per-wave kernel has an 8-byte twin of its chain-rule instance it keeps the odd tables: N3 tetrahedra at the
+                // 23-point rule 198 us there against 213 here)
+                const bool odd_pt = ((long long)rows * npts) % 2 != 0;
+                const bool twin2 = (k.sd == 3 && (k.n == 3 || k.n == 4) && npts <= 24) || (k.sd == 2 && k.n == 5 && npts >= 25);
+                const bool window = npts > 48 || (k.sd == 2 && k.n == 5 && npts >= 25 && npts <= 33) ||
+                                    (k.sd == 3 && k.n == 3 && e->vdim > 1 && npts >= 13 && npts <= 15) ||
+                                    (odd_pt && npts >= 17 && npts <= 48 && !twin2);
+                if (!(window || (ctx->policy & FX_POLICY_WG_SMALL))) return false;
                 const int g = npts > 64 ? 1 : std::min(12, 128 / npts);
                 const int ctn = std::max(4, (g * npts + 15) / 16);
                 const int ctm = fxwg::mix_ct(k.sd, k.n, ctn);
@@ -1836,7 +1848,15 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     // cells: values straight from the kernel, derivatives + the table-mixing pass
                     const bool nomix = (ctx->policy & FX_POLICY_NO_STACKED_MIX) != 0;
                     const bool want_mix = verts && order == 1 && !nomix;
-                    if (npts <= 48 && !(ctx->policy & FX_POLICY_WG_SMALL) && !(small_window && (!verts || want_mix))) continue;
+                    // (tables of an odd number of doubles at 17..48 points had only the point chunks: P5 triangles with gradients at 19
+                    // points 361 -> 201 us, values of P4 tetrahedra at 31 points 515 -> 394; with cells 586 -> 459)
+                    // (not where a whole-request instance has an 8-byte twin: values of P4 tetrahedra at the 23-point rule 315 us there,
+                    // 422 here)
+                    const bool twin1 = (k.sd == 3 && (k.n == 3 || k.n == 4) && npts <= 24) || (k.sd == 2 && k.n == 5 && npts >= 25 && npts <= 32);
+                    const bool odd_window = !even && npts >= 17 && npts <= 48 && (!verts || order == 0) && !twin1;
+                    if (npts <= 48 && !(ctx->policy & FX_POLICY_WG_SMALL) && !(small_window && (!verts || want_mix)) && !odd_window &&
+                        !(want_mix && wg_mix_takes(k)))
+                        continue;
                     // requests per slab of <= 128 columns and the instance's column tiles
                     wg_g = npts > 64 ? 1 : std::min(12, 128 / npts);
                     wg_ctw = std::max(4, (wg_g * npts + 15) / 16);
@@ -1867,7 +1887,8 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                         if (!fxwg::has_instance(k.sd, k.n, wg_ctw, wg_odd)) continue;
                     }
                     // (49..64 points: where a whole-request instance of four column tiles exists it keeps the rule)
-                    if (!wg_mix1 && npts > 48 && npts <= 64 && even && !(ctx->policy & FX_POLICY_WG_SMALL)) {
+                    // (... except degree >= 5 tetrahedra: two requests per slab 0.87-0.93 of the four-tile instance at 57 points)
+                    if (!wg_mix1 && npts > 48 && npts <= 64 && even && !(ctx->policy & FX_POLICY_WG_SMALL) && !(k.sd == 3 && k.n >= 5)) {
                         bool whole = false;
                         for (const StackedShape& o : kStackedShapes)
                             whole = whole || (o.sd == k.sd && o.n == k.n && o.rtc == 0 && o.g == 1 && o.ct == 4);

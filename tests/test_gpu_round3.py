@@ -431,7 +431,7 @@ ROUTES = [
     ("Lagrange", 3, 4, 57, 2, True, "stacked<3,4,2,1,-5>"), ("Lagrange", 3, 3, 57, 2, True, "stacked<3,3,4,1,0>"),
     ("Lagrange", 2, 5, 50, 1, True, "stacked<2,5,4,1,0>"), ("Lagrange", 2, 6, 57, 2, True, "stacked<2,6,3,1,-5>"),
     ("Nedelec", 3, 3, 57, 1, True, "wg<3,3,8>x2+mix"), ("Nedelec", 3, 3, 16, 2, True, "kernel"),
-    ("Nedelec", 3, 3, 14, 1, True, "stacked<3,3,3,3,0>"), ("RaviartThomas", 3, 3, 11, 2, True, "kernel"),
+    ("Nedelec", 3, 3, 14, 1, True, "wg<3,3,8>x9+mix"), ("RaviartThomas", 3, 3, 11, 2, True, "kernel"),
     ("Nedelec", 3, 3, 23, 2, True, "stacked<3,3,3,2,-3>"),
     # round 4: rules of 49..128 points on the element's own cell take the request-per-workgroup kernel (were point chunks of two
     # or three column tiles; those instances stay behind policy no_wg: tests/test_gpu_round4.py)

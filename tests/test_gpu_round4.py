@@ -265,6 +265,9 @@ WG_MIX = [("Lagrange", 3, 6, 122, "8>+mix"), ("DiscontinuousLagrange", 3, 5, 74,
           # 49..64 points: two requests per slab
           ("Nedelec", 3, 3, 57, "8>x2+mix"), ("Lagrange", 3, 6, 57, "8>x2+mix"), ("Lagrange", 3, 4, 64, "8>x2+mix"), ("Lagrange", 2, 6, 49, "8>x2+mix"),
           ("Lagrange", 2, 5, 55, "8>x2+mix"),
+          # windows found by the off-default audits: vector-valued degree 3 at 13..15 points, odd tables without an 8-byte twin
+          ("Nedelec", 3, 3, 14, "8>x9+mix"), ("RaviartThomas", 3, 3, 15, "8>x8+mix"), ("Lagrange", 2, 5, 19, "8>x6+mix"),
+          ("Lagrange", 3, 4, 31, "8>x4+mix"), ("Lagrange", 2, 5, 21, "8>x6+mix"),
           # several small requests per slab (the default windows and policy wg_small), odd table sizes
           ("Lagrange", 2, 5, 25, "8>x5+mix"), ("DiscontinuousLagrange", 2, 5, 33, "8>x3+mix")]
 
@@ -294,3 +297,33 @@ def test_chain_rule_inside_the_request_per_workgroup_kernel(family, sd, degree, 
     two = ps.tabulate_batch(1, pts, verts=verts).cpu().numpy()
     for t in range(got.shape[1]):
         assert rel(two[:, t], ref[:, t]) <= (TOL_VAL if t == 0 else TOL_DER)
+
+
+@pytest.mark.parametrize("family,sd,degree,npts,order,cells,suffix", [
+    ("Lagrange", 2, 5, 19, 1, False, "8>x6"), ("Lagrange", 2, 5, 21, 2, False, None), ("Lagrange", 3, 4, 31, 0, False, "8>x4"),
+    ("Lagrange", 3, 4, 31, 0, True, "8>x4"), ("Lagrange", 3, 4, 23, 0, False, None), ("Nedelec", 3, 3, 23, 1, True, None),
+    ("Lagrange", 3, 5, 57, 0, False, "8>x2"), ("Lagrange", 3, 5, 57, 2, False, "8>x2"), ("Lagrange", 3, 4, 58, 0, False, None), ("Lagrange", 3, 4, 57, 0, False, "8>x2")])
+def test_windows_of_grouped_requests(family, sd, degree, npts, order, cells, suffix, kernel_policy):
+    """Where several requests per workgroup are the default below 65 points (round 4, sustained A/B in DESIGN.md 4.16): tables of an
+    odd number of doubles at 17..48 points that only the point chunks held, degree >= 5 tetrahedra at 49..64 points -- and where they
+    are not (shapes whose whole-request instance has an 8-byte twin, four-tile instances of lower degrees).  Tables against the oracle
+    either way, and equal under policy no_wg."""
+    import fiat_amd as fa
+    el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
+    ps = el.device_polyset()
+    n = el.get_nodal_basis().get_embedded_degree()
+    nreq = 517
+    name = ps.kernel_name(order, nreq, npts, has_verts=cells, instance=True)
+    if suffix is None:
+        assert "simplex_wg" not in name, name
+    else:
+        assert name == f"fxk::tabulate_simplex_wg<{sd},{n},{suffix}", name
+    pts, verts = batch(sd, nreq, npts, 5 * npts + order, cells)
+    got = ps.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    ref = oracle_tables(el, sd, order, pts, verts, got.shape)
+    for t in range(got.shape[1]):
+        assert rel(got[:, t], ref[:, t]) <= (TOL_VAL if t == 0 else TOL_DER), (name, t)
+    kernel_policy("no_wg")
+    other = ps.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    for t in range(got.shape[1]):
+        assert rel(other[:, t], ref[:, t]) <= (TOL_VAL if t == 0 else TOL_DER)
