@@ -1760,8 +1760,11 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 // 23-point rule 198 us there against 213 here)
                 const bool odd_pt = ((long long)rows * npts) % 2 != 0;
                 const bool twin2 = (k.sd == 3 && (k.n == 3 || k.n == 4) && npts <= 24) || (k.sd == 2 && k.n == 5 && npts >= 25);
+                // (... and vector-valued degree-3 tetrahedra of 180 rows a table -- BDM3, N2 of degree 3 -- at 17..24 points: 223 -> 198 us at
+                // the 23-point rule, five requests per slab)
                 const bool window = npts > 48 || (k.sd == 2 && k.n == 5 && npts >= 25 && npts <= 33) ||
                                     (k.sd == 3 && k.n == 3 && e->vdim > 1 && npts >= 13 && npts <= 15) ||
+                                    (k.sd == 3 && k.n == 3 && e->vdim > 1 && rows >= 160 && npts >= 17 && npts <= 24) ||
                                     (odd_pt && npts >= 17 && npts <= 48 && !twin2);
                 if (!(window || (ctx->policy & FX_POLICY_WG_SMALL))) return false;
                 const int g = npts > 64 ? 1 : std::min(12, 128 / npts);
@@ -1842,8 +1845,15 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     // P5 triangles with derivatives at 25..33 points 232 / 183 / 252 -> 189 / 169 / 225 us, degree-6 tetrahedra with
                     // Hessians at 33..48 points 432 -> 352 us.  Elsewhere the two are within +-10 % of each other with either sign,
                     // and the map's short interleaved runs disagree with the sustained ones: opt-in, policy wg_small)
+                    // (round 4, audits off the default rule sizes, sustained: vector-valued degree-3 tetrahedra at 13..15 points, nine
+                    // requests per slab against the three-request instance -- RT3 with Hessians / N3 with gradients / BDM3 values at the
+                    // 14-point rule 218 / 175 / 164 -> 157 / 158 / 159 us; with cells, values: N3 / BDM3 / N2 217 / 166 / 171 -> 196 / 151 / 148)
+                    const bool vec3_window = k.sd == 3 && k.n == 3 && e->vdim > 1 && npts >= 13 && npts <= 15;
+                    // (... and those of 180 rows a table -- BDM3, N2 of degree 3 -- at 17..24 points with cells, values: 181 / 195 -> 171 / 173 us
+                    // at the 23-point rule)
+                    const bool vec3_rows = k.sd == 3 && k.n == 3 && e->vdim > 1 && rows >= 160;
                     const bool small_window = (k.sd == 2 && k.n == 5 && order >= 1 && npts >= 25 && npts <= 33) ||
-                                              (k.sd == 3 && k.n == 6 && order == 2 && npts >= 33 && npts <= 48);
+                                              (k.sd == 3 && k.n == 6 && order == 2 && npts >= 33 && npts <= 48) || vec3_window;
                     // per-request cells with gradients: the chain rule on the accumulators (MIX instances); other orders with
                     // cells: values straight from the kernel, derivatives + the table-mixing pass
                     const bool nomix = (ctx->policy & FX_POLICY_NO_STACKED_MIX) != 0;
@@ -1855,6 +1865,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     const bool twin1 = (k.sd == 3 && (k.n == 3 || k.n == 4) && npts <= 24) || (k.sd == 2 && k.n == 5 && npts >= 25 && npts <= 32);
                     const bool odd_window = !even && npts >= 17 && npts <= 48 && (!verts || order == 0) && !twin1;
                     if (npts <= 48 && !(ctx->policy & FX_POLICY_WG_SMALL) && !(small_window && (!verts || want_mix)) && !odd_window &&
+                        !(verts && order == 0 && (vec3_window || (vec3_rows && npts >= 17 && npts <= 24))) &&
                         !(want_mix && wg_mix_takes(k)))
                         continue;
                     // requests per slab of <= 128 columns and the instance's column tiles
@@ -1888,7 +1899,10 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     }
                     // (49..64 points: where a whole-request instance of four column tiles exists it keeps the rule)
                     // (... except degree >= 5 tetrahedra: two requests per slab 0.87-0.93 of the four-tile instance at 57 points)
-                    if (!wg_mix1 && npts > 48 && npts <= 64 && even && !(ctx->policy & FX_POLICY_WG_SMALL) && !(k.sd == 3 && k.n >= 5)) {
+                    // (... and vector-valued degree-3 tetrahedra of 180 rows a table with derivatives: BDM3 with gradients / Hessians at 57
+                    // points 196 / 200 -> 157 / 160 us)
+                    if (!wg_mix1 && npts > 48 && npts <= 64 && even && !(ctx->policy & FX_POLICY_WG_SMALL) && !(k.sd == 3 && k.n >= 5) &&
+                        !(vec3_rows && order >= 1 && !verts)) {
                         bool whole = false;
                         for (const StackedShape& o : kStackedShapes)
                             whole = whole || (o.sd == k.sd && o.n == k.n && o.rtc == 0 && o.g == 1 && o.ct == 4);

@@ -51,6 +51,25 @@ __device__ __forceinline__ long long wg_dbg_check(long long idx, long long lim, 
 }
 #endif
 
+#ifndef FX_WG_TIME
+#define FX_WG_TIME 0  // measurement build: workgroup 0 sums the clock ticks of its phases (production, barrier, first operands, sweep) per wave
+#endif
+#if FX_WG_TIME
+#define WG_TICK(i)                                          \
+    do {                                                    \
+        const long long t_ = __builtin_readcyclecounter(); \
+        tacc[i] += t_ - tprev;                              \
+        tprev = t_;                                         \
+    } while (0)
+#else
+#define WG_TICK(i)
+#endif
+
+template <bool FIRST, class A, class B> __device__ __forceinline__ auto& choose_ref(A& x, B& y) {
+    if constexpr (FIRST) return x;
+    else return y;
+}
+
 constexpr int WG_NW = 4;  // one wave per SIMD
 // LDS doubles: control block, recurrence coefficients [3 (4 KS - 1)] (rounded up), expansion values [4 KS][16 CT], per-wave
 // row-tile images [16][<= 16 CT] + dump row
@@ -69,6 +88,14 @@ template <int SD, int N, int NSUB> struct StepSubsets {
     constexpr StepSubsets() {
         StepTable<SD, N> T{};
         int cur_owner = 0;
+        // (subset 0 also stores the lower levels, and computes all of them -- the others only the chain heads they need: it
+        // starts with a handicap of half the lower levels' steps.  FX_WG_TIME, degree 5: 144 against 85 fp64 instructions, 2560
+        // against 1620 clocks before)
+        if (SD >= 2 && NSUB > 1) {
+            int shared = 0;
+            for (int s = 0; s < T.count; ++s) shared += T.codim[s] < SD - 1 ? 1 : 0;
+            load[0] = shared / 2;
+        }
         for (int s = 0; s < T.count; ++s) {
             if (SD < 2 || T.codim[s] < SD - 1) {
                 owner[s] = -1;
@@ -86,6 +113,41 @@ template <int SD, int N, int NSUB> struct StepSubsets {
     }
 };
 
+// the steps subset SUB runs, in table order (its recurrence coefficients are fetched ahead in batches)
+template <int SD, int N, int NSUB, int SUB> struct SubsetSteps {
+    static constexpr int NS = StepTable<SD, N>::NSTEPS;
+    int list[NS] = {};
+    int count = 0;
+    constexpr SubsetSteps() {
+        StepSubsets<SD, N, NSUB> S{};
+        StepTable<SD, N> T{};
+        int raw[NS] = {};
+        int nraw = 0;
+        for (int s = 0; s < StepTable<SD, N>::NEXP - 1; ++s)
+            if (S.owner[s] < 0 || S.owner[s] == SUB) raw[nraw++] = s;
+        // Within a recurrence level the chains are independent of each other and a step needs the two steps before it in its
+        // chain: step by step down ONE chain, every fp64 instruction waits for the one before (a wave has its SIMD to itself --
+        // ~16 clocks an instruction instead of 4, FX_WG_TIME).  So the chains of a level advance together: first steps of all
+        // chains, second steps, ...
+        int pos = 0;
+        while (pos < nraw) {
+            const int cd = T.codim[raw[pos]];
+            int end = pos;
+            while (end < nraw && T.codim[raw[end]] == cd) ++end;
+            int start[NS] = {}, len[NS] = {};
+            int nch = 0;
+            for (int i = pos; i < end; ++i) {
+                if (T.prv[raw[i]] < 0 || nch == 0) start[nch++] = i;
+                len[nch - 1]++;
+            }
+            for (int d = 0; d < end - pos; ++d)
+                for (int c = 0; c < nch; ++c)
+                    if (d < len[c]) list[count++] = raw[start[c] + d];
+            pos = end;
+        }
+    }
+};
+
 // PC: waves that share a row tile (each takes CT / PC of its column tiles); PR = 4 / PC row tiles are in work at a time.
 //   PC 1: a wave owns whole row tiles, waves never wait for each other inside a request -- but a request's RT row tiles go
 //         round robin over four waves (values only, degree 6: 6 tiles -> 2, 2, 1, 1: a third of the MFMA slots idle);
@@ -99,7 +161,9 @@ template <int SD, int N, int NSUB> struct StepSubsets {
 //         its dof tile, applies the chain rule d/dx_d = sum_c K[c][d] d/dX_c to them (lane-local in the MFMA result layout; K of
 //         the column's request from LDS) and flushes table by table under the next dof tile's MFMAs: one pass instead of
 //         kernel + table_mix_kernel (FIAT/expansions.py:411-447 through Jinv).
-template <int SD, int N, int CT, bool ODD, int PC, int MIX = 0>
+// FAST (PC 1, at most four row tiles -- values-only requests of up to 64 rows): every wave has ONE row tile a group; its own
+//         instances, so that the accumulators that cross the production phase are there only
+template <int SD, int N, int CT, bool ODD, int PC, int MIX = 0, bool FAST = false>
 __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const StackedArgs<FixedNC<SD, N>::value> a, double* __restrict__ trash,
                                                                    unsigned int* __restrict__ gctr) {
     constexpr StepTable<SD, N> TBL{};
@@ -117,6 +181,7 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
     double* kbuf = lds + WQ_CTL_DOUBLES;          // (MIX) [G][SD][SD]
     double* cof = kbuf + WG_KBUF;                 // [nsteps][3] = A, B, C of the recurrence steps
     static_assert(MIX == 0 || (MIX == 1 && PC >= 2 && SD >= 2), "chain rule on the accumulators: order 1, two or four waves per row tile");
+    static_assert(!FAST || (PC == 1 && MIX == 0 && !(FX_WG_ABL & 12)), "one row tile per wave: one wave per row tile, no chain rule");
     double* phi = cof + wg_coef_doubles(KS);
     static_assert((PC == 1 || PC == 2 || PC == 4) && CT % PC == 0, "column tiles split evenly over the waves of a row tile");
     constexpr int PR = WG_NW / PC, CTW = CT / PC;
@@ -200,7 +265,7 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
         if (wg_dbg_check(((long long)rr * npts + pp_) * SD, a.lim_pts - SD + 1, 1, grp, trash) < 0) ppt = trash;
 #endif
 #pragma unroll
-        for (int d = 0; d < SD; ++d) x[d] = pcol < LDC ? ppt[d] : 0.0;
+        for (int d = 0; d < SD; ++d) x[d] = ppt[d];   // (threads past the slab read its last column's point: no branch, exact waits)
     };
     // once per launch: the recurrence coefficients from the kernel arguments to LDS (broadcast reads in the recurrence: in
     // order with the slab writes, so the waits are exact counts -- scalar loads return out of order and made every step wait
@@ -213,16 +278,48 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
     long long cur = blockIdx.x, nxt = (long long)blockIdx.x + gridDim.x;
     double xcur[SD], xnext[SD];
     load_points(cur, xcur);
+    // (complete before the loop: pending at the loop header, they made the loop's first use of xcur a wait for everything but the
+    // loads just issued -- on the back edge that is a wait for the previous group's output stores)
+#pragma unroll
+    for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xcur[d]));
 
     // (PC 1) the wave's last full row tile of the previous group, not yet written: accumulators, output base and first row
-    v4d accP[PC == 1 ? CTW : 1];
+    v4d accP[PC == 1 && !FAST ? CTW : 1];
     bool pend = false;
-    double* pend_base = a.out;
-    int pend_frow = 0;
+    double* pend_base = FAST ? trash : a.out;
+    int pend_frow = 0, pend_lim = 0;
+    // (PC 1) ONE row tile per wave and group -- values-only requests of up to 64 rows: the two accumulator sets alternate between
+    // groups and a group's tile leaves from where it was computed, under the next group's MFMAs in the other set (the copy to
+    // accP was 40 v_accvgpr_read + 40 v_cndmask behind the last MFMA, ~600 of the 11 700 clocks of a degree-5 request); the wave's
+    // A fragments are the same for every group and stay in registers
+    v4d accA0[FAST ? CTW : 1], accB0[FAST ? CTW : 1];
+    bool flip = false;   // the pending tile is in set A
+    if constexpr (FAST) {
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) accB0[c] = v4d{0.0, 0.0, 0.0, 0.0};
+    }
+    double faF[FAST ? KS : 1];
+    constexpr bool fast = FAST;
+    if constexpr (FAST) {
+        const double* ap0 = a.afrag + (size_t)min(pr, a.RT) * KS * 64 + lane;   // (waves past the last row tile: the zero tile)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) faF[ks] = ap0[ks * 64];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(faF[ks]));   // (complete before the loop, like the first points)
+    }
+#if FX_WG_TIME
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#endif
     while (cur < ngroups) {
-        // A fragments of this wave's first row tile: in flight during the production phase
+        WG_TICK(4);
+        // next group's points, then the A fragments of this wave's first row tile: in flight during the production phase (the
+        // points first: the wait for the fragments after the slab barrier is then a wait for everything, an exact count)
+        load_points(nxt, xnext);
         double fa0[KS], fa1[KS];
-        {
+        if constexpr (FAST) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) fa0[ks] = faF[ks];
+        } else {
             const double* ap0 = a.afrag + (size_t)(MIX ? min(pr, (a.R / (1 + SD) + 15) / 16) * (1 + SD) : min(pr, a.RT)) * KS * 64 + lane;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) fa0[ks] = ap0[ks * 64];
@@ -249,29 +346,60 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                     X[i] = t;
                 }
             }
+            // The coefficients of a step are broadcast LDS reads, and the compiler may not move them across the slab writes of
+            // the steps before (same LDS array): read next to their use, every step waited a whole LDS round trip -- ~108 clocks a
+            // step, 3800 of the 11 700 clocks of a values-only degree-5 request (FX_WG_TIME).  So they are fetched a batch of CB
+            // steps ahead: the reads of batch b + 1 stand in front of the arithmetic and the writes of batch b.
             auto produce_subset = [&](auto sub_c) {
                 constexpr int SUB = decltype(sub_c)::value;
+                constexpr SubsetSteps<SD, N, NSUB, SUB> SL{};
+                constexpr int CB = MIX ? 4 : 8, NBATCH = (SL.count + CB - 1) / CB;
                 double mem[NEXP];
                 double ufa = 0.0, ufb = 0.0, ufc = 0.0;
                 int fcodim = -1;
                 mem[0] = a.phi0;
                 if constexpr (SUB == 0) phi[pcol] = mem[0];
+                double cfe[3 * CB], cfo[3 * CB];   // batches of even / odd index
+                auto fetch = [&](int b, double (&cf)[3 * CB]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int s = 0; s < NEXP - 1; ++s) {
-                    if (SUBS.owner[s] >= 0 && SUBS.owner[s] != SUB) continue;
-                    if ((FX_WG_ABL & 1) && nreq > 8) continue;
-                    const double cA = cof[3 * s], cB = cof[3 * s + 1], cC = cof[3 * s + 2];
-                    if (TBL.codim[s] != fcodim) {
-                        fcodim = TBL.codim[s];
-                        point_factors<SD>(fcodim, X, ufa, ufb, ufc);
+                    for (int i = 0; i < CB; ++i) {
+                        if (b * CB + i >= SL.count) continue;
+                        const int s = SL.list[b * CB + i];
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) cf[3 * i + e] = cof[3 * s + e];
                     }
-                    const double f = cA * ufa - cB * ufb;
-                    double v = mem[TBL.cur[s]] * f;
-                    if (TBL.prv[s] >= 0) v -= cC * ufc * mem[TBL.prv[s]];
-                    mem[TBL.dst[s]] = v;
-                    if (SUBS.owner[s] == SUB || (SUBS.owner[s] < 0 && SUB == 0)) phi[(s + 1) * LDC + pcol] = v;
+                };
+                auto run = [&](int b, const double (&cf)[3 * CB]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int i = 0; i < CB; ++i) {
+                        if (b * CB + i >= SL.count) continue;
+                        if ((FX_WG_ABL & 1) && nreq > 8) continue;
+                        const int s = SL.list[b * CB + i];
+                        const double cA = cf[3 * i], cB = cf[3 * i + 1], cC = cf[3 * i + 2];
+                        if (TBL.codim[s] != fcodim) {
+                            fcodim = TBL.codim[s];
+                            point_factors<SD>(fcodim, X, ufa, ufb, ufc);
+                        }
+                        const double f = cA * ufa - cB * ufb;
+                        double v = mem[TBL.cur[s]] * f;
+                        if (TBL.prv[s] >= 0) v -= cC * ufc * mem[TBL.prv[s]];
+                        mem[TBL.dst[s]] = v;
+                        if (SUBS.owner[s] == SUB || (SUBS.owner[s] < 0 && SUB == 0)) phi[(s + 1) * LDC + pcol] = v;
+                    }
+                };
+                fetch(0, cfe);
+#pragma unroll
+                for (int b = 0; b < NBATCH; ++b) {
+                    if (b & 1) {
+                        if (b + 1 < NBATCH) fetch(b + 1, cfe);
+                        run(b, cfo);
+                    } else {
+                        if (b + 1 < NBATCH) fetch(b + 1, cfo);
+                        run(b, cfe);
+                    }
                 }
             };
+            WG_TICK(5);
             if constexpr (NSUB == 2) {
                 if (psub == 0) produce_subset(std::integral_constant<int, 0>{});
                 else produce_subset(std::integral_constant<int, 1>{});
@@ -299,10 +427,13 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                     }
             }
         }
+        WG_TICK(0);
         wg_lds_barrier();  // slab complete
-
-        // next request's points: in flight during the sweep
-        load_points(nxt, xnext);
+        WG_TICK(1);
+        // (the next group's points have had the production phase to arrive; waiting here keeps the wait at the end of the
+        // iteration from counting the sweep's stores)
+#pragma unroll
+        for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
 
         // ---------------- sweep: row tiles pr, pr + PR, ... of A_stack, column tiles c0 .. c0 + CTW - 1 ----------------
         const int RT = a.RT;
@@ -332,6 +463,18 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
             }
 #endif
             if constexpr (ODD) *g2 = f;  // 8-byte pieces, lines shared with the neighbours: plain stores
+            else stream_store(g2, f);
+        };
+        auto image_out1 = [&](const FlushT& f, int q, int frow, double* fbase, int plim) {  // (PC 1: piece min(u, plim) of the tile)
+            char* tb = reinterpret_cast<char*>(fbase + (size_t)frow * npts);
+            FlushT* g2 = reinterpret_cast<FlushT*>(tb + (unsigned)min(pu_l[q], plim) * (unsigned)(8 * EPP));
+#if FX_WG_DBG
+            {
+                const long long idx = (reinterpret_cast<double*>(g2) - a.out);
+                if (wg_dbg_check(idx, a.lim_out - (EPP - 1), 4, cur, trash) < 0) g2 = reinterpret_cast<FlushT*>(trash);
+            }
+#endif
+            if constexpr (ODD) *g2 = f;
             else stream_store(g2, f);
         };
         // B fragments of K-step ks: members 4 ks + kk at this lane's column of the wave's column tiles
@@ -371,8 +514,10 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
         double b0[CTW], b1[CTW];
         // (ntile: fragment tile to prefetch, clamped to the zero tile `nzero` that ends the buffer; frow: first output row of the
         // tile in `prev`)
+        // (plim, PC 1 only -- one request per slab, so piece u of a tile is at u in the image and 8 EPP u bytes into the output:
+        // the last piece of the tile in `prev`, which may have fewer than 16 rows)
         auto stage = [&](int ntile, int nzero, int frow, v4d (&acc)[CTW], const v4d (&prev)[CTW], double* img, const double (&af)[KS], double (&an)[KS],
-                         bool flush, double* fbase) __attribute__((always_inline)) {
+                         bool flush, double* fbase, int plim = 0) __attribute__((always_inline)) {
             FlushT fb[2][PB];
             const double* ap = a.afrag + (size_t)min(ntile, nzero) * KS * 64 + lane;
 #pragma unroll
@@ -387,7 +532,7 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                     if (ks & 1) b0[c] = phi[(4 * kn + kk) * LDC + 16 * (c0 + c) + col];
                     else b1[c] = phi[(4 * kn + kk) * LDC + 16 * (c0 + c) + col];
                     // A fragments of the next step's tile: first third of the stage (older than every output store of the stage)
-                    if (ks < T3) {
+                    if (!FAST && ks < T3) {   // (FAST: the wave's one tile of fragments stays in registers)
 #pragma unroll
                         for (int l = ks * LPK; l < (ks + 1) * LPK && l < KS; ++l)
                             if (l % CTW == c) an[l] = ap[l * 64];
@@ -409,12 +554,18 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                             if (j >= 1) {
 #pragma unroll
                                 for (int q = 0; q < PB; ++q)
-                                    if (q % CTW == c && (j - 1) * PB + q < NRW) image_out(fb[(j - 1) & 1][q], (j - 1) * PB + q, frow, fbase);
+                                    if (q % CTW == c && (j - 1) * PB + q < NRW) {
+                                        if constexpr (PC == 1) image_out1(fb[(j - 1) & 1][q], (j - 1) * PB + q, frow, fbase, plim);
+                                        else image_out(fb[(j - 1) & 1][q], (j - 1) * PB + q, frow, fbase);
+                                    }
                             }
                             if (j < NB) {
 #pragma unroll
                                 for (int q = 0; q < PB; ++q)
-                                    if ((q + CTW / 2) % CTW == c && j * PB + q < NRW) image_get(img, fb[j & 1][q], j * PB + q);
+                                    if ((q + CTW / 2) % CTW == c && j * PB + q < NRW) {
+                                        if constexpr (PC == 1) fb[j & 1][q] = reinterpret_cast<const FlushT*>(img)[min(pu_l[j * PB + q], plim)];
+                                        else image_get(img, fb[j & 1][q], j * PB + q);
+                                    }
                             }
                         }
                     }
@@ -436,48 +587,68 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
             }
             wave_lds_fence();  // the image has been read
             // first use of the prefetched fragments in the same block as the stores: exact vmcnt
+            if constexpr (!FAST) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(an[ks]));
+                for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(an[ks]));
+            }
         };
 
         if constexpr (MIX == 0) {
         if (nsteps > 0) {
-            v4d accA[CTW], accB[CTW];
+            v4d accA1[FAST ? 1 : CTW], accB1[FAST ? 1 : CTW];
+            auto& accA = choose_ref<FAST>(accA0, accA1);
+            auto& accB = choose_ref<FAST>(accB0, accB1);
             load_b(b0, 0);
+            if constexpr (!FAST) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa0[ks]));
+                for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(fa0[ks]));
+            }
+            WG_TICK(2);
+            if constexpr (fast) {
+                // (the first group "flushes" the other set's garbage to the scratch buffer: piece 0 only -- no flag in the slices)
+                if (flip) stage(RT, RT, pend_frow, accB, accA, image_of(1), fa0, fa1, true, pend_base, pend_lim);
+                else stage(RT, RT, pend_frow, accA, accB, image_of(1), fa0, fa1, true, pend_base, pend_lim);
+                flip = !flip;
+                pend = true;
+                pend_base = obase;
+                pend_frow = 16 * pr;
+                pend_lim = (pr == RT - 1 ? last_rows : 16) * npts / EPP - 1;
+            } else {
             // even steps: fragments fa0, accumulators A; odd steps: fa1, B.  The tile of step s lives in image s & 1 (PC 1: the
             // wave's one image) from the first K-steps of step s + 1 until that step has sent it out.
             if constexpr (PC == 1) {
                 // (one wave per row tile: the previous group's last tile, kept in accP, leaves under this group's first MFMAs)
-                if (pend) stage(pr + PR, RT, pend_frow, accA, accP, image_of(1), fa0, fa1, true, pend_base);
+                if (pend) stage(pr + PR, RT, pend_frow, accA, accP, image_of(1), fa0, fa1, true, pend_base, pend_lim);
                 else stage(pr + PR, RT, 0, accA, accB, image_of(1), fa0, fa1, false, obase);
             } else {
                 stage(pr + PR, RT, 0, accA, accB, image_of(1), fa0, fa1, false, obase);  // first step: nothing to flush yet
             }
             int i = 1;
             for (; i + 1 < nsteps; i += 2) {
-                stage(pr + PR * (i + 1), RT, 16 * (pr + PR * (i - 1)), accB, accA, image_of(0), fa1, fa0, true, obase);
-                stage(pr + PR * (i + 2), RT, 16 * (pr + PR * i), accA, accB, image_of(1), fa0, fa1, true, obase);
+                stage(pr + PR * (i + 1), RT, 16 * (pr + PR * (i - 1)), accB, accA, image_of(0), fa1, fa0, true, obase, BLK - 1);
+                stage(pr + PR * (i + 2), RT, 16 * (pr + PR * i), accA, accB, image_of(1), fa0, fa1, true, obase, BLK - 1);
             }
             if (i < nsteps) {
-                stage(pr + PR * (i + 1), RT, 16 * (pr + PR * (i - 1)), accB, accA, image_of(0), fa1, fa0, true, obase);
+                stage(pr + PR * (i + 1), RT, 16 * (pr + PR * (i - 1)), accB, accA, image_of(0), fa1, fa0, true, obase, BLK - 1);
                 ++i;
             }
             // the last step's tile (the only one that may have fewer than 16 rows, or -- PC 2 -- not exist).  One wave per row tile
-            // (PC 1, always one request per slab): a full tile stays in registers (accP) and leaves under the first MFMAs of the
+            // (PC 1, always one request per slab): the tile stays in registers (accP) and leaves under the first MFMAs of the
             // wave's next group -- with one or two row tiles per wave and group (values-only requests) the flush was a fifth of
-            // the launch.  Otherwise: image, then out.
+            // the launch; a tile of fewer than 16 rows too (its rows that do not exist land in unused rows of the image, its
+            // pieces stop at pend_lim): the wave that flushed it on the spot kept the other three waiting at the slab barrier,
+            // 1000 of 11 700 clocks a request for 56 rows (FX_WG_TIME).  Otherwise: image, then out.
             const int ltile = pr + PR * (i - 1);
             const int lrows = ltile == RT - 1 ? last_rows : 16;
             bool defer = false;
-            if constexpr (PC == 1) defer = lrows == 16 && !(FX_WG_ABL & 12);
+            if constexpr (PC == 1) defer = !(FX_WG_ABL & 12);
             if (defer) {
 #pragma unroll
                 for (int c = 0; c < CTW; ++c) accP[c] = ((i - 1) & 1) ? accB[c] : accA[c];
                 pend = true;
                 pend_base = obase;
                 pend_frow = 16 * ltile;
+                pend_lim = lrows * npts / EPP - 1;
             } else {
                 if constexpr (PC == 1) pend = false;
                 double* imgl = image_of((i - 1) & 1);
@@ -504,9 +675,8 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                 }
                 wave_lds_fence();
             }
-            // first use of the prefetched points in the same block as the last stores: exact vmcnt
-#pragma unroll
-            for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
+            }
+            WG_TICK(3);
         }
         } else {
             // ---------------- dof-major sweep with the chain rule on the accumulators (MIX 1) ----------------
@@ -607,8 +777,6 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
                 if (i < RTd && nrows < 16) build_pieces(G - 1, 16);
                 wave_lds_fence();
             }
-#pragma unroll
-            for (int d = 0; d < SD; ++d) asm volatile("" : "+v"(xnext[d]));
         }
         wg_lds_barrier();  // every wave is done with the slab
         cur = nxt;
@@ -616,19 +784,29 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
 #pragma unroll
         for (int d = 0; d < SD; ++d) xcur[d] = xnext[d];
     }
+#if FX_WG_TIME
+    if (blockIdx.x == 0 && lane == 0) {
+        for (int i = 0; i < 6; ++i) trash[8192 + wave * 8 + i] = (double)tacc[i];
+        trash[8192 + wave * 8 + 6] = (double)((ngroups + gridDim.x - 1) / gridDim.x);
+    }
+#endif
     if constexpr (PC == 1 && MIX == 0) {  // the tile still in registers
         if (pend) {
             double* imgl = imgs + (size_t)wave * wg_image_doubles(CT);
 #pragma unroll
             for (int c = 0; c < CTW; ++c)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) imgl[ioff[c][jj]] = accP[c][jj];
+                for (int jj = 0; jj < 4; ++jj) {
+                    if constexpr (FAST) imgl[ioff[c][jj]] = flip ? accA0[c][jj] : accB0[c][jj];
+                    else imgl[ioff[c][jj]] = accP[c][jj];
+                }
             wave_lds_fence();
             char* tb = reinterpret_cast<char*>(pend_base + (size_t)pend_frow * npts);
 #pragma unroll
             for (int q = 0; q < NRW; ++q) {
-                const FlushT f = reinterpret_cast<const FlushT*>(imgl)[pu_l[q]];
-                FlushT* g2 = reinterpret_cast<FlushT*>(tb + pu_o[q]);
+                const int u = min(pu_l[q], pend_lim);
+                const FlushT f = reinterpret_cast<const FlushT*>(imgl)[u];
+                FlushT* g2 = reinterpret_cast<FlushT*>(tb + (unsigned)u * (unsigned)(8 * EPP));
                 if constexpr (ODD) *g2 = f;
                 else stream_store(g2, f);
             }

@@ -13,13 +13,13 @@ namespace {
 // (two waves per row tile wherever the column tiles split evenly: DESIGN.md 4.5c)
 constexpr int wg_pc(int ct) { return ct % 2 == 0 ? 2 : 1; }
 
-template <int SD, int N, int CT, bool ODD, int PC, int MIX>
+template <int SD, int N, int CT, bool ODD, int PC, int MIX, bool FAST = false>
 hipError_t launch(const fxk::StackedArgs<0>& h, const double* coef, int ncoef, int lds_bytes, int grid, double* trash, unsigned int* queue,
                   hipStream_t s) {
     constexpr int NC = fxk::FixedNC<SD, N>::value;
     constexpr int KS = (fxk::StepTable<SD, N>::NEXP + 3) / 4;
     if (ncoef != NC || lds_bytes != fxk::wg_lds_doubles(CT, KS) * 8 || h.npts < 1 || h.gslab < 1 || (long long)h.gslab * h.npts > 16 * CT ||
-        (long long)grid * h.gslab > h.nreq + h.gslab - 1)
+        (long long)grid * h.gslab > h.nreq + h.gslab - 1 || (PC == 1 && h.gslab != 1) || (FAST && h.RT > fxk::WG_NW))
         return hipErrorInvalidValue;
     fxk::StackedArgs<NC> ka;
     memset(&ka, 0, sizeof ka);
@@ -41,7 +41,7 @@ hipError_t launch(const fxk::StackedArgs<0>& h, const double* coef, int ncoef, i
     ka.lim_out = h.lim_out;
     ka.lim_afrag = h.lim_afrag;
     memcpy(ka.coef, coef, NC * sizeof(double));
-    auto kern = fxk::tabulate_simplex_wg<SD, N, CT, ODD, PC, MIX>;
+    auto kern = fxk::tabulate_simplex_wg<SD, N, CT, ODD, PC, MIX, FAST>;
     static thread_local bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -75,6 +75,19 @@ hipError_t launch(const fxk::StackedArgs<0>& h, const double* coef, int ncoef, i
         (void)hipMemset(trash + 4096, 0, sizeof rep);
     }
 #endif
+#if FX_WG_TIME
+    {
+        static int tl = 0;
+        if (h.nreq > 8 && (tl++ % 64) == 40) {
+            double rep[32];
+            if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(rep, trash + 8192, sizeof rep, hipMemcpyDeviceToHost) != hipSuccess) return hipErrorUnknown;
+            for (int w = 0; w < 4; ++w)
+                fprintf(stderr, "[fiat_amd] WG TIME <%d,%d,%d,pc%d,mix%d> wave %d: %.0f groups; ticks per group: top %.0f production %.0f barrier %.0f operands %.0f sweep %.0f tail %.0f\n",
+                        SD, N, CT, PC, MIX, w, rep[8 * w + 6], rep[8 * w + 5] / rep[8 * w + 6], rep[8 * w] / rep[8 * w + 6], rep[8 * w + 1] / rep[8 * w + 6], rep[8 * w + 2] / rep[8 * w + 6],
+                        rep[8 * w + 3] / rep[8 * w + 6], rep[8 * w + 4] / rep[8 * w + 6]);
+        }
+    }
+#endif
     return hipGetLastError();
 }
 
@@ -95,6 +108,11 @@ hipError_t launch_odd(bool odd, int mix, const fxk::StackedArgs<0>& h, const dou
                 return launch<SD, N, CT, true, wg_mix_pc(SD, CT, true), 1>(h, coef, ncoef, lds_bytes, grid, trash, queue, s);
         }
         return hipErrorInvalidValue;
+    }
+    if constexpr (wg_pc(CT) == 1) {   // at most one row tile per wave (values-only requests of up to 64 rows): the FAST instances
+        if (h.RT <= fxk::WG_NW)
+            return odd ? launch<SD, N, CT, true, 1, 0, true>(h, coef, ncoef, lds_bytes, grid, trash, queue, s)
+                       : launch<SD, N, CT, false, 1, 0, true>(h, coef, ncoef, lds_bytes, grid, trash, queue, s);
     }
     return odd ? launch<SD, N, CT, true, wg_pc(CT), 0>(h, coef, ncoef, lds_bytes, grid, trash, queue, s)
                : launch<SD, N, CT, false, wg_pc(CT), 0>(h, coef, ncoef, lds_bytes, grid, trash, queue, s);

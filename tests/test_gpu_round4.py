@@ -46,7 +46,10 @@ WG = [("DiscontinuousLagrange", 3, 6, 122), ("Lagrange", 3, 6, 74), ("Lagrange",
       ("Lagrange", 3, 4, 70), ("Lagrange", 3, 4, 97), ("Lagrange", 3, 4, 122), ("Lagrange", 3, 3, 70), ("Lagrange", 3, 3, 97),
       ("Nedelec", 3, 3, 74), ("RaviartThomas", 3, 3, 81), ("Lagrange", 2, 6, 73), ("Lagrange", 2, 5, 79), ("Lagrange", 2, 6, 128),
       # odd table sizes: the 8-byte flush twins (35 x 97, 21 x 79 / 63 x 79 doubles a request ...)
-      ("Lagrange", 3, 4, 97), ("Lagrange", 2, 5, 79), ("DiscontinuousLagrange", 2, 5, 65), ("RaviartThomas", 3, 3, 81)]
+      ("Lagrange", 3, 4, 97), ("Lagrange", 2, 5, 79), ("DiscontinuousLagrange", 2, 5, 65), ("RaviartThomas", 3, 3, 81),
+      # one row tile per wave (values-only requests of up to 64 rows: the FAST instances, both flush widths; 35 rows: a wave without
+      # a tile) and one wave per row tile with a last tile of 7 rows x 75 points (deferred like the full ones)
+      ("Lagrange", 3, 4, 75), ("DiscontinuousLagrange", 3, 5, 80), ("Nedelec", 3, 3, 75)]
 
 
 @pytest.mark.parametrize("family,sd,degree,npts", WG, ids=[f"{m[0][:3]}{m[2]}-sd{m[1]}-{m[3]}pt" for m in WG])
@@ -302,7 +305,13 @@ def test_chain_rule_inside_the_request_per_workgroup_kernel(family, sd, degree, 
 @pytest.mark.parametrize("family,sd,degree,npts,order,cells,suffix", [
     ("Lagrange", 2, 5, 19, 1, False, "8>x6"), ("Lagrange", 2, 5, 21, 2, False, None), ("Lagrange", 3, 4, 31, 0, False, "8>x4"),
     ("Lagrange", 3, 4, 31, 0, True, "8>x4"), ("Lagrange", 3, 4, 23, 0, False, None), ("Nedelec", 3, 3, 23, 1, True, None),
-    ("Lagrange", 3, 5, 57, 0, False, "8>x2"), ("Lagrange", 3, 5, 57, 2, False, "8>x2"), ("Lagrange", 3, 4, 58, 0, False, None), ("Lagrange", 3, 4, 57, 0, False, "8>x2")])
+    ("Lagrange", 3, 5, 57, 0, False, "8>x2"), ("Lagrange", 3, 5, 57, 2, False, "8>x2"), ("Lagrange", 3, 4, 58, 0, False, None), ("Lagrange", 3, 4, 57, 0, False, "8>x2"),
+    # vector-valued degree-3 tetrahedra: 13..15 points (nine requests per slab), and the 180-row tables at 17..24 points with cells /
+    # at 49..64 points with derivatives
+    ("RaviartThomas", 3, 3, 14, 2, False, "8>x9"), ("Nedelec", 3, 3, 14, 1, False, "8>x9"), ("BrezziDouglasMarini", 3, 3, 14, 0, True, "8>x9"),
+    ("Nedelec", 3, 3, 16, 1, False, None), ("BrezziDouglasMarini", 3, 3, 23, 0, True, "8>x5"), ("NedelecSecondKind", 3, 3, 23, 1, True, "8>x5+mix"),
+    ("RaviartThomas", 3, 3, 23, 0, True, None), ("BrezziDouglasMarini", 3, 3, 57, 1, False, "8>x2"), ("BrezziDouglasMarini", 3, 3, 57, 0, False, None),
+    ("RaviartThomas", 3, 3, 57, 2, False, None)])
 def test_windows_of_grouped_requests(family, sd, degree, npts, order, cells, suffix, kernel_policy):
     """Where several requests per workgroup are the default below 65 points (round 4, sustained A/B in DESIGN.md 4.16): tables of an
     odd number of doubles at 17..48 points that only the point chunks held, degree >= 5 tetrahedra at 49..64 points -- and where they
