@@ -1885,8 +1885,11 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                         // P3 528 / 232 against 345 / 217, P5 triangles at 79 points 556 / 358 against 334 / 234, P6 triangles values
                         // 455 against 320 -- while degree >= 5 tetrahedra (K steps >= 14) and P6 triangles with Hessians win, as does
                         // everything at 97..128 points.  Policy wg_small opts in regardless.)
+                        // (... except requests of 33..64 rows on five column tiles -- values of P4 tetrahedra at 65..80 points: one row tile
+                        // per wave, no accumulator hand-over, 358 / 394 us at 74 / 75 points against 432 / 429 on the point chunks)
+                        const bool one_tile = k.sd == 3 && order == 0 && (wg_g * npts + 15) / 16 == 5 && RT >= 3 && RT <= 4;
                         if (npts > 64 && (wg_g * npts + 15) / 16 <= 6 && !(ctx->policy & FX_POLICY_WG_SMALL) &&
-                            !((e->nexp + 3) / 4 >= 14 || (k.sd == 2 && k.n == 6 && order == 2)))
+                            !((e->nexp + 3) / 4 >= 14 || (k.sd == 2 && k.n == 6 && order == 2) || one_tile))
                             continue;
                         wg_odd = !even;
                         wg_ctw = std::max(4, (wg_g * npts + 15) / 16);
@@ -2012,7 +2015,10 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 // one workgroup per CU = one wave per SIMD (measured: a second wave per SIMD at half the registers
                 // spills in the production phase and gains nothing, 1.45 -> 1.48 ms: the kernel is bound by the
                 // shared fp64 MFMA/VALU pipe, not by latencies)
-                L.kgrid = (int)std::max<long long>(1, std::min<long long>((groups + STACKED_NW - 1) / STACKED_NW, ctx->num_cu));
+                // (the request-per-workgroup kernel's one-row-tile instances -- values-only requests of up to 64 rows -- are the
+                // exception: 256 registers, two workgroups a CU, 320 -> 298 us for degree-5 tetrahedra at 74 points)
+                const int wgs = wgk ? fxwg::workgroups_per_cu(k.sd, k.n, wg_ctw, wg_odd, wg_mix1 ? 1 : 0, RT) : 1;
+                L.kgrid = (int)std::max<long long>(1, std::min<long long>((groups + STACKED_NW - 1) / STACKED_NW, (long long)ctx->num_cu * wgs));
                 L.ncu = ctx->num_cu;
                 L.trash = ctx->d_trash;
                 L.queue = ctx->d_queue + (size_t)(ctx->launch_seq++ % FX_QUEUE_SLOTS) * 16;

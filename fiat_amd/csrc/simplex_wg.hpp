@@ -162,9 +162,12 @@ template <int SD, int N, int NSUB, int SUB> struct SubsetSteps {
 //         the column's request from LDS) and flushes table by table under the next dof tile's MFMAs: one pass instead of
 //         kernel + table_mix_kernel (FIAT/expansions.py:411-447 through Jinv).
 // FAST (PC 1, at most four row tiles -- values-only requests of up to 64 rows): every wave has ONE row tile a group; its own
-//         instances, so that the accumulators that cross the production phase are there only
+//         instances, so that the accumulators that cross the production phase are there only.  With 16-byte flush pieces they are
+//         compiled for 256 registers and two workgroups share a CU (one's recurrence phase under the other's MFMAs: degree-5
+//         tetrahedra at 74 points 320 -> 298 us; the 8-byte twins spill in the sweep at 256 registers, 394 -> 850 us, and stay
+//         at one workgroup a CU)
 template <int SD, int N, int CT, bool ODD, int PC, int MIX = 0, bool FAST = false>
-__global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const StackedArgs<FixedNC<SD, N>::value> a, double* __restrict__ trash,
+__global__ __launch_bounds__(64 * WG_NW, FAST && !ODD ? 2 : 1) void tabulate_simplex_wg(const StackedArgs<FixedNC<SD, N>::value> a, double* __restrict__ trash,
                                                                    unsigned int* __restrict__ gctr) {
     constexpr StepTable<SD, N> TBL{};
     constexpr int NEXP = StepTable<SD, N>::NEXP;
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(64 * WG_NW, 1) void tabulate_simplex_wg(const Stack
             auto produce_subset = [&](auto sub_c) {
                 constexpr int SUB = decltype(sub_c)::value;
                 constexpr SubsetSteps<SD, N, NSUB, SUB> SL{};
-                constexpr int CB = MIX ? 4 : 8, NBATCH = (SL.count + CB - 1) / CB;
+                constexpr int CB = (MIX || FAST) ? 4 : 8, NBATCH = (SL.count + CB - 1) / CB;
                 double mem[NEXP];
                 double ufa = 0.0, ufb = 0.0, ufc = 0.0;
                 int fcodim = -1;

@@ -147,6 +147,12 @@ bool has_instance(int sd, int n, int ct, bool odd) {
     return (sd == 3 && n >= 3 && n <= 6) || (sd == 2 && (n == 5 || n == 6));
 }
 
+// (the one-row-tile instances -- one wave per row tile, at most four row tiles, no chain rule -- with 16-byte flush pieces are compiled for 256 registers: two
+// workgroups share a CU where two slabs fit its LDS, one's recurrence phase under the other's MFMAs)
+int workgroups_per_cu(int sd, int n, int ct, bool odd, int mix, int rt) {
+    return (wg_pc(ct) == 1 && !odd && !mix && rt <= fxk::WG_NW && 2 * lds_bytes(sd, n, ct) <= 160 * 1024) ? 2 : 1;
+}
+
 bool has_mix_instance(int sd, int n, int ct, bool odd) { return has_instance(sd, n, ct, odd) && wg_has_mix(sd, n, ct) && !(odd && sd == 3 && n == 6 && ct == 8); }
 
 int mix_ct(int sd, int n, int ctn) {

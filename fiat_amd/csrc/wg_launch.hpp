@@ -14,6 +14,8 @@ bool has_instance(int sd, int n, int ct, bool odd);
 bool has_mix_instance(int sd, int n, int ct, bool odd);
 // column tiles of the chain-rule instance that holds ctn column tiles of points (0: none)
 int mix_ct(int sd, int n, int ctn);
+// persistent workgroups a CU holds of the instance that takes requests of rt row tiles (2: the one-row-tile instances)
+int workgroups_per_cu(int sd, int n, int ct, bool odd, int mix, int rt);
 // one launch: `grid` persistent workgroups of 256 threads, requests handed out through queue[0] (zero before the launch,
 // zero again after it), queue[1] = finished workgroups
 hipError_t launch_simplex_wg(int sd, int n, int ct, bool odd, int mix, const fxk::StackedArgs<0>& head, const double* coef, int ncoef, int lds_bytes,
