@@ -1760,11 +1760,11 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 // 23-point rule 198 us there against 213 here)
                 const bool odd_pt = ((long long)rows * npts) % 2 != 0;
                 const bool twin2 = (k.sd == 3 && (k.n == 3 || k.n == 4) && npts <= 24) || (k.sd == 2 && k.n == 5 && npts >= 25);
-                // (... and vector-valued degree-3 tetrahedra of 180 rows a table -- BDM3, N2 of degree 3 -- at 17..24 points: 223 -> 198 us at
-                // the 23-point rule, five requests per slab)
                 const bool window = npts > 48 || (k.sd == 2 && k.n == 5 && npts >= 25 && npts <= 33) ||
                                     (k.sd == 3 && k.n == 3 && e->vdim > 1 && npts >= 13 && npts <= 15) ||
-                                    (k.sd == 3 && k.n == 3 && e->vdim > 1 && rows >= 160 && npts >= 17 && npts <= 24) ||
+                                    // (degree >= 4 tetrahedra at 13..15 points, nine requests per slab: P4 / P5 / P6 at 14 points 403 / 485 / 580 ->
+                                    // 272 / 292 / 393 us)
+                                    (k.sd == 3 && k.n >= 4 && npts >= 13 && npts <= 15) ||
                                     (odd_pt && npts >= 17 && npts <= 48 && !twin2);
                 if (!(window || (ctx->policy & FX_POLICY_WG_SMALL))) return false;
                 const int g = npts > 64 ? 1 : std::min(12, 128 / npts);
@@ -1845,15 +1845,22 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     // P5 triangles with derivatives at 25..33 points 232 / 183 / 252 -> 189 / 169 / 225 us, degree-6 tetrahedra with
                     // Hessians at 33..48 points 432 -> 352 us.  Elsewhere the two are within +-10 % of each other with either sign,
                     // and the map's short interleaved runs disagree with the sustained ones: opt-in, policy wg_small)
-                    // (round 4, audits off the default rule sizes, sustained: vector-valued degree-3 tetrahedra at 13..15 points, nine
-                    // requests per slab against the three-request instance -- RT3 with Hessians / N3 with gradients / BDM3 values at the
-                    // 14-point rule 218 / 175 / 164 -> 157 / 158 / 159 us; with cells, values: N3 / BDM3 / N2 217 / 166 / 171 -> 196 / 151 / 148)
-                    const bool vec3_window = k.sd == 3 && k.n == 3 && e->vdim > 1 && npts >= 13 && npts <= 15;
-                    // (... and those of 180 rows a table -- BDM3, N2 of degree 3 -- at 17..24 points with cells, values: 181 / 195 -> 171 / 173 us
-                    // at the 23-point rule)
+                    // (vector-valued degree-3 tetrahedra of 180 rows a table -- BDM3, N2 of degree 3 -- at 17..24 points with cells, values:
+                    // 892 -> 744 us at the 23-point rule in 4 GB batches.  What the 0.8 GB runs of the audits showed beside it -- their
+                    // other orders, 13..15 points on the own cell, 49..64 points with derivatives -- is within +-4 % at 4 GB: not taken)
                     const bool vec3_rows = k.sd == 3 && k.n == 3 && e->vdim > 1 && rows >= 160;
+                    // (after the kernel's second half of round 4, sustained default / wg_small sweep over 135 shapes, own cell and cells:
+                    // degree >= 5 tetrahedra at 13..15 points, nine requests per slab -- P5 / P6 at 14 points, values / gradients / Hessians
+                    // 352 / 272 / 302 -> 316 / 237 / 236 us and 465 / 371 / 439 -> 401 / 328 / 314, with cells 368 / - / 571 -> 351 / - / 472 and
+                    // 477 / - / 697 -> 422 / - / 549; P4 with Hessians 208 -> 187, with cells 477 -> 438; values of degree >= 5 at 25..32
+                    // points, four per slab, 363 / 466 -> 319 / 410.  Confirmed in 4 GB batches (CAP_GB=4): 0.91-0.97 of the per-wave
+                    // instances there, 0.89 / 0.91 at 25..32 points -- while P6 with Hessians at the 23-point rule, 438 -> 366 us at 0.8 GB,
+                    // is 1.04 at 4 GB and 7.51 against 6.93 ms in bench.py --workload dg6tet: heavy requests are few at 0.8 GB and the
+                    // two kernels quantise differently over the chip; windows are taken from the larger batches)
+                    const bool hi14 = k.sd == 3 && npts >= 13 && npts <= 15 && (k.n >= 5 || (k.n == 4 && order == 2));
+                    const bool hi_more = k.sd == 3 && k.n >= 5 && order == 0 && npts >= 25 && npts <= 32;
                     const bool small_window = (k.sd == 2 && k.n == 5 && order >= 1 && npts >= 25 && npts <= 33) ||
-                                              (k.sd == 3 && k.n == 6 && order == 2 && npts >= 33 && npts <= 48) || vec3_window;
+                                              (k.sd == 3 && k.n == 6 && order == 2 && npts >= 33 && npts <= 48) || hi14 || (hi_more && !verts);
                     // per-request cells with gradients: the chain rule on the accumulators (MIX instances); other orders with
                     // cells: values straight from the kernel, derivatives + the table-mixing pass
                     const bool nomix = (ctx->policy & FX_POLICY_NO_STACKED_MIX) != 0;
@@ -1865,7 +1872,8 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     const bool twin1 = (k.sd == 3 && (k.n == 3 || k.n == 4) && npts <= 24) || (k.sd == 2 && k.n == 5 && npts >= 25 && npts <= 32);
                     const bool odd_window = !even && npts >= 17 && npts <= 48 && (!verts || order == 0) && !twin1;
                     if (npts <= 48 && !(ctx->policy & FX_POLICY_WG_SMALL) && !(small_window && (!verts || want_mix)) && !odd_window &&
-                        !(verts && order == 0 && (vec3_window || (vec3_rows && npts >= 17 && npts <= 24))) &&
+                        !(verts && order == 0 && vec3_rows && npts >= 17 && npts <= 24) &&
+                        !(verts && order != 1 && (hi14 || hi_more)) &&
                         !(want_mix && wg_mix_takes(k)))
                         continue;
                     // requests per slab of <= 128 columns and the instance's column tiles
@@ -1878,19 +1886,13 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                         wg_mix1 = wg_ctw > 0 && fxwg::has_mix_instance(k.sd, k.n, wg_ctw, wg_odd) && wg_mix_takes(k);
                     }
                     if (!wg_mix1) {
-                        if (verts && order >= 1 && npts <= 48 && !(ctx->policy & FX_POLICY_WG_SMALL)) continue;
+                        if (verts && order >= 1 && npts <= 48 && !(ctx->policy & FX_POLICY_WG_SMALL) && !(hi14 && order == 2)) continue;
                         // (65..96 points -- five or six column tiles -- with a short K loop: a stage is a few dozen MFMAs and the
                         // per-request recurrence + barriers dominate.  tools/instance_ab.py --own-cell [--policy no_wg], 0.8 GB, this
                         // kernel against the point chunks: P4 tetrahedra at 70 points, values / gradients 779 / 435 against 455 / 270 us,
                         // P3 528 / 232 against 345 / 217, P5 triangles at 79 points 556 / 358 against 334 / 234, P6 triangles values
                         // 455 against 320 -- while degree >= 5 tetrahedra (K steps >= 14) and P6 triangles with Hessians win, as does
                         // everything at 97..128 points.  Policy wg_small opts in regardless.)
-                        // (... except requests of 33..64 rows on five column tiles -- values of P4 tetrahedra at 65..80 points: one row tile
-                        // per wave, no accumulator hand-over, 358 / 394 us at 74 / 75 points against 432 / 429 on the point chunks)
-                        const bool one_tile = k.sd == 3 && order == 0 && (wg_g * npts + 15) / 16 == 5 && RT >= 3 && RT <= 4;
-                        if (npts > 64 && (wg_g * npts + 15) / 16 <= 6 && !(ctx->policy & FX_POLICY_WG_SMALL) &&
-                            !((e->nexp + 3) / 4 >= 14 || (k.sd == 2 && k.n == 6 && order == 2) || one_tile))
-                            continue;
                         wg_odd = !even;
                         wg_ctw = std::max(4, (wg_g * npts + 15) / 16);
                         if (wg_ctw == 7) wg_ctw = 8;        // (no seven-tile instance)
@@ -1898,14 +1900,20 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                             const long long one = (long long)((RT + 3) / 4) * 5, two = (long long)((RT + 1) / 2) * 3;
                             if (two < one) wg_ctw = 6;
                         }
+                        // (... except the instances of one wave per row tile on five column tiles, since the recurrence coefficients are
+                        // fetched ahead and the last tile of a group leaves under the next group's MFMAs (second half of round 4;
+                        // sustained, same tool): values of P4 tetrahedra at 74 / 75 points 358 / 394 us against 432 / 429 on the point
+                        // chunks, RT3 values / P3 Hessians at 74 points 175 / 164 against 202 / 197, P5 triangles with gradients at 65 / 72 /
+                        // 79 points 240 / 187 / 224 against 261 / 240 / 235 -- while two waves per row tile on six column tiles still lose
+                        // with few rows: P6 triangles, values at 79 points 359 against 296, P3 tetrahedra at 70 points 460 against 348)
+                        if (npts > 64 && (wg_g * npts + 15) / 16 <= 6 && !(ctx->policy & FX_POLICY_WG_SMALL) &&
+                            !((e->nexp + 3) / 4 >= 14 || (k.sd == 2 && k.n == 6 && order == 2) || wg_ctw == 5))
+                            continue;
                         if (!fxwg::has_instance(k.sd, k.n, wg_ctw, wg_odd)) continue;
                     }
                     // (49..64 points: where a whole-request instance of four column tiles exists it keeps the rule)
                     // (... except degree >= 5 tetrahedra: two requests per slab 0.87-0.93 of the four-tile instance at 57 points)
-                    // (... and vector-valued degree-3 tetrahedra of 180 rows a table with derivatives: BDM3 with gradients / Hessians at 57
-                    // points 196 / 200 -> 157 / 160 us)
-                    if (!wg_mix1 && npts > 48 && npts <= 64 && even && !(ctx->policy & FX_POLICY_WG_SMALL) && !(k.sd == 3 && k.n >= 5) &&
-                        !(vec3_rows && order >= 1 && !verts)) {
+                    if (!wg_mix1 && npts > 48 && npts <= 64 && even && !(ctx->policy & FX_POLICY_WG_SMALL) && !(k.sd == 3 && k.n >= 5)) {
                         bool whole = false;
                         for (const StackedShape& o : kStackedShapes)
                             whole = whole || (o.sd == k.sd && o.n == k.n && o.rtc == 0 && o.g == 1 && o.ct == 4);

@@ -62,10 +62,10 @@ def test_request_per_workgroup_kernel(family, sd, degree, npts, order, nreq, ker
     n = el.get_nodal_basis().get_embedded_degree()
     # 65..96 points with a short K loop (degree <= 4 tetrahedra, triangles except P6 with Hessians) stay on the point chunks by
     # default (the planner's measured rule); policy wg_small brings them here: every instance is tested either way
-    # (... except values-only requests of 33..64 rows on five column tiles: one row tile per wave, the FAST instances)
-    rows = int(np.prod(ps.out_shape(0, 1, npts)[2:-1]))
-    one_tile = order == 0 and (npts + 15) // 16 == 5 and 33 <= rows <= 64
-    if 64 < npts <= 96 and not ((sd == 3 and n >= 5) or (sd == 2 and n == 6 and order == 2) or one_tile):
+    # (... except where the five-tile instance -- one wave per row tile -- has no more MFMA slots per wave than the six-tile one)
+    rt = -(-int(np.prod(ps.out_shape(order, 1, npts)[1:-1])) // 16)
+    five = (npts + 15) // 16 == 5 and -(-rt // 4) * 5 <= -(-rt // 2) * 3
+    if 64 < npts <= 96 and not ((sd == 3 and n >= 5) or (sd == 2 and n == 6 and order == 2) or five):
         assert "simplex_wg" not in ps.kernel_name(order, nreq, npts)
         kernel_policy("wg_small")
     name = ps.kernel_name(order, nreq, npts, instance=True)
@@ -309,12 +309,16 @@ def test_chain_rule_inside_the_request_per_workgroup_kernel(family, sd, degree, 
     ("Lagrange", 2, 5, 19, 1, False, "8>x6"), ("Lagrange", 2, 5, 21, 2, False, None), ("Lagrange", 3, 4, 31, 0, False, "8>x4"),
     ("Lagrange", 3, 4, 31, 0, True, "8>x4"), ("Lagrange", 3, 4, 23, 0, False, None), ("Nedelec", 3, 3, 23, 1, True, None),
     ("Lagrange", 3, 5, 57, 0, False, "8>x2"), ("Lagrange", 3, 5, 57, 2, False, "8>x2"), ("Lagrange", 3, 4, 58, 0, False, None), ("Lagrange", 3, 4, 57, 0, False, "8>x2"),
-    # vector-valued degree-3 tetrahedra: 13..15 points (nine requests per slab), and the 180-row tables at 17..24 points with cells /
-    # at 49..64 points with derivatives
-    ("RaviartThomas", 3, 3, 14, 2, False, "8>x9"), ("Nedelec", 3, 3, 14, 1, False, "8>x9"), ("BrezziDouglasMarini", 3, 3, 14, 0, True, "8>x9"),
-    ("Nedelec", 3, 3, 16, 1, False, None), ("BrezziDouglasMarini", 3, 3, 23, 0, True, "8>x5"), ("NedelecSecondKind", 3, 3, 23, 1, True, "8>x5+mix"),
-    ("RaviartThomas", 3, 3, 23, 0, True, None), ("BrezziDouglasMarini", 3, 3, 57, 1, False, "8>x2"), ("BrezziDouglasMarini", 3, 3, 57, 0, False, None),
-    ("RaviartThomas", 3, 3, 57, 2, False, None)])
+    # vector-valued degree-3 tetrahedra of 180 rows a table at 17..24 points with cells, values only (windows the 0.8 GB audits
+    # suggested beside it did not hold in 4 GB batches: not taken)
+    ("RaviartThomas", 3, 3, 14, 2, False, None), ("Nedelec", 3, 3, 14, 1, False, None), ("BrezziDouglasMarini", 3, 3, 14, 0, True, None),
+    ("Nedelec", 3, 3, 16, 1, False, None), ("BrezziDouglasMarini", 3, 3, 23, 0, True, "8>x5"), ("NedelecSecondKind", 3, 3, 23, 1, True, None),
+    ("RaviartThomas", 3, 3, 23, 0, True, None), ("BrezziDouglasMarini", 3, 3, 57, 1, False, None), ("BrezziDouglasMarini", 3, 3, 57, 0, False, None),
+    ("RaviartThomas", 3, 3, 57, 2, False, None),
+    # degree >= 4 tetrahedra at 13..15 points (nine requests per slab), values of degree >= 5 at 25..32; P6 Hessians at 17..24 stay
+    ("Lagrange", 3, 5, 14, 0, False, "8>x9"), ("Lagrange", 3, 6, 14, 2, True, "8>x9"), ("Lagrange", 3, 4, 14, 1, True, "8>x9+mix"),
+    ("Lagrange", 3, 4, 14, 1, False, None), ("Lagrange", 3, 4, 15, 2, False, "8>x8"), ("Lagrange", 3, 5, 31, 0, True, "8>x4"),
+    ("Lagrange", 3, 6, 23, 2, False, None), ("Lagrange", 3, 6, 23, 2, True, None), ("Lagrange", 3, 5, 13, 1, True, "8>x9+mix")])
 def test_windows_of_grouped_requests(family, sd, degree, npts, order, cells, suffix, kernel_policy):
     """Where several requests per workgroup are the default below 65 points (round 4, sustained A/B in DESIGN.md 4.16): tables of an
     odd number of doubles at 17..48 points that only the point chunks held, degree >= 5 tetrahedra at 49..64 points -- and where they
