@@ -122,3 +122,50 @@ def test_full_size_with_device_constructed_elements(rt, golden, family, degree, 
     assert err[0] <= 1e-12 and err[1:].max() <= 1e-10, err
     del out
     torch.cuda.empty_cache()
+
+
+def test_c4_stress_122_points_full_size(rt, golden):
+    """The C4 stress variant of bench.py --workload dg6tet122 (8000 requests of the 122-point rule, order 2, 6.6 GB of tables) on the
+    request-per-workgroup kernel: partition of unity, vanishing derivative sums, a sample against the C oracle."""
+    import torch
+    from oracle import c_oracle
+    co = golden("elements")["c4_dg6tet_q6_coeffs"]
+    nreq, npts = 8000, 122
+    rng = np.random.default_rng(122)
+    pts = simplex_points(rng, 3, (nreq, npts))
+    ps = rt.SimplexPolySet(3, 6, coeffs=co)
+    assert ps.kernel_name(2, nreq, npts) == "fxk::tabulate_simplex_wg"
+    out = ps.tabulate_batch(2, pts)
+    s = out.sum(dim=2)
+    assert float((s[:, 0] - 1.0).abs().max()) <= 1e-11
+    assert float(s[:, 1:4].abs().max()) <= 1e-9
+    assert float(s[:, 4:].abs().max()) <= 1e-7
+    assert bool(torch.isfinite(out).all())
+    idx = rng.choice(nreq, 60, replace=False)
+    got = out[torch.as_tensor(idx).cuda()].cpu().numpy()
+    ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[3], 6, co, 2, pts[idx]).reshape(got.shape)
+    err = (np.abs(got - ref).max(axis=(2, 3)) / np.maximum(1.0, np.abs(ref).max(axis=(2, 3)))).max(axis=0)
+    assert err[0] <= 1e-12 and err[1:].max() <= 1e-10, err
+
+
+@pytest.mark.parametrize("npts,nreq", [(74, 60001), (75, 30011)])
+def test_values_only_requests_of_one_row_tile_per_wave_at_size(rt, npts, nreq):
+    """Values of P5 / P4 tetrahedra at 74 / 75 points -- the one-row-tile instances of the request-per-workgroup kernel, 16-byte flush
+    pieces with two workgroups per CU (56 rows x 74 points) and the 8-byte twin (35 x 75) -- over > 100 groups per workgroup, an odd
+    number of requests: partition of unity over the whole batch, first / last / sampled requests against the C oracle."""
+    import torch
+    import fiat_amd
+    from oracle import c_oracle
+    el = fiat_amd.Lagrange(fiat_amd.ufc_simplex(3), 5 if npts == 74 else 4)
+    ps = el.device_polyset()
+    assert ps.kernel_name(0, nreq, npts, instance=True) == f"fxk::tabulate_simplex_wg<3,{5 if npts == 74 else 4},5>"
+    rng = np.random.default_rng(npts)
+    pts = simplex_points(rng, 3, (nreq, npts))
+    out = ps.tabulate_batch(0, pts)
+    assert float((out.sum(dim=2) - 1.0).abs().max()) <= 1e-11
+    idx = np.concatenate([[0, 1, nreq - 2, nreq - 1], rng.choice(nreq, 200, replace=False)])
+    got = out[torch.as_tensor(idx).cuda()].cpu().numpy()
+    n = el.get_nodal_basis().get_embedded_degree()
+    ref = c_oracle.tabulate_batch(fo.UFC_SIMPLEX[3], n, el.get_coeffs(), 0, pts[idx], scale=el._expansion_scale,
+                                  variant=el._expansion_variant).reshape(got.shape)
+    assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
