@@ -1644,7 +1644,10 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                 if (values_only_shape && e->sd == 3 && npts > 16) continue;   // (P3 tetrahedra: up to the 14-point rule)
                 if (!small_table_matches((int)i, e->prog) || (int)e->prog.steps.size() > fxk::SMALL_MAXSTEPS) continue;
                 int P = std::max(1, 64 / npts);
-                while (P > 1 && P * reqbytes8 > 12 * 1024) --P;  // per-wave image: several workgroups per CU
+                // (17-24 rows -- vector-valued degree-2 triangles -- with Hessians: 6.9 KB a request left ONE request a wave, six of 64 lanes
+                // at the 6-point rule, and the shape went to the generic kernel at 31 % of the HBM peak; up to 28 KB a wave there)
+                const long long image_cap = ((rows > 16 && e->sd == 2) || rows > 24) ? 28 * 1024 : 12 * 1024;   // (N1 tetrahedra, 18 rows, with Hessians: 199 us at two requests a wave, 213 at four)
+                while (P > 1 && P * reqbytes8 > image_cap) --P;  // per-wave image: several workgroups per CU
                 // many rows (vector-valued elements): the MFMA contraction of the generic / stacked kernels wins over
                 // rows x members FMAs per lane (tools/coverage_map.py: 30+ rows 15-30 % here against 26-48 % there; 17-24 rows
                 // only while several requests share a wave)
@@ -1654,7 +1657,12 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                                         e->vdim == e->sd && rows % e->sd == 0 && L.fixed_id < 0 && L.coop_id < 0 && !L.fused_mapping &&
                                         !(e->sd == 3 && e->n == 2 && order == 2);  // (that instance spills 39 registers)
                 if (fuse_small && rows > 24 && order >= 1 && stacked_pio_ok) break;
-                if (fuse_small ? rows > 36 : !values_only_shape && (rows > 24 || (rows > 16 && P == 1))) break;
+                // (36 rows of degree-1 tetrahedra -- BDM1, N2 of degree 1 -- stayed generic at 42-46 %: four members, 144 FMAs a table.
+                // Second half of round 4, tools/instance_ab.py, 0.8 GB, generic -> lane-local: BDM2 / N2 triangles with Hessians at 6 / 12
+                // points 306 / 251 -> 188 / 188 us (with cells 319 / 260 -> 188 / 188), BDM1 tetrahedra values / gradients at 4 points
+                // 159 / 216 -> 141 / 169, at 11 points 231 -> 177; with Hessians the ten tables of 36 rows are slower here, 209 -> 350: not taken)
+                const int row_cap = (e->sd == 3 && e->n == 1 && order <= 1) ? 36 : 24;
+                if (fuse_small ? rows > 36 : !values_only_shape && (rows > row_cap || (rows > 16 && P == 1))) break;
                 fxk::SmallArgs& sa = L.sargs;
                 memset(&sa, 0, sizeof sa);
                 if (fuse_small) {

@@ -343,3 +343,23 @@ def test_windows_of_grouped_requests(family, sd, degree, npts, order, cells, suf
     other = ps.tabulate_batch(order, pts, verts=verts).cpu().numpy()
     for t in range(got.shape[1]):
         assert rel(other[:, t], ref[:, t]) <= (TOL_VAL if t == 0 else TOL_DER)
+
+
+@pytest.mark.parametrize("family,sd,degree,npts,order,cells,kernel", [
+    ("BrezziDouglasMarini", 2, 2, 6, 2, False, "small"), ("BrezziDouglasMarini", 2, 2, 12, 2, True, "small"), ("NedelecSecondKind", 2, 2, 6, 2, True, "small"),
+    ("NedelecSecondKind", 2, 2, 3, 2, False, "small"), ("BrezziDouglasMarini", 3, 1, 4, 0, False, "small"), ("BrezziDouglasMarini", 3, 1, 4, 1, True, "small"),
+    ("NedelecSecondKind", 3, 1, 11, 1, False, "small"), ("BrezziDouglasMarini", 3, 1, 4, 2, False, "kernel"), ("Nedelec", 3, 1, 4, 2, False, "small")])
+@pytest.mark.parametrize("nreq", [1, 37, 2051])
+def test_vector_valued_low_degree_requests_on_the_lane_local_kernel(family, sd, degree, npts, order, cells, kernel, nreq):
+    """Second half of round 4: vector-valued degree-2 triangles with Hessians (24 rows, 6.9 KB a request at the 6-point rule: up to four
+    requests share a wave now) and BDM1 / N2 tetrahedra of degree 1 with values / gradients (36 rows) moved from the generic kernel to
+    the lane-local one; BDM1 with Hessians stays.  Tables against the oracle, odd batch sizes (a last wave with missing requests)."""
+    import fiat_amd as fa
+    el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
+    ps = el.device_polyset()
+    assert ps.kernel_name(order, nreq, npts, has_verts=cells) == f"fxk::tabulate_simplex_{kernel}"
+    pts, verts = batch(sd, nreq, npts, 7 * npts + order + nreq, cells)
+    got = ps.tabulate_batch(order, pts, verts=verts).cpu().numpy()
+    ref = oracle_tables(el, sd, order, pts, verts, got.shape)
+    for t in range(got.shape[1]):
+        assert rel(got[:, t], ref[:, t]) <= (TOL_VAL if t == 0 else TOL_DER), (family, t, rel(got[:, t], ref[:, t]))
