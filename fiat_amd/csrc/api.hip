@@ -1856,6 +1856,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     // (vector-valued degree-3 tetrahedra of 180 rows a table -- BDM3, N2 of degree 3 -- at 17..24 points with cells, values:
                     // 892 -> 744 us at the 23-point rule in 4 GB batches.  What the 0.8 GB runs of the audits showed beside it -- their
                     // other orders, 13..15 points on the own cell, 49..64 points with derivatives -- is within +-4 % at 4 GB: not taken)
+                    // (... and on the own cell: 904 -> 742 us; gradients / Hessians there 1.07 / 1.01, RT3 / N3 values 0.91 / 1.10: not taken)
                     const bool vec3_rows = k.sd == 3 && k.n == 3 && e->vdim > 1 && rows >= 160;
                     // (after the kernel's second half of round 4, sustained default / wg_small sweep over 135 shapes, own cell and cells:
                     // degree >= 5 tetrahedra at 13..15 points, nine requests per slab -- P5 / P6 at 14 points, values / gradients / Hessians
@@ -1880,7 +1881,7 @@ int plan_launch(fx_ctx* ctx, const fx_element* e, int order, int64_t nreq, int n
                     const bool twin1 = (k.sd == 3 && (k.n == 3 || k.n == 4) && npts <= 24) || (k.sd == 2 && k.n == 5 && npts >= 25 && npts <= 32);
                     const bool odd_window = !even && npts >= 17 && npts <= 48 && (!verts || order == 0) && !twin1;
                     if (npts <= 48 && !(ctx->policy & FX_POLICY_WG_SMALL) && !(small_window && (!verts || want_mix)) && !odd_window &&
-                        !(verts && order == 0 && vec3_rows && npts >= 17 && npts <= 24) &&
+                        !(order == 0 && vec3_rows && npts >= 17 && npts <= 24) &&
                         !(verts && order != 1 && (hi14 || hi_more)) &&
                         !(want_mix && wg_mix_takes(k)))
                         continue;

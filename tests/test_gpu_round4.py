@@ -313,6 +313,7 @@ def test_chain_rule_inside_the_request_per_workgroup_kernel(family, sd, degree, 
     # suggested beside it did not hold in 4 GB batches: not taken)
     ("RaviartThomas", 3, 3, 14, 2, False, None), ("Nedelec", 3, 3, 14, 1, False, None), ("BrezziDouglasMarini", 3, 3, 14, 0, True, None),
     ("Nedelec", 3, 3, 16, 1, False, None), ("BrezziDouglasMarini", 3, 3, 23, 0, True, "8>x5"), ("NedelecSecondKind", 3, 3, 23, 1, True, None),
+    ("BrezziDouglasMarini", 3, 3, 23, 0, False, "8>x5"), ("NedelecSecondKind", 3, 3, 21, 0, False, "8>x6"), ("BrezziDouglasMarini", 3, 3, 23, 1, False, None),
     ("RaviartThomas", 3, 3, 23, 0, True, None), ("BrezziDouglasMarini", 3, 3, 57, 1, False, None), ("BrezziDouglasMarini", 3, 3, 57, 0, False, None),
     ("RaviartThomas", 3, 3, 57, 2, False, None),
     # degree >= 4 tetrahedra at 13..15 points (nine requests per slab), values of degree >= 5 at 25..32; P6 Hessians at 17..24 stay
