@@ -2355,6 +2355,22 @@ int fx_tabulate_batch_shared(fx_ctx* ctx, const fx_element* e, int mapping, int 
     const int rows = e->ndof * e->vdim;
     const size_t need = (size_t)ntab * rows * npts * sizeof(double);
     hipStream_t s = (hipStream_t)stream;
+    // Tiny requests (<= 2 KB of tables each: P0-P2, N1 / RT1 / BDM1 at their small rules, with derivatives or a Piola map): the
+    // streaming kernels below spend a block pass on K, two divisions per output double and stores of a few hundred bytes -- 20-46 % of
+    // the HBM peak (tools/coverage_map_cells.py) where the lane-local kernel, which RE-COMPUTES the tables per request from the
+    // point's jets, reaches 60-90 % on per-request points (tools/coverage_map.py --verts --pushforward).  It takes them here too:
+    // same kernel, `pts` = the one reference point set (SmallArgs::shared_pts), chain rule and Piola map through the request's cell
+    // as for per-request points.  Scalar values-only requests stay (a copy of the reference table: 0.8-1.2 x), as does everything
+    // the planner would not give to the lane-local kernel.
+    if (need <= 2048 && !(ctx->policy & FX_POLICY_NO_SMALL) && !(order == 0 && mapping == FX_MAP_AFFINE) && e->sd >= 2) {
+        Launch L;
+        const int prc = plan_launch(ctx, e, order, nreq, npts, ref_pts, verts, out, L, mapping);
+        if (prc == FX_OK && L.small_id >= 0 && L.fixed_id < 0 && L.stacked_id < 0 && L.coop_id < 0 &&
+            (mapping == FX_MAP_AFFINE || L.fused_mapping)) {
+            L.sargs.shared_pts = 1;
+            return run_small(order, L, s);
+        }
+    }
     // Reference-cell tables: scratch of THIS call, allocated and released in stream order (hipMallocAsync /
     // hipFreeAsync on the caller's stream), so calls on different streams never share a buffer and the memory
     // returns to the pool only after the streaming kernel below has read it.

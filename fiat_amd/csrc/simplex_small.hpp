@@ -33,6 +33,8 @@ struct SmallArgs {
     int debug;
     int piola;          // PIOLA instances: 1 covariant, 2 contravariant map of the request's cell (rows = dofs x SD components)
     double G[9];        // A0 / 2 (piola_matrix, aux_kernels.hpp)
+    int shared_pts;     // 1: `pts` is ONE point set [npts][SD] on the element's own cell, pushed forward to every request's cell
+                        // (fx_tabulate_batch_shared's route for tiny requests): X from (A0, b0), derivatives through the request's cell
 };
 
 // PIOLA: vector-valued functions on per-request cells leave already pushed forward (phi = M Phi per dof, M from
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_small(const SmallArg
         double J[SD][SD];
         {
             double x[SD];
-            const double* pp = a.pts + ((size_t)req * npts + (active ? pl : 0)) * SD;
+            const double* pp = a.pts + ((size_t)(a.shared_pts ? 0 : req) * npts + (active ? pl : 0)) * SD;
 #pragma unroll
             for (int d = 0; d < SD; ++d) x[d] = pp[d];
             double bb[SD];
@@ -88,12 +90,22 @@ __global__ __launch_bounds__(64 * NW) void tabulate_simplex_small(const SmallArg
                     for (int d = 0; d < SD; ++d) J[i][d] = a.A0[i * SD + d];
                 }
             }
+            if (a.shared_pts) {  // (uniform branch) the point is on the element's cell: the same X for every request
 #pragma unroll
-            for (int i = 0; i < SD; ++i) {
-                double t = bb[i];
+                for (int i = 0; i < SD; ++i) {
+                    double t = a.b0[i];
 #pragma unroll
-                for (int d = 0; d < SD; ++d) t += J[i][d] * x[d];
-                X[i] = t;
+                    for (int d = 0; d < SD; ++d) t += a.A0[i * SD + d] * x[d];
+                    X[i] = t;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < SD; ++i) {
+                    double t = bb[i];
+#pragma unroll
+                    for (int d = 0; d < SD; ++d) t += J[i][d] * x[d];
+                    X[i] = t;
+                }
             }
         }
 

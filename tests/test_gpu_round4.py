@@ -364,3 +364,37 @@ def test_vector_valued_low_degree_requests_on_the_lane_local_kernel(family, sd, 
     ref = oracle_tables(el, sd, order, pts, verts, got.shape)
     for t in range(got.shape[1]):
         assert rel(got[:, t], ref[:, t]) <= (TOL_VAL if t == 0 else TOL_DER), (family, t, rel(got[:, t], ref[:, t]))
+
+
+@pytest.mark.parametrize("family,sd,degree,npts,order", [
+    ("Lagrange", 2, 1, 3, 2), ("Lagrange", 2, 1, 3, 1), ("Lagrange", 3, 1, 4, 2), ("DiscontinuousLagrange", 3, 0, 1, 2), ("DiscontinuousLagrange", 2, 0, 1, 1),
+    ("Lagrange", 2, 2, 6, 2), ("Nedelec", 2, 1, 3, 1), ("RaviartThomas", 3, 1, 4, 0), ("BrezziDouglasMarini", 2, 1, 3, 2), ("Nedelec", 3, 1, 4, 1),
+    ("Lagrange", 2, 2, 6, 0), ("Lagrange", 3, 2, 11, 1)])
+@pytest.mark.parametrize("nreq", [1, 65, 4099])
+def test_one_rule_in_many_cells_tiny_requests(family, sd, degree, npts, order, nreq, kernel_policy):
+    """Second half of round 4: requests of <= 2 KB of tables with derivatives or a Piola map take the lane-local kernel on the ONE
+    reference point set (SmallArgs::shared_pts) instead of the streaming kernels of shared_points.hpp.  Scalar elements: tables against
+    the C oracle's recurrence on the physical cells; all: equal to the per-request-point path with the element's mapping and to the
+    streaming kernels (policy no_small); the last two shapes stay on the streaming kernels (scalar values, > 2 KB)."""
+    import fiat_amd as fa
+    from oracle import fiat_oracle as fo
+    el = getattr(fa, family)(fa.ufc_simplex(sd), degree)
+    rng = np.random.default_rng(11 * npts + order + nreq)
+    e = rng.exponential(size=(npts, sd + 1))
+    bary = e / e.sum(axis=1, keepdims=True)
+    ref_pts = bary @ fo.UFC_SIMPLEX[sd]
+    A = np.eye(sd) + 0.2 * rng.standard_normal((nreq, sd, sd))
+    A[::3, :, 0] *= -1.0
+    verts = np.einsum("vd,red->rve", fo.UFC_SIMPLEX[sd], A) + rng.standard_normal((nreq, 1, sd))
+    pts = np.einsum("pv,rvd->rpd", bary, verts)
+    got = el.tabulate_cells(order, ref_pts, verts).cpu().numpy()
+    if el.mapping()[0] == "affine":
+        ref = oracle_tables(el, sd, order, pts, verts, got.shape)
+        for t in range(got.shape[1]):
+            assert rel(got[:, t], ref[:, t]) <= (TOL_VAL if t == 0 else TOL_DER), (family, "oracle", t, rel(got[:, t], ref[:, t]))
+    want = el.tabulate_batch(order, pts, verts=verts, pushforward=True).cpu().numpy()
+    kernel_policy("no_small")
+    old = el.tabulate_cells(order, ref_pts, verts).cpu().numpy()
+    for t in range(got.shape[1]):
+        assert rel(got[:, t], want[:, t]) <= (TOL_VAL if t == 0 else TOL_DER), (family, "per-request points", t)
+        assert rel(got[:, t], old[:, t]) <= (TOL_VAL if t == 0 else TOL_DER), (family, "streaming kernels", t)
