@@ -2362,7 +2362,10 @@ int fx_tabulate_batch_shared(fx_ctx* ctx, const fx_element* e, int mapping, int 
     // same kernel, `pts` = the one reference point set (SmallArgs::shared_pts), chain rule and Piola map through the request's cell
     // as for per-request points.  Scalar values-only requests stay (a copy of the reference table: 0.8-1.2 x), as does everything
     // the planner would not give to the lane-local kernel.
-    if (need <= 2048 && !(ctx->policy & FX_POLICY_NO_SMALL) && !(order == 0 && mapping == FX_MAP_AFFINE) && e->sd >= 2) {
+    // (triangles: up to 3 KB, and scalar values of degree >= 2 too -- P2 / P3 / P4 at their default rules 0.78-0.88 of the streaming
+    // kernels' time in the two maps; P1 values, P2 tetrahedra values and N1 tetrahedra with gradients at 2.3 KB are 1.12-1.23: they stay)
+    const bool scalar_values = order == 0 && mapping == FX_MAP_AFFINE;
+    if (need <= (e->sd == 2 ? 3072u : 2048u) && !(ctx->policy & FX_POLICY_NO_SMALL) && !(scalar_values && !(e->sd == 2 && e->n >= 2)) && e->sd >= 2) {
         Launch L;
         const int prc = plan_launch(ctx, e, order, nreq, npts, ref_pts, verts, out, L, mapping);
         if (prc == FX_OK && L.small_id >= 0 && L.fixed_id < 0 && L.stacked_id < 0 && L.coop_id < 0 &&
